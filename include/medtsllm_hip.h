@@ -1,0 +1,207 @@
+/* medtsllm_hip.h — C-ABI of libmedtsllm_hip.so (MI355X / gfx950 kernels for the MedTsLLM hot path).
+ *
+ * The reference (flixpar/med-ts-llm @ 2024_10_08) has NO native/FFI layer: its hot path is PyTorch ATen
+ * ops + HuggingFace `transformers` modules called from Python. Each entry point below
+ * therefore names the reference Python call site (R: = /root/reference, HF: = transformers 5.15.0) whose
+ * device arithmetic it replaces. Host side binds these with ctypes (med-ts-llm_amd/hip/_native.py) from
+ * torch.autograd.Function.forward/backward — see INTEGRATION.md for the reference-side stub.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer unless named host_*.
+ *   - no allocation, no ownership transfer, no host synchronisation inside; the caller passes
+ *     PyTorch-allocated outputs/workspaces and the stream (hipStream_t as void*).
+ *   - bf16 tensors are raw uint16 storage; row-major; `ld*` are row strides in ELEMENTS.
+ *   - return 0 on success, negative MTL_ERR_* otherwise (mtl_strerror gives the text).
+ *   - re-entrant / thread-compatible: no mutable globals.
+ */
+#ifndef MEDTSLLM_HIP_H
+#define MEDTSLLM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTL_ABI_VERSION 1
+
+enum { MTL_OK = 0, MTL_ERR_ARG = -1, MTL_ERR_ALIGN = -2, MTL_ERR_UNSUPPORTED = -3, MTL_ERR_LAUNCH = -4,
+       MTL_ERR_WORKSPACE = -5 };
+enum { MTL_F32 = 0, MTL_BF16 = 1 };
+
+int mtl_abi_version(void);
+const char* mtl_strerror(int code);
+
+/* ------------------------------------------------------------------ patch tokeniser (a1-a4)
+ * Replaces RevIN "norm" (R:models/layers/RevIN.py:37-56), permute (R:models/medtsllm.py:272),
+ * ReplicationPad1d + unfold + reshape (R:models/layers/embed.py:160-163,188-191), TokenEmbedding Conv1d
+ * k=3 circular, no bias (R:models/layers/embed.py:44-46) and the concat relayout (R:models/medtsllm.py:276-279).
+ *   x        f32 [B, L, C]
+ *   conv_w   f32 [d_patch, patch_len, 3]
+ *   out      bf16; concat==0: [B*C, P, ld_out] (cols >= d_patch zero-filled up to ld_out)
+ *                  concat==1: [B, P, ld_out]   (col = c*d_patch + o; cols >= C*d_patch zero-filled)
+ *   mean, stdev  f32 [B, C]  (stdev = sqrt(biased var + eps), as RevIN stores them for the de-norm)
+ * P = (L + stride - patch_len)/stride + 1 (== R:models/medtsllm.py:52 for the supported L). */
+int mtl_patch_tokenize_fwd(const float* x, const float* conv_w, void* out, float* mean, float* stdev,
+                           int64_t B, int64_t L, int64_t C, int64_t patch_len, int64_t stride, int64_t d_patch,
+                           int64_t ld_out, int concat, float eps, void* stream);
+/* dW of the token conv (x_enc needs no gradient; RevIN statistics are detached in the reference).
+ *   dout  bf16, same layout as `out`;  partial f32 [B*C, d_patch*patch_len*3] workspace;  dw f32 [d_patch, patch_len, 3] */
+int mtl_patch_tokenize_bwd(const float* x, const float* mean, const float* stdev, const void* dout, float* partial,
+                           float* dw, int64_t B, int64_t L, int64_t C, int64_t patch_len, int64_t stride,
+                           int64_t d_patch, int64_t ld_out, int concat, void* stream);
+/* int32 [P, patch_len] source-index map idx[p][j] = min(p*stride + j, L-1), produced by the SAME device
+ * function the tokeniser uses (bit-exact parity target). */
+int mtl_patch_index_map(int32_t* idx, int64_t L, int64_t patch_len, int64_t stride, void* stream);
+/* RevIN "denorm" (R:models/layers/RevIN.py:58-69): out[b,t,c] = y[b,t,c]*stdev[b,c] + mean[b,c]; y/out f32 [B,T,C].
+ * With dy != NULL instead computes the backward dy_in[b,t,c] = dy[b,t,c]*stdev[b,c]. */
+int mtl_revin_denorm(const float* y, const float* mean, const float* stdev, float* out, int64_t B, int64_t T,
+                     int64_t C, void* stream);
+
+/* ------------------------------------------------------------------ bf16 MFMA GEMM (NT)
+ * C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T + bias[N]),  fp32 accumulation on v_mfma_f32_16x16x32_bf16.
+ * Replaces every nn.Linear / HF Conv1D / einsum-free matmul on the path: mapping_layer (R:models/medtsllm.py:281),
+ * ReprogrammingLayer projections (R:models/medtsllm.py:571-573,579), embedding_downsample_layer (:358),
+ * FlattenHead.linear (:550), GPT-2 c_attn/c_proj/c_fc (HF:models/gpt2/modeling_gpt2.py:185,238-243),
+ * Llama q/k/v/o/gate/up/down (HF:models/llama/modeling_llama.py:174-176,254-256,280) and their dX / dW.
+ * Requirements: K % 64 == 0, lda % 8 == 0, ldb % 8 == 0, A/B 16-byte aligned (callers zero-pad K). */
+enum { MTL_EPI_STORE = 0,   /* C = v                                  (C bf16 or f32)                       */
+       MTL_EPI_GELU = 1,    /* aux_out(bf16) = v ; C(bf16) = gelu_new(v)   (HF:activations.py:65-66)         */
+       MTL_EPI_RESID = 2,   /* C(f32) = aux_in(f32) + v               (residual stream update)              */
+       MTL_EPI_DGELU = 3,   /* C(bf16) = v * gelu_new'(aux_in(bf16))  (backward through the activation)     */
+       MTL_EPI_ACCUM = 4 }; /* C(f32) += v                            (gradient accumulation)               */
+typedef struct {
+    const void* A; int64_t lda;      /* bf16 [M, K]                                                          */
+    const void* B; int64_t ldb;      /* bf16 [N, K]                                                          */
+    void* C; int64_t ldc; int c_dtype;
+    int64_t M, N, K;
+    /* optional A-row gather: logical row m reads physical row (m / a_group_rows)*a_group_stride + a_row_offset
+     * + (m % a_group_rows); a_group_rows == 0 -> identity. Used to slice "the last n_patches tokens of every
+     * sample" (R:models/medtsllm.py:353) without a copy. Same for C rows (c_group_*).                       */
+    int64_t a_group_rows, a_group_stride, a_row_offset;
+    int64_t c_group_rows, c_group_stride, c_row_offset;
+    const float* bias;               /* f32 [N] or NULL                                                      */
+    int epilogue;
+    const void* aux_in; int64_t ld_aux_in;
+    void* aux_out; int64_t ld_aux_out;
+    float alpha;
+    int split_k;                     /* >1: fp32 partial slabs in `workspace`, reduced by a second kernel    */
+    void* workspace; size_t workspace_bytes;
+} mtl_gemm_args;
+size_t mtl_gemm_workspace_bytes(int64_t M, int64_t N, int split_k);
+int mtl_gemm_nt(const mtl_gemm_args* args, void* stream);
+
+/* ------------------------------------------------------------------ layout / cast helpers
+ * f32 [R, Cc] (ld_src) -> bf16 [R, ld_dst] zero-padding cols >= Cc; optionally also the transpose
+ * dst_t bf16 [Cc, ld_dst_t] (zero-padded cols >= R). Used once per step on trainable fp32 master weights
+ * (autocast's weight cast, tasks/forecasting.py:22) and on gradients. */
+int mtl_cast_pad_f32_bf16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, void* dst_t, int64_t ld_dst_t,
+                          int64_t R, int64_t Cc, void* stream);
+/* bf16 [R, Cc] (ld_src) -> bf16 [Cc, ld_dst] transpose, zero-padding cols >= R up to ld_dst. */
+int mtl_transpose_bf16(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t R, int64_t Cc, void* stream);
+/* elementwise casts of contiguous buffers */
+int mtl_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+int mtl_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
+/* column sums of a bf16 [R, Cc] matrix into f32 [Cc] (bias gradients) */
+int mtl_colsum_bf16(const void* src, int64_t ld_src, float* dst, int64_t R, int64_t Cc, void* stream);
+
+/* ------------------------------------------------------------------ attention (flash-style, never materialises scores)
+ * O = softmax(scale * Q K^T [+ causal mask]) V per (batch, head); fp32 softmax statistics, bf16 I/O.
+ * Replaces (a) the reprogramming cross-attention einsum/softmax/einsum (R:models/medtsllm.py:586-589;
+ * no mask, K/V shared by every batch element -> k_bs = v_bs = 0) and (b) the backbone's eager causal
+ * attention (HF:models/gpt2/modeling_gpt2.py:54-72, HF:models/llama/modeling_llama.py:191-213 incl. GQA repeat_kv).
+ * Strides are in elements: *_bs batch, *_ts token, *_hs head. head_dim D in {32, 64, 128}.
+ * lse f32 [B, Hq, Tq] (natural-log sum-exp of the scaled scores), saved for the backward. */
+typedef struct {
+    const void* q; int64_t q_bs, q_ts, q_hs;
+    const void* k; int64_t k_bs, k_ts, k_hs;
+    const void* v; int64_t v_bs, v_ts, v_hs;
+    void* o; int64_t o_bs, o_ts, o_hs;
+    float* lse;
+    int64_t B, Hq, Hkv, Tq, Tk, D;
+    float scale;
+    int causal;
+} mtl_attn_fwd_args;
+int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream);
+typedef struct {
+    mtl_attn_fwd_args f;            /* same tensors as the forward (o = forward output, lse = saved)        */
+    const void* dout; int64_t do_bs, do_ts, do_hs;
+    void* dq; int64_t dq_bs, dq_ts, dq_hs;
+    void* dk; int64_t dk_bs, dk_ts, dk_hs;   /* with k_bs == 0 the batch is reduced into dk/dv              */
+    void* dv; int64_t dv_bs, dv_ts, dv_hs;
+    float* delta;                   /* f32 [B, Hq, Tq] workspace: rowsum(dO * O)                            */
+} mtl_attn_bwd_args;
+int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream);
+
+/* ------------------------------------------------------------------ norms (fp32 statistics)
+ * LayerNorm eps 1e-5 (HF:models/gpt2/modeling_gpt2.py:252,254,497) and LlamaRMSNorm
+ * (HF:models/llama/modeling_llama.py:62-67). x f32 [M, d] (the fp32 residual stream of dtype="mixed"),
+ * y bf16 [M, d] (ld_y). rms != 0 -> RMSNorm (beta ignored). stats f32 [M, 2] = (mean, rstd).
+ * Row gather like the GEMM: logical row m -> (m / group_rows)*group_stride + row_offset + m % group_rows. */
+int mtl_norm_fwd(const float* x, const float* gamma, const float* beta, void* y, int64_t ld_y, float* stats,
+                 int64_t M, int64_t d, float eps, int rms, int64_t group_rows, int64_t group_stride,
+                 int64_t row_offset, void* stream);
+/* dX only (gamma/beta are frozen). dres_out[m] = (dres_in ? dres_in[m] : 0) + LN'(dy[m]); optionally also
+ * a bf16 copy of dres_out (A operand of the next dX GEMM). dres_in may alias dres_out. */
+int mtl_norm_bwd(const void* dy, int64_t ld_dy, const float* x, const float* gamma, const float* stats,
+                 const float* dres_in, float* dres_out, void* dres_out_bf16, int64_t M, int64_t d, int rms,
+                 int64_t group_rows, int64_t group_stride, int64_t row_offset, void* stream);
+
+/* ------------------------------------------------------------------ Llama elementwise
+ * RoPE, half-split rotate_half form (HF:models/llama/modeling_llama.py:130-160), in place on the q and k
+ * heads of a fused qkv buffer bf16 [M, ld] laid out [q heads | k heads | v heads]; cos/sin f32 [T, D].
+ * inverse != 0 applies the transpose rotation (backward). Row m has position m % T. */
+int mtl_rope_inplace(void* qkv, int64_t ld, const float* cos_t, const float* sin_t, int64_t M, int64_t T,
+                     int64_t n_rot_heads, int64_t D, int inverse, void* stream);
+/* SwiGLU (HF:models/llama/modeling_llama.py:174-176): gu bf16 [M, 2F] = [gate | up] -> h bf16 [M, F] = silu(gate)*up.
+ * bwd: dgu[M, 2F] from dh[M, F] and the saved gu. */
+int mtl_swiglu_fwd(const void* gu, void* h, int64_t M, int64_t F, void* stream);
+int mtl_swiglu_bwd(const void* gu, const void* dh, void* dgu, int64_t M, int64_t F, void* stream);
+
+/* ------------------------------------------------------------------ LLM input assembly (a6 tail, K10/K11)
+ * h0[b, t, :] = (t < n_tok ? embed[ids[b, t]] : x_tok[b, t - n_tok, :]) + (wpe ? wpe[t] : 0)   -> f32 [B, T, d]
+ * Replaces the embedding gather, left padding (ids are already left-padded with pad_token_id host-side,
+ * identical to padding with the pad embedding, R:models/medtsllm.py:304-311) and torch.cat (:349), plus
+ * GPT-2's position add (HF:models/gpt2/modeling_gpt2.py:576-577). ids int32 [ids_B, n_tok] with ids_B == B or 1
+ * (1 = the same constant prompt for every sample). x_tok bf16 [B, P, d]. embed f32 [V, d]. */
+int mtl_assemble_llm_input(const int32_t* ids, int64_t ids_B, const float* embed, const void* x_tok, const float* wpe,
+                           float* h0, int64_t B, int64_t n_tok, int64_t P, int64_t d, void* stream);
+
+/* ------------------------------------------------------------------ frozen backbone stack (a7)
+ * Whole GPT-2 / Llama decoder stack forward and activation-gradient-only backward as ONE host call each
+ * (the kernels above chained on `stream`, no host work in between). Replaces
+ * self.llm(inputs_embeds=enc).last_hidden_state (R:models/medtsllm.py:350) = HF GPT2Model.forward
+ * (HF:models/gpt2/modeling_gpt2.py:514-628) / LlamaModel.forward (HF:models/llama/modeling_llama.py:367-417),
+ * eager attention semantics (R:models/medtsllm.py:159-160 always selects "eager"), all dropouts off.
+ * Weights: bf16 [out, in] row-major plus the transposed copy [in, out] (frozen, prepared once);
+ * per-layer pointer arrays live in HOST memory. */
+enum { MTL_ARCH_GPT2 = 0, MTL_ARCH_LLAMA = 1 };
+typedef struct {
+    int arch, n_layers;
+    int64_t d, n_heads, n_kv_heads, head_dim, ffn;
+    float eps;
+    const void* const* w_qkv;   const void* const* w_qkv_t;  const float* const* b_qkv;   /* [(Hq+2Hkv)*hd, d]        */
+    const void* const* w_o;     const void* const* w_o_t;    const float* const* b_o;     /* [d, Hq*hd]               */
+    const void* const* w_fc;    const void* const* w_fc_t;   const float* const* b_fc;    /* gpt2 [ffn,d]; llama [2ffn,d] = gate|up */
+    const void* const* w_proj;  const void* const* w_proj_t; const float* const* b_proj;  /* [d, ffn]                 */
+    const float* const* ln1_w;  const float* const* ln1_b;
+    const float* const* ln2_w;  const float* const* ln2_b;
+    const float* lnf_w; const float* lnf_b;
+    const float* rope_cos; const float* rope_sin;                                         /* llama: f32 [T, hd]       */
+} mtl_backbone_weights;
+/* bytes of the `saved` buffer (activations kept for the backward) and of the scratch `work` buffer */
+size_t mtl_backbone_saved_bytes(const mtl_backbone_weights* w, int64_t B, int64_t T);
+size_t mtl_backbone_work_bytes(const mtl_backbone_weights* w, int64_t B, int64_t T);
+/* h0 f32 [B, T, d] (input embeddings, wpe already added for GPT-2). out bf16 [B, n_last, d]: final norm applied
+ * to the last n_last tokens of every sample (only those are consumed downstream, R:models/medtsllm.py:353). */
+int mtl_backbone_fwd(const mtl_backbone_weights* w, const float* h0, void* out, void* saved, void* work,
+                     int64_t B, int64_t T, int64_t n_last, void* stream);
+/* dout bf16 [B, n_last, d] -> dh0 f32 [B, T, d]. `saved` from the matching forward. */
+int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, const void* dout, float* dh0, void* saved,
+                     void* work, int64_t B, int64_t T, int64_t n_last, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEDTSLLM_HIP_H */

@@ -1,0 +1,415 @@
+// mtl_attention.hip — flash-style attention forward / backward on MFMA (never materialises the score matrix).
+//
+// One kernel family serves (a) the backbone's causal self-attention (GPT-2 MHA, Llama MHA/GQA) and (b) the
+// reprogramming cross-attention (no mask, K/V = the shared vocabulary prototypes, batch stride 0).
+//
+// Layout trick (wave64, v_mfma_f32_16x16x32_bf16): scores are computed TRANSPOSED, S^T[key][q] = K . Q^T, so a
+// lane owns one query column (q = lane & 15) and 4 keys per 16-key tile. Softmax statistics are then per-lane
+// scalars (+ two cross-lane-group shuffles), and the exponentiated P values of two 16-key tiles ARE the B operand
+// of the P.V MFMA without any cross-lane movement: the contraction index of that MFMA is mapped to keys as
+//     k-index (g, j)  <->  key  g*4 + j (j < 4)   |   16 + g*4 + (j - 4) (j >= 4),        g = lane >> 4
+// and the V^T operand is gathered from the LDS V tile with the same mapping. The backward kernels use the same
+// idea (dS / P in registers feed the dQ, dK, dV MFMAs directly).
+//
+// v1 structure: 4 waves x 16 query rows per workgroup, 64-key K/V chunks staged through padded LDS tiles
+// (row stride D+8 bf16: conflict-free 16-B fragment reads), fp32 online softmax.
+#include "mtl_common.h"
+
+namespace {
+
+constexpr int KC = 64;  // keys (or queries, in the dK/dV kernel) per LDS chunk
+
+union frag8 {
+    bf16x8 v;
+    u32x4 u;
+};
+
+__device__ __forceinline__ bf16x8 pack8(const float* a, const float* b) {
+    frag8 f;
+    f.u = (u32x4){pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+    return f.v;
+}
+
+// operand gathered down a column of a row-major LDS tile: elements j<4 from rows ra+j, j>=4 from rows rb+(j-4)
+__device__ __forceinline__ bf16x8 gather_col(const bf16_t* tile, int ldt, int ra, int rb, int col) {
+    const bf16_t* pa = tile + ra * ldt + col;
+    const bf16_t* pb = tile + rb * ldt + col;
+    frag8 f;
+    f.u = (u32x4){(uint32_t)pa[0] | ((uint32_t)pa[ldt] << 16), (uint32_t)pa[2 * ldt] | ((uint32_t)pa[3 * ldt] << 16),
+                  (uint32_t)pb[0] | ((uint32_t)pb[ldt] << 16), (uint32_t)pb[2 * ldt] | ((uint32_t)pb[3 * ldt] << 16)};
+    return f.v;
+}
+
+// cooperative load of `rows` x D bf16 (row stride src_ts elements) into a padded LDS tile; rows >= limit are clamped
+template <int D>
+__device__ __forceinline__ void load_tile(bf16_t* tile, const bf16_t* src, int64_t src_ts, int64_t row0, int64_t limit) {
+    constexpr int LDT = D + 8, CPR = D / 8;
+    for (int s = threadIdx.x; s < KC * CPR; s += 256) {
+        const int r = s / CPR, c = s % CPR;
+        int64_t gr = row0 + r;
+        if (gr > limit - 1) gr = limit - 1;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + gr * src_ts + c * 8);
+        *reinterpret_cast<u32x4*>(tile + r * LDT + c * 8) = v;
+    }
+}
+
+#define NEG_BIG (-1.0e30f)
+
+// =============================================================================================== forward
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a) {
+    constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
+    __shared__ __attribute__((aligned(16))) bf16_t ktile[KC * LDT];
+    __shared__ __attribute__((aligned(16))) bf16_t vtile[KC * LDT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+    const int64_t b = blockIdx.z, h = blockIdx.y, hk = h / (a.Hq / a.Hkv);
+    const int64_t qblk0 = (int64_t)blockIdx.x * 64;
+    const int64_t q0 = qblk0 + wave * 16;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * a.q_hs;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + hk * a.k_hs;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + hk * a.v_hs;
+
+    int64_t qrow = q0 + l15;
+    const bool q_valid = qrow < a.Tq;
+    if (qrow > a.Tq - 1) qrow = a.Tq - 1;
+    bf16x8 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + qrow * a.q_ts + ks * 32 + g * 8);
+
+    f32x4 o[NDT];
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = NEG_BIG, l_run = 0.f;
+
+    int64_t k_end = a.Tk;
+    if (CAUSAL) {
+        const int64_t lim = qblk0 + 64 < a.Tq ? qblk0 + 64 : a.Tq;  // keys <= last query of the block
+        k_end = lim < a.Tk ? lim : a.Tk;
+    }
+    const int64_t wave_qmax = (q0 + 15 < a.Tq - 1) ? q0 + 15 : a.Tq - 1;
+
+    for (int64_t kc0 = 0; kc0 < k_end; kc0 += KC) {
+        __syncthreads();
+        load_tile<D>(ktile, K, a.k_ts, kc0, a.Tk);
+        load_tile<D>(vtile, V, a.v_ts, kc0, a.Tk);
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int64_t kb = kc0 + sub * 32;
+            if (kb >= k_end) continue;
+            if (CAUSAL && kb > wave_qmax) continue;  // whole 32-key slab is above the diagonal for this wave
+            f32x4 s[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const bf16_t* kr = ktile + (sub * 32 + t * 16 + l15) * LDT + g * 8;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks)
+                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kr + ks * 32), qf[ks], s[t], 0, 0, 0);
+            }
+            float p[2][4];
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t key = kb + t * 16 + g * 4 + r;
+                    float v = s[t][r] * a.scale;
+                    if (key >= a.Tk || (CAUSAL && key > qrow)) v = NEG_BIG;
+                    p[t][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __expf(m_run - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[t][r] = __expf(p[t][r] - m_new);
+                    psum += p[t][r];
+                }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+            const bf16x8 pf = pack8(p[0], p[1]);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                o[dt] *= alpha;
+                const bf16x8 vt = gather_col(vtile, LDT, sub * 32 + g * 4, sub * 32 + 16 + g * 4, dt * 16 + l15);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pf, o[dt], 0, 0, 0);
+            }
+        }
+    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (!q_valid) return;
+    const float inv_l = 1.0f / l_run;
+    bf16_t* O = reinterpret_cast<bf16_t*>(a.o) + b * a.o_bs + h * a.o_hs + qrow * a.o_ts;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+        u32x2 pk = {pack_bf16x2(o[dt][0] * inv_l, o[dt][1] * inv_l), pack_bf16x2(o[dt][2] * inv_l, o[dt][3] * inv_l)};
+        *reinterpret_cast<u32x2*>(O + dt * 16 + g * 4) = pk;
+    }
+    if (g == 0 && a.lse) a.lse[(b * a.Hq + h) * a.Tq + qrow] = m_run + __logf(l_run);
+}
+
+// =============================================================================================== backward: dQ (+ delta)
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_args a) {
+    constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
+    __shared__ __attribute__((aligned(16))) bf16_t ktile[KC * LDT];
+    __shared__ __attribute__((aligned(16))) bf16_t vtile[KC * LDT];
+    const mtl_attn_fwd_args& f = a.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+    const int64_t b = blockIdx.z, h = blockIdx.y, hk = h / (f.Hq / f.Hkv);
+    const int64_t qblk0 = (int64_t)blockIdx.x * 64;
+    const int64_t q0 = qblk0 + wave * 16;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(f.q) + b * f.q_bs + h * f.q_hs;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(f.k) + b * f.k_bs + hk * f.k_hs;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(f.v) + b * f.v_bs + hk * f.v_hs;
+    const bf16_t* O = reinterpret_cast<const bf16_t*>(f.o) + b * f.o_bs + h * f.o_hs;
+    const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dout) + b * a.do_bs + h * a.do_hs;
+
+    int64_t qrow = q0 + l15;
+    const bool q_valid = qrow < f.Tq;
+    if (qrow > f.Tq - 1) qrow = f.Tq - 1;
+    bf16x8 qf[NKS], dof[NKS];
+    float dl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        qf[ks] = *reinterpret_cast<const bf16x8*>(Q + qrow * f.q_ts + ks * 32 + g * 8);
+        frag8 d8, o8;
+        d8.v = *reinterpret_cast<const bf16x8*>(dO + qrow * a.do_ts + ks * 32 + g * 8);
+        o8.v = *reinterpret_cast<const bf16x8*>(O + qrow * f.o_ts + ks * 32 + g * 8);
+        dof[ks] = d8.v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dl += __uint_as_float(d8.u[e] << 16) * __uint_as_float(o8.u[e] << 16);
+            dl += __uint_as_float(d8.u[e] & 0xffff0000u) * __uint_as_float(o8.u[e] & 0xffff0000u);
+        }
+    }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    const int64_t stat_idx = (b * f.Hq + h) * f.Tq + qrow;
+    if (g == 0 && q_valid) a.delta[stat_idx] = dl;
+    const float lse = f.lse[stat_idx];
+
+    f32x4 dq[NDT];
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int64_t k_end = f.Tk;
+    if (CAUSAL) {
+        const int64_t lim = qblk0 + 64 < f.Tq ? qblk0 + 64 : f.Tq;
+        k_end = lim < f.Tk ? lim : f.Tk;
+    }
+    const int64_t wave_qmax = (q0 + 15 < f.Tq - 1) ? q0 + 15 : f.Tq - 1;
+
+    for (int64_t kc0 = 0; kc0 < k_end; kc0 += KC) {
+        __syncthreads();
+        load_tile<D>(ktile, K, f.k_ts, kc0, f.Tk);
+        load_tile<D>(vtile, V, f.v_ts, kc0, f.Tk);
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int64_t kb = kc0 + sub * 32;
+            if (kb >= k_end) continue;
+            if (CAUSAL && kb > wave_qmax) continue;
+            float ds[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                const bf16_t* kr = ktile + (sub * 32 + t * 16 + l15) * LDT + g * 8;
+                const bf16_t* vr = vtile + (sub * 32 + t * 16 + l15) * LDT + g * 8;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kr + ks * 32), qf[ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(vr + ks * 32), dof[ks], dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t key = kb + t * 16 + g * 4 + r;
+                    const bool masked = key >= f.Tk || (CAUSAL && key > qrow);
+                    const float p = masked ? 0.f : __expf(s[r] * f.scale - lse);
+                    ds[t][r] = p * (dp[r] - dl);
+                }
+            }
+            const bf16x8 dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const bf16x8 kt = gather_col(ktile, LDT, sub * 32 + g * 4, sub * 32 + 16 + g * 4, dt * 16 + l15);
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf, dq[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (!q_valid) return;
+    bf16_t* DQ = reinterpret_cast<bf16_t*>(a.dq) + b * a.dq_bs + h * a.dq_hs + qrow * a.dq_ts;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+        u32x2 pk = {pack_bf16x2(dq[dt][0] * f.scale, dq[dt][1] * f.scale), pack_bf16x2(dq[dt][2] * f.scale, dq[dt][3] * f.scale)};
+        *reinterpret_cast<u32x2*>(DQ + dt * 16 + g * 4) = pk;
+    }
+}
+
+// =============================================================================================== backward: dK, dV
+// One workgroup per (64-key tile, kv head, batch or ALL batches when K/V are batch-shared); loops over the query
+// heads of the GQA group and over 64-query chunks. Lane owns key = lane & 15 of its wave's 16 keys.
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const mtl_attn_bwd_args a) {
+    constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
+    __shared__ __attribute__((aligned(16))) bf16_t qtile[KC * LDT];
+    __shared__ __attribute__((aligned(16))) bf16_t dotile[KC * LDT];
+    __shared__ float lse_s[KC], delta_s[KC];
+    const mtl_attn_fwd_args& f = a.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+    const int64_t hk = blockIdx.y;
+    const int group = (int)(f.Hq / f.Hkv);
+    const bool shared_kv = (f.k_bs == 0);
+    const int64_t b_begin = shared_kv ? 0 : blockIdx.z, b_end = shared_kv ? f.B : blockIdx.z + 1;
+    const int64_t kblk0 = (int64_t)blockIdx.x * 64;
+    const int64_t k0 = kblk0 + wave * 16;
+    int64_t krow = k0 + l15;
+    const bool k_valid = krow < f.Tk;
+    if (krow > f.Tk - 1) krow = f.Tk - 1;
+
+    f32x4 dk[NDT], dv[NDT];
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) {
+        dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int64_t b = b_begin; b < b_end; ++b) {
+        const bf16_t* K = reinterpret_cast<const bf16_t*>(f.k) + b * f.k_bs + hk * f.k_hs;
+        const bf16_t* V = reinterpret_cast<const bf16_t*>(f.v) + b * f.v_bs + hk * f.v_hs;
+        bf16x8 kf[NKS], vf[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            kf[ks] = *reinterpret_cast<const bf16x8*>(K + krow * f.k_ts + ks * 32 + g * 8);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(V + krow * f.v_ts + ks * 32 + g * 8);
+        }
+        for (int hg = 0; hg < group; ++hg) {
+            const int64_t h = hk * group + hg;
+            const bf16_t* Q = reinterpret_cast<const bf16_t*>(f.q) + b * f.q_bs + h * f.q_hs;
+            const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dout) + b * a.do_bs + h * a.do_hs;
+            const int64_t stat0 = (b * f.Hq + h) * f.Tq;
+            const int64_t qc_begin = CAUSAL ? (kblk0 / KC) * KC : 0;  // queries before the key tile never see it
+            for (int64_t qc0 = qc_begin; qc0 < f.Tq; qc0 += KC) {
+                __syncthreads();
+                load_tile<D>(qtile, Q, f.q_ts, qc0, f.Tq);
+                load_tile<D>(dotile, dO, a.do_ts, qc0, f.Tq);
+                if (threadIdx.x < KC) {
+                    int64_t qq = qc0 + threadIdx.x;
+                    if (qq > f.Tq - 1) qq = f.Tq - 1;
+                    lse_s[threadIdx.x] = f.lse[stat0 + qq];
+                    delta_s[threadIdx.x] = a.delta[stat0 + qq];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) {
+                    const int64_t qb = qc0 + sub * 32;
+                    if (qb >= f.Tq) continue;
+                    if (CAUSAL && qb + 31 < k0) continue;  // every query of the slab precedes this wave's keys
+                    float p[2][4], ds[2][4];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                        const bf16_t* qr = qtile + (sub * 32 + t * 16 + l15) * LDT + g * 8;
+                        const bf16_t* dr = dotile + (sub * 32 + t * 16 + l15) * LDT + g * 8;
+#pragma unroll
+                        for (int ks = 0; ks < NKS; ++ks) {
+                            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(qr + ks * 32), kf[ks], s, 0, 0, 0);
+                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(dr + ks * 32), vf[ks], dp, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int ql = sub * 32 + t * 16 + g * 4 + r;
+                            const int64_t q = qc0 + ql;
+                            const bool masked = q >= f.Tq || (CAUSAL && krow > q);
+                            const float pv = masked ? 0.f : __expf(s[r] * f.scale - lse_s[ql]);
+                            p[t][r] = pv;
+                            ds[t][r] = pv * (dp[r] - delta_s[ql]);
+                        }
+                    }
+                    const bf16x8 pf = pack8(p[0], p[1]);
+                    const bf16x8 dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+                    for (int dt = 0; dt < NDT; ++dt) {
+                        const bf16x8 dot = gather_col(dotile, LDT, sub * 32 + g * 4, sub * 32 + 16 + g * 4, dt * 16 + l15);
+                        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pf, dv[dt], 0, 0, 0);
+                        const bf16x8 qt = gather_col(qtile, LDT, sub * 32 + g * 4, sub * 32 + 16 + g * 4, dt * 16 + l15);
+                        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf, dk[dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (!k_valid) return;
+    const int64_t bo = shared_kv ? 0 : (int64_t)blockIdx.z;
+    bf16_t* DK = reinterpret_cast<bf16_t*>(a.dk) + bo * a.dk_bs + hk * a.dk_hs + krow * a.dk_ts;
+    bf16_t* DV = reinterpret_cast<bf16_t*>(a.dv) + bo * a.dv_bs + hk * a.dv_hs + krow * a.dv_ts;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+        u32x2 pk = {pack_bf16x2(dk[dt][0] * f.scale, dk[dt][1] * f.scale), pack_bf16x2(dk[dt][2] * f.scale, dk[dt][3] * f.scale)};
+        *reinterpret_cast<u32x2*>(DK + dt * 16 + g * 4) = pk;
+        u32x2 pv = {pack_bf16x2(dv[dt][0], dv[dt][1]), pack_bf16x2(dv[dt][2], dv[dt][3])};
+        *reinterpret_cast<u32x2*>(DV + dt * 16 + g * 4) = pv;
+    }
+}
+
+int check_fwd(const mtl_attn_fwd_args& f) {
+    if (!f.q || !f.k || !f.v || !f.o) return MTL_ERR_ARG;
+    if (f.B <= 0 || f.Hq <= 0 || f.Hkv <= 0 || f.Tq <= 0 || f.Tk <= 0 || f.Hq % f.Hkv != 0) return MTL_ERR_ARG;
+    if (f.D != 32 && f.D != 64 && f.D != 128) return MTL_ERR_UNSUPPORTED;
+    const int64_t st[] = {f.q_bs, f.q_ts, f.q_hs, f.k_bs, f.k_ts, f.k_hs, f.v_bs, f.v_ts, f.v_hs, f.o_bs, f.o_ts, f.o_hs};
+    for (int64_t s : st) if (s % 8 != 0) return MTL_ERR_ALIGN;
+    if (((uintptr_t)f.q % 16) || ((uintptr_t)f.k % 16) || ((uintptr_t)f.v % 16) || ((uintptr_t)f.o % 16)) return MTL_ERR_ALIGN;
+    return MTL_OK;
+}
+
+}  // namespace
+
+extern "C" int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream) {
+    if (!a) return MTL_ERR_ARG;
+    const int rc = check_fwd(*a);
+    if (rc != MTL_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((a->Tq + 63) / 64), (unsigned)a->Hq, (unsigned)a->B), block(256);
+#define MTL_FWD(DD)                                                                                        \
+    if (a->causal) hipLaunchKernelGGL((attn_fwd_kernel<DD, true>), grid, block, 0, st, *a);                \
+    else hipLaunchKernelGGL((attn_fwd_kernel<DD, false>), grid, block, 0, st, *a)
+    if (a->D == 32) { MTL_FWD(32); } else if (a->D == 64) { MTL_FWD(64); } else { MTL_FWD(128); }
+#undef MTL_FWD
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
+    if (!a) return MTL_ERR_ARG;
+    const mtl_attn_fwd_args& f = a->f;
+    const int rc = check_fwd(f);
+    if (rc != MTL_OK) return rc;
+    if (!a->dout || !a->dq || !a->dk || !a->dv || !a->delta || !f.lse) return MTL_ERR_ARG;
+    if ((f.k_bs == 0) != (f.v_bs == 0)) return MTL_ERR_ARG;
+    const int64_t sts[] = {a->do_bs, a->do_ts, a->do_hs, a->dq_bs, a->dq_ts, a->dq_hs, a->dk_bs, a->dk_ts, a->dk_hs, a->dv_bs, a->dv_ts, a->dv_hs};
+    for (int64_t s : sts) if (s % 4 != 0) return MTL_ERR_ALIGN;
+    if (a->do_ts % 8 != 0 || a->do_hs % 8 != 0 || a->do_bs % 8 != 0 || ((uintptr_t)a->dout % 16)) return MTL_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 block(256);
+    const dim3 gq((unsigned)((f.Tq + 63) / 64), (unsigned)f.Hq, (unsigned)f.B);
+    const dim3 gk((unsigned)((f.Tk + 63) / 64), (unsigned)f.Hkv, (unsigned)(f.k_bs == 0 ? 1 : f.B));
+#define MTL_BWD(DD)                                                                                        \
+    if (f.causal) {                                                                                        \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, true>), gq, block, 0, st, *a);                          \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<DD, true>), gk, block, 0, st, *a);                         \
+    } else {                                                                                               \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, false>), gq, block, 0, st, *a);                         \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<DD, false>), gk, block, 0, st, *a);                        \
+    }
+    if (f.D == 32) { MTL_BWD(32) } else if (f.D == 64) { MTL_BWD(64) } else { MTL_BWD(128) }
+#undef MTL_BWD
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}

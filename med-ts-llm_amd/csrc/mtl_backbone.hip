@@ -1,0 +1,224 @@
+// mtl_backbone.hip — the frozen GPT-2 / Llama decoder stack as ONE host call per direction.
+//
+// Pure launch sequencing over the kernels in mtl_gemm/mtl_attention/mtl_norm/mtl_elementwise on the caller's
+// stream: no host synchronisation, no allocation (the caller owns `saved` and `work`). The backward is
+// activation-gradient only — the backbone is frozen (R:models/medtsllm.py:231-233), so no dW is ever formed and
+// LN/attention-projection INPUTS need not be saved; what is saved per layer is exactly
+//   residual stream before each norm (fp32), norm statistics, fused qkv (bf16), attention output (bf16), LSE,
+//   MLP pre-activation (GPT-2) / gate|up (Llama).
+#include "mtl_common.h"
+
+namespace {
+
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Dims {
+    int64_t B, T, M, d, Hq, Hkv, hd, ffn, Nqkv, No, Nfc;
+    int L;
+    bool llama;
+};
+
+Dims dims_of(const mtl_backbone_weights* w, int64_t B, int64_t T) {
+    Dims D;
+    D.B = B; D.T = T; D.M = B * T; D.d = w->d; D.Hq = w->n_heads; D.Hkv = w->n_kv_heads; D.hd = w->head_dim; D.ffn = w->ffn;
+    D.Nqkv = (D.Hq + 2 * D.Hkv) * D.hd; D.No = D.Hq * D.hd; D.L = w->n_layers; D.llama = (w->arch == MTL_ARCH_LLAMA);
+    D.Nfc = D.llama ? 2 * D.ffn : D.ffn;
+    return D;
+}
+
+// ---- `saved` layout
+struct SavedLayout {
+    size_t h, stats, qkv, attn, lse, fc, stats_f, total;  // base offsets; per-layer strides below
+    size_t h_stride, stats_stride, qkv_stride, attn_stride, lse_stride, fc_stride;
+};
+SavedLayout saved_layout(const Dims& D, int64_t n_last) {
+    SavedLayout s;
+    s.h_stride = align_up((size_t)D.M * D.d * 4);
+    s.stats_stride = align_up((size_t)D.M * 2 * 4);
+    s.qkv_stride = align_up((size_t)D.M * D.Nqkv * 2);
+    s.attn_stride = align_up((size_t)D.M * D.No * 2);
+    s.lse_stride = align_up((size_t)D.B * D.Hq * D.T * 4);
+    s.fc_stride = align_up((size_t)D.M * D.Nfc * 2);
+    size_t off = 0;
+    s.h = off; off += s.h_stride * 2 * D.L;          // H[1 .. 2L]
+    s.stats = off; off += s.stats_stride * 2 * D.L;  // (ln1, ln2) per layer
+    s.qkv = off; off += s.qkv_stride * D.L;
+    s.attn = off; off += s.attn_stride * D.L;
+    s.lse = off; off += s.lse_stride * D.L;
+    s.fc = off; off += s.fc_stride * D.L;
+    s.stats_f = off; off += align_up((size_t)D.B * (n_last > 0 ? n_last : D.T) * 2 * 4);
+    s.total = off;
+    return s;
+}
+
+// ---- `work` layout (scratch shared by fwd and bwd)
+struct WorkLayout {
+    size_t xln, act, dres_b, dact, dx, dqkv, dO, delta, dhact, total;
+};
+WorkLayout work_layout(const Dims& D) {
+    WorkLayout w;
+    size_t off = 0;
+    w.xln = off; off += align_up((size_t)D.M * D.d * 2);
+    w.act = off; off += align_up((size_t)D.M * D.ffn * 2);
+    w.dres_b = off; off += align_up((size_t)D.M * D.d * 2);
+    w.dact = off; off += align_up((size_t)D.M * D.Nfc * 2);
+    w.dx = off; off += align_up((size_t)D.M * D.d * 2);
+    w.dqkv = off; off += align_up((size_t)D.M * D.Nqkv * 2);
+    w.dO = off; off += align_up((size_t)D.M * D.No * 2);
+    w.delta = off; off += align_up((size_t)D.B * D.Hq * D.T * 4);
+    w.dhact = off; off += D.llama ? align_up((size_t)D.M * D.ffn * 2) : 0;
+    w.total = off;
+    return w;
+}
+
+int gemm(const void* A, int64_t lda, const void* Bm, int64_t ldb, void* C, int64_t ldc, int cdt, int64_t M, int64_t N, int64_t K,
+         const float* bias, int epi, const void* aux_in, int64_t ld_aux_in, void* aux_out, int64_t ld_aux_out, void* stream) {
+    mtl_gemm_args g = {};
+    g.A = A; g.lda = lda; g.B = Bm; g.ldb = ldb; g.C = C; g.ldc = ldc; g.c_dtype = cdt;
+    g.M = M; g.N = N; g.K = K; g.bias = bias; g.epilogue = epi;
+    g.aux_in = aux_in; g.ld_aux_in = ld_aux_in; g.aux_out = aux_out; g.ld_aux_out = ld_aux_out;
+    g.alpha = 1.0f; g.split_k = 1;
+    return mtl_gemm_nt(&g, stream);
+}
+
+#define MTL_TRY(expr)                 \
+    do {                              \
+        const int rc__ = (expr);      \
+        if (rc__ != MTL_OK) return rc__; \
+    } while (0)
+
+void attn_args(const Dims& D, char* qkv, char* attn, float* lse, mtl_attn_fwd_args* f) {
+    bf16_t* q = reinterpret_cast<bf16_t*>(qkv);
+    f->q = q; f->q_bs = D.T * D.Nqkv; f->q_ts = D.Nqkv; f->q_hs = D.hd;
+    f->k = q + D.Hq * D.hd; f->k_bs = D.T * D.Nqkv; f->k_ts = D.Nqkv; f->k_hs = D.hd;
+    f->v = q + (D.Hq + D.Hkv) * D.hd; f->v_bs = D.T * D.Nqkv; f->v_ts = D.Nqkv; f->v_hs = D.hd;
+    f->o = attn; f->o_bs = D.T * D.No; f->o_ts = D.No; f->o_hs = D.hd;
+    f->lse = lse;
+    f->B = D.B; f->Hq = D.Hq; f->Hkv = D.Hkv; f->Tq = D.T; f->Tk = D.T; f->D = D.hd;
+    f->scale = 1.0f / sqrtf((float)D.hd);
+    f->causal = 1;
+}
+
+int check_weights(const mtl_backbone_weights* w) {
+    if (!w) return MTL_ERR_ARG;
+    if (w->arch != MTL_ARCH_GPT2 && w->arch != MTL_ARCH_LLAMA) return MTL_ERR_UNSUPPORTED;
+    if (w->n_layers <= 0 || w->d <= 0 || w->n_heads <= 0 || w->n_kv_heads <= 0 || w->head_dim <= 0 || w->ffn <= 0) return MTL_ERR_ARG;
+    if (!w->w_qkv || !w->w_qkv_t || !w->w_o || !w->w_o_t || !w->w_fc || !w->w_fc_t || !w->w_proj || !w->w_proj_t) return MTL_ERR_ARG;
+    if (!w->ln1_w || !w->ln2_w || !w->lnf_w) return MTL_ERR_ARG;
+    if (w->arch == MTL_ARCH_GPT2 && (!w->ln1_b || !w->ln2_b || !w->lnf_b)) return MTL_ERR_ARG;
+    if (w->arch == MTL_ARCH_LLAMA && (!w->rope_cos || !w->rope_sin)) return MTL_ERR_ARG;
+    return MTL_OK;
+}
+
+}  // namespace
+
+extern "C" size_t mtl_backbone_saved_bytes(const mtl_backbone_weights* w, int64_t B, int64_t T) {
+    if (check_weights(w) != MTL_OK || B <= 0 || T <= 0) return 0;
+    return saved_layout(dims_of(w, B, T), T).total;
+}
+
+extern "C" size_t mtl_backbone_work_bytes(const mtl_backbone_weights* w, int64_t B, int64_t T) {
+    if (check_weights(w) != MTL_OK || B <= 0 || T <= 0) return 0;
+    return work_layout(dims_of(w, B, T)).total;
+}
+
+extern "C" int mtl_backbone_fwd(const mtl_backbone_weights* w, const float* h0, void* out, void* saved, void* work, int64_t B,
+                                int64_t T, int64_t n_last, void* stream) {
+    MTL_TRY(check_weights(w));
+    if (!h0 || !out || !saved || !work || B <= 0 || T <= 0 || n_last <= 0 || n_last > T) return MTL_ERR_ARG;
+    const Dims D = dims_of(w, B, T);
+    const SavedLayout S = saved_layout(D, T);
+    const WorkLayout W = work_layout(D);
+    char* sv = reinterpret_cast<char*>(saved);
+    char* wk = reinterpret_cast<char*>(work);
+    const int rms = D.llama ? 1 : 0;
+    auto H = [&](int idx) -> float* {  // residual stream H[0] = h0, H[1..2L] in saved
+        return idx == 0 ? const_cast<float*>(h0) : reinterpret_cast<float*>(sv + S.h + S.h_stride * (size_t)(idx - 1));
+    };
+    for (int i = 0; i < D.L; ++i) {
+        float* st1 = reinterpret_cast<float*>(sv + S.stats + S.stats_stride * (size_t)(2 * i));
+        float* st2 = reinterpret_cast<float*>(sv + S.stats + S.stats_stride * (size_t)(2 * i + 1));
+        char* qkv = sv + S.qkv + S.qkv_stride * (size_t)i;
+        char* attn = sv + S.attn + S.attn_stride * (size_t)i;
+        float* lse = reinterpret_cast<float*>(sv + S.lse + S.lse_stride * (size_t)i);
+        char* fc = sv + S.fc + S.fc_stride * (size_t)i;
+        const float* bq = w->b_qkv ? w->b_qkv[i] : nullptr;
+        const float* bo = w->b_o ? w->b_o[i] : nullptr;
+        const float* bf = w->b_fc ? w->b_fc[i] : nullptr;
+        const float* bp = w->b_proj ? w->b_proj[i] : nullptr;
+        // --- attention block
+        MTL_TRY(mtl_norm_fwd(H(2 * i), w->ln1_w[i], w->ln1_b ? w->ln1_b[i] : nullptr, wk + W.xln, D.d, st1, D.M, D.d, w->eps, rms, 0, 0, 0, stream));
+        MTL_TRY(gemm(wk + W.xln, D.d, w->w_qkv[i], D.d, qkv, D.Nqkv, MTL_BF16, D.M, D.Nqkv, D.d, bq, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream));
+        if (D.llama) MTL_TRY(mtl_rope_inplace(qkv, D.Nqkv, w->rope_cos, w->rope_sin, D.M, D.T, D.Hq + D.Hkv, D.hd, 0, stream));
+        mtl_attn_fwd_args fa;
+        attn_args(D, qkv, attn, lse, &fa);
+        MTL_TRY(mtl_attention_fwd(&fa, stream));
+        MTL_TRY(gemm(attn, D.No, w->w_o[i], D.No, H(2 * i + 1), D.d, MTL_F32, D.M, D.d, D.No, bo, MTL_EPI_RESID, H(2 * i), D.d, nullptr, 0, stream));
+        // --- MLP block
+        MTL_TRY(mtl_norm_fwd(H(2 * i + 1), w->ln2_w[i], w->ln2_b ? w->ln2_b[i] : nullptr, wk + W.xln, D.d, st2, D.M, D.d, w->eps, rms, 0, 0, 0, stream));
+        if (D.llama) {
+            MTL_TRY(gemm(wk + W.xln, D.d, w->w_fc[i], D.d, fc, D.Nfc, MTL_BF16, D.M, D.Nfc, D.d, bf, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream));
+            MTL_TRY(mtl_swiglu_fwd(fc, wk + W.act, D.M, D.ffn, stream));
+        } else {
+            MTL_TRY(gemm(wk + W.xln, D.d, w->w_fc[i], D.d, wk + W.act, D.ffn, MTL_BF16, D.M, D.ffn, D.d, bf, MTL_EPI_GELU, nullptr, 0, fc, D.ffn, stream));
+        }
+        MTL_TRY(gemm(wk + W.act, D.ffn, w->w_proj[i], D.ffn, H(2 * i + 2), D.d, MTL_F32, D.M, D.d, D.ffn, bp, MTL_EPI_RESID, H(2 * i + 1), D.d, nullptr, 0, stream));
+    }
+    float* stf = reinterpret_cast<float*>(sv + S.stats_f);
+    return mtl_norm_fwd(H(2 * D.L), w->lnf_w, w->lnf_b, out, D.d, stf, D.B * n_last, D.d, w->eps, rms, n_last, D.T, D.T - n_last, stream);
+}
+
+extern "C" int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, const void* dout, float* dh0, void* saved, void* work,
+                                int64_t B, int64_t T, int64_t n_last, void* stream) {
+    MTL_TRY(check_weights(w));
+    if (!h0 || !dout || !dh0 || !saved || !work || B <= 0 || T <= 0 || n_last <= 0 || n_last > T) return MTL_ERR_ARG;
+    const Dims D = dims_of(w, B, T);
+    const SavedLayout S = saved_layout(D, T);
+    const WorkLayout W = work_layout(D);
+    char* sv = reinterpret_cast<char*>(saved);
+    char* wk = reinterpret_cast<char*>(work);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int rms = D.llama ? 1 : 0;
+    auto H = [&](int idx) -> float* {
+        return idx == 0 ? const_cast<float*>(h0) : reinterpret_cast<float*>(sv + S.h + S.h_stride * (size_t)(idx - 1));
+    };
+    // final norm: only the last n_last rows of each sample carry gradient; everything else starts at zero
+    if (n_last < T) {
+        if (hipMemsetAsync(dh0, 0, (size_t)D.M * D.d * 4, st) != hipSuccess) return MTL_ERR_LAUNCH;
+        if (hipMemsetAsync(wk + W.dres_b, 0, (size_t)D.M * D.d * 2, st) != hipSuccess) return MTL_ERR_LAUNCH;
+    }
+    const float* stf = reinterpret_cast<const float*>(sv + S.stats_f);
+    MTL_TRY(mtl_norm_bwd(dout, D.d, H(2 * D.L), w->lnf_w, stf, nullptr, dh0, wk + W.dres_b, D.B * n_last, D.d, rms, n_last, D.T, D.T - n_last, stream));
+    for (int i = D.L - 1; i >= 0; --i) {
+        const float* st1 = reinterpret_cast<const float*>(sv + S.stats + S.stats_stride * (size_t)(2 * i));
+        const float* st2 = reinterpret_cast<const float*>(sv + S.stats + S.stats_stride * (size_t)(2 * i + 1));
+        char* qkv = sv + S.qkv + S.qkv_stride * (size_t)i;
+        char* attn = sv + S.attn + S.attn_stride * (size_t)i;
+        float* lse = reinterpret_cast<float*>(sv + S.lse + S.lse_stride * (size_t)i);
+        char* fc = sv + S.fc + S.fc_stride * (size_t)i;
+        // --- MLP block backward: h_out = h_mid + proj(act(fc(norm2(h_mid))))
+        if (D.llama) {
+            MTL_TRY(gemm(wk + W.dres_b, D.d, w->w_proj_t[i], D.d, wk + W.dhact, D.ffn, MTL_BF16, D.M, D.ffn, D.d, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream));
+            MTL_TRY(mtl_swiglu_bwd(fc, wk + W.dhact, wk + W.dact, D.M, D.ffn, stream));
+        } else {
+            MTL_TRY(gemm(wk + W.dres_b, D.d, w->w_proj_t[i], D.d, wk + W.dact, D.ffn, MTL_BF16, D.M, D.ffn, D.d, nullptr, MTL_EPI_DGELU, fc, D.ffn, nullptr, 0, stream));
+        }
+        MTL_TRY(gemm(wk + W.dact, D.Nfc, w->w_fc_t[i], D.Nfc, wk + W.dx, D.d, MTL_BF16, D.M, D.d, D.Nfc, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream));
+        MTL_TRY(mtl_norm_bwd(wk + W.dx, D.d, H(2 * i + 1), w->ln2_w[i], st2, dh0, dh0, wk + W.dres_b, D.M, D.d, rms, 0, 0, 0, stream));
+        // --- attention block backward: h_mid = h_in + o_proj(attn(qkv(norm1(h_in))))
+        MTL_TRY(gemm(wk + W.dres_b, D.d, w->w_o_t[i], D.d, wk + W.dO, D.No, MTL_BF16, D.M, D.No, D.d, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream));
+        mtl_attn_bwd_args ba = {};
+        attn_args(D, qkv, attn, lse, &ba.f);
+        bf16_t* dq = reinterpret_cast<bf16_t*>(wk + W.dqkv);
+        ba.dout = wk + W.dO; ba.do_bs = D.T * D.No; ba.do_ts = D.No; ba.do_hs = D.hd;
+        ba.dq = dq; ba.dq_bs = D.T * D.Nqkv; ba.dq_ts = D.Nqkv; ba.dq_hs = D.hd;
+        ba.dk = dq + D.Hq * D.hd; ba.dk_bs = D.T * D.Nqkv; ba.dk_ts = D.Nqkv; ba.dk_hs = D.hd;
+        ba.dv = dq + (D.Hq + D.Hkv) * D.hd; ba.dv_bs = D.T * D.Nqkv; ba.dv_ts = D.Nqkv; ba.dv_hs = D.hd;
+        ba.delta = reinterpret_cast<float*>(wk + W.delta);
+        MTL_TRY(mtl_attention_bwd(&ba, stream));
+        if (D.llama) MTL_TRY(mtl_rope_inplace(wk + W.dqkv, D.Nqkv, w->rope_cos, w->rope_sin, D.M, D.T, D.Hq + D.Hkv, D.hd, 1, stream));
+        MTL_TRY(gemm(wk + W.dqkv, D.Nqkv, w->w_qkv_t[i], D.Nqkv, wk + W.dx, D.d, MTL_BF16, D.M, D.d, D.Nqkv, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream));
+        MTL_TRY(mtl_norm_bwd(wk + W.dx, D.d, H(2 * i), w->ln1_w[i], st1, dh0, dh0, wk + W.dres_b, D.M, D.d, rms, 0, 0, 0, stream));
+    }
+    return MTL_OK;
+}

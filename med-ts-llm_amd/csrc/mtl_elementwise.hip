@@ -1,0 +1,314 @@
+// mtl_elementwise.hip — HBM-bound layout / cast / elementwise kernels (all 8-16 B per lane, coalesced).
+#include "mtl_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- f32 -> bf16 cast with zero padding (+ optional transpose)
+// 64x64 tile per block; element (r, c) = (r < R && c < Cc) ? src[r][c] : 0.
+__global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ src, int64_t ld_src, bf16_t* __restrict__ dst,
+                                                       int64_t ld_dst, bf16_t* __restrict__ dst_t, int64_t ld_dst_t, int64_t R,
+                                                       int64_t Cc) {
+    __shared__ bf16_t tile[64][66];
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int rr = ty * 16 + i;
+        const int64_t r = r0 + rr, c = c0 + tx;
+        const float v = (r < R && c < Cc) ? src[r * ld_src + c] : 0.f;
+        const bf16_t b = f32_to_bf16(v);
+        tile[rr][tx] = b;
+        if (dst && r < R && c < ld_dst) dst[r * ld_dst + c] = b;
+    }
+    if (!dst_t) return;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int cc = ty * 16 + i;
+        const int64_t c = c0 + cc, r = r0 + tx;
+        if (c < Cc && r < ld_dst_t) dst_t[c * ld_dst_t + r] = tile[tx][cc];
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, int64_t ld_src, bf16_t* __restrict__ dst,
+                                                             int64_t ld_dst, int64_t R, int64_t Cc) {
+    __shared__ bf16_t tile[64][66];
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int rr = ty * 16 + i;
+        const int64_t r = r0 + rr, c = c0 + tx;
+        tile[rr][tx] = (r < R && c < Cc) ? src[r * ld_src + c] : (bf16_t)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int cc = ty * 16 + i;
+        const int64_t c = c0 + cc, r = r0 + tx;
+        if (c < Cc && r < ld_dst) dst[c * ld_dst + r] = tile[tx][cc];
+    }
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n) {
+            const float4 v = *reinterpret_cast<const float4*>(src + i);
+            u32x2 pk = {pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+            *reinterpret_cast<u32x2*>(dst + i) = pk;
+        } else {
+            for (int64_t j = i; j < n; ++j) dst[j] = f32_to_bf16(src[j]);
+        }
+    }
+}
+
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n) {
+            const u32x2 v = *reinterpret_cast<const u32x2*>(src + i);
+            *reinterpret_cast<float4*>(dst + i) = make_float4(__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u),
+                                                              __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u));
+        } else {
+            for (int64_t j = i; j < n; ++j) dst[j] = bf16_to_f32(src[j]);
+        }
+    }
+}
+
+// column sums: grid (ceil(Cc/64), row chunks of 256); 256 threads = 64 cols x 4 row lanes; fp32 atomics into dst (pre-zeroed)
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ src, int64_t ld_src, float* __restrict__ dst, int64_t R,
+                                                     int64_t Cc) {
+    __shared__ float part[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 64 + tx;
+    const int64_t r0 = (int64_t)blockIdx.y * 256;
+    float s = 0.f;
+    if (c < Cc) {
+        const int64_t rend = (r0 + 256 < R) ? r0 + 256 : R;
+        for (int64_t r = r0 + ty; r < rend; r += 4) s += bf16_to_f32(src[r * ld_src + c]);
+    }
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < Cc) atomicAdd(dst + c, (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]));
+}
+
+// ---------------------------------------------------------------- RoPE (half-split), in place on q|k heads
+__global__ void rope_kernel(bf16_t* __restrict__ qkv, int64_t ld, const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                            int64_t M, int64_t T, int n_heads, int D, int inverse) {
+    const int half = D >> 1;
+    const int pairs_per_row = n_heads * (half >> 1);  // two rotation pairs (i, i+1) per thread -> 4-byte accesses
+    const int64_t total = M * pairs_per_row;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = idx / pairs_per_row;
+        const int rem = (int)(idx % pairs_per_row);
+        const int h = rem / (half >> 1), i = (rem % (half >> 1)) * 2;
+        const int64_t pos = m % T;
+        bf16_t* base = qkv + m * ld + (int64_t)h * D;
+        const uint32_t lo = *reinterpret_cast<const uint32_t*>(base + i);
+        const uint32_t hi = *reinterpret_cast<const uint32_t*>(base + half + i);
+        const float x1a = __uint_as_float(lo << 16), x1b = __uint_as_float(lo & 0xffff0000u);
+        const float x2a = __uint_as_float(hi << 16), x2b = __uint_as_float(hi & 0xffff0000u);
+        const float ca = cos_t[pos * D + i], cb = cos_t[pos * D + i + 1];
+        float sa = sin_t[pos * D + i], sb = sin_t[pos * D + i + 1];
+        if (inverse) { sa = -sa; sb = -sb; }
+        // y1 = x1*c - x2*s ; y2 = x2*c + x1*s   (q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1))
+        *reinterpret_cast<uint32_t*>(base + i) = pack_bf16x2(x1a * ca - x2a * sa, x1b * cb - x2b * sb);
+        *reinterpret_cast<uint32_t*>(base + half + i) = pack_bf16x2(x2a * ca + x1a * sa, x2b * cb + x1b * sb);
+    }
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ h, int64_t M, int64_t F) {
+    const int64_t total = M * (F >> 1);
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = idx / (F >> 1), f = (idx % (F >> 1)) * 2;
+        const uint32_t g = *reinterpret_cast<const uint32_t*>(gu + m * 2 * F + f);
+        const uint32_t u = *reinterpret_cast<const uint32_t*>(gu + m * 2 * F + F + f);
+        const float g0 = __uint_as_float(g << 16), g1 = __uint_as_float(g & 0xffff0000u);
+        const float u0 = __uint_as_float(u << 16), u1 = __uint_as_float(u & 0xffff0000u);
+        // silu output is a bf16 tensor in the reference (act_fn on a bf16 Linear output), then multiplied by up
+        const float s0 = bf16_to_f32(f32_to_bf16(g0 * sigmoid_f(g0))), s1 = bf16_to_f32(f32_to_bf16(g1 * sigmoid_f(g1)));
+        *reinterpret_cast<uint32_t*>(h + m * F + f) = pack_bf16x2(s0 * u0, s1 * u1);
+    }
+}
+
+__global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dh, bf16_t* __restrict__ dgu, int64_t M,
+                                  int64_t F) {
+    const int64_t total = M * (F >> 1);
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = idx / (F >> 1), f = (idx % (F >> 1)) * 2;
+        const uint32_t g = *reinterpret_cast<const uint32_t*>(gu + m * 2 * F + f);
+        const uint32_t u = *reinterpret_cast<const uint32_t*>(gu + m * 2 * F + F + f);
+        const uint32_t d = *reinterpret_cast<const uint32_t*>(dh + m * F + f);
+        float gv[2] = {__uint_as_float(g << 16), __uint_as_float(g & 0xffff0000u)};
+        float uv[2] = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+        float dv[2] = {__uint_as_float(d << 16), __uint_as_float(d & 0xffff0000u)};
+        float dg[2], du[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float sg = sigmoid_f(gv[e]);
+            du[e] = dv[e] * gv[e] * sg;
+            dg[e] = dv[e] * uv[e] * sg * (1.0f + gv[e] * (1.0f - sg));
+        }
+        *reinterpret_cast<uint32_t*>(dgu + m * 2 * F + f) = pack_bf16x2(dg[0], dg[1]);
+        *reinterpret_cast<uint32_t*>(dgu + m * 2 * F + F + f) = pack_bf16x2(du[0], du[1]);
+    }
+}
+
+// ---------------------------------------------------------------- LLM input assembly: one block per (b, t) row
+__global__ __launch_bounds__(256) void assemble_kernel(const int32_t* __restrict__ ids, int64_t ids_B, const float* __restrict__ embed,
+                                                       const bf16_t* __restrict__ x_tok, const float* __restrict__ wpe,
+                                                       float* __restrict__ h0, int64_t n_tok, int64_t P, int64_t d) {
+    const int64_t T = n_tok + P;
+    const int64_t row = blockIdx.x, b = row / T, t = row % T;
+    float* out = h0 + row * d;
+    const float* pe = wpe ? wpe + t * d : nullptr;
+    if (t < n_tok) {
+        const int64_t id = ids[(ids_B == 1 ? 0 : b) * n_tok + t];
+        const float* e = embed + id * d;
+        for (int64_t c = (int64_t)threadIdx.x * 4; c < d; c += 1024) {
+            float4 v = *reinterpret_cast<const float4*>(e + c);
+            if (pe) { const float4 p4 = *reinterpret_cast<const float4*>(pe + c); v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w; }
+            *reinterpret_cast<float4*>(out + c) = v;
+        }
+    } else {
+        const bf16_t* xr = x_tok + (b * P + (t - n_tok)) * d;
+        for (int64_t c = (int64_t)threadIdx.x * 4; c < d; c += 1024) {
+            const u32x2 k = *reinterpret_cast<const u32x2*>(xr + c);
+            float4 v = make_float4(__uint_as_float(k[0] << 16), __uint_as_float(k[0] & 0xffff0000u), __uint_as_float(k[1] << 16),
+                                   __uint_as_float(k[1] & 0xffff0000u));
+            if (pe) { const float4 p4 = *reinterpret_cast<const float4*>(pe + c); v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w; }
+            *reinterpret_cast<float4*>(out + c) = v;
+        }
+    }
+}
+
+__global__ void revin_denorm_kernel(const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ stdev,
+                                    float* __restrict__ out, int64_t B, int64_t T, int64_t C) {
+    const int64_t total = B * T * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = i % C, b = i / (T * C);
+        out[i] = y[i] * stdev[b * C + c] + (mean ? mean[b * C + c] : 0.f);
+    }
+}
+
+inline unsigned grid_for(int64_t items, int block) {
+    int64_t g = (items + block - 1) / block;
+    if (g > 2048 * 4) g = 2048 * 4;  // grid-stride the rest (GUIDE Guideline 11)
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" int mtl_cast_pad_f32_bf16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, void* dst_t, int64_t ld_dst_t,
+                                     int64_t R, int64_t Cc, void* stream) {
+    if (!src || (!dst && !dst_t) || R <= 0 || Cc <= 0) return MTL_ERR_ARG;
+    if ((dst && ld_dst < Cc) || (dst_t && ld_dst_t < R)) return MTL_ERR_ARG;
+    const int64_t rmax = (dst_t && ld_dst_t > R) ? ld_dst_t : R;
+    const int64_t cmax = (dst && ld_dst > Cc) ? ld_dst : Cc;
+    dim3 grid((unsigned)((cmax + 63) / 64), (unsigned)((rmax + 63) / 64));
+    hipLaunchKernelGGL(cast_pad_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, (bf16_t*)dst, ld_dst, (bf16_t*)dst_t,
+                       ld_dst_t, R, Cc);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+extern "C" int mtl_transpose_bf16(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t R, int64_t Cc, void* stream) {
+    if (!src || !dst || R <= 0 || Cc <= 0 || ld_dst < R) return MTL_ERR_ARG;
+    const int64_t rmax = ld_dst > R ? ld_dst : R;
+    dim3 grid((unsigned)((Cc + 63) / 64), (unsigned)((rmax + 63) / 64));
+    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst,
+                       R, Cc);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+extern "C" int mtl_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    if (!src || !dst || n <= 0) return MTL_ERR_ARG;
+    if (((uintptr_t)src % 16) || ((uintptr_t)dst % 8)) return MTL_ERR_ALIGN;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+extern "C" int mtl_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream) {
+    if (!src || !dst || n <= 0) return MTL_ERR_ARG;
+    if (((uintptr_t)src % 8) || ((uintptr_t)dst % 16)) return MTL_ERR_ALIGN;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, n);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+extern "C" int mtl_colsum_bf16(const void* src, int64_t ld_src, float* dst, int64_t R, int64_t Cc, void* stream) {
+    if (!src || !dst || R <= 0 || Cc <= 0) return MTL_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dst, 0, (size_t)Cc * sizeof(float), st) != hipSuccess) return MTL_ERR_LAUNCH;
+    dim3 grid((unsigned)((Cc + 63) / 64), (unsigned)((R + 255) / 256));
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, (const bf16_t*)src, ld_src, dst, R, Cc);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+extern "C" int mtl_rope_inplace(void* qkv, int64_t ld, const float* cos_t, const float* sin_t, int64_t M, int64_t T,
+                                int64_t n_rot_heads, int64_t D, int inverse, void* stream) {
+    if (!qkv || !cos_t || !sin_t || M <= 0 || T <= 0 || n_rot_heads <= 0) return MTL_ERR_ARG;
+    if (D % 4 != 0 || ld % 2 != 0) return MTL_ERR_ALIGN;
+    const int64_t items = M * n_rot_heads * (D / 4);
+    hipLaunchKernelGGL(rope_kernel, dim3(grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)qkv, ld, cos_t, sin_t, M, T,
+                       (int)n_rot_heads, (int)D, inverse);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+extern "C" int mtl_swiglu_fwd(const void* gu, void* h, int64_t M, int64_t F, void* stream) {
+    if (!gu || !h || M <= 0 || F <= 0) return MTL_ERR_ARG;
+    if (F % 2 != 0) return MTL_ERR_ALIGN;
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(M * F / 2, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gu, (bf16_t*)h, M, F);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+extern "C" int mtl_swiglu_bwd(const void* gu, const void* dh, void* dgu, int64_t M, int64_t F, void* stream) {
+    if (!gu || !dh || !dgu || M <= 0 || F <= 0) return MTL_ERR_ARG;
+    if (F % 2 != 0) return MTL_ERR_ALIGN;
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(M * F / 2, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gu,
+                       (const bf16_t*)dh, (bf16_t*)dgu, M, F);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+extern "C" int mtl_assemble_llm_input(const int32_t* ids, int64_t ids_B, const float* embed, const void* x_tok, const float* wpe,
+                                      float* h0, int64_t B, int64_t n_tok, int64_t P, int64_t d, void* stream) {
+    if (!x_tok || !h0 || B <= 0 || P <= 0 || d <= 0 || n_tok < 0) return MTL_ERR_ARG;
+    if (n_tok > 0 && (!ids || !embed || (ids_B != 1 && ids_B != B))) return MTL_ERR_ARG;
+    if (d % 4 != 0) return MTL_ERR_ALIGN;
+    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)(B * (n_tok + P))), dim3(256), 0, (hipStream_t)stream, ids, ids_B, embed,
+                       (const bf16_t*)x_tok, wpe, h0, n_tok, P, d);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+extern "C" int mtl_revin_denorm(const float* y, const float* mean, const float* stdev, float* out, int64_t B, int64_t T, int64_t C,
+                                void* stream) {
+    if (!y || !stdev || !out || B <= 0 || T <= 0 || C <= 0) return MTL_ERR_ARG;
+    hipLaunchKernelGGL(revin_denorm_kernel, dim3(grid_for(B * T * C, 256)), dim3(256), 0, (hipStream_t)stream, y, mean, stdev, out, B, T, C);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+extern "C" int mtl_abi_version(void) { return MTL_ABI_VERSION; }
+
+extern "C" const char* mtl_strerror(int code) {
+    switch (code) {
+        case MTL_OK: return "ok";
+        case MTL_ERR_ARG: return "invalid argument (null pointer / non-positive size / inconsistent shape)";
+        case MTL_ERR_ALIGN: return "alignment requirement violated (K % 64, ld % 8, 16-byte pointers, d % 4)";
+        case MTL_ERR_UNSUPPORTED: return "unsupported configuration (head_dim, epilogue or size out of range)";
+        case MTL_ERR_LAUNCH: return "HIP kernel launch failed";
+        case MTL_ERR_WORKSPACE: return "workspace missing or too small";
+        default: return "unknown error";
+    }
+}

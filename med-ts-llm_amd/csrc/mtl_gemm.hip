@@ -1,0 +1,315 @@
+// mtl_gemm.hip — bf16 MFMA GEMM (NT): C[M,N] = epi(alpha * A[M,K] . B[N,K]^T + bias)
+//
+// gfx950 design (GUIDE cdna_hip_programming.md §5):
+//   * 128x128x64 tile, 4 waves (2x2), each wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16 tiles, fp32 accumulate.
+//   * A/B tiles staged HBM -> LDS with the 16-byte LDS-DMA (global_load_lds_dwordx4): no VGPR round trip.
+//     The LDS image is lane-linear, so the bank-conflict swizzle is applied on the per-lane SOURCE address
+//     and again on the ds_read_b128 (rule 21): physical 16-B chunk = logical chunk ^ ((row >> 1) & 7).
+//   * double-buffered LDS (2 x 32 KiB), one barrier per K tile, next tile's DMA issued before the MFMAs.
+//   * MFMA operands are swapped (D = Btile . Atile^T) so each lane owns 4 CONSECUTIVE output columns of one
+//     row: epilogue stores are 8-byte (bf16) / 16-byte (f32) vectors and bias/residual loads are vectors too.
+//   * XCD-aware bijective block remap: each of the 8 XCDs gets a contiguous run of tiles that share A panels
+//     in its private L2.
+//   * split-K (fp32 slabs + reduce kernel) for the batch-independent mapping GEMM (M=1024, N=d_llm, K=V).
+#include "mtl_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+__device__ __forceinline__ int64_t remap_row(int64_t m, int64_t group_rows, int64_t group_stride, int64_t off) {
+    if (group_rows == 0) return m;
+    return (m / group_rows) * group_stride + off + (m % group_rows);
+}
+
+template <int EPI, int CDT>
+__device__ __forceinline__ void epilogue4(const mtl_gemm_args& p, int64_t m, int64_t n, f32x4 v, bool vec_ok) {
+    const int64_t crow = remap_row(m, p.c_group_rows, p.c_group_stride, p.c_row_offset);
+    float o[4];
+    const int nvalid = (p.N - n) >= 4 ? 4 : (int)(p.N - n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = v[e] * p.alpha;
+    if (p.bias) {
+        if (vec_ok) {
+            const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+            o[0] += b4.x; o[1] += b4.y; o[2] += b4.z; o[3] += b4.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e < nvalid) o[e] += p.bias[n + e];
+        }
+    }
+    if constexpr (EPI == MTL_EPI_GELU) {
+        bf16_t* aux = reinterpret_cast<bf16_t*>(p.aux_out) + crow * p.ld_aux_out + n;
+        if (vec_ok) {
+            u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+            *reinterpret_cast<u32x2*>(aux) = pk;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e < nvalid) aux[e] = f32_to_bf16(o[e]);
+        }
+        // the activation sees the bf16-rounded pre-activation, exactly like a bf16 Linear followed by gelu_new
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = gelu_new_f(bf16_to_f32(f32_to_bf16(o[e])));
+    } else if constexpr (EPI == MTL_EPI_RESID) {
+        // v is rounded to bf16 first (a bf16 Linear output) and then added to the fp32 residual stream
+        const float* r = reinterpret_cast<const float*>(p.aux_in) + crow * p.ld_aux_in + n;
+        if (vec_ok) {
+            const float4 r4 = *reinterpret_cast<const float4*>(r);
+            o[0] = r4.x + bf16_to_f32(f32_to_bf16(o[0])); o[1] = r4.y + bf16_to_f32(f32_to_bf16(o[1]));
+            o[2] = r4.z + bf16_to_f32(f32_to_bf16(o[2])); o[3] = r4.w + bf16_to_f32(f32_to_bf16(o[3]));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e < nvalid) o[e] = r[e] + bf16_to_f32(f32_to_bf16(o[e]));
+        }
+    } else if constexpr (EPI == MTL_EPI_DGELU) {
+        const bf16_t* h = reinterpret_cast<const bf16_t*>(p.aux_in) + crow * p.ld_aux_in + n;
+        if (vec_ok) {
+            const u32x2 hk = *reinterpret_cast<const u32x2*>(h);
+            o[0] *= dgelu_new_f(__uint_as_float(hk[0] << 16));
+            o[1] *= dgelu_new_f(__uint_as_float(hk[0] & 0xffff0000u));
+            o[2] *= dgelu_new_f(__uint_as_float(hk[1] << 16));
+            o[3] *= dgelu_new_f(__uint_as_float(hk[1] & 0xffff0000u));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e < nvalid) o[e] *= dgelu_new_f(bf16_to_f32(h[e]));
+        }
+    }
+    if constexpr (CDT == MTL_BF16) {
+        bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + n;
+        if (vec_ok) {
+            u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+            *reinterpret_cast<u32x2*>(c) = pk;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e < nvalid) c[e] = f32_to_bf16(o[e]);
+        }
+    } else {
+        float* c = reinterpret_cast<float*>(p.C) + crow * p.ldc + n;
+        if constexpr (EPI == MTL_EPI_ACCUM) {
+            if (vec_ok) {
+                float4 c4 = *reinterpret_cast<float4*>(c);
+                c4.x += o[0]; c4.y += o[1]; c4.z += o[2]; c4.w += o[3];
+                *reinterpret_cast<float4*>(c) = c4;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (e < nvalid) c[e] += o[e];
+            }
+        } else {
+            if (vec_ok) {
+                *reinterpret_cast<float4*>(c) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (e < nvalid) c[e] = o[e];
+            }
+        }
+    }
+}
+
+// SPLIT: raw fp32 partial sums go to workspace slab [split][M][N]; epilogue runs in splitk_reduce_kernel.
+template <int EPI, int CDT, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const mtl_gemm_args p, const int vec_ok_i) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [buf][A|B]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l15 = lane & 15, g = lane >> 4;
+    const bool vec_ok = vec_ok_i != 0;
+
+    // ---- XCD-aware bijective tile remap (GUIDE §5.5 T1): block b runs on XCD b % 8
+    const int tiles_n = (int)((p.N + BN - 1) / BN);
+    const int nwg = gridDim.x;
+    int wgid;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = wgid / tiles_n, tn = wgid % tiles_n;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+    const int nkt_total = (int)(p.K / BK);
+    int kt_begin = 0, kt_end = nkt_total;
+    if constexpr (SPLIT) {
+        const int S = gridDim.y, s = blockIdx.y;
+        kt_begin = (int)((int64_t)s * nkt_total / S);
+        kt_end = (int)((int64_t)(s + 1) * nkt_total / S);
+    }
+
+    // ---- per-thread staging sources: 4 x 16 B for A and for B per K tile
+    const bf16_t* asrc[4];
+    const bf16_t* bsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int s = i * 256 + tid;       // 16-B slot in the lane-linear LDS image
+        const int r = s >> 3, pc = s & 7;
+        const int c = pc ^ ((r >> 1) & 7); // source-side swizzle
+        int64_t am = m0 + r; if (am > p.M - 1) am = p.M - 1;
+        int64_t bn = n0 + r; if (bn > p.N - 1) bn = p.N - 1;
+        const int64_t arow = remap_row(am, p.a_group_rows, p.a_group_stride, p.a_row_offset);
+        asrc[i] = reinterpret_cast<const bf16_t*>(p.A) + arow * p.lda + c * 8;
+        bsrc[i] = reinterpret_cast<const bf16_t*>(p.B) + bn * p.ldb + c * 8;
+    }
+
+    auto stage = [&](int buf, int kt) {
+        char* la = smem + buf * 2 * TILE_BYTES;
+        char* lb = la + TILE_BYTES;
+        const int64_t koff = (int64_t)kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[i] + koff),
+                                             (lds_void_t*)(la + (i * 256 + wave * 64) * 16), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(bsrc[i] + koff),
+                                             (lds_void_t*)(lb + (i * 256 + wave * 64) * 16), 16, 0, 0);
+    };
+
+    f32x4 acc[4][4];  // [ni][mi]; element e <-> column n + e
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets: row r -> r*128 B, physical chunk = (ks*4 + g) ^ ((r >> 1) & 7); the wave/mi parts of
+    // r are multiples of 16, so ((r >> 1) & 7) == (l15 >> 1).
+    const int sw = l15 >> 1;
+    const int a_off = (wr * 64 + l15) * 128;
+    const int b_off = (wc * 64 + l15) * 128;
+
+    if (kt_begin < kt_end) {
+        stage(0, kt_begin);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const int cur = (kt - kt_begin) & 1;
+            if (kt + 1 < kt_end) stage(cur ^ 1, kt + 1);
+            const char* la = smem + cur * 2 * TILE_BYTES;
+            const char* lb = la + TILE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int pc16 = ((ks * 4 + g) ^ sw) * 16;
+                bf16x8 af[4], bfr[4];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    af[mi] = *reinterpret_cast<const bf16x8*>(la + a_off + mi * 16 * 128 + pc16);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    bfr[ni] = *reinterpret_cast<const bf16x8*>(lb + b_off + ni * 16 * 128 + pc16);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: lane owns row m = ... + l15, columns n .. n+3 with n = ... + g*4
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int64_t m = m0 + wr * 64 + mi * 16 + l15;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int64_t n = n0 + wc * 64 + ni * 16 + g * 4;
+            if (n >= p.N) continue;
+            if constexpr (SPLIT) {
+                float* w = reinterpret_cast<float*>(p.workspace) + ((int64_t)blockIdx.y * p.M + m) * p.N + n;
+                const int nvalid = (p.N - n) >= 4 ? 4 : (int)(p.N - n);
+                if (vec_ok) {
+                    *reinterpret_cast<float4*>(w) = make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (e < nvalid) w[e] = acc[ni][mi][e];
+                }
+            } else {
+                epilogue4<EPI, CDT>(p, m, n, acc[ni][mi], vec_ok);
+            }
+        }
+    }
+}
+
+template <int EPI, int CDT>
+__global__ void splitk_reduce_kernel(const mtl_gemm_args p, const int S, const int vec_ok_i) {
+    const int64_t nq = (p.N + 3) / 4;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.M * nq) return;
+    const int64_t m = idx / nq, n = (idx % nq) * 4;
+    const float* w = reinterpret_cast<const float*>(p.workspace) + m * p.N + n;
+    const int nvalid = (p.N - n) >= 4 ? 4 : (int)(p.N - n);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+        const float* ws = w + (int64_t)s * p.M * p.N;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < nvalid) v[e] += ws[e];
+    }
+    epilogue4<EPI, CDT>(p, m, n, v, vec_ok_i != 0);
+}
+
+bool aligned(const void* ptr, size_t a) { return (reinterpret_cast<uintptr_t>(ptr) % a) == 0; }
+
+template <int EPI, int CDT>
+int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
+    const int tiles_m = (int)((p.M + BM - 1) / BM), tiles_n = (int)((p.N + BN - 1) / BN);
+    const int S = p.split_k > 1 ? p.split_k : 1;
+    if (S == 1) {
+        hipLaunchKernelGGL((gemm_nt_kernel<EPI, CDT, false>), dim3(tiles_m * tiles_n, 1), dim3(256), 0, st, p, vec_ok);
+    } else {
+        const int ws_vec = (p.N % 4 == 0) && aligned(p.workspace, 16);
+        hipLaunchKernelGGL((gemm_nt_kernel<EPI, CDT, true>), dim3(tiles_m * tiles_n, S), dim3(256), 0, st, p, ws_vec);
+        const int64_t items = p.M * ((p.N + 3) / 4);
+        hipLaunchKernelGGL((splitk_reduce_kernel<EPI, CDT>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, p, S, vec_ok);
+    }
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+}  // namespace
+
+extern "C" size_t mtl_gemm_workspace_bytes(int64_t M, int64_t N, int split_k) {
+    return split_k > 1 ? (size_t)split_k * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+extern "C" int mtl_gemm_nt(const mtl_gemm_args* a, void* stream) {
+    if (!a || !a->A || !a->B || !a->C) return MTL_ERR_ARG;
+    const mtl_gemm_args& p = *a;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MTL_ERR_ARG;
+    if (p.K % BK != 0 || p.lda % 8 != 0 || p.ldb % 8 != 0) return MTL_ERR_ALIGN;
+    if (!aligned(p.A, 16) || !aligned(p.B, 16)) return MTL_ERR_ALIGN;
+    if (p.c_dtype != MTL_F32 && p.c_dtype != MTL_BF16) return MTL_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int S = p.split_k > 1 ? p.split_k : 1;
+    if (S > 1) {
+        if (!p.workspace || p.workspace_bytes < mtl_gemm_workspace_bytes(p.M, p.N, S)) return MTL_ERR_WORKSPACE;
+        if (S > p.K / BK) return MTL_ERR_ARG;
+    }
+    const size_t ce = p.c_dtype == MTL_BF16 ? 2 : 4;
+    int vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && aligned(p.C, 4 * ce) && (!p.bias || aligned(p.bias, 16));
+    switch (p.epilogue) {
+        case MTL_EPI_STORE:
+            return p.c_dtype == MTL_BF16 ? launch<MTL_EPI_STORE, MTL_BF16>(p, vec_ok, st) : launch<MTL_EPI_STORE, MTL_F32>(p, vec_ok, st);
+        case MTL_EPI_GELU:
+            if (p.c_dtype != MTL_BF16 || !p.aux_out) return MTL_ERR_ARG;
+            vec_ok = vec_ok && (p.ld_aux_out % 4 == 0) && aligned(p.aux_out, 8);
+            return launch<MTL_EPI_GELU, MTL_BF16>(p, vec_ok, st);
+        case MTL_EPI_RESID:
+            if (p.c_dtype != MTL_F32 || !p.aux_in) return MTL_ERR_ARG;
+            vec_ok = vec_ok && (p.ld_aux_in % 4 == 0) && aligned(p.aux_in, 16);
+            return launch<MTL_EPI_RESID, MTL_F32>(p, vec_ok, st);
+        case MTL_EPI_DGELU:
+            if (p.c_dtype != MTL_BF16 || !p.aux_in) return MTL_ERR_ARG;
+            vec_ok = vec_ok && (p.ld_aux_in % 4 == 0) && aligned(p.aux_in, 8);
+            return launch<MTL_EPI_DGELU, MTL_BF16>(p, vec_ok, st);
+        case MTL_EPI_ACCUM:
+            if (p.c_dtype != MTL_F32 || S > 1) return MTL_ERR_ARG;
+            return launch<MTL_EPI_ACCUM, MTL_F32>(p, vec_ok, st);
+        default:
+            return MTL_ERR_UNSUPPORTED;
+    }
+}

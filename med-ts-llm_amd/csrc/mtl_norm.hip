@@ -1,0 +1,188 @@
+// mtl_norm.hip — LayerNorm / RMSNorm forward and dX-only backward over the fp32 residual stream.
+//
+// HBM-bound: one wave64 per row, the whole row lives in registers (NV float4 per lane, 16 B/lane coalesced
+// loads), statistics by wave shuffles in fp32, bf16x4 (8 B/lane) stores. Algorithmic bytes per row:
+// fwd 4d (read) + 2d (write); bwd 2d (dy) + 4d (x) + 4d (dres in) + 4d (+2d) (dres out).
+#include "mtl_common.h"
+#include <type_traits>
+
+namespace {
+
+__device__ __forceinline__ int64_t remap_row(int64_t m, int64_t group_rows, int64_t group_stride, int64_t off) {
+    if (group_rows == 0) return m;
+    return (m / group_rows) * group_stride + off + (m % group_rows);
+}
+
+template <int NV, bool RMS>
+__global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                       int64_t ld_y, float* __restrict__ stats, int64_t M, int d, float eps,
+                                                       int64_t group_rows, int64_t group_stride, int64_t row_offset) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + remap_row(row, group_rows, group_stride, row_offset) * (int64_t)d;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < d) {
+            v[i] = *reinterpret_cast<const float4*>(xr + c);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float inv_d = 1.0f / (float)d;
+    float mean = 0.f;
+    if (!RMS) mean = wave_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < d) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
+            q += (a * a + b * b) + (cc * cc + dd * dd);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * inv_d + eps);
+    bf16_t* yr = y + row * ld_y;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < d) {
+            const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+            float o0, o1, o2, o3;
+            if (RMS) {
+                // HF LlamaRMSNorm: weight * (x * rsqrt(var + eps)).to(input_dtype) ; input dtype is fp32 here
+                o0 = gm.x * (v[i].x * rstd); o1 = gm.y * (v[i].y * rstd);
+                o2 = gm.z * (v[i].z * rstd); o3 = gm.w * (v[i].w * rstd);
+            } else {
+                const float4 bt = *reinterpret_cast<const float4*>(beta + c);
+                o0 = (v[i].x - mean) * rstd * gm.x + bt.x; o1 = (v[i].y - mean) * rstd * gm.y + bt.y;
+                o2 = (v[i].z - mean) * rstd * gm.z + bt.z; o3 = (v[i].w - mean) * rstd * gm.w + bt.w;
+            }
+            u32x2 pk = {pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)};
+            *reinterpret_cast<u32x2*>(yr + c) = pk;
+        }
+    }
+    if (lane == 0 && stats) {
+        stats[row * 2] = mean;
+        stats[row * 2 + 1] = rstd;
+    }
+}
+
+template <int NV, bool RMS>
+__global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict__ dy, int64_t ld_dy, const float* __restrict__ x,
+                                                       const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                       const float* dres_in, float* dres_out, bf16_t* dres_out_bf16,
+                                                       int64_t M, int d, int64_t group_rows, int64_t group_stride,
+                                                       int64_t row_offset) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int64_t prow = remap_row(row, group_rows, group_stride, row_offset);
+    const float* xr = x + prow * (int64_t)d;
+    const bf16_t* dyr = dy + row * ld_dy;
+    const float mean = RMS ? 0.f : stats[row * 2];
+    const float rstd = stats[row * 2 + 1];
+    float4 g[NV], xh[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < d) {
+            const u32x2 dk = *reinterpret_cast<const u32x2*>(dyr + c);
+            const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+            const float4 xv = *reinterpret_cast<const float4*>(xr + c);
+            g[i].x = __uint_as_float(dk[0] << 16) * gm.x; g[i].y = __uint_as_float(dk[0] & 0xffff0000u) * gm.y;
+            g[i].z = __uint_as_float(dk[1] << 16) * gm.z; g[i].w = __uint_as_float(dk[1] & 0xffff0000u) * gm.w;
+            xh[i].x = (xv.x - mean) * rstd; xh[i].y = (xv.y - mean) * rstd;
+            xh[i].z = (xv.z - mean) * rstd; xh[i].w = (xv.w - mean) * rstd;
+            s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+            s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+        } else {
+            g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            xh[i] = g[i];
+        }
+    }
+    const float inv_d = 1.0f / (float)d;
+    const float c1 = RMS ? 0.f : wave_sum(s1) * inv_d;
+    const float c2 = wave_sum(s2) * inv_d;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < d) {
+            float4 o;
+            o.x = rstd * (g[i].x - c1 - xh[i].x * c2); o.y = rstd * (g[i].y - c1 - xh[i].y * c2);
+            o.z = rstd * (g[i].z - c1 - xh[i].z * c2); o.w = rstd * (g[i].w - c1 - xh[i].w * c2);
+            if (dres_in) {
+                const float4 r = *reinterpret_cast<const float4*>(dres_in + prow * (int64_t)d + c);
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            *reinterpret_cast<float4*>(dres_out + prow * (int64_t)d + c) = o;
+            if (dres_out_bf16) {
+                u32x2 pk = {pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w)};
+                *reinterpret_cast<u32x2*>(dres_out_bf16 + prow * (int64_t)d + c) = pk;
+            }
+        }
+    }
+}
+
+template <bool RMS, typename F>
+int dispatch_nv(int64_t d, F&& f) {
+    const int64_t nv = (d + 255) / 256;
+    if (nv <= 1) return f(std::integral_constant<int, 1>{});
+    if (nv <= 2) return f(std::integral_constant<int, 2>{});
+    if (nv <= 3) return f(std::integral_constant<int, 3>{});
+    if (nv <= 4) return f(std::integral_constant<int, 4>{});
+    if (nv <= 8) return f(std::integral_constant<int, 8>{});
+    if (nv <= 16) return f(std::integral_constant<int, 16>{});
+    if (nv <= 32) return f(std::integral_constant<int, 32>{});
+    return MTL_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int mtl_norm_fwd(const float* x, const float* gamma, const float* beta, void* y, int64_t ld_y, float* stats,
+                            int64_t M, int64_t d, float eps, int rms, int64_t group_rows, int64_t group_stride,
+                            int64_t row_offset, void* stream) {
+    if (!x || !gamma || !y || M <= 0 || d <= 0 || (!rms && !beta)) return MTL_ERR_ARG;
+    if (d % 4 != 0 || ld_y % 4 != 0) return MTL_ERR_ALIGN;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((M + 3) / 4)), block(256);
+    auto go = [&](auto nv) -> int {
+        constexpr int NV = decltype(nv)::value;
+        if (rms)
+            hipLaunchKernelGGL((norm_fwd_kernel<NV, true>), grid, block, 0, st, x, gamma, beta, (bf16_t*)y, ld_y, stats, M, (int)d,
+                               eps, group_rows, group_stride, row_offset);
+        else
+            hipLaunchKernelGGL((norm_fwd_kernel<NV, false>), grid, block, 0, st, x, gamma, beta, (bf16_t*)y, ld_y, stats, M, (int)d,
+                               eps, group_rows, group_stride, row_offset);
+        MTL_CHECK_LAUNCH();
+        return MTL_OK;
+    };
+    return dispatch_nv<false>(d, go);
+}
+
+extern "C" int mtl_norm_bwd(const void* dy, int64_t ld_dy, const float* x, const float* gamma, const float* stats,
+                            const float* dres_in, float* dres_out, void* dres_out_bf16, int64_t M, int64_t d, int rms,
+                            int64_t group_rows, int64_t group_stride, int64_t row_offset, void* stream) {
+    if (!dy || !x || !gamma || !stats || !dres_out || M <= 0 || d <= 0) return MTL_ERR_ARG;
+    if (d % 4 != 0 || ld_dy % 4 != 0) return MTL_ERR_ALIGN;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((M + 3) / 4)), block(256);
+    auto go = [&](auto nv) -> int {
+        constexpr int NV = decltype(nv)::value;
+        if (rms)
+            hipLaunchKernelGGL((norm_bwd_kernel<NV, true>), grid, block, 0, st, (const bf16_t*)dy, ld_dy, x, gamma, stats, dres_in,
+                               dres_out, (bf16_t*)dres_out_bf16, M, (int)d, group_rows, group_stride, row_offset);
+        else
+            hipLaunchKernelGGL((norm_bwd_kernel<NV, false>), grid, block, 0, st, (const bf16_t*)dy, ld_dy, x, gamma, stats, dres_in,
+                               dres_out, (bf16_t*)dres_out_bf16, M, (int)d, group_rows, group_stride, row_offset);
+        MTL_CHECK_LAUNCH();
+        return MTL_OK;
+    };
+    return dispatch_nv<false>(d, go);
+}

@@ -1,0 +1,416 @@
+"""Raw wrappers over the C-ABI (tensors in, tensors out) and the torch.autograd.Function ops built on them.
+
+PyTorch here is plumbing only: device memory (caching allocator), the current stream and autograd bookkeeping.
+All device arithmetic of the hot path runs in libmedtsllm_hip.so; nothing in this file falls back to ATen math for
+a kernel that failed to load — `_native.lib()` raises instead.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _native as N
+from ._native import ptr, stream, check, lib
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def pad64(n):
+    return (int(n) + 63) // 64 * 64
+
+
+def _dt(t):
+    return N.MTL_BF16 if t.dtype == BF16 else N.MTL_F32
+
+
+def _req(cond, msg):
+    if not cond:
+        raise ValueError(msg)
+
+
+# =============================================================================================== raw wrappers
+def gemm_nt(A, B, out=None, out_dtype=BF16, bias=None, epilogue=N.EPI_STORE, aux_in=None, aux_out=None, alpha=1.0,
+            split_k=1, M=None, a_rows=None, c_rows=None):
+    """C[M,N] = epi(alpha * A[M,K] @ B[N,K]^T + bias). A, B bf16 with unit inner stride, K % 64 == 0."""
+    _req(A.dtype == BF16 and B.dtype == BF16 and A.dim() == 2 and B.dim() == 2, "gemm_nt: bf16 2-D operands")
+    _req(A.stride(1) == 1 and B.stride(1) == 1 and A.shape[1] == B.shape[1], "gemm_nt: K mismatch / inner stride")
+    K, Nn = A.shape[1], B.shape[0]
+    M = A.shape[0] if M is None else M
+    if out is None:
+        out = torch.empty((M, Nn), dtype=out_dtype, device=A.device)
+    g = N.GemmArgs()
+    g.A, g.lda, g.B, g.ldb = A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0)
+    g.C, g.ldc, g.c_dtype = out.data_ptr(), out.stride(0), _dt(out)
+    g.M, g.N, g.K = M, Nn, K
+    if a_rows is not None:
+        g.a_group_rows, g.a_group_stride, g.a_row_offset = a_rows
+    if c_rows is not None:
+        g.c_group_rows, g.c_group_stride, g.c_row_offset = c_rows
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.epilogue = epilogue
+    if aux_in is not None:
+        g.aux_in, g.ld_aux_in = aux_in.data_ptr(), aux_in.stride(0)
+    if aux_out is not None:
+        g.aux_out, g.ld_aux_out = aux_out.data_ptr(), aux_out.stride(0)
+    g.alpha, g.split_k = alpha, split_k
+    ws = None
+    if split_k > 1:
+        nbytes = lib().mtl_gemm_workspace_bytes(M, Nn, split_k)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=A.device)
+        g.workspace, g.workspace_bytes = ws.data_ptr(), nbytes
+    check(lib().mtl_gemm_nt(C.byref(g), stream()), "mtl_gemm_nt")
+    return out
+
+
+def cast_pad(src, ld_dst=None, want_t=False, ld_dst_t=None, dst=None, dst_t=None):
+    """f32 [R, Cc] -> bf16 [R, ld_dst] (zero padded) and optionally the transpose bf16 [Cc, ld_dst_t]."""
+    _req(src.dtype == F32 and src.dim() == 2 and src.stride(1) == 1, "cast_pad: f32 2-D")
+    R, Cc = src.shape
+    ld_dst = Cc if ld_dst is None else ld_dst
+    if dst is None:
+        dst = torch.empty((R, ld_dst), dtype=BF16, device=src.device)
+    if want_t and dst_t is None:
+        ld_dst_t = R if ld_dst_t is None else ld_dst_t
+        dst_t = torch.empty((Cc, ld_dst_t), dtype=BF16, device=src.device)
+    check(lib().mtl_cast_pad_f32_bf16(ptr(src), src.stride(0), ptr(dst), dst.stride(0), ptr(dst_t),
+                                      dst_t.stride(0) if dst_t is not None else 0, R, Cc, stream()), "mtl_cast_pad_f32_bf16")
+    return (dst, dst_t) if (want_t or dst_t is not None) else dst
+
+
+def transpose_bf16(src, ld_dst=None):
+    """bf16 [R, Cc] -> bf16 [Cc, ld_dst] with zero padding of columns >= R."""
+    _req(src.dtype == BF16 and src.dim() == 2 and src.stride(1) == 1, "transpose_bf16: bf16 2-D")
+    R, Cc = src.shape
+    ld_dst = R if ld_dst is None else ld_dst
+    dst = torch.empty((Cc, ld_dst), dtype=BF16, device=src.device)
+    check(lib().mtl_transpose_bf16(ptr(src), src.stride(0), ptr(dst), ld_dst, R, Cc, stream()), "mtl_transpose_bf16")
+    return dst
+
+
+def to_bf16(x):
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    check(lib().mtl_cast_f32_to_bf16(ptr(x), ptr(out), x.numel(), stream()), "mtl_cast_f32_to_bf16")
+    return out
+
+
+def to_f32(x):
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=F32, device=x.device)
+    check(lib().mtl_cast_bf16_to_f32(ptr(x), ptr(out), x.numel(), stream()), "mtl_cast_bf16_to_f32")
+    return out
+
+
+def colsum(x):
+    _req(x.dtype == BF16 and x.dim() == 2 and x.stride(1) == 1, "colsum: bf16 2-D")
+    out = torch.empty(x.shape[1], dtype=F32, device=x.device)
+    check(lib().mtl_colsum_bf16(ptr(x), x.stride(0), ptr(out), x.shape[0], x.shape[1], stream()), "mtl_colsum_bf16")
+    return out
+
+
+def patch_index_map(L, patch_len, stride, device):
+    P = (L + stride - patch_len) // stride + 1
+    idx = torch.empty((P, patch_len), dtype=torch.int32, device=device)
+    check(lib().mtl_patch_index_map(ptr(idx), L, patch_len, stride, stream()), "mtl_patch_index_map")
+    return idx
+
+
+def patch_tokenize_fwd(x, conv_w, patch_len, stride, concat, eps=1e-5):
+    B, L, Cc = x.shape
+    d_patch = conv_w.shape[0]
+    P = (L + stride - patch_len) // stride + 1
+    width = Cc * d_patch if concat else d_patch
+    ld = pad64(width)
+    rows = B if concat else B * Cc
+    out = torch.empty((rows, P, ld), dtype=BF16, device=x.device)
+    mean = torch.empty((B, Cc), dtype=F32, device=x.device)
+    stdev = torch.empty((B, Cc), dtype=F32, device=x.device)
+    check(lib().mtl_patch_tokenize_fwd(ptr(x), ptr(conv_w), ptr(out), ptr(mean), ptr(stdev), B, L, Cc, patch_len, stride,
+                                       d_patch, ld, 1 if concat else 0, eps, stream()), "mtl_patch_tokenize_fwd")
+    return out, mean, stdev
+
+
+def patch_tokenize_bwd(x, mean, stdev, dout, conv_w_shape, patch_len, stride, concat):
+    B, L, Cc = x.shape
+    d_patch = conv_w_shape[0]
+    nw = d_patch * patch_len * 3
+    partial = torch.empty((B * Cc, nw), dtype=F32, device=x.device)
+    dw = torch.empty(conv_w_shape, dtype=F32, device=x.device)
+    check(lib().mtl_patch_tokenize_bwd(ptr(x), ptr(mean), ptr(stdev), ptr(dout), ptr(partial), ptr(dw), B, L, Cc, patch_len,
+                                       stride, d_patch, dout.shape[-1], 1 if concat else 0, stream()), "mtl_patch_tokenize_bwd")
+    return dw
+
+
+def revin_denorm(y, mean, stdev):
+    """y f32 [B,T,C]; mean None -> multiply by stdev only (the backward)."""
+    y = y.contiguous()
+    B, T, Cc = y.shape
+    out = torch.empty_like(y)
+    check(lib().mtl_revin_denorm(ptr(y), ptr(mean), ptr(stdev), ptr(out), B, T, Cc, stream()), "mtl_revin_denorm")
+    return out
+
+
+def _attn_fwd_args(q, k, v, o, lse, B, Hq, Hkv, Tq, Tk, D, scale, causal, qs, ks, vs, os_):
+    a = N.AttnFwdArgs()
+    a.q, (a.q_bs, a.q_ts, a.q_hs) = q.data_ptr(), qs
+    a.k, (a.k_bs, a.k_ts, a.k_hs) = k.data_ptr(), ks
+    a.v, (a.v_bs, a.v_ts, a.v_hs) = v.data_ptr(), vs
+    a.o, (a.o_bs, a.o_ts, a.o_hs) = o.data_ptr(), os_
+    a.lse = lse.data_ptr()
+    a.B, a.Hq, a.Hkv, a.Tq, a.Tk, a.D = B, Hq, Hkv, Tq, Tk, D
+    a.scale, a.causal = scale, 1 if causal else 0
+    return a
+
+
+def attention_fwd(q, k, v, Hq, Hkv, D, scale, causal, shared_kv=False):
+    """q [B,Tq,Hq*D] bf16; k, v [B,Tk,Hkv*D] (or [Tk,Hkv*D] when shared_kv). Views with unit inner stride allowed."""
+    B, Tq = q.shape[0], q.shape[1]
+    Tk = k.shape[-2]
+    o = torch.empty((B, Tq, Hq * D), dtype=BF16, device=q.device)
+    lse = torch.empty((B, Hq, Tq), dtype=F32, device=q.device)
+    ks = (0, k.stride(-2), D) if shared_kv else (k.stride(0), k.stride(1), D)
+    vs = (0, v.stride(-2), D) if shared_kv else (v.stride(0), v.stride(1), D)
+    a = _attn_fwd_args(q, k, v, o, lse, B, Hq, Hkv, Tq, Tk, D, scale, causal, (q.stride(0), q.stride(1), D), ks, vs,
+                       (o.stride(0), o.stride(1), D))
+    check(lib().mtl_attention_fwd(C.byref(a), stream()), "mtl_attention_fwd")
+    return o, lse
+
+
+def attention_bwd(q, k, v, o, lse, dout, Hq, Hkv, D, scale, causal, shared_kv=False):
+    B, Tq = q.shape[0], q.shape[1]
+    Tk = k.shape[-2]
+    dout = dout.contiguous()
+    dq = torch.empty((B, Tq, Hq * D), dtype=BF16, device=q.device)
+    dk = torch.empty(k.shape, dtype=BF16, device=q.device)
+    dv = torch.empty(v.shape, dtype=BF16, device=q.device)
+    delta = torch.empty((B, Hq, Tq), dtype=F32, device=q.device)
+    ks = (0, k.stride(-2), D) if shared_kv else (k.stride(0), k.stride(1), D)
+    vs = (0, v.stride(-2), D) if shared_kv else (v.stride(0), v.stride(1), D)
+    b = N.AttnBwdArgs()
+    b.f = _attn_fwd_args(q, k, v, o, lse, B, Hq, Hkv, Tq, Tk, D, scale, causal, (q.stride(0), q.stride(1), D), ks, vs,
+                         (o.stride(0), o.stride(1), D))
+    b.dout, (b.do_bs, b.do_ts, b.do_hs) = dout.data_ptr(), (dout.stride(0), dout.stride(1), D)
+    b.dq, (b.dq_bs, b.dq_ts, b.dq_hs) = dq.data_ptr(), (dq.stride(0), dq.stride(1), D)
+    dks = (0, dk.stride(-2), D) if shared_kv else (dk.stride(0), dk.stride(1), D)
+    b.dk, (b.dk_bs, b.dk_ts, b.dk_hs) = dk.data_ptr(), dks
+    b.dv, (b.dv_bs, b.dv_ts, b.dv_hs) = dv.data_ptr(), dks
+    b.delta = delta.data_ptr()
+    check(lib().mtl_attention_bwd(C.byref(b), stream()), "mtl_attention_bwd")
+    return dq, dk, dv
+
+
+def norm_fwd(x, gamma, beta, eps, rms=False, rows=None, M=None):
+    """x f32 [Mx, d] -> y bf16 [M, d], stats f32 [M, 2]. rows=(group_rows, group_stride, row_offset) gathers."""
+    d = x.shape[-1]
+    M = x.shape[0] if M is None else M
+    y = torch.empty((M, d), dtype=BF16, device=x.device)
+    stats = torch.empty((M, 2), dtype=F32, device=x.device)
+    gr, gs, ro = rows if rows is not None else (0, 0, 0)
+    check(lib().mtl_norm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), d, ptr(stats), M, d, eps, 1 if rms else 0, gr, gs, ro,
+                             stream()), "mtl_norm_fwd")
+    return y, stats
+
+
+def norm_bwd(dy, x, gamma, stats, dres_in=None, rms=False, rows=None, want_bf16=False, dres_out=None):
+    d = x.shape[-1]
+    M = dy.shape[0]
+    if dres_out is None:
+        dres_out = torch.zeros_like(x) if rows is not None else torch.empty_like(x)
+    dres_b = (torch.zeros(x.shape, dtype=BF16, device=x.device) if rows is not None
+              else torch.empty(x.shape, dtype=BF16, device=x.device)) if want_bf16 else None
+    gr, gs, ro = rows if rows is not None else (0, 0, 0)
+    check(lib().mtl_norm_bwd(ptr(dy), dy.stride(0), ptr(x), ptr(gamma), ptr(stats), ptr(dres_in), ptr(dres_out), ptr(dres_b),
+                             M, d, 1 if rms else 0, gr, gs, ro, stream()), "mtl_norm_bwd")
+    return (dres_out, dres_b) if want_bf16 else dres_out
+
+
+def rope_inplace(qkv, cos, sin, T, n_rot_heads, D, inverse=False):
+    M = qkv.shape[0]
+    check(lib().mtl_rope_inplace(ptr(qkv), qkv.stride(0), ptr(cos), ptr(sin), M, T, n_rot_heads, D, 1 if inverse else 0,
+                                 stream()), "mtl_rope_inplace")
+    return qkv
+
+
+def swiglu_fwd(gu):
+    M, F2 = gu.shape
+    h = torch.empty((M, F2 // 2), dtype=BF16, device=gu.device)
+    check(lib().mtl_swiglu_fwd(ptr(gu), ptr(h), M, F2 // 2, stream()), "mtl_swiglu_fwd")
+    return h
+
+
+def swiglu_bwd(gu, dh):
+    M, F2 = gu.shape
+    dgu = torch.empty_like(gu)
+    check(lib().mtl_swiglu_bwd(ptr(gu), ptr(dh), ptr(dgu), M, F2 // 2, stream()), "mtl_swiglu_bwd")
+    return dgu
+
+
+def assemble_llm_input(ids, embed, x_tok, wpe):
+    B, P, d = x_tok.shape
+    n_tok = 0 if ids is None else ids.shape[1]
+    h0 = torch.empty((B, n_tok + P, d), dtype=F32, device=x_tok.device)
+    check(lib().mtl_assemble_llm_input(ptr(ids), 0 if ids is None else ids.shape[0], ptr(embed), ptr(x_tok), ptr(wpe), ptr(h0),
+                                       B, n_tok, P, d, stream()), "mtl_assemble_llm_input")
+    return h0
+
+
+# =============================================================================================== autograd ops
+class PatchTokenizeFn(torch.autograd.Function):
+    """(x_enc f32 [B,L,C], conv_w) -> (tokens bf16 [B or B*C, P, K64], mean [B,C], stdev [B,C]).  a1-a4."""
+
+    @staticmethod
+    def forward(ctx, x, conv_w, patch_len, stride, concat):
+        x = x.contiguous().float()
+        w = conv_w.detach().contiguous().float()
+        out, mean, stdev = patch_tokenize_fwd(x, w, patch_len, stride, concat)
+        ctx.save_for_backward(x, mean, stdev)
+        ctx.meta = (tuple(conv_w.shape), patch_len, stride, concat)
+        ctx.mark_non_differentiable(mean, stdev)
+        return out, mean, stdev
+
+    @staticmethod
+    def backward(ctx, dout, _dm, _ds):
+        x, mean, stdev = ctx.saved_tensors
+        shape, patch_len, stride, concat = ctx.meta
+        dw = patch_tokenize_bwd(x, mean, stdev, dout.contiguous(), shape, patch_len, stride, concat)
+        return None, dw, None, None, None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x @ W^T + b with bf16 MFMA GEMMs. x bf16 [..., Kx] (Kx % 64 == 0, Kx >= W.shape[1], extra cols zero);
+    W f32 [N, Kin] master weight (cast to bf16 per call, as autocast does); y bf16 [..., N]."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        Kx = x.shape[-1]
+        Nn, Kin = W.shape
+        _req(x.dtype == BF16 and Kx % 64 == 0 and Kx >= Kin, "LinearFn: x must be bf16 with K padded to 64")
+        x2 = x.reshape(-1, Kx)
+        if x2.stride(1) != 1 or x2.stride(0) % 8 != 0:
+            x2 = x2.contiguous()
+        Np = pad64(Nn)
+        Wd = W.detach().contiguous().float()
+        wb = torch.empty((Nn, Kx), dtype=BF16, device=x.device)
+        wt = torch.zeros((Kx, Np), dtype=BF16, device=x.device) if (Kx > Kin) else torch.empty((Kx, Np), dtype=BF16, device=x.device)
+        cast_pad(Wd, dst=wb, dst_t=wt)
+        y = gemm_nt(x2, wb, bias=None if b is None else b.detach().float().contiguous())
+        ctx.save_for_backward(x2, wt)
+        ctx.meta = (tuple(x.shape), Nn, Kin, b is not None)
+        return y.reshape(*x.shape[:-1], Nn)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wt = ctx.saved_tensors
+        xshape, Nn, Kin, has_b = ctx.meta
+        M, Kx = x2.shape
+        Np = wt.shape[1]
+        dy2 = dy.reshape(M, Nn)
+        if dy2.dtype != BF16:
+            dy2 = dy2.to(BF16)
+        dy2 = dy2.contiguous()
+        dyp = dy2 if Np == Nn else torch.nn.functional.pad(dy2, (0, Np - Nn))
+        dx = gemm_nt(dyp, wt).reshape(xshape) if ctx.needs_input_grad[0] else None
+        dW = None
+        if ctx.needs_input_grad[1]:
+            Mp = pad64(M)
+            dyT = transpose_bf16(dy2, Mp)            # [N, Mp]
+            xT = transpose_bf16(x2[:, :Kin] if Kin != Kx else x2, Mp)  # [Kin, Mp]
+            dW = gemm_nt(dyT, xT, out_dtype=F32)     # [N, Kin] fp32
+        db = colsum(dy2) if (has_b and ctx.needs_input_grad[2]) else None
+        return dx, dW, db
+
+
+class MappingFn(torch.autograd.Function):
+    """source[S, d] = Wmap[S, V] @ Wemb[V, d] + b[:, None]   (R:models/medtsllm.py:281), batch independent.
+
+    The bias rides in the K padding: column V of the bf16 Wmap copy holds b and row V of Wemb^T holds ones.
+    `emb` = FrozenEmbedding-like object with .wT bf16 [d, Vp] (ones at column V) and .w bf16 [V, d]."""
+
+    @staticmethod
+    def forward(ctx, Wmap, b, wT, w, split_k):
+        S, V = Wmap.shape
+        Vp = wT.shape[1]
+        wm = torch.empty((S, Vp), dtype=BF16, device=Wmap.device)
+        cast_pad(Wmap.detach().contiguous().float(), dst=wm)
+        wm[:, V] = b.detach().to(BF16)
+        src = gemm_nt(wm, wT, split_k=split_k)
+        ctx.save_for_backward(w)
+        ctx.meta = (S, V)
+        return src
+
+    @staticmethod
+    def backward(ctx, dsrc):
+        (w,) = ctx.saved_tensors
+        S, V = ctx.meta
+        dsrc = dsrc.contiguous()
+        dW = gemm_nt(dsrc, w, out_dtype=F32) if ctx.needs_input_grad[0] else None   # [S, V] = dsrc[S,d] @ Wemb[V,d]^T
+        db = colsum(transpose_bf16(dsrc)) if ctx.needs_input_grad[1] else None       # row sums of dsrc
+        return dW, db, None, None, None
+
+
+class CrossAttnFn(torch.autograd.Function):
+    """Reprogramming attention (R:models/medtsllm.py:581-591): q [B,L,H*E], k/v [S,H*E] shared by every sample."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, H, E):
+        scale = 1.0 / math.sqrt(E)
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        o, lse = attention_fwd(q, k, v, H, H, E, scale, causal=False, shared_kv=True)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.meta = (H, E, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        H, E, scale = ctx.meta
+        dq, dk, dv = attention_bwd(q, k, v, o, lse, do, H, H, E, scale, causal=False, shared_kv=True)
+        return dq, dk, dv, None, None
+
+
+class AssembleFn(torch.autograd.Function):
+    """h0 = cat[embed[ids], x_tok] (+ wpe) in fp32 (R:models/medtsllm.py:331-337,349; HF gpt2 :576-577)."""
+
+    @staticmethod
+    def forward(ctx, x_tok, ids, embed, wpe):
+        h0 = assemble_llm_input(ids, embed, x_tok.contiguous(), wpe)
+        ctx.n_tok = 0 if ids is None else ids.shape[1]
+        return h0
+
+    @staticmethod
+    def backward(ctx, dh0):
+        return to_bf16(dh0[:, ctx.n_tok:, :]), None, None, None
+
+
+class BackboneFn(torch.autograd.Function):
+    """Frozen decoder stack (R:models/medtsllm.py:350) fwd + activation-gradient-only bwd, one C call each."""
+
+    @staticmethod
+    def forward(ctx, h0, backbone, n_last):
+        h0 = h0.contiguous()
+        out, saved = backbone.run_forward(h0, n_last, keep=ctx.needs_input_grad[0])
+        ctx.backbone, ctx.n_last, ctx.saved = backbone, n_last, saved
+        ctx.save_for_backward(h0)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (h0,) = ctx.saved_tensors
+        dh0 = ctx.backbone.run_backward(h0, dout.contiguous(), ctx.saved, ctx.n_last)
+        ctx.saved = None
+        return dh0, None, None
+
+
+class RevinDenormFn(torch.autograd.Function):
+    """y * stdev + mean (R:models/layers/RevIN.py:58-69); statistics are detached constants."""
+
+    @staticmethod
+    def forward(ctx, y, mean, stdev):
+        ctx.save_for_backward(stdev)
+        ctx.in_dtype = y.dtype
+        return revin_denorm(y.float(), mean, stdev)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (stdev,) = ctx.saved_tensors
+        return revin_denorm(dout.float(), None, stdev).to(ctx.in_dtype), None, None

@@ -1,0 +1,217 @@
+"""Frozen GPT-2 / Llama backbone for the HIP path: weight preparation (once) + the two C-ABI stack calls.
+
+Replaces `AutoModel.from_pretrained(...)` + `self.llm(inputs_embeds=...)` of the reference
+(R:models/medtsllm.py:175-185,350). Weights come from a HuggingFace-format directory (config.json +
+*.safetensors, read with `safetensors` directly) or from an in-memory state dict (random init for benchmarks).
+
+HBM layout (prepared once, the backbone is frozen — R:models/medtsllm.py:231-233):
+  per layer bf16 [out, in] row-major weights for the forward NT GEMMs AND their transposes [in, out] for the
+  activation-gradient GEMMs (2x weight memory, trivially affordable in 288 GB; no per-step transposes);
+  q/k/v fused into one [(Hq+2Hkv)*hd, d] matrix, Llama gate/up fused into [2*ffn, d];
+  fp32 norm parameters / biases; fp32 embedding table (prompt gather) + bf16 [d, Vp] transposed table
+  (mapping GEMM operand, bias-carrier ones in column V) + bf16 [V, d] (mapping dW operand).
+"""
+import ctypes as C
+import json
+import os
+
+import torch
+
+from ..hip import _native as N
+from ..hip import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def load_hf_dir(path):
+    """(config dict, state dict of CPU tensors) from a HuggingFace-format directory."""
+    from safetensors.torch import load_file
+    with open(os.path.join(path, "config.json")) as f:
+        cfg = json.load(f)
+    sd = {}
+    files = sorted(fn for fn in os.listdir(path) if fn.endswith(".safetensors"))
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors under {path}")
+    for fn in files:
+        sd.update(load_file(os.path.join(path, fn)))
+    sd = {(k[len("model."):] if k.startswith("model.") else k[len("transformer."):] if k.startswith("transformer.") else k): v
+          for k, v in sd.items()}
+    return cfg, sd
+
+
+def normalise_config(cfg):
+    """Common view over GPT2Config / LlamaConfig json (SURVEY.md Appendix B constants)."""
+    mt = cfg["model_type"]
+    if mt == "gpt2":
+        d, H = cfg["n_embd"], cfg["n_head"]
+        return dict(arch="gpt2", n_layers=cfg["n_layer"], d=d, n_heads=H, n_kv_heads=H, head_dim=d // H,
+                    ffn=cfg.get("n_inner") or 4 * d, eps=cfg.get("layer_norm_epsilon", 1e-5), vocab=cfg["vocab_size"],
+                    n_positions=cfg.get("n_positions", 1024))
+    if mt == "llama":
+        d, H = cfg["hidden_size"], cfg["num_attention_heads"]
+        theta = cfg.get("rope_theta")
+        if theta is None:
+            theta = (cfg.get("rope_parameters") or {}).get("rope_theta", 10000.0)
+        return dict(arch="llama", n_layers=cfg["num_hidden_layers"], d=d, n_heads=H,
+                    n_kv_heads=cfg.get("num_key_value_heads") or H, head_dim=cfg.get("head_dim") or d // H,
+                    ffn=cfg["intermediate_size"], eps=cfg.get("rms_norm_eps", 1e-6), vocab=cfg["vocab_size"],
+                    rope_theta=float(theta))
+    raise ValueError(f"unsupported backbone model_type {mt!r} (HIP path implements gpt2 and llama)")
+
+
+class FrozenBackbone:
+    """Device-resident frozen stack. Not an nn.Module on purpose: nothing here is a parameter of the trainer."""
+
+    def __init__(self, cfg, state_dict, device, n_layers=-1):
+        self.cfg = c = normalise_config(cfg)
+        if 0 < n_layers < c["n_layers"]:     # R:models/medtsllm.py:145-146 (llm_layers)
+            c["n_layers"] = n_layers
+        self.device = torch.device(device)
+        self.arch = c["arch"]
+        L, d = c["n_layers"], c["d"]
+        sd = state_dict
+        dev = self.device
+
+        def bf(t):
+            return t.to(dev, BF16).contiguous()
+
+        def f32(t):
+            return t.to(dev, F32).contiguous()
+
+        k = {n: [] for n in ("w_qkv", "w_qkv_t", "b_qkv", "w_o", "w_o_t", "b_o", "w_fc", "w_fc_t", "b_fc", "w_proj", "w_proj_t",
+                             "b_proj", "ln1_w", "ln1_b", "ln2_w", "ln2_b")}
+        for i in range(L):
+            if self.arch == "gpt2":
+                p = f"h.{i}."
+                # HF Conv1D stores [in, out]  (HF:pytorch_utils.py:117-121): that IS the transposed copy
+                for name, key in (("qkv", "attn.c_attn"), ("o", "attn.c_proj"), ("fc", "mlp.c_fc"), ("proj", "mlp.c_proj")):
+                    w_io = sd[p + key + ".weight"]
+                    k["w_" + name + "_t"].append(bf(w_io))
+                    k["w_" + name].append(bf(w_io.t()))
+                    k["b_" + name].append(f32(sd[p + key + ".bias"]))
+                k["ln1_w"].append(f32(sd[p + "ln_1.weight"])); k["ln1_b"].append(f32(sd[p + "ln_1.bias"]))
+                k["ln2_w"].append(f32(sd[p + "ln_2.weight"])); k["ln2_b"].append(f32(sd[p + "ln_2.bias"]))
+            else:
+                p = f"layers.{i}."
+                wq = torch.cat([sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.v_proj.weight"]], 0)
+                wg = torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 0)
+                for name, w_oi in (("qkv", wq), ("o", sd[p + "self_attn.o_proj.weight"]), ("fc", wg), ("proj", sd[p + "mlp.down_proj.weight"])):
+                    k["w_" + name].append(bf(w_oi))
+                    k["w_" + name + "_t"].append(bf(w_oi.t()))
+                k["ln1_w"].append(f32(sd[p + "input_layernorm.weight"]))
+                k["ln2_w"].append(f32(sd[p + "post_attention_layernorm.weight"]))
+        self._t = k
+        if self.arch == "gpt2":
+            self.lnf_w, self.lnf_b = f32(sd["ln_f.weight"]), f32(sd["ln_f.bias"])
+            self.wpe = f32(sd["wpe.weight"])
+            emb = sd["wte.weight"]
+            self.rope = None
+        else:
+            self.lnf_w, self.lnf_b = f32(sd["norm.weight"]), None
+            self.wpe = None
+            emb = sd["embed_tokens.weight"]
+            self.rope = {}
+        self.embed_f32 = f32(emb)            # [V_full, d] prompt-token gather table
+        self._arrays = {n: _ptr_array(v) for n, v in k.items() if v}
+        self._structs = {}
+
+    # ---- RoPE tables (HF:models/llama/modeling_llama.py:113-127), fp32, cached per T
+    def _rope(self, T):
+        if T not in self.rope:
+            hd, theta = self.cfg["head_dim"], self.cfg["rope_theta"]
+            inv_freq = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.int64).float() / hd))
+            freqs = torch.arange(T).float().unsqueeze(1) * inv_freq.unsqueeze(0)
+            emb = torch.cat([freqs, freqs], dim=-1)
+            self.rope[T] = (emb.cos().to(self.device).contiguous(), emb.sin().to(self.device).contiguous())
+        return self.rope[T]
+
+    def _struct(self, T):
+        if T in self._structs:
+            return self._structs[T]
+        c = self.cfg
+        w = N.BackboneWeights()
+        w.arch = N.ARCH_GPT2 if self.arch == "gpt2" else N.ARCH_LLAMA
+        w.n_layers, w.d, w.n_heads, w.n_kv_heads = c["n_layers"], c["d"], c["n_heads"], c["n_kv_heads"]
+        w.head_dim, w.ffn, w.eps = c["head_dim"], c["ffn"], c["eps"]
+        for n in ("w_qkv", "w_qkv_t", "b_qkv", "w_o", "w_o_t", "b_o", "w_fc", "w_fc_t", "b_fc", "w_proj", "w_proj_t", "b_proj",
+                  "ln1_w", "ln1_b", "ln2_w", "ln2_b"):
+            if n in self._arrays:
+                setattr(w, n, C.cast(self._arrays[n], N.PP))
+        w.lnf_w = self.lnf_w.data_ptr()
+        w.lnf_b = self.lnf_b.data_ptr() if self.lnf_b is not None else None
+        if self.arch == "llama":
+            cos, sin = self._rope(T)
+            w.rope_cos, w.rope_sin = cos.data_ptr(), sin.data_ptr()
+        self._structs[T] = w
+        return w
+
+    def run_forward(self, h0, n_last, keep=True):
+        """h0 f32 [B,T,d] (wpe already added for GPT-2) -> (out bf16 [B,n_last,d], saved buffer)."""
+        B, T, d = h0.shape
+        if self.arch == "gpt2" and T > self.cfg["n_positions"]:
+            raise ValueError(f"sequence length {T} exceeds GPT-2's {self.cfg['n_positions']} learned positions")
+        w = self._struct(T)
+        lib = N.lib()
+        saved = torch.empty(lib.mtl_backbone_saved_bytes(C.byref(w), B, T), dtype=torch.uint8, device=h0.device)
+        work = torch.empty(lib.mtl_backbone_work_bytes(C.byref(w), B, T), dtype=torch.uint8, device=h0.device)
+        out = torch.empty((B, n_last, d), dtype=BF16, device=h0.device)
+        N.check(lib.mtl_backbone_fwd(C.byref(w), N.ptr(h0), N.ptr(out), N.ptr(saved), N.ptr(work), B, T, n_last, N.stream()),
+                "mtl_backbone_fwd")
+        return out, (saved if keep else None)
+
+    def run_backward(self, h0, dout, saved, n_last):
+        B, T, d = h0.shape
+        if saved is None:
+            raise RuntimeError("backbone backward without saved activations (forward ran under no_grad)")
+        w = self._struct(T)
+        lib = N.lib()
+        work = torch.empty(lib.mtl_backbone_work_bytes(C.byref(w), B, T), dtype=torch.uint8, device=h0.device)
+        dh0 = torch.empty_like(h0)
+        N.check(lib.mtl_backbone_bwd(C.byref(w), N.ptr(h0), N.ptr(dout), N.ptr(dh0), N.ptr(saved), N.ptr(work), B, T, n_last,
+                                     N.stream()), "mtl_backbone_bwd")
+        return dh0
+
+    def state_tensors(self):
+        return self._t
+
+
+def random_state_dict(cfg, seed=0, std=0.02):
+    """Seeded random-init weights of the given architecture (bench / tests: no checkpoints are downloadable)."""
+    c = normalise_config(cfg)
+    g = torch.Generator().manual_seed(seed)
+
+    def rn(*shape, s=std):
+        return torch.randn(*shape, generator=g) * s
+
+    sd = {}
+    d, L, ffn = c["d"], c["n_layers"], c["ffn"]
+    if c["arch"] == "gpt2":
+        sd["wte.weight"] = rn(c["vocab"], d)
+        sd["wpe.weight"] = rn(c["n_positions"], d, s=0.01)
+        for i in range(L):
+            p = f"h.{i}."
+            sd[p + "ln_1.weight"] = 1 + rn(d, s=0.05); sd[p + "ln_1.bias"] = rn(d)
+            sd[p + "attn.c_attn.weight"] = rn(d, 3 * d); sd[p + "attn.c_attn.bias"] = rn(3 * d)
+            sd[p + "attn.c_proj.weight"] = rn(d, d); sd[p + "attn.c_proj.bias"] = rn(d)
+            sd[p + "ln_2.weight"] = 1 + rn(d, s=0.05); sd[p + "ln_2.bias"] = rn(d)
+            sd[p + "mlp.c_fc.weight"] = rn(d, ffn); sd[p + "mlp.c_fc.bias"] = rn(ffn)
+            sd[p + "mlp.c_proj.weight"] = rn(ffn, d); sd[p + "mlp.c_proj.bias"] = rn(d)
+        sd["ln_f.weight"] = 1 + rn(d, s=0.05); sd["ln_f.bias"] = rn(d)
+    else:
+        H, Hkv, hd = c["n_heads"], c["n_kv_heads"], c["head_dim"]
+        sd["embed_tokens.weight"] = rn(c["vocab"], d)
+        for i in range(L):
+            p = f"layers.{i}."
+            sd[p + "input_layernorm.weight"] = 1 + rn(d, s=0.05)
+            sd[p + "self_attn.q_proj.weight"] = rn(H * hd, d); sd[p + "self_attn.k_proj.weight"] = rn(Hkv * hd, d)
+            sd[p + "self_attn.v_proj.weight"] = rn(Hkv * hd, d); sd[p + "self_attn.o_proj.weight"] = rn(d, H * hd)
+            sd[p + "post_attention_layernorm.weight"] = 1 + rn(d, s=0.05)
+            sd[p + "mlp.gate_proj.weight"] = rn(ffn, d); sd[p + "mlp.up_proj.weight"] = rn(ffn, d)
+            sd[p + "mlp.down_proj.weight"] = rn(d, ffn)
+        sd["norm.weight"] = 1 + rn(d, s=0.05)
+    return sd

@@ -1,0 +1,321 @@
+"""Drop-in `MedTsLLM` for the reference's plugin surface, running on the gfx950 HIP path.
+
+Mirrors R:models/medtsllm.py: same constructor `(config, dataset)`, same derived sizes, same trainable parameter
+names / shapes (checkpoints interchange), same `forward(dict) -> Tensor`, `state_dict()` filtering and
+`load_pretrained`. The arithmetic does not go through ATen/HF: every device op is a kernel of
+libmedtsllm_hip.so (see hip/ops.py); there is no CPU fallback — forward on a non-ROCm device raises.
+
+Numerics follow the reference's default `setup.dtype = "mixed"`: fp32 master weights and fp32 residual stream,
+bf16 GEMM/attention operands with fp32 accumulation, fp32 norm/softmax statistics.
+"""
+import math
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..hip import ops
+from ..hip.ops import (PatchTokenizeFn, LinearFn, MappingFn, CrossAttnFn, AssembleFn, BackboneFn, RevinDenormFn, pad64)
+from . import prompt as P
+from .backbone import FrozenBackbone, load_hf_dir, normalise_config
+
+BF16 = torch.bfloat16
+
+FORECAST_LIKE = ("forecasting", "reconstruction", "anomaly_detection", "pretraining")
+
+
+class _TokenEmbedding(nn.Module):
+    """Parameter holder named like R:models/layers/embed.py:29-42 (Conv1d weight [d_model, patch_len, 3], kaiming init)."""
+
+    def __init__(self, c_in, d_model):
+        super().__init__()
+        self.tokenConv = nn.Conv1d(c_in, d_model, kernel_size=3, padding=1, padding_mode="circular", bias=False)
+        nn.init.kaiming_normal_(self.tokenConv.weight, mode="fan_in", nonlinearity="leaky_relu")
+
+
+class _PatchEmbedding(nn.Module):
+    def __init__(self, d_model, patch_len, stride, dropout):
+        super().__init__()
+        self.patch_len, self.stride, self.p = patch_len, stride, dropout
+        self.value_embedding = _TokenEmbedding(patch_len, d_model)
+
+
+class _ReprogrammingLayer(nn.Module):
+    """Parameter holder named like R:models/medtsllm.py:555-564."""
+
+    def __init__(self, d_model, n_heads, d_keys, d_llm):
+        super().__init__()
+        self.query_projection = nn.Linear(d_model, d_keys * n_heads)
+        self.key_projection = nn.Linear(d_llm, d_keys * n_heads)
+        self.value_projection = nn.Linear(d_llm, d_keys * n_heads)
+        self.out_projection = nn.Linear(d_keys * n_heads, d_llm)
+        self.n_heads = n_heads
+
+
+class _FlattenHead(nn.Module):
+    def __init__(self, nf, target_window):
+        super().__init__()
+        self.linear = nn.Linear(nf, target_window)
+
+
+class MedTsLLM(nn.Module):
+
+    supported_tasks = ["forecasting", "reconstruction", "anomaly_detection", "semantic_segmentation", "segmentation", "pretraining"]
+    supported_modes = ["univariate", "multivariate"]
+
+    def __init__(self, config, dataset, backbone_state=None):
+        """`backbone_state=(hf_config_dict, state_dict)` bypasses the on-disk HF directory (benchmarks, tests)."""
+        super().__init__()
+        self.config = config
+        self.model_config = config.models.medtsllm if "medtsllm" in config.models else config.models.timellm
+        mc = self.model_config
+        self.device = None
+        self.pred_len, self.seq_len = config.pred_len, config.history_len
+        self.task = config.task
+        self.task_description = P.task_description(self.task, self.pred_len, self.seq_len, dataset)
+        self.dataset_description = dataset.description
+        self.d_ff, self.d_model = mc.d_ff, mc.d_model
+        self.n_attention_heads, self.num_tokens = mc.n_heads, mc.num_tokens
+        self.dropout = config.training.dropout
+        self.n_lags = P.N_LAGS
+        self.patch_len, self.stride = mc.patching.patch_len, mc.patching.stride
+        self.n_patches = int((self.seq_len - self.patch_len) / self.stride + 2)     # R:models/medtsllm.py:52
+        self.d_patch = self.d_model
+        self.covariate_mode = mc.covariate_mode
+        self.n_features = dataset.n_features
+        self.n_classes = dataset.n_classes if self.task in ["classification", "semantic_segmentation"] else 0
+
+        if self.task in FORECAST_LIKE:
+            self.n_outputs_per_step = self.n_features
+        elif self.task == "semantic_segmentation":
+            self.n_outputs_per_step = self.n_classes if self.n_classes > 2 else 1
+        elif self.task == "segmentation":
+            self.n_outputs_per_step = 1
+            assert config.tasks.segmentation.mode in ["boundary-prediction", "steps-to-boundary"]
+        else:
+            raise ValueError(f"Task {self.task} is not supported.")
+        self.n_outputs = self.n_outputs_per_step * self.pred_len
+
+        cm = self.covariate_mode
+        if cm == "univariate":
+            assert self.n_features == 1
+        elif cm == "interleave":
+            self.n_patches *= self.n_features
+        elif cm == "concat":
+            self.d_model *= self.n_features
+        elif cm == "merge-end":
+            self.feature_weighting = nn.Linear(self.n_features * self.n_outputs_per_step, self.n_outputs_per_step)
+        elif cm == "weighted-average":
+            self.feature_weighting = nn.Linear(self.n_features, 1)
+        elif cm not in ("independent", "add"):
+            raise ValueError(f"Unknown covariate mode {cm}")
+
+        self._setup_llm(backbone_state)
+
+        self.mapping_layer = nn.Linear(self.vocab_size, self.num_tokens)
+        self.patch_embedding = _PatchEmbedding(self.d_patch, self.patch_len, self.stride, self.dropout)
+        self.reprogramming_layer = _ReprogrammingLayer(self.d_model, self.n_attention_heads, self.d_ff, self.d_llm)
+        self.output_projection = _FlattenHead(self.d_ff * self.n_patches, self.n_outputs)
+        self.embedding_downsample_mode = mc.embedding_downsample_mode
+        if self.embedding_downsample_mode == "linear":
+            self.embedding_downsample_layer = nn.Linear(self.d_llm, self.d_ff)
+        elif self.embedding_downsample_mode == "average":
+            assert self.d_llm % self.d_ff == 0
+        elif self.embedding_downsample_mode != "truncate":
+            raise ValueError(f"Unknown embedding downsample mode {self.embedding_downsample_mode}")
+        if self.d_ff not in (32, 64, 128):
+            raise ValueError(f"HIP reprogramming attention supports d_ff (head dim) in 32/64/128, got {self.d_ff}")
+        self.lora_enabled = False
+        self._id_cache = {}
+        self._mask_seed = 0
+
+    # ------------------------------------------------------------------ construction (a11)
+    def _setup_llm(self, backbone_state):
+        """R:models/medtsllm.py:129-233 without HF model classes: config + safetensors -> FrozenBackbone (lazily on device)."""
+        llm = self.model_config.llm
+        if not llm.enabled:
+            raise NotImplementedError("llm.enabled = false (llm_replacement MLP) is outside the HIP hot path")
+        if llm.get("load_in_4bit", False) or llm.get("load_in_8bit", False) or ("lora" in self.model_config and self.model_config.lora.enabled):
+            raise NotImplementedError("LoRA / 4-8 bit quantised backbones are outside the HIP hot path (SURVEY.md §2 #16)")
+        self.llm_enabled, self.llm_id, self.llm_layers = True, llm.llm, llm.llm_layers
+        if backbone_state is None:
+            hf_cfg, sd = load_hf_dir(self.llm_id)
+        else:
+            hf_cfg, sd = backbone_state
+        self._hf_cfg, self._hf_state = hf_cfg, sd
+        bc = normalise_config(hf_cfg)
+        self.d_llm = bc["d"]
+        if bc["head_dim"] not in (32, 64, 128):
+            raise ValueError(f"HIP attention supports head_dim 32/64/128, got {bc['head_dim']}")
+        emb = sd["wte.weight"] if bc["arch"] == "gpt2" else sd["embed_tokens.weight"]
+        if emb.shape[0] > 100_000:
+            # R:models/medtsllm.py:220-222 makes a TRAINABLE 100 000-row sub-sample (Llama-3). Not on the HIP path yet.
+            raise NotImplementedError("vocabularies > 100 000 (trainable sub-sampled word_embeddings) are a 'next' row (DESIGN.md)")
+        # registered like the reference (alias of the frozen input-embedding table; filtered from state_dict)
+        self.word_embeddings = nn.Parameter(emb.detach().float().clone(), requires_grad=False)
+        self.vocab_size = emb.shape[0]
+        self.backbone = None
+        self.tokenizer = None
+        self._tok_dir = self.llm_id if (isinstance(self.llm_id, str) and os.path.isdir(self.llm_id)) else None
+
+    def _get_tokenizer(self):
+        if self.tokenizer is None:
+            if self._tok_dir is None:
+                raise RuntimeError("text prompts need a tokenizer directory (config.models.*.llm.llm)")
+            from transformers import AutoTokenizer
+            tok = AutoTokenizer.from_pretrained(self._tok_dir)
+            if tok.eos_token:                      # R:models/medtsllm.py:212-217
+                tok.pad_token = tok.eos_token
+            else:
+                tok.add_special_tokens({"pad_token": "[PAD]"})
+                tok.pad_token = "[PAD]"
+            self.tokenizer = tok
+        return self.tokenizer
+
+    def _ensure_backbone(self, device):
+        if device.type != "cuda":
+            raise RuntimeError("MedTsLLM (HIP path) needs a ROCm GPU tensor; there is no CPU fallback")
+        if self.backbone is None or self.backbone.device != device:
+            self.backbone = FrozenBackbone(self._hf_cfg, self._hf_state, device, n_layers=self.llm_layers)
+            bb = self.backbone
+            V, d = self.vocab_size, self.d_llm
+            Vp = pad64(V + 1)
+            wT = torch.zeros((d, Vp), dtype=BF16, device=device)
+            wT[:, :V] = bb.embed_f32.t().to(BF16)
+            wT[:, V] = 1.0                                   # bias carrier (see MappingFn)
+            self._wT, self._w = wT, bb.embed_f32.to(BF16).contiguous()
+            self._hf_state = None if False else self._hf_state
+            nkt = Vp // 64
+            tiles = ((self.num_tokens + 127) // 128) * ((d + 127) // 128)
+            self._map_split_k = max(1, min(nkt, 16, (512 + tiles - 1) // tiles))
+        return self.backbone
+
+    def state_dict(self, *args, **kwargs):
+        """R:models/medtsllm.py:235-246 — only trainable front/back-end weights are checkpointed."""
+        sd = super().state_dict(*args, **kwargs)
+        for k in [k for k in sd.keys() if k[:4] == "llm."]:
+            del sd[k]
+        if "word_embeddings" in sd:
+            del sd["word_embeddings"]
+        return sd
+
+    def load_pretrained(self, saved_state):
+        """R:models/medtsllm.py:515-527."""
+        for k in ("word_embeddings", "output_projection.linear.bias", "output_projection.linear.weight"):
+            if k in saved_state:
+                del saved_state[k]
+        incompat = self.load_state_dict(saved_state, strict=False)
+        assert len(incompat.unexpected_keys) == 0, f"Unexpected keys in model state: {incompat.unexpected_keys}"
+        return list(saved_state.keys())
+
+    # ------------------------------------------------------------------ prompt (a6, host side)
+    def build_prompt(self, inputs):
+        cfg = self.model_config.get("prompting")
+        if cfg is None:
+            cfg = P.DEFAULT_PROMPTING
+        on = any((cfg.get(k, False) if hasattr(cfg, "get") else cfg[k]) for k in ("dataset", "clip", "input_stats", "task", "examples"))
+        bos = self._get_tokenizer().bos_token if on else None
+        return P.build_prompt_parts(inputs, cfg, self.dataset_description, self.task_description, bos)
+
+    def _prompt_ids(self, inputs, device):
+        """-> int32 [B or 1, n_tok] left-padded ids (None when prompting is off). Constant parts are tokenised once."""
+        prompts = self.build_prompt(inputs)
+        if len(prompts[0]) == 0:
+            return None
+        tok = self._get_tokenizer()
+        id_lists = []
+        for parts in prompts:
+            ids = []
+            for p in parts:
+                if not isinstance(p, str):
+                    raise NotImplementedError("'examples' prompting (tensor parts inside the prompt) is a 'next' row (DESIGN.md)")
+                if p not in self._id_cache:
+                    if len(self._id_cache) > 4096:
+                        self._id_cache.clear()
+                    self._id_cache[p] = tok(p, padding=False, truncation=False).input_ids   # each part separately
+                ids.append(self._id_cache[p])
+            id_lists.append(ids)
+        rows = P.left_pad_ids(id_lists, tok.pad_token_id)
+        if all(r == rows[0] for r in rows):
+            rows = rows[:1]                       # one shared prompt: the kernel broadcasts it
+        return torch.tensor(rows, dtype=torch.int32, device=device)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, inputs):
+        pred = self.predict(inputs)
+        if not self.training:   # R:models/medtsllm.py:251-259
+            if self.task == "semantic_segmentation":
+                pred = F.softmax(pred, dim=-1) if self.n_classes > 2 else torch.sigmoid(pred)
+            elif self.task == "segmentation" and self.config.tasks.segmentation.mode == "boundary-prediction":
+                pred = torch.sigmoid(pred)
+        return pred
+
+    def encode_ts(self, x_enc):
+        """R:models/medtsllm.py:263-297 -> (x_tok bf16 [B', P', d_llm], mean [B,C], stdev [B,C])."""
+        if x_enc.ndim == 2:
+            x_enc = x_enc.unsqueeze(-1)
+        bs, _, C = x_enc.shape
+        assert C == self.n_features
+        concat = self.covariate_mode == "concat"
+        rl = self.reprogramming_layer
+        tokens, mean, stdev = PatchTokenizeFn.apply(x_enc, self.patch_embedding.value_embedding.tokenConv.weight,
+                                                    self.patch_len, self.stride, concat)
+        if self.training and self.dropout > 0:
+            tokens = F.dropout(tokens, self.dropout, True)
+        source = MappingFn.apply(self.mapping_layer.weight, self.mapping_layer.bias, self._wT, self._w, self._map_split_k)
+        q = LinearFn.apply(tokens, rl.query_projection.weight, rl.query_projection.bias)
+        k = LinearFn.apply(source, rl.key_projection.weight, rl.key_projection.bias)
+        v = LinearFn.apply(source, rl.value_projection.weight, rl.value_projection.bias)
+        if self.training and self.dropout > 0:
+            raise NotImplementedError("attention dropout inside the fused reprogramming kernel is a 'next' row; use training.dropout = 0")
+        a = CrossAttnFn.apply(q, k, v, self.n_attention_heads, self.d_ff)
+        enc = LinearFn.apply(a, rl.out_projection.weight, rl.out_projection.bias)     # [B', P, d_llm]
+        n_patches, d_llm = enc.shape[1], self.d_llm
+        cm = self.covariate_mode
+        if cm == "add":
+            enc = enc.reshape(bs, C, n_patches, d_llm).float().mean(dim=1).to(BF16)
+        elif cm == "weighted-average":
+            enc = enc.reshape(bs, C, n_patches, d_llm).permute(0, 2, 3, 1).float()
+            enc = F.linear(enc, self.feature_weighting.weight, self.feature_weighting.bias).squeeze(-1).to(BF16)
+        elif cm == "interleave":
+            enc = enc.reshape(bs, C, -1, d_llm).permute(0, 2, 1, 3).reshape(bs, -1, d_llm)
+        return enc, mean, stdev
+
+    def predict(self, inputs):
+        x_enc = inputs["x_enc"]
+        bs, _, C = x_enc.size()
+        if self.device is None:
+            self.device = x_enc.device
+        bb = self._ensure_backbone(x_enc.device)
+        ids = self._prompt_ids(inputs, x_enc.device)
+        x_tok, mean, stdev = self.encode_ts(x_enc)
+        cm = self.covariate_mode
+        if ids is not None and cm in ("independent", "merge-end") and ids.shape[0] != 1:
+            ids = ids.repeat_interleave(C, dim=0)        # R:models/medtsllm.py:343-344
+        h0 = AssembleFn.apply(x_tok, ids, bb.embed_f32, bb.wpe)
+        dec = BackboneFn.apply(h0, bb, self.n_patches)   # [B', n_patches, d_llm] (final norm on the consumed rows only)
+        mode = self.embedding_downsample_mode
+        if mode == "truncate":
+            dec = dec[:, :, :self.d_ff]
+        elif mode == "linear":
+            dec = LinearFn.apply(dec, self.embedding_downsample_layer.weight, self.embedding_downsample_layer.bias)
+        else:
+            dec = dec.reshape(dec.shape[0], self.n_patches, self.d_ff, -1).float().mean(dim=-1).to(BF16)
+        head_in = dec.permute(0, 2, 1).reshape(dec.shape[0], -1)       # feature index = f * P + p (R:models/medtsllm.py:366,549)
+        kp = pad64(head_in.shape[1])
+        if kp != head_in.shape[1]:
+            head_in = F.pad(head_in, (0, kp - head_in.shape[1]))
+        out = LinearFn.apply(head_in.contiguous(), self.output_projection.linear.weight, self.output_projection.linear.bias)
+        if cm == "independent":
+            out = out.float().view(bs, C, self.pred_len, self.n_outputs_per_step).mean(dim=1)
+        elif cm == "merge-end":
+            out = out.float().view(bs, C, self.pred_len, self.n_outputs_per_step).permute(0, 2, 3, 1).reshape(bs, self.pred_len, -1)
+            out = F.linear(out, self.feature_weighting.weight, self.feature_weighting.bias)
+        else:
+            out = out.view(bs, self.pred_len, self.n_outputs_per_step)
+        if self.task in FORECAST_LIKE:
+            out = RevinDenormFn.apply(out, mean, stdev)
+        else:
+            out = out.squeeze(-1).float()
+        return out

@@ -1,0 +1,120 @@
+"""Host-side prompt construction with the reference's exact strings (R:models/medtsllm.py:386-513,530-538).
+
+Pure host logic (strings, tokenizer calls); the device part (embedding gather, left pad, concat) is
+mtl_assemble_llm_input. Byte-exact parity of the part lists is pinned by tests/test_prompt_host.py against
+goldens captured from the reference.
+"""
+import torch
+
+N_LAGS = 5  # R:models/medtsllm.py:48
+
+
+def task_description(task, pred_len, seq_len, dataset=None):
+    """R:models/medtsllm.py:497-513."""
+    if getattr(dataset, "task_description", None) is not None:
+        return dataset.task_description
+    if task in ("forecasting", "pretraining"):
+        return f"Forecast the next {pred_len} steps given the previous {seq_len} steps of data."
+    if task in ("anomaly_detection", "reconstruction"):
+        return f"Reconstruct the past {seq_len} steps of data as accurately as possible using the following information."
+    if task == "semantic_segmentation":
+        return f"Classify the past {seq_len} steps of data as accurately as possible using the following information."
+    if task == "segmentation":
+        return f"Identify the change points in the past {seq_len} steps of data to segment the sequence."
+    raise ValueError(f"Task {task} is not supported.")
+
+
+def calc_lags(x, n_lags=N_LAGS):
+    """R:models/medtsllm.py:530-538 — top-k lags of the channel-mean circular autocorrelation (rFFT)."""
+    x = x.permute(0, 2, 1).contiguous() if x.ndim == 3 else x.unsqueeze(1)
+    f = torch.fft.rfft(x, dim=-1)
+    corr = torch.fft.irfft(f * torch.conj(f), dim=-1)
+    return torch.topk(corr.mean(dim=1), n_lags, dim=-1).indices
+
+
+def _fmt_list(xs):
+    return "[" + ", ".join(xs) + "]"
+
+
+def _fmt_float(x):
+    if isinstance(x, list):
+        return _fmt_list([_fmt_float(v) for v in x])
+    return f"{x:.3f}"
+
+
+def _fmt_trend(x):
+    if x is True:
+        return "upward"
+    if x is False:
+        return "downward"
+    if isinstance(x, (list, tuple)):
+        return _fmt_list([_fmt_trend(v) for v in x])
+    return x
+
+
+def input_stats_prompts(x_enc, input_stats_dim, input_stats_select="all", n_lags=N_LAGS):
+    """R:models/medtsllm.py:441-495."""
+    xs = x_enc.detach()
+    if xs.ndim == 2:
+        xs = xs.unsqueeze(-1)
+    assert input_stats_select == "all"
+    if input_stats_dim == "all":
+        insert, s = "per feature", "s"
+    else:
+        insert, s = f"feature {input_stats_dim}", ""
+        xs = xs[:, :, input_stats_dim]
+    with torch.no_grad():
+        mins = torch.min(xs, dim=1).values.tolist()
+        maxs = torch.max(xs, dim=1).values.tolist()
+        meds = torch.median(xs.float(), dim=1).values.tolist()
+        trends = (xs.diff(dim=1).sum(dim=1) > 0).tolist()
+        lags = calc_lags(xs.float(), n_lags).tolist()
+    return [
+        f"Input statistics ({insert}): "
+        f"min value{s} = {_fmt_float(mins[b])}, "
+        f"max value{s} = {_fmt_float(maxs[b])}, "
+        f"median value{s} = {_fmt_float(meds[b])}, "
+        f"the trend of input is {_fmt_trend(trends[b])}, "
+        f"the top {n_lags} lags are {lags[b]}."
+        for b in range(xs.size(0))
+    ]
+
+
+DEFAULT_PROMPTING = {"dataset": True, "clip": True, "input_stats": True, "task": True, "examples": False,
+                     "input_stats_dim": 0, "input_stats_select": "all"}
+
+
+def build_prompt_parts(inputs, cfg, dataset_description, task_desc, bos_token):
+    """R:models/medtsllm.py:386-439 — per-sample list of string parts (all but the first get a trailing space)."""
+    bs = inputs["x_enc"].size(0)
+    get = cfg.get if hasattr(cfg, "get") else (lambda k, d=None: cfg[k] if k in cfg else d)
+    on = {k: get(k, False) for k in ("dataset", "clip", "input_stats", "task", "examples")}
+    if not any(on.values()):
+        return [[] for _ in range(bs)]
+    dataset_prompt = f"Dataset: {dataset_description}" if on["dataset"] else ""
+    if on["examples"]:
+        example_prompts = inputs["examples"]
+    else:
+        example_prompts = [("",)] * bs
+    clip_prompts = inputs.get("descriptions", [""] * bs) if on["clip"] else [""] * bs
+    if on["input_stats"]:
+        stats = input_stats_prompts(inputs["x_enc"], get("input_stats_dim", 0), get("input_stats_select", "all"))
+    else:
+        stats = [""] * bs
+    task_prompt = f"Task: {task_desc}" if on["task"] else ""
+    bos = bos_token if bos_token is not None else ""
+    prompts = []
+    for b in range(bs):
+        parts = [bos, dataset_prompt, *example_prompts[b], clip_prompts[b], stats[b], task_prompt, "Time series:"]
+        parts = [p for p in parts if not (isinstance(p, str) and p == "")]
+        parts = [(p + " " if isinstance(p, str) and (i != 0) else p) for i, p in enumerate(parts)]
+        prompts.append(parts)
+    return prompts
+
+
+def left_pad_ids(id_lists, pad_token_id):
+    """Concatenate each sample's per-part id lists and LEFT-pad to the batch max with pad_token_id
+    (== left-padding the embeddings with the pad embedding, R:models/medtsllm.py:304-311,334-335)."""
+    flat = [[i for part in parts for i in part] for parts in id_lists]
+    n = max(len(f) for f in flat)
+    return [[pad_token_id] * (n - len(f)) + f for f in flat]

@@ -1,0 +1,257 @@
+"""BaseTask-compatible trainer (reference: tasks/base.py). The optimisation step is the reference's loop body
+(R:tasks/forecasting.py:19-30) in the same order:
+
+    prepare_batch (H2D + cast) -> autocast(bf16) iff dtype == "mixed" -> model(inputs) -> loss -> backward
+    -> [DP: one flat all-reduce of the trainable grads] -> optimizer.step -> zero_grad -> log_step(loss.item())
+
+Only what drives the hot path is built: device/dtype resolution, loaders, model/optimizer/loss construction,
+checkpoint surface. Eval stitching / metrics / wandb / tensorboard are out of scope (SURVEY.md §8 "next" rank 1).
+"""
+import os
+from abc import ABC, abstractmethod
+from datetime import datetime
+from pathlib import Path
+
+import torch
+from torch import optim
+from torch.utils.data import DataLoader, default_collate
+from torch.utils.data.distributed import DistributedSampler
+
+from ..models import model_lookup
+from ..utils import set_seed
+from .. import parallel
+from .synthetic import get_dataset
+
+
+class PrintLogger:
+    """Minimal sink with the reference logger's surface (log_scores / save_state / log_end); rank 0 only."""
+
+    def __init__(self, trainer, config, newrun=True):
+        self.trainer, self.config = trainer, config
+        self.debug = bool(config.get("DEBUG", False))
+        base = config.get("paths", {}).get("logdir") if hasattr(config.get("paths", {}), "get") else None
+        self.logdir = Path(base or "outputs/logs") / trainer.run_id
+        self.history = []
+
+    def log_scores(self, scores):
+        self.history.append(dict(scores))
+        if self.trainer.rank == 0 and not self.config.setup.get("quiet", False):
+            print(" ".join(f"{k}={v:.6g}" if isinstance(v, float) else f"{k}={v}" for k, v in scores.items()))
+
+    def save_state(self, name):
+        """Checkpoint format of R:loggers/base_logger.py:29-40 (model.state_dict() is already filtered)."""
+        if self.debug or self.trainer.rank != 0:
+            return
+        d = self.logdir / "checkpoints"
+        d.mkdir(parents=True, exist_ok=True)
+        torch.save({"run_id": self.trainer.run_id, "epoch": self.trainer.epoch, "step": self.trainer.step,
+                    "datetime": datetime.now().isoformat(), "model": self.trainer.model.state_dict()}, d / f"{name}.pt")
+
+    def log_end(self):
+        pass
+
+
+class BaseTask(ABC):
+    target_key = "y"
+
+    def __init__(self, run_id, config, newrun=True):
+        self.run_id, self.config, self.newrun = run_id, config, newrun
+        self.task = config.task
+        self.device = self.get_device()
+        self.dtype = self.get_dtype()
+        self.rank, self.world_size, self.local_rank = parallel.init_from_env(self.device.type)
+        if self.device.type == "cuda" and self.world_size > 1:
+            self.device = torch.device("cuda", self.local_rank)
+        set_seed(self.config.setup.seed)
+        self.build_datasets()
+        self.build_dataloaders()
+        self.model = self.build_model().to(self.device, self.dtype)
+        self.finetuning = False
+        self.optimizer = self.build_optimizer()
+        self.scheduler = self.build_scheduler()
+        self.loss_fn = self.build_loss().to(device=self.device)
+        self.grad_sync = parallel.FlatGradAllReduce(self.model.parameters()) if self.world_size > 1 else None
+        self.epoch, self.step = 1, 0
+        metric_dir = self.config.training.eval_metric_direction
+        self.best_score = float("inf") if metric_dir == "min" else float("-inf")
+        self.logger = PrintLogger(self, self.config, self.newrun)
+
+    # ---- construction (R:tasks/base.py:81-108,157-198,248-275)
+    def build_model(self):
+        self.model = model_lookup[self.config.model](self.config, self.train_dataset)
+        assert self.task in self.model.supported_tasks, f"{self.task} not supported by {self.config.model}"
+        return self.model
+
+    def build_optimizer(self):
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        lr = self.config.training.learning_rate
+        opt = self.config.training.optimizer
+        if opt == "adam":
+            return optim.Adam(params, lr=lr)
+        if opt == "adamw":
+            return optim.AdamW(params, lr=lr, weight_decay=0.01)
+        if opt == "sgd":
+            return optim.SGD(params, lr=lr, momentum=0.9, nesterov=True)
+        raise ValueError(f"Invalid optimizer selection: {opt}")
+
+    def build_scheduler(self):
+        st = self.config.training.get("lr_scheduler")
+        if st in (None, "none", "constant"):
+            return optim.lr_scheduler.StepLR(self.optimizer, step_size=1, gamma=1)
+        raise ValueError(f"Invalid scheduler selection: {st}")
+
+    def build_datasets(self):
+        self.train_dataset = get_dataset(self.config, "train")
+        self.val_dataset = get_dataset(self.config, "val")
+        self.test_dataset = get_dataset(self.config, "test")
+
+    def build_dataloaders(self):
+        nw = self.config.setup.num_workers
+        if nw == "auto":
+            n_cpu = os.environ.get("SLURM_CPUS_ON_NODE")
+            nw = (int(n_cpu) if n_cpu else os.cpu_count()) // 2
+        collate = getattr(self.train_dataset, "collate_fn", default_collate)
+        bs = self.config.training.batch_size
+        shuffle = self.config.training.get("shuffle", True)
+
+        def mk(ds, train):
+            sampler = None
+            if self.world_size > 1:
+                sampler = DistributedSampler(ds, num_replicas=self.world_size, rank=self.rank, shuffle=train and shuffle,
+                                             seed=self.config.setup.seed, drop_last=train)
+            return DataLoader(ds, batch_size=bs // self.world_size if self.world_size > 1 else bs, collate_fn=collate,
+                              shuffle=(train and shuffle and sampler is None), sampler=sampler, num_workers=nw,
+                              pin_memory=(self.device.type == "cuda"), drop_last=(train and self.world_size > 1))
+
+        self.train_dataloader = mk(self.train_dataset, True)
+        self.val_dataloader = mk(self.val_dataset, False)
+        self.test_dataloader = mk(self.test_dataset, False)
+
+    def prepare_batch(self, batch):
+        """R:tasks/base.py:200-211."""
+        if isinstance(batch, dict):
+            return {k: self.prepare_batch(v) for k, v in batch.items()}
+        if isinstance(batch, (list, tuple)):
+            return [self.prepare_batch(x) for x in batch]
+        if isinstance(batch, torch.Tensor):
+            batch = batch.to(self.device)
+            if batch.dtype.is_floating_point:
+                batch = batch.to(self.dtype)
+            return batch
+        return batch
+
+    def get_device(self):
+        d = self.config.setup.device
+        if d == "auto":
+            return torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        return torch.device(d)
+
+    def get_dtype(self):
+        self.use_gpu = self.device.type == "cuda"
+        name = self.config.setup.dtype
+        self.mixed = name == "mixed"
+        if name in ("bfloat16", "bf16") and self.use_gpu:
+            return torch.bfloat16
+        if name in ("float16", "half", "fp16", "16", 16):
+            return torch.float16
+        if name in ("float32", "float", "fp32", "32", 32, "mixed"):
+            return torch.float32
+        raise ValueError(f"Invalid dtype selection: {name}")
+
+    # ---- the optimisation step (a10)
+    def compute_loss(self, inputs):
+        pred = self.model(inputs)
+        return self.loss_fn(pred, inputs[self.target_key])
+
+    def train_step(self, inputs):
+        inputs = self.prepare_batch(inputs)
+        with torch.autocast(self.device.type, dtype=torch.bfloat16, enabled=self.mixed):
+            loss = self.compute_loss(inputs)
+        loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync()
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        self.log_step(loss.item())
+        return loss
+
+    def train(self):
+        for epoch in range(self.config.training.epochs):
+            if self.rank == 0:
+                print(f"Epoch {epoch + 1}/{self.config.training.epochs}")
+            if self.world_size > 1:
+                self.train_dataloader.sampler.set_epoch(epoch)
+            self.model.train()
+            for inputs in self.train_dataloader:
+                self.train_step(inputs)
+            val_scores = self.val()
+            self.log_epoch(val_scores)
+            self.scheduler.step()
+        self.model.eval()
+
+    def _eval_loss(self, loader, prefix):
+        self.model.eval()
+        tot, n = 0.0, 0
+        with torch.no_grad():
+            for inputs in loader:
+                inputs = self.prepare_batch(inputs)
+                with torch.autocast(self.device.type, dtype=torch.bfloat16, enabled=self.mixed):
+                    loss = self.compute_loss(inputs)
+                bs = inputs["x_enc"].shape[0]
+                tot, n = tot + loss.item() * bs, n + bs
+        scores = {f"{prefix}/{self.config.training.eval_metric}": tot / max(n, 1)}
+        self.log_scores(scores)
+        return scores
+
+    def val(self):
+        return self._eval_loss(self.val_dataloader, "val")
+
+    def test(self):
+        return self._eval_loss(self.test_dataloader, "test")
+
+    def predict(self, dataloader):
+        self.model.eval()
+        preds = []
+        with torch.no_grad():
+            for inputs in dataloader:
+                preds.append(self.model(self.prepare_batch(inputs)).float().cpu())
+        return torch.cat(preds, dim=0)
+
+    @abstractmethod
+    def build_loss(self):
+        pass
+
+    # ---- logging / checkpoint hooks (R:tasks/base.py:213-246)
+    def log_end(self):
+        self.logger.log_end()
+
+    def log_step(self, loss):
+        self.step += self.config.training.batch_size
+        self.logger.log_scores({"train/loss": loss})
+
+    def log_scores(self, scores={}, **kw):
+        self.logger.log_scores({**scores, **kw})
+
+    def log_epoch(self, scores={}, **kw):
+        lrs = self.scheduler.get_last_lr()
+        scores = {**scores, **kw, **({"train/lr": lrs[0]} if len(lrs) == 1 else {})}
+        self.logger.log_scores(scores)
+        self.logger.save_state("latest")
+        metric = "val/" + self.config.training.eval_metric
+        d = self.config.training.eval_metric_direction
+        if metric in scores and ((d == "min" and scores[metric] < self.best_score) or (d == "max" and scores[metric] > self.best_score)):
+            self.best_score = scores[metric]
+            if self.config.training.get("save_best", True):
+                self.logger.save_state("best")
+        if self.epoch < self.config.training.epochs:
+            self.epoch += 1
+
+    @classmethod
+    def from_run_id(cls, run_id, config, ckpt="latest", basepath="outputs/logs"):
+        """R:tasks/base.py:283-306 (the config object is passed in; TOML parsing is the CLI's job)."""
+        trainer = cls(run_id, config, newrun=False)
+        state = torch.load(Path(basepath) / run_id / f"checkpoints/{ckpt or 'latest'}.pt")
+        _, unexpected = trainer.model.load_state_dict(state["model"], strict=False)
+        assert not unexpected, f"Unexpected keys in model state: {unexpected}"
+        trainer.epoch, trainer.step = state["epoch"], state["step"]
+        return trainer

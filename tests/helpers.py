@@ -57,3 +57,44 @@ def golden_loss(pred, target, task):
     if task == "segmentation":
         return F.binary_cross_entropy_with_logits(pred, torch.as_tensor(target).float())
     return F.mse_loss(pred, torch.as_tensor(target).float())
+
+
+# ----------------------------------------------------------------------------- GPU-test model configs (HIP-friendly sizes)
+def hf_cfg(kind, vocab=512):
+    if kind == "gpt2":
+        return {"model_type": "gpt2", "vocab_size": vocab, "n_positions": 256, "n_embd": 128, "n_layer": 2, "n_head": 2,
+                "layer_norm_epsilon": 1e-5}
+    if kind == "llama":
+        return {"model_type": "llama", "vocab_size": vocab, "hidden_size": 256, "intermediate_size": 384, "num_hidden_layers": 2,
+                "num_attention_heads": 4, "num_key_value_heads": 4, "head_dim": 64, "rms_norm_eps": 1e-5, "rope_theta": 10000.0}
+    if kind == "llama_gqa":
+        return {"model_type": "llama", "vocab_size": vocab, "hidden_size": 256, "intermediate_size": 384, "num_hidden_layers": 2,
+                "num_attention_heads": 4, "num_key_value_heads": 2, "head_dim": 64, "rms_norm_eps": 1e-5, "rope_theta": 500000.0}
+    raise ValueError(kind)
+
+
+def model_config(task, L, pred, cov, down, prompting, d_model=8, d_ff=64, H=2, num_tokens=64, dropout=0.0, llm_layers=-1):
+    return {
+        "DEBUG": True, "task": task, "model": "medtsllm", "history_len": L, "pred_len": pred,
+        "training": {"dropout": dropout}, "setup": {"dtype": "mixed"},
+        "tasks": {"segmentation": {"mode": "boundary-prediction"}},
+        "models": {"timellm": {
+            "d_model": d_model, "d_ff": d_ff, "n_heads": H, "num_tokens": num_tokens, "covariate_mode": cov,
+            "embedding_downsample_mode": down, "patching": {"patch_len": 16, "stride": 8}, "prompting": prompting,
+            "llm": {"enabled": True, "llm": "in-memory", "llm_layers": llm_layers, "load_in_4bit": False, "load_in_8bit": False},
+        }},
+    }
+
+
+class FakeDataset:
+    def __init__(self, n_features, n_classes=0):
+        self.description = "synthetic multichannel physiological waveforms sampled at 125 Hz."
+        self.n_features, self.n_classes, self.task_description = n_features, n_classes, None
+
+
+def fixture_tokenizer(kind="gpt2"):
+    from transformers import PreTrainedTokenizerFast
+    tok = PreTrainedTokenizerFast(tokenizer_file=str(GOLDEN / f"tokenizer_{kind}.json"), bos_token="<|endoftext|>",
+                                  eos_token="<|endoftext|>")
+    tok.pad_token = tok.eos_token
+    return tok

@@ -1,0 +1,328 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP kernel, through the C-ABI, against the oracle /
+a plain torch fp32 statement of the same op on the SAME bf16-rounded inputs.
+
+Tolerances (norm-wise relative): fp32 outputs of bf16-input GEMMs 2e-5 (accumulation order only);
+bf16 outputs 4e-3 (one bf16 rounding, 2^-9 per element); integer maps bit-exact.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_err, GOLDEN, load_case
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+TOL_F32, TOL_BF16 = 2e-5, 4e-3
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no ROCm device is visible")
+    from med_ts_llm_amd.hip import ops as o
+    return o
+
+
+def rb(t):
+    """round to bf16 and back (what the kernels see)"""
+    return t.to(BF16).float()
+
+
+def dev(t):
+    return t.to("cuda")
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (100, 72, 192), (8192, 768, 768), (33, 50257 // 16, 64), (512, 130, 256)])
+def test_gemm_store(ops, M, N, K):
+    A = torch.randn(M, K, generator=g(1)).to(BF16)
+    B = torch.randn(N, K, generator=g(2)).to(BF16)
+    bias = torch.randn(N, generator=g(3))
+    ref = A.float() @ B.float().t() + bias
+    c32 = ops.gemm_nt(dev(A), dev(B), out_dtype=F32, bias=dev(bias))
+    assert rel_err(c32, ref) < TOL_F32
+    c16 = ops.gemm_nt(dev(A), dev(B), out_dtype=BF16, bias=dev(bias))
+    assert rel_err(c16.float(), ref) < TOL_BF16
+    # transpose detection: asymmetric operands, exact small-integer arithmetic
+    Ai = torch.randint(-3, 4, (M, K), generator=g(4)).float()
+    Bi = torch.randint(-3, 4, (N, K), generator=g(5)).float()
+    ci = ops.gemm_nt(dev(Ai.to(BF16)), dev(Bi.to(BF16)), out_dtype=F32)
+    assert torch.equal(ci.cpu(), Ai @ Bi.t())
+
+
+def test_gemm_epilogues(ops):
+    from med_ts_llm_amd.hip import _native as Nn
+    from oracle.medtsllm_oracle import gelu_new
+    M, N, K = 200, 192, 128
+    A = torch.randn(M, K, generator=g(1)).to(BF16)
+    B = (0.1 * torch.randn(N, K, generator=g(2))).to(BF16)
+    bias = torch.randn(N, generator=g(3))
+    v = A.float() @ B.float().t() + bias
+    # GELU: aux_out = pre-activation (bf16), C = gelu_new(bf16(pre))
+    aux = torch.empty(M, N, dtype=BF16, device="cuda")
+    c = ops.gemm_nt(dev(A), dev(B), bias=dev(bias), epilogue=Nn.EPI_GELU, aux_out=aux)
+    assert rel_err(aux.float(), v) < TOL_BF16
+    assert rel_err(c.float(), gelu_new(rb(v))) < TOL_BF16
+    # RESID: C(f32) = resid + bf16(v)
+    resid = torch.randn(M, N, generator=g(4))
+    c = ops.gemm_nt(dev(A), dev(B), out_dtype=F32, bias=dev(bias), epilogue=Nn.EPI_RESID, aux_in=dev(resid))
+    assert rel_err(c, resid + v) < 2e-3
+    # DGELU: C = v * gelu_new'(h)
+    h = torch.randn(M, N, generator=g(5)).to(BF16)
+    hf = h.float().requires_grad_(True)
+    gelu_new(hf).sum().backward()
+    c = ops.gemm_nt(dev(A), dev(B), epilogue=Nn.EPI_DGELU, aux_in=dev(h))
+    assert rel_err(c.float(), (A.float() @ B.float().t()) * hf.grad) < TOL_BF16
+    # ACCUM
+    base = torch.randn(M, N, generator=g(6))
+    out = dev(base).clone()
+    ops.gemm_nt(dev(A), dev(B), out=out, epilogue=Nn.EPI_ACCUM)
+    assert rel_err(out, base + A.float() @ B.float().t()) < TOL_F32
+
+
+def test_gemm_splitk_and_row_gather(ops):
+    M, N, K = 256, 128, 64 * 37
+    A = torch.randn(M, K, generator=g(1)).to(BF16)
+    B = (0.05 * torch.randn(N, K, generator=g(2))).to(BF16)
+    ref = A.float() @ B.float().t()
+    for sk in (2, 5, 8):
+        c = ops.gemm_nt(dev(A), dev(B), out_dtype=F32, split_k=sk)
+        assert rel_err(c, ref) < TOL_F32
+    # "last P tokens of every sample" gather on A rows: [Bt, T, K] -> rows (b, T-P+p)
+    Bt, T, Pp, K2 = 3, 10, 4, 64
+    X = torch.randn(Bt * T, K2, generator=g(3)).to(BF16)
+    W = torch.randn(96, K2, generator=g(4)).to(BF16)
+    c = ops.gemm_nt(dev(X), dev(W), out_dtype=F32, M=Bt * Pp, a_rows=(Pp, T, T - Pp))
+    ref = X.float().view(Bt, T, K2)[:, -Pp:, :].reshape(Bt * Pp, K2) @ W.float().t()
+    assert rel_err(c, ref) < TOL_F32
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def ref_attention(q, k, v, Hq, Hkv, D, scale, causal):
+    """q [B,Tq,Hq*D], k/v [B,Tk,Hkv*D] fp32 -> (o, grads fn)"""
+    B, Tq, _ = q.shape
+    Tk = k.shape[1]
+    qh = q.view(B, Tq, Hq, D).transpose(1, 2)
+    kh = k.view(B, Tk, Hkv, D).transpose(1, 2).repeat_interleave(Hq // Hkv, dim=1)
+    vh = v.view(B, Tk, Hkv, D).transpose(1, 2).repeat_interleave(Hq // Hkv, dim=1)
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    if causal:
+        s = s.masked_fill(~torch.ones(Tq, Tk, dtype=torch.bool).tril(), float("-inf"))
+    a = torch.softmax(s, dim=-1)
+    return (a @ vh).transpose(1, 2).reshape(B, Tq, Hq * D)
+
+
+@pytest.mark.parametrize("B,T,Hq,Hkv,D,causal", [(2, 64, 2, 2, 64, True), (2, 173, 4, 4, 64, True), (3, 256, 4, 2, 128, True),
+                                                 (2, 100, 2, 2, 32, True), (2, 96, 4, 1, 64, False)])
+def test_attention_self(ops, B, T, Hq, Hkv, D, causal):
+    q = torch.randn(B, T, Hq * D, generator=g(1)).to(BF16)
+    k = torch.randn(B, T, Hkv * D, generator=g(2)).to(BF16)
+    v = torch.randn(B, T, Hkv * D, generator=g(3)).to(BF16)
+    do = torch.randn(B, T, Hq * D, generator=g(4)).to(BF16)
+    scale = 1.0 / math.sqrt(D)
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    ref = ref_attention(qf, kf, vf, Hq, Hkv, D, scale, causal)
+    ref.backward(do.float())
+    o, lse = ops.attention_fwd(dev(q), dev(k), dev(v), Hq, Hkv, D, scale, causal)
+    assert rel_err(o.float(), ref) < TOL_BF16
+    dq, dk, dv = ops.attention_bwd(dev(q), dev(k), dev(v), o, lse, dev(do), Hq, Hkv, D, scale, causal)
+    # backward consumes the bf16-rounded O (for delta) and bf16 P/dS operands: 1e-2 norm-wise
+    assert rel_err(dq.float(), qf.grad) < 1e-2
+    assert rel_err(dk.float(), kf.grad) < 1e-2
+    assert rel_err(dv.float(), vf.grad) < 1e-2
+
+
+def test_attention_fused_qkv_views(ops):
+    """strided q/k/v views into one fused [B,T,(Hq+2Hkv)*D] buffer, as the backbone uses them"""
+    B, T, Hq, Hkv, D = 2, 80, 4, 2, 64
+    qkv = torch.randn(B, T, (Hq + 2 * Hkv) * D, generator=g(1)).to(BF16)
+    dq_ = dev(qkv)
+    q, k, v = dq_[..., : Hq * D], dq_[..., Hq * D: (Hq + Hkv) * D], dq_[..., (Hq + Hkv) * D:]
+    scale = 1.0 / math.sqrt(D)
+    o, _ = ops.attention_fwd(q, k, v, Hq, Hkv, D, scale, True)
+    ref = ref_attention(qkv[..., : Hq * D].float(), qkv[..., Hq * D: (Hq + Hkv) * D].float(), qkv[..., (Hq + Hkv) * D:].float(),
+                        Hq, Hkv, D, scale, True)
+    assert rel_err(o.float(), ref) < TOL_BF16
+
+
+@pytest.mark.parametrize("B,L,S,H,E", [(2, 8, 32, 2, 32), (3, 20, 1024, 8, 128), (2, 128, 200, 2, 64)])
+def test_attention_cross_shared_kv(ops, B, L, S, H, E):
+    """reprogramming attention: K/V [S, H*E] shared by every sample; dK/dV are summed over the batch"""
+    q = torch.randn(B, L, H * E, generator=g(1)).to(BF16)
+    k = torch.randn(S, H * E, generator=g(2)).to(BF16)
+    v = torch.randn(S, H * E, generator=g(3)).to(BF16)
+    do = torch.randn(B, L, H * E, generator=g(4)).to(BF16)
+    scale = 1.0 / math.sqrt(E)
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    scores = torch.einsum("blhe,she->bhls", qf.view(B, L, H, E), kf.view(S, H, E))
+    A = torch.softmax(scale * scores, dim=-1)
+    ref = torch.einsum("bhls,she->blhe", A, vf.view(S, H, E)).reshape(B, L, H * E)
+    ref.backward(do.float())
+    o, lse = ops.attention_fwd(dev(q), dev(k), dev(v), H, H, E, scale, False, shared_kv=True)
+    assert rel_err(o.float(), ref) < TOL_BF16
+    dq, dk, dv = ops.attention_bwd(dev(q), dev(k), dev(v), o, lse, dev(do), H, H, E, scale, False, shared_kv=True)
+    assert rel_err(dq.float(), qf.grad) < 1e-2
+    assert rel_err(dk.float(), kf.grad) < 1e-2
+    assert rel_err(dv.float(), vf.grad) < 1e-2
+
+
+def test_attention_online_softmax_rescale(ops):
+    """force the running-max rescale branch: one key far above the rest, placed in the LAST chunk"""
+    B, T, H, D = 1, 192, 1, 64
+    q = torch.randn(B, T, D, generator=g(1))
+    k = torch.randn(B, T, D, generator=g(2))
+    v = torch.randn(B, T, D, generator=g(3))
+    k[0, 180] = 6.0 * q[0, 190] / q[0, 190].norm() * math.sqrt(D)
+    q, k, v = q.to(BF16), k.to(BF16), v.to(BF16)
+    ref = ref_attention(q.double(), k.double(), v.double(), H, H, D, 1 / math.sqrt(D), False)
+    o, _ = ops.attention_fwd(dev(q), dev(k), dev(v), H, H, D, 1 / math.sqrt(D), False)
+    assert rel_err(o.float(), ref) < TOL_BF16
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("M,d", [(7, 64), (300, 768), (64, 4096), (10, 1000)])
+def test_layernorm(ops, M, d):
+    x = torch.randn(M, d, generator=g(1)) * 2 + 0.5
+    w, b = 1 + 0.1 * torch.randn(d, generator=g(2)), 0.1 * torch.randn(d, generator=g(3))
+    dy = torch.randn(M, d, generator=g(4)).to(BF16)
+    dres = torch.randn(M, d, generator=g(5))
+    xf = x.clone().requires_grad_(True)
+    ref = F.layer_norm(xf, (d,), w, b, 1e-5)
+    ref.backward(dy.float())
+    y, stats = ops.norm_fwd(dev(x), dev(w), dev(b), 1e-5)
+    assert rel_err(y.float(), ref) < TOL_BF16
+    assert rel_err(stats[:, 0], x.mean(1)) < 1e-5
+    dx, dxb = ops.norm_bwd(dev(dy), dev(x), dev(w), stats, dres_in=dev(dres), want_bf16=True)
+    assert rel_err(dx, dres + xf.grad) < 1e-5
+    assert rel_err(dxb.float(), dres + xf.grad) < TOL_BF16
+
+
+@pytest.mark.parametrize("M,d", [(9, 128), (130, 4096)])
+def test_rmsnorm(ops, M, d):
+    from oracle.medtsllm_oracle import rms_norm
+    x = torch.randn(M, d, generator=g(1)) * 3
+    w = 1 + 0.1 * torch.randn(d, generator=g(2))
+    dy = torch.randn(M, d, generator=g(4)).to(BF16)
+    xf = x.clone().requires_grad_(True)
+    ref = rms_norm(xf, w, 1e-5)
+    ref.backward(dy.float())
+    y, stats = ops.norm_fwd(dev(x), dev(w), None, 1e-5, rms=True)
+    assert rel_err(y.float(), ref) < TOL_BF16
+    dx = ops.norm_bwd(dev(dy), dev(x), dev(w), stats, rms=True)
+    assert rel_err(dx, xf.grad) < 1e-5
+
+
+def test_norm_row_gather(ops):
+    B, T, Pn, d = 3, 12, 5, 256
+    x = torch.randn(B * T, d, generator=g(1))
+    w, b = torch.randn(d, generator=g(2)), torch.randn(d, generator=g(3))
+    y, stats = ops.norm_fwd(dev(x), dev(w), dev(b), 1e-5, rows=(Pn, T, T - Pn), M=B * Pn)
+    sel = x.view(B, T, d)[:, -Pn:, :].reshape(B * Pn, d)
+    assert rel_err(y.float(), F.layer_norm(sel, (d,), w, b, 1e-5)) < TOL_BF16
+    dy = torch.randn(B * Pn, d, generator=g(4)).to(BF16)
+    sf = sel.clone().requires_grad_(True)
+    F.layer_norm(sf, (d,), w, b, 1e-5).backward(dy.float())
+    dx = ops.norm_bwd(dev(dy), dev(x), dev(w), stats, rows=(Pn, T, T - Pn))
+    full = torch.zeros(B, T, d)
+    full[:, -Pn:, :] = sf.grad.view(B, Pn, d)
+    assert rel_err(dx, full.view(B * T, d)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ tokenizer
+@pytest.mark.parametrize("name", ["gpt2_concat_fc", "llama_concat_semseg", "gpt2_indep_recon"])
+def test_patch_index_map_bit_exact(ops, name):
+    meta, data, _, _ = load_case(name)
+    idx = ops.patch_index_map(meta["L"], meta["patch_len"], meta["stride"], "cuda").cpu().numpy()
+    assert idx.dtype == np.int32 and np.array_equal(idx, data["patch_index_map"])
+
+
+@pytest.mark.parametrize("B,L,C,pl,st,dm,concat", [(2, 64, 3, 16, 8, 8, True), (2, 100, 3, 16, 8, 8, False), (4, 1024, 12, 16, 8, 32, True),
+                                                    (3, 512, 1, 16, 8, 32, False)])
+def test_patch_tokenizer(ops, B, L, C, pl, st, dm, concat):
+    from oracle import medtsllm_oracle as O
+    x = torch.randn(B, L, C, generator=g(1)) * torch.linspace(0.3, 3, C) + torch.linspace(-2, 2, C)
+    x[0, :, 0] = 1.25  # constant channel: stdev = sqrt(eps)
+    w = torch.randn(dm, pl, 3, generator=g(2)) * 0.3
+    wf = w.clone().requires_grad_(True)
+    mean, stdev = O.revin_stats(x)
+    ref = O.patch_embed(O.revin_norm(x, mean, stdev), wf, pl, st)          # [B*C, P, dm]
+    P = ref.shape[1]
+    if concat:
+        ref = ref.reshape(B, C, P, dm).permute(0, 2, 1, 3).reshape(B, P, C * dm)
+    out, m, s = ops.patch_tokenize_fwd(dev(x), dev(w), pl, st, concat)
+    width = ref.shape[-1]
+    assert out.shape[-1] % 64 == 0 and torch.all(out[..., width:] == 0)
+    assert rel_err(m, mean.view(B, C)) < 1e-6 and rel_err(s, stdev.view(B, C)) < 1e-6
+    assert rel_err(out[..., :width].float(), ref) < TOL_BF16
+    dout = torch.randn(ref.shape, generator=g(3)).to(BF16)
+    ref.backward(dout.float())
+    dpad = torch.zeros(out.shape, dtype=BF16)
+    dpad[..., :width] = dout
+    dw = ops.patch_tokenize_bwd(dev(x), m, s, dev(dpad), tuple(w.shape), pl, st, concat)
+    assert rel_err(dw, wf.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ elementwise / layout
+def test_cast_transpose_colsum(ops):
+    src = torch.randn(70, 50, generator=g(1))
+    d, dt = ops.cast_pad(dev(src), ld_dst=64, want_t=True, ld_dst_t=128)
+    assert torch.equal(d[:, :50].cpu(), src.to(BF16)) and torch.all(d[:, 50:] == 0)
+    assert torch.equal(dt[:, :70].cpu(), src.to(BF16).t()) and torch.all(dt[:, 70:] == 0)
+    xb = torch.randn(130, 70, generator=g(2)).to(BF16)
+    t = ops.transpose_bf16(dev(xb), 192)
+    assert torch.equal(t[:, :130].cpu(), xb.t()) and torch.all(t[:, 130:] == 0)
+    assert rel_err(ops.colsum(dev(xb)), xb.float().sum(0)) < 1e-5
+    big = torch.randn(1001, generator=g(3))
+    assert torch.equal(ops.to_bf16(dev(big)).cpu(), big.to(BF16))
+    assert torch.equal(ops.to_f32(dev(big.to(BF16))).cpu(), big.to(BF16).float())
+
+
+def test_rope_and_swiglu(ops):
+    from oracle import medtsllm_oracle as O
+    B, T, H, Hkv, D = 2, 37, 4, 2, 64
+    M = B * T
+    qkv = torch.randn(M, (H + 2 * Hkv) * D, generator=g(1)).to(BF16)
+    cos, sin = O.rope_tables(T, D, 10000.0)
+    x = qkv.float().view(B, T, H + 2 * Hkv, D)
+    rot = x[:, :, : H + Hkv]
+    ref = rot * cos[None, :, None, :] + O.rotate_half(rot) * sin[None, :, None, :]
+    out = ops.rope_inplace(dev(qkv).clone(), dev(cos), dev(sin), T, H + Hkv, D)
+    o4 = out.float().cpu().view(B, T, H + 2 * Hkv, D)
+    assert rel_err(o4[:, :, : H + Hkv], ref) < TOL_BF16
+    assert torch.equal(o4[:, :, H + Hkv:], x[:, :, H + Hkv:])          # v heads untouched
+    back = ops.rope_inplace(out.clone(), dev(cos), dev(sin), T, H + Hkv, D, inverse=True)
+    assert rel_err(back.float().cpu(), qkv.float()) < 2 * TOL_BF16      # R^T R = I
+    Fd = 96
+    gu = torch.randn(M, 2 * Fd, generator=g(2)).to(BF16)
+    dh = torch.randn(M, Fd, generator=g(3)).to(BF16)
+    gf = gu.float().requires_grad_(True)
+    ref = F.silu(gf[:, :Fd]) * gf[:, Fd:]
+    ref.backward(dh.float())
+    h = ops.swiglu_fwd(dev(gu))
+    assert rel_err(h.float(), ref) < 2 * TOL_BF16
+    assert rel_err(ops.swiglu_bwd(dev(gu), dev(dh)).float(), gf.grad) < TOL_BF16
+
+
+def test_assemble_and_denorm(ops):
+    B, n_tok, Pn, d, V = 3, 5, 4, 128, 50
+    emb = torch.randn(V, d, generator=g(1))
+    wpe = torch.randn(n_tok + Pn, d, generator=g(2))
+    xt = torch.randn(B, Pn, d, generator=g(3)).to(BF16)
+    ids = torch.randint(0, V, (B, n_tok), generator=g(4), dtype=torch.int32)
+    ref = torch.cat([emb[ids.long()], xt.float()], dim=1) + wpe
+    assert rel_err(ops.assemble_llm_input(dev(ids), dev(emb), dev(xt), dev(wpe)), ref) < 1e-7
+    ref1 = torch.cat([emb[ids[:1].long()].expand(B, -1, -1), xt.float()], dim=1)
+    assert rel_err(ops.assemble_llm_input(dev(ids[:1]), dev(emb), dev(xt), None), ref1) < 1e-7
+    assert rel_err(ops.assemble_llm_input(None, None, dev(xt), None), xt.float()) < 1e-7
+    y = torch.randn(B, 7, 3, generator=g(5))
+    mean, sd = torch.randn(B, 3, generator=g(6)), torch.rand(B, 3, generator=g(7)) + 0.1
+    assert rel_err(ops.revin_denorm(dev(y), dev(mean), dev(sd)), y * sd[:, None] + mean[:, None]) < 1e-6
+    assert rel_err(ops.revin_denorm(dev(y), None, dev(sd)), y * sd[:, None]) < 1e-6

@@ -1,0 +1,124 @@
+"""GPU parity of the assembled path against the oracle: frozen backbone stack (fwd + activation-gradient bwd)
+and the full MedTsLLM forward/backward with every trainable gradient.
+
+Ladder: the HIP path computes GEMM/attention operands in bf16 with fp32 accumulation, the oracle is
+fp32, so the bar is L3: norm-wise error <= 1.5 x the reference's own bf16-vs-fp32 deviation (7.8e-3) = 1.2e-2.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_err, hf_cfg, model_config, FakeDataset, fixture_tokenizer, oracle_mcfg, golden_loss
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+L3 = 1.2e-2
+
+
+def _oracle_bcfg(cfg):
+    c = dict(cfg)
+    return c
+
+
+@pytest.mark.parametrize("kind,B,T,n_last", [("gpt2", 2, 100, 37), ("gpt2", 3, 64, 64), ("llama", 2, 100, 37), ("llama_gqa", 2, 130, 20)])
+def test_backbone_stack(kind, B, T, n_last):
+    from med_ts_llm_amd.models.backbone import FrozenBackbone, random_state_dict
+    from oracle import medtsllm_oracle as O
+    cfg = hf_cfg(kind)
+    sd = random_state_dict(cfg, seed=3, std=0.06)
+    bb = FrozenBackbone(cfg, sd, "cuda")
+    d = bb.cfg["d"]
+    g = torch.Generator().manual_seed(5)
+    h0 = torch.randn(B, T, d, generator=g)
+    dout = torch.randn(B, n_last, d, generator=g).to(BF16)
+    h0r = h0.clone().requires_grad_(True)
+    ref = O.backbone_forward(h0r, sd, cfg)[:, -n_last:, :]
+    (ref * dout.float()).sum().backward()
+    h_in = h0 + sd["wpe.weight"][:T] if kind == "gpt2" else h0     # the GPT-2 position add is part of the assembly kernel
+    h_in = h_in.cuda()
+    out, saved = bb.run_forward(h_in, n_last)
+    assert rel_err(out.float(), ref) < L3
+    dh0 = bb.run_backward(h_in, dout.cuda(), saved, n_last)
+    assert rel_err(dh0, h0r.grad) < 2 * L3
+
+
+CASES = [
+    # kind, task, B, L, C, pred, cov, down, prompt on
+    ("gpt2", "forecasting", 2, 64, 3, 16, "concat", "linear", True),
+    ("gpt2", "reconstruction", 2, 64, 3, 64, "independent", "truncate", True),
+    ("gpt2", "anomaly_detection", 2, 64, 2, 64, "interleave", "average", False),
+    ("llama", "semantic_segmentation", 2, 100, 3, 100, "concat", "linear", True),
+    ("llama_gqa", "forecasting", 3, 72, 2, 24, "add", "linear", True),
+    ("llama", "forecasting", 2, 64, 3, 16, "weighted-average", "linear", False),
+    ("llama", "forecasting", 2, 64, 3, 16, "merge-end", "linear", True),
+    ("gpt2", "segmentation", 2, 64, 1, 64, "univariate", "linear", True),
+]
+
+
+@pytest.mark.parametrize("kind,task,B,L,C,pred,cov,down,prompt_on", CASES)
+def test_full_model_fwd_bwd(kind, task, B, L, C, pred, cov, down, prompt_on):
+    from med_ts_llm_amd.models import model_lookup
+    from med_ts_llm_amd.models.backbone import random_state_dict
+    from med_ts_llm_amd.utils import dict_to_object
+    from oracle import medtsllm_oracle as O
+
+    cfg = hf_cfg(kind)
+    sd = random_state_dict(cfg, seed=7, std=0.06)
+    prompting = {"dataset": prompt_on, "task": prompt_on, "clip": False, "input_stats": prompt_on, "examples": False,
+                 "input_stats_dim": 0, "input_stats_select": "all"}
+    n_classes = 4 if task == "semantic_segmentation" else 0
+    config = dict_to_object(model_config(task, L, pred, cov, down, prompting))
+    torch.manual_seed(11)
+    model = model_lookup["medtsllm"](config, FakeDataset(C, n_classes), backbone_state=(cfg, sd))
+    model.tokenizer = fixture_tokenizer()
+    with torch.no_grad():   # make every trainable weight O(0.1) so all branches matter
+        for n, p in model.named_parameters():
+            if p.requires_grad and p.ndim == 1:
+                p.copy_(0.1 * torch.randn(p.shape))
+        model.mapping_layer.weight.mul_(3.0)
+    model = model.to("cuda")
+    model.train()
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(B, L, C, generator=g) * torch.tensor([1.0, 2.5, 0.3][:C]) + torch.tensor([0.5, -1.0, 3.0][:C])
+    inputs = {"x_enc": x.cuda()}
+    pred_hip = model(inputs)
+
+    # ---- oracle on the same weights / prompt ids
+    p = {n: t.detach().cpu().float().clone().requires_grad_(t.requires_grad) for n, t in model.named_parameters() if n != "word_embeddings"}
+    tok_ids = None
+    if prompt_on:
+        parts = model.build_prompt({"x_enc": x})
+        tok_ids = [[model.tokenizer(s, padding=False, truncation=False).input_ids for s in ps] for ps in parts]
+    meta = {"task": task, "pred_len": pred, "patch_len": 16, "stride": 8, "n_heads": 2, "d_ff": 64, "covariate_mode": cov,
+            "embedding_downsample_mode": down, "n_classes": n_classes, "C": C}
+    m = oracle_mcfg(meta)
+    ref = O.medtsllm_forward(x, p, sd, cfg, m, token_ids=tok_ids, pad_token_id=model.tokenizer.pad_token_id, training=True)
+    assert pred_hip.shape == ref.shape
+    assert rel_err(pred_hip, ref) < L3, rel_err(pred_hip, ref)
+
+    if task == "semantic_segmentation":
+        tgt = torch.randint(0, n_classes, (B, pred), generator=g)
+    elif task == "segmentation":
+        tgt = (torch.rand(B, pred, generator=g) > 0.8).float()
+    else:
+        tgt = torch.randn(ref.shape, generator=g)
+    golden_loss(ref, tgt, task).backward()
+    loss = golden_loss(pred_hip, tgt.cuda(), task)
+    loss.backward()
+    worst = {}
+    for n, t in model.named_parameters():
+        if not t.requires_grad:
+            continue
+        assert t.grad is not None, n
+        gref = p[n].grad
+        # analytically-zero gradients (key bias: softmax shift invariance) are compared on an absolute scale
+        scale = max(float(gref.norm()), 1e-3 * float(p[n].norm()) + 1e-6)
+        worst[n] = float((t.grad.cpu().float() - gref).norm()) / scale
+    bad = {n: e for n, e in worst.items() if e > 3 * L3}
+    assert not bad, bad
+
+    model.eval()
+    with torch.no_grad():
+        pe = model(inputs)
+        pr = O.medtsllm_forward(x, p, sd, cfg, m, token_ids=tok_ids, pad_token_id=model.tokenizer.pad_token_id, training=False)
+    assert rel_err(pe, pr) < L3
