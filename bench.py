@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""bench.py — samples/s of the MedTsLLM fwd+bwd(+optimizer) hot path on N MI355X (one process per GPU).
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE from env). Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json metric, SURVEY.md §8d "M"): synthetic [B=32, L=1024, C=12] windows per GPU, patch 16/8 ->
+P=128, d_model=32, d_ff=128, 8 heads, 1024 prototype tokens, concat covariates, linear down-sample, forecasting
+pred_len=96, fixed 128-token prompt -> T=256, frozen GPT-2-small backbone (12 x 768, random init, bf16 operands,
+fp32 residual/statistics = the reference's dtype="mixed"), dropout 0. A step = forward + MSE loss + backward +
+[DP all-reduce] + Adam step + zero_grad. Weak scaling: per-GPU batch fixed at 32.
+
+Extra objects on the JSON line:
+  roofline     the dominant kernel (bf16 MFMA GEMM instance with the largest total time): achieved TFLOP/s =
+               algorithmic 2MNK FLOPs / HIP-event duration per launch, measured in this process on the launch stream
+               in a profiled replay of the same steps right after the timed region (events off while timing `value`).
+  cpu_baseline the oracle (a plain-torch port of the reference math, pinned to reference goldens) timed on the host
+               cores, rank 0, N = 1 only, on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GPT2_SMALL = {"model_type": "gpt2", "vocab_size": 50257, "n_positions": 1024, "n_embd": 768, "n_layer": 12, "n_head": 12,
+              "layer_norm_epsilon": 1e-5}
+WORKLOADS = {
+    # name: (hf cfg, B per GPU, L, C, pred_len, n_tok)
+    "gpt2s_B32_L1024_C12": (GPT2_SMALL, 32, 1024, 12, 96, 128),
+    "gpt2s_etth1_B32_L512_C7": (GPT2_SMALL, 32, 512, 7, 96, 128),
+}
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md
+
+
+def model_cfg(L, pred):
+    return {
+        "DEBUG": True, "task": "forecasting", "model": "medtsllm", "history_len": L, "pred_len": pred,
+        "training": {"dropout": 0.0}, "setup": {"dtype": "mixed"},
+        "models": {"timellm": {
+            "d_model": 32, "d_ff": 128, "n_heads": 8, "num_tokens": 1024, "covariate_mode": "concat",
+            "embedding_downsample_mode": "linear", "patching": {"patch_len": 16, "stride": 8},
+            "prompting": {"dataset": False, "task": False, "clip": False, "input_stats": False, "examples": False,
+                          "input_stats_dim": 0, "input_stats_select": "all"},
+            "llm": {"enabled": True, "llm": "random-init", "llm_layers": -1, "load_in_4bit": False, "load_in_8bit": False},
+        }},
+    }
+
+
+class DS:
+    def __init__(self, C_):
+        self.description, self.n_features, self.n_classes, self.task_description = "synthetic", C_, 0, None
+
+
+def make_batch(B, L, C_, pred, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, L, C_, generator=g) + (torch.rand(C_, generator=g) * 4 - 2)
+    y = torch.randn(B, pred, C_, generator=g)
+    return {"x_enc": x.to(device), "y": y.to(device)}
+
+
+def flops_per_step(cfg, B, T, P, C_, n_out, V, S=1024, d_model=32, d_ff=128, H=8):
+    """Algorithmic fwd+bwd FLOPs: frozen GEMMs 2x fwd, attention 3x fwd, trainables 3x fwd, mapping 2x."""
+    d, L_, ffn = cfg["n_embd"], cfg["n_layer"], 4 * cfg["n_embd"]
+    M = B * T
+    gemm_fwd = L_ * 2 * M * (d * 3 * d + d * d + 2 * d * ffn)
+    attn_fwd = L_ * 4 * B * T * T * d
+    HE = H * d_ff
+    front = 2 * B * P * (C_ * d_model) * HE + 2 * 2 * S * d * HE + 4 * B * P * S * HE + 2 * B * P * HE * d
+    tail = 2 * B * P * d * d_ff + 2 * B * d_ff * P * n_out
+    mapping = 2 * S * V * d
+    return 2 * gemm_fwd + 3 * attn_fwd + 3 * (front + tail) + 2 * mapping
+
+
+def cpu_baseline(hf_cfg, sd, L, C_, pred, n_tok, prompt_ids, max_seconds=30.0):
+    """Oracle fwd+bwd on the host cores on a bounded sample of the same workload (same shapes, smaller batch)."""
+    from oracle import medtsllm_oracle as O
+    Bs = 4
+    g = torch.Generator().manual_seed(123)
+    d = hf_cfg["n_embd"]
+    p = {
+        "patch_embedding.value_embedding.tokenConv.weight": torch.randn(32, 16, 3, generator=g) * 0.2,
+        "mapping_layer.weight": torch.randn(1024, hf_cfg["vocab_size"], generator=g) * 0.01,
+        "mapping_layer.bias": torch.zeros(1024),
+        "reprogramming_layer.query_projection.weight": torch.randn(1024, C_ * 32, generator=g) * 0.05,
+        "reprogramming_layer.query_projection.bias": torch.zeros(1024),
+        "reprogramming_layer.key_projection.weight": torch.randn(1024, d, generator=g) * 0.03,
+        "reprogramming_layer.key_projection.bias": torch.zeros(1024),
+        "reprogramming_layer.value_projection.weight": torch.randn(1024, d, generator=g) * 0.03,
+        "reprogramming_layer.value_projection.bias": torch.zeros(1024),
+        "reprogramming_layer.out_projection.weight": torch.randn(d, 1024, generator=g) * 0.03,
+        "reprogramming_layer.out_projection.bias": torch.zeros(d),
+        "embedding_downsample_layer.weight": torch.randn(128, d, generator=g) * 0.03,
+        "embedding_downsample_layer.bias": torch.zeros(128),
+    }
+    P = (L + 8 - 16) // 8 + 1
+    p["output_projection.linear.weight"] = torch.randn(pred * C_, 128 * P, generator=g) * 0.01
+    p["output_projection.linear.bias"] = torch.zeros(pred * C_)
+    for t in p.values():
+        t.requires_grad_(True)
+    m = dict(task="forecasting", pred_len=pred, patch_len=16, stride=8, n_heads=8, d_ff=128, covariate_mode="concat",
+             embedding_downsample_mode="linear", n_outputs_per_step=C_, n_classes=0)
+    b = make_batch(Bs, L, C_, pred, 7, "cpu")
+    tok = [[prompt_ids] for _ in range(Bs)]
+
+    def step():
+        out = O.medtsllm_forward(b["x_enc"], p, sd, hf_cfg, m, token_ids=tok, pad_token_id=0, training=True)
+        torch.nn.functional.mse_loss(out, b["y"]).backward()
+        for t in p.values():
+            t.grad = None
+
+    # pick the thread count that runs this workload fastest (256 SMT threads are far slower than ~1 per core-complex)
+    ncpu = os.cpu_count() or 1
+    best = None
+    for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+        torch.set_num_threads(nt)
+        if best is None:
+            step()  # warm-up (first touch, allocator)
+        t0 = time.perf_counter()
+        step()
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[1]:
+            best = (nt, dt)
+        if time.perf_counter() - t0 > max_seconds / 4:
+            break
+    torch.set_num_threads(best[0])
+    n, t0 = 0, time.perf_counter()
+    while n < 3 or (time.perf_counter() - t0 < max_seconds / 3 and n < 10):
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(Bs / dt, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} timed fwd+bwd steps of B={Bs} windows [L={L}, C={C_}] (same model/shapes as the GPU workload, fp32, "
+                      f"plain-torch oracle; optimizer step excluded), {dt:.2f} s/step"}
+
+
+def read_prof(lib):
+    cap = 32
+    keys = (C.c_int * cap)()
+    launches = (C.c_int64 * cap)()
+    ms = (C.c_double * cap)()
+    fl = (C.c_double * cap)()
+    n = lib.mtl_prof_read(keys, launches, ms, fl, cap)
+    names = {0: "store", 1: "gelu", 2: "resid", 3: "dgelu", 4: "accum"}
+    rows = []
+    for i in range(n):
+        k = keys[i]
+        rows.append({"kernel": f"gemm_nt_kernel<{names[k // 4]},{'bf16' if (k // 2) % 2 else 'f32'},{'splitk' if k % 2 else 'direct'}>",
+                     "launches": int(launches[i]), "total_ms": ms[i], "flops": fl[i]})
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="gpt2s_B32_L1024_C12", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from med_ts_llm_amd import parallel
+    from med_ts_llm_amd.hip import _native
+    from med_ts_llm_amd.models import model_lookup
+    from med_ts_llm_amd.models.backbone import random_state_dict
+    from med_ts_llm_amd.utils import dict_to_object
+
+    rank, world, local_rank = parallel.init_from_env("cuda")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    hf_cfg, B, L, C_, pred, n_tok = WORKLOADS[args.workload]
+    sd = random_state_dict(hf_cfg, seed=0, std=0.02)
+    torch.manual_seed(0)
+    model = model_lookup["medtsllm"](dict_to_object(model_cfg(L, pred)), DS(C_), backbone_state=(hf_cfg, sd)).to(device)
+    prompt_ids = torch.randint(0, hf_cfg["vocab_size"], (1, n_tok), generator=torch.Generator().manual_seed(1), dtype=torch.int32)
+    model.fixed_prompt_ids = prompt_ids
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-4)
+    sync = parallel.FlatGradAllReduce(params) if world > 1 else None
+    loss_fn = torch.nn.MSELoss()
+    batches = [make_batch(B, L, C_, pred, 1000 + rank * 97 + i, device) for i in range(4)]
+
+    def step(i):
+        inputs = batches[i % len(batches)]
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=True):
+            loss = loss_fn(model(inputs), inputs["y"])
+        loss.backward()
+        if sync is not None:
+            sync()
+        opt.step()
+        opt.zero_grad()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.item())
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        lib = _native.lib()
+        lib.mtl_prof_enable(1)
+        for i in range(min(args.steps, 5)):
+            step(i)
+        torch.cuda.synchronize()
+        rows = read_prof(lib)
+        lib.mtl_prof_enable(0)
+        if rows:
+            dom = max(rows, key=lambda r: r["total_ms"])
+            per_launch_ms = dom["total_ms"] / dom["launches"]
+            achieved = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                        "launches": dom["launches"], "avg_launch_us": round(per_launch_ms * 1e3, 2),
+                        "flops_per_launch": dom["flops"] / dom["launches"],
+                        "all_gemm_instances": [{"kernel": r["kernel"], "launches": r["launches"], "avg_us": round(r["total_ms"] / r["launches"] * 1e3, 2),
+                                                "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 1)} for r in rows]}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(hf_cfg, sd, L, C_, pred, n_tok, prompt_ids[0].tolist())
+
+    if rank == 0:
+        P = (L + 8 - 16) // 8 + 1
+        T = n_tok + P
+        fl = flops_per_step(hf_cfg, B, T, P, C_, pred * C_, hf_cfg["vocab_size"])
+        value = B * world * args.steps / elapsed
+        out = {
+            "metric": "samples/sec (1024-step, 12-ch windows) through MedTsLLM fwd+bwd", "value": round(value, 2), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: [B={B}/GPU, L={L}, C={C_}] windows, P={P}, prompt {n_tok} tok -> T={T}, "
+                                   f"frozen GPT-2-small (random init) backbone, concat covariates, forecasting pred_len={pred}, "
+                                   f"step = fwd+loss+bwd+{'allreduce+' if world > 1 else ''}Adam", "global_batch": B * world,
+                       "parallelism": f"dp{world}"},
+            "final_loss": final_loss,
+            "algorithmic_tflop_per_step_per_gpu": round(fl / 1e12, 3),
+            "step_mfma_frac": round(fl / (elapsed / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,7 +12,7 @@
  *     PyTorch-allocated outputs/workspaces and the stream (hipStream_t as void*).
  *   - bf16 tensors are raw uint16 storage; row-major; `ld*` are row strides in ELEMENTS.
  *   - return 0 on success, negative MTL_ERR_* otherwise (mtl_strerror gives the text).
- *   - re-entrant / thread-compatible: no mutable globals.
+ *   - re-entrant / thread-compatible: no mutable globals except the opt-in, mutex-guarded launch profiler.
  */
 #ifndef MEDTSLLM_HIP_H
 #define MEDTSLLM_HIP_H
@@ -55,7 +55,7 @@ int mtl_patch_tokenize_bwd(const float* x, const float* mean, const float* stdev
  * function the tokeniser uses (bit-exact parity target). */
 int mtl_patch_index_map(int32_t* idx, int64_t L, int64_t patch_len, int64_t stride, void* stream);
 /* RevIN "denorm" (R:models/layers/RevIN.py:58-69): out[b,t,c] = y[b,t,c]*stdev[b,c] + mean[b,c]; y/out f32 [B,T,C].
- * With dy != NULL instead computes the backward dy_in[b,t,c] = dy[b,t,c]*stdev[b,c]. */
+ * mean == NULL multiplies by stdev only (its backward: statistics are detached constants). */
 int mtl_revin_denorm(const float* y, const float* mean, const float* stdev, float* out, int64_t B, int64_t T,
                      int64_t C, void* stream);
 
@@ -91,6 +91,11 @@ typedef struct {
 } mtl_gemm_args;
 size_t mtl_gemm_workspace_bytes(int64_t M, int64_t N, int split_k);
 int mtl_gemm_nt(const mtl_gemm_args* args, void* stream);
+/* Measurement aid (bench.py roofline leg; off by default, no effect on results): while enabled every GEMM launch is
+ * bracketed by HIP events on its launch stream. mtl_prof_read aggregates per kernel instance
+ * key = epilogue*4 + c_dtype*2 + (split_k > 1): launches, total ms, total algorithmic FLOPs (2*M*N*K). */
+int mtl_prof_enable(int on);
+int mtl_prof_read(int* keys, int64_t* launches, double* total_ms, double* total_flops, int cap);
 
 /* ------------------------------------------------------------------ layout / cast helpers
  * f32 [R, Cc] (ld_src) -> bf16 [R, ld_dst] zero-padding cols >= Cc; optionally also the transpose

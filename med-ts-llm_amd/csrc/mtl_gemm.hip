@@ -13,7 +13,22 @@
 //   * split-K (fp32 slabs + reduce kernel) for the batch-independent mapping GEMM (M=1024, N=d_llm, K=V).
 #include "mtl_common.h"
 
+#include <mutex>
+#include <vector>
+
 namespace {
+
+// ---------------------------------------------------------------- optional launch profiler (bench.py roofline leg)
+// When enabled, every GEMM launch is bracketed by two HIP events on the launch stream; mtl_prof_read() then
+// reports, per kernel instance (epilogue, c_dtype, split), launches / total ms / total algorithmic FLOPs.
+// Disabled by default: zero cost on the product path (one relaxed flag test per launch).
+struct ProfRec { hipEvent_t e0, e1; int key; double flops; };
+struct Profiler {
+    std::mutex mu;
+    bool on = false;
+    std::vector<ProfRec> recs;
+};
+Profiler& prof() { static Profiler p; return p; }
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
@@ -258,6 +273,28 @@ template <int EPI, int CDT>
 int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
     const int tiles_m = (int)((p.M + BM - 1) / BM), tiles_n = (int)((p.N + BN - 1) / BN);
     const int S = p.split_k > 1 ? p.split_k : 1;
+    Profiler& pf = prof();
+    ProfRec rec;
+    bool recording = false;
+    if (pf.on) {
+        std::lock_guard<std::mutex> lk(pf.mu);
+        if (pf.on && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess) {
+            rec.key = EPI * 4 + CDT * 2 + (S > 1 ? 1 : 0);
+            rec.flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
+            recording = true;
+            hipEventRecord(rec.e0, st);
+        }
+    }
+    struct Closer {
+        Profiler& pf; ProfRec& rec; bool& recording; hipStream_t st;
+        ~Closer() {
+            if (recording) {
+                hipEventRecord(rec.e1, st);
+                std::lock_guard<std::mutex> lk(pf.mu);
+                pf.recs.push_back(rec);
+            }
+        }
+    } closer{pf, rec, recording, st};
     if (S == 1) {
         hipLaunchKernelGGL((gemm_nt_kernel<EPI, CDT, false>), dim3(tiles_m * tiles_n, 1), dim3(256), 0, st, p, vec_ok);
     } else {
@@ -271,6 +308,34 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int mtl_prof_enable(int on) {
+    Profiler& pf = prof();
+    std::lock_guard<std::mutex> lk(pf.mu);
+    pf.on = on != 0;
+    if (on) {
+        for (auto& r : pf.recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+        pf.recs.clear();
+    }
+    return MTL_OK;
+}
+
+// fills up to `cap` rows of (key, launches, total_ms, total_flops); returns the number of rows. Synchronises the events.
+extern "C" int mtl_prof_read(int* keys, int64_t* launches, double* total_ms, double* total_flops, int cap) {
+    Profiler& pf = prof();
+    std::lock_guard<std::mutex> lk(pf.mu);
+    int n = 0;
+    for (auto& r : pf.recs) {
+        if (hipEventSynchronize(r.e1) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+        int i = 0;
+        for (; i < n; ++i) if (keys[i] == r.key) break;
+        if (i == n) { if (n >= cap) continue; keys[n] = r.key; launches[n] = 0; total_ms[n] = 0; total_flops[n] = 0; ++n; }
+        launches[i] += 1; total_ms[i] += ms; total_flops[i] += r.flops;
+    }
+    return n;
+}
 
 extern "C" size_t mtl_gemm_workspace_bytes(int64_t M, int64_t N, int split_k) {
     return split_k > 1 ? (size_t)split_k * (size_t)M * (size_t)N * sizeof(float) : 0;

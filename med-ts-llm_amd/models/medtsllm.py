@@ -128,7 +128,7 @@ class MedTsLLM(nn.Module):
             raise ValueError(f"HIP reprogramming attention supports d_ff (head dim) in 32/64/128, got {self.d_ff}")
         self.lora_enabled = False
         self._id_cache = {}
-        self._mask_seed = 0
+        self.fixed_prompt_ids = None   # int32 [1 or B, n_tok]: synthetic-benchmark prompt (no tokenizer files needed)
 
     # ------------------------------------------------------------------ construction (a11)
     def _setup_llm(self, backbone_state):
@@ -185,7 +185,6 @@ class MedTsLLM(nn.Module):
             wT[:, :V] = bb.embed_f32.t().to(BF16)
             wT[:, V] = 1.0                                   # bias carrier (see MappingFn)
             self._wT, self._w = wT, bb.embed_f32.to(BF16).contiguous()
-            self._hf_state = None if False else self._hf_state
             nkt = Vp // 64
             tiles = ((self.num_tokens + 127) // 128) * ((d + 127) // 128)
             self._map_split_k = max(1, min(nkt, 16, (512 + tiles - 1) // tiles))
@@ -220,6 +219,8 @@ class MedTsLLM(nn.Module):
 
     def _prompt_ids(self, inputs, device):
         """-> int32 [B or 1, n_tok] left-padded ids (None when prompting is off). Constant parts are tokenised once."""
+        if self.fixed_prompt_ids is not None:
+            return self.fixed_prompt_ids.to(device=device, dtype=torch.int32)
         prompts = self.build_prompt(inputs)
         if len(prompts[0]) == 0:
             return None
