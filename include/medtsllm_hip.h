@@ -95,6 +95,9 @@ int mtl_gemm_nt(const mtl_gemm_args* args, void* stream);
  * bracketed by HIP events on its launch stream. mtl_prof_read aggregates per kernel instance
  * key = epilogue*4 + c_dtype*2 + (split_k > 1): launches, total ms, total algorithmic FLOPs (2*M*N*K). */
 int mtl_prof_enable(int on);
+/* Experiment knob for A/B runs: mode 0 = one output tile per workgroup, 1 = persistent flat-K (default);
+ * bn 0 = automatic tile width, 64 or 128 forced; stages = depth of the LDS ring (2..4). Results are identical in every mode. */
+int mtl_gemm_tune(int mode, int bn, int stages);
 int mtl_prof_read(int* keys, int64_t* launches, double* total_ms, double* total_flops, int cap);
 
 /* ------------------------------------------------------------------ layout / cast helpers
@@ -136,6 +139,8 @@ typedef struct {
     void* dk; int64_t dk_bs, dk_ts, dk_hs;   /* with k_bs == 0 the batch is reduced into dk/dv              */
     void* dv; int64_t dv_bs, dv_ts, dv_hs;
     float* delta;                   /* f32 [B, Hq, Tq] workspace: rowsum(dO * O)                            */
+    float* dkv_ws; int64_t kv_splits; /* batch-shared K/V only: fp32 [2, Tk, Hkv, D] accumulation workspace; the batch is
+                                       split into kv_splits chunks reduced with float atomics (NULL / <=1: one pass) */
 } mtl_attn_bwd_args;
 int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream);
 

@@ -267,7 +267,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const mtl_attn_bwd_ar
     const int64_t hk = blockIdx.y;
     const int group = (int)(f.Hq / f.Hkv);
     const bool shared_kv = (f.k_bs == 0);
-    const int64_t b_begin = shared_kv ? 0 : blockIdx.z, b_end = shared_kv ? f.B : blockIdx.z + 1;
+    // shared K/V (reprogramming attention): blockIdx.z is a CHUNK of the batch; partial dK/dV are accumulated into the
+    // fp32 workspace with hardware float atomics and converted afterwards (dkv_convert_kernel)
+    const int64_t chunk = shared_kv ? (f.B + gridDim.z - 1) / gridDim.z : 1;
+    const int64_t b_begin = shared_kv ? (int64_t)blockIdx.z * chunk : blockIdx.z;
+    const int64_t b_end = shared_kv ? ((b_begin + chunk < f.B) ? b_begin + chunk : f.B) : blockIdx.z + 1;
     const int64_t kblk0 = (int64_t)blockIdx.x * 64;
     const int64_t k0 = kblk0 + wave * 16;
     int64_t krow = k0 + l15;
@@ -347,6 +351,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const mtl_attn_bwd_ar
         }
     }
     if (!k_valid) return;
+    if (shared_kv && gridDim.z > 1) {
+        float* wk = a.dkv_ws + (krow * f.Hkv + hk) * D;
+        float* wv = wk + f.Tk * f.Hkv * D;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                unsafeAtomicAdd(wk + dt * 16 + g * 4 + r, dk[dt][r] * f.scale);
+                unsafeAtomicAdd(wv + dt * 16 + g * 4 + r, dv[dt][r]);
+            }
+        return;
+    }
     const int64_t bo = shared_kv ? 0 : (int64_t)blockIdx.z;
     bf16_t* DK = reinterpret_cast<bf16_t*>(a.dk) + bo * a.dk_bs + hk * a.dk_hs + krow * a.dk_ts;
     bf16_t* DV = reinterpret_cast<bf16_t*>(a.dv) + bo * a.dv_bs + hk * a.dv_hs + krow * a.dv_ts;
@@ -356,6 +372,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const mtl_attn_bwd_ar
         *reinterpret_cast<u32x2*>(DK + dt * 16 + g * 4) = pk;
         u32x2 pv = {pack_bf16x2(dv[dt][0], dv[dt][1]), pack_bf16x2(dv[dt][2], dv[dt][3])};
         *reinterpret_cast<u32x2*>(DV + dt * 16 + g * 4) = pv;
+    }
+}
+
+// fp32 workspace [2][Tk][Hkv][D] -> bf16 dk / dv (strided)
+__global__ void dkv_convert_kernel(const mtl_attn_bwd_args a) {
+    const mtl_attn_fwd_args& f = a.f;
+    const int64_t n = f.Tk * f.Hkv * f.D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t d = i % f.D, hk = (i / f.D) % f.Hkv, t = i / (f.D * f.Hkv);
+        reinterpret_cast<bf16_t*>(a.dk)[hk * a.dk_hs + t * a.dk_ts + d] = f32_to_bf16(a.dkv_ws[i]);
+        reinterpret_cast<bf16_t*>(a.dv)[hk * a.dv_hs + t * a.dv_ts + d] = f32_to_bf16(a.dkv_ws[n + i]);
     }
 }
 
@@ -399,7 +426,12 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const dim3 block(256);
     const dim3 gq((unsigned)((f.Tq + 63) / 64), (unsigned)f.Hq, (unsigned)f.B);
-    const dim3 gk((unsigned)((f.Tk + 63) / 64), (unsigned)f.Hkv, (unsigned)(f.k_bs == 0 ? 1 : f.B));
+    int splits = 1;
+    if (f.k_bs == 0 && a->dkv_ws && a->kv_splits > 1) {
+        splits = (int)(a->kv_splits < f.B ? a->kv_splits : f.B);
+        if (hipMemsetAsync(a->dkv_ws, 0, (size_t)2 * f.Tk * f.Hkv * f.D * sizeof(float), st) != hipSuccess) return MTL_ERR_LAUNCH;
+    }
+    const dim3 gk((unsigned)((f.Tk + 63) / 64), (unsigned)f.Hkv, (unsigned)(f.k_bs == 0 ? splits : f.B));
 #define MTL_BWD(DD)                                                                                        \
     if (f.causal) {                                                                                        \
         hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, true>), gq, block, 0, st, *a);                          \
@@ -410,6 +442,10 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
     }
     if (f.D == 32) { MTL_BWD(32) } else if (f.D == 64) { MTL_BWD(64) } else { MTL_BWD(128) }
 #undef MTL_BWD
+    if (splits > 1) {
+        const int64_t n = f.Tk * f.Hkv * f.D;
+        hipLaunchKernelGGL(dkv_convert_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, st, *a);
+    }
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }

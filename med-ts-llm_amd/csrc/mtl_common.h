@@ -38,17 +38,21 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// gelu_new (HF:activations.py:65-66) and its derivative, fp32
+// gelu_new (HF:activations.py:65-66) and its derivative, fp32.
+// 0.5*x*(1+tanh(u)) == x*sigmoid(2u), u = k0*(x + k1*x^3): one v_exp_f32 + one v_rcp_f32 instead of tanhf.
 __device__ __forceinline__ float gelu_new_f(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float t = tanhf(k0 * (x + k1 * x * x * x));
-    return 0.5f * x * (1.0f + t);
+    const float u2 = 2.0f * k0 * (x + k1 * x * x * x);
+    const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-u2));
+    return x * s;
 }
 __device__ __forceinline__ float dgelu_new_f(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float x2 = x * x;
-    float t = tanhf(k0 * (x + k1 * x * x2));
-    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * k0 * (1.0f + 3.0f * k1 * x2);
+    const float x2 = x * x;
+    const float u2 = 2.0f * k0 * (x + k1 * x * x2);
+    const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-u2));
+    // d/dx [x*s(2u)] = s + x * s*(1-s) * 2u'   with u' = k0*(1 + 3*k1*x^2)
+    return s + x * s * (1.0f - s) * (2.0f * k0 * (1.0f + 3.0f * k1 * x2));
 }
 
 #define MTL_CHECK_LAUNCH()                                   \

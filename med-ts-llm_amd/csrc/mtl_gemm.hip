@@ -250,6 +250,191 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const mtl_gemm_args p, 
     }
 }
 
+// ---------------------------------------------------------------- persistent variant (short-K shapes)
+// One workgroup per (CU slot) walks several output tiles; the K loop is FLAT over (tile, k-tile) pairs so the
+// first LDS-DMA of the next tile is already in flight while the current tile's epilogue runs — with K = 768
+// (12 k-tiles) the per-tile prologue latency and store tail are otherwise ~40 % of a tile's life time.
+// Tiles are dealt per XCD in contiguous runs (blocks with equal blockIdx % 8 share an L2).
+// BN_ = 128 (2 blocks/CU) or 64 (3 blocks/CU; used when N is small so that the tile count fills the chip evenly).
+// swizzle of the 16-B chunk index inside a 128-B tile row: slot = (r&1)*8 + (c ^ (r>>1 & 7)) -> conflict-free
+// ds_read_b128 lane groups (SQ_LDS_BANK_CONFLICT == 0 measured).
+__device__ __forceinline__ int swz64(int row) { return (row >> 1) & 7; }
+
+// grouped (GM rows at a time) tile order: consecutive linear ids form compact GM x n patches, so the workgroups that
+// run concurrently on one XCD stream the SAME few A/B panels through its 4 MiB L2 (measured: the flat row-major
+// order re-fetched B once per tile row -> 38x the algorithmic HBM bytes on the Llama shapes).
+__device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int& tm, int& tn) {
+    constexpr int GM = 8;
+    const int gsize = GM * tiles_n;
+    const int grp = t / gsize, rem = t - grp * gsize;
+    const int first_m = grp * GM;
+    const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    tm = first_m + rem % gm;
+    tn = rem / gm;
+}
+
+// STAGES-deep LDS ring, ONE raw s_barrier per K tile, counted s_waitcnt vmcnt: STAGES-1 tiles of LDS-DMA stay in
+// flight across the barrier (GUIDE §5 "Pipelining across barriers"); __syncthreads() would drain them (vmcnt(0)).
+template <int EPI, int CDT, int BN_, int STAGES>
+__global__ __launch_bounds__(256) void gemm_nt_persist_kernel(const mtl_gemm_args p, const int vec_ok_i, const int tiles_m,
+                                                             const int tiles_n) {
+    constexpr int BK_ = 64;
+    constexpr int NI = BN_ / 32;               // 16-wide n tiles per wave (wave covers BN_/2 columns)
+    constexpr int CPR = BK_ / 8;               // 16-B chunks per tile row
+    constexpr int ROWB = BK_ * 2;              // bytes per tile row
+    constexpr int NA = BM * CPR / 256;         // 16-B staging slots per thread, A tile
+    constexpr int NB = BN_ * CPR / 256;        // ... B tile
+    constexpr int NL = NA + NB;                // LDS-DMA instructions per wave per stage
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN_ * ROWB;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l15 = lane & 15, g = lane >> 4;
+    const bool vec_ok = vec_ok_i != 0;
+
+    const int ntiles = tiles_m * tiles_n;
+    const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int xblocks = (nblk - xcd + 7) >> 3;                 // blocks living on this XCD
+    const int q = ntiles >> 3, r8 = ntiles & 7;
+    const int t0 = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
+    const int cnt = q + (xcd < r8 ? 1 : 0);
+    if (slot >= cnt) return;
+    const int my_count = (cnt - slot + xblocks - 1) / xblocks;
+    const int nkt = (int)(p.K / BK_);
+    const int total = my_count * nkt;
+
+    const bf16_t* asrc[NA];
+    const bf16_t* bsrc[NB];
+    auto set_sources = [&](int tile) {
+        int tm, tn;
+        tile_coords(tile, tiles_m, tiles_n, tm, tn);
+        const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN_;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int sl = i * 256 + tid;
+            const int rr = sl / CPR, pc = sl % CPR;
+            const int c = pc ^ swz64(rr);
+            int64_t am = m0 + rr; if (am > p.M - 1) am = p.M - 1;
+            asrc[i] = reinterpret_cast<const bf16_t*>(p.A) + remap_row(am, p.a_group_rows, p.a_group_stride, p.a_row_offset) * p.lda + c * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int sl = i * 256 + tid;
+            const int rr = sl / CPR, pc = sl % CPR;
+            const int c = pc ^ swz64(rr);
+            int64_t bn = n0 + rr; if (bn > p.N - 1) bn = p.N - 1;
+            bsrc[i] = reinterpret_cast<const bf16_t*>(p.B) + bn * p.ldb + c * 8;
+        }
+    };
+    auto stage = [&](int buf, int kt) {
+        char* la = smem + buf * STAGE;
+        char* lb = la + A_BYTES;
+        const int64_t koff = (int64_t)kt * BK_;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[i] + koff), (lds_void_t*)(la + (i * 256 + wave * 64) * 16), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(bsrc[i] + koff), (lds_void_t*)(lb + (i * 256 + wave * 64) * 16), 16, 0, 0);
+    };
+
+    f32x4 acc[NI][4];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int sw = swz64(l15);                 // wave / mi / ni row offsets are multiples of 16: swz unchanged
+    const int a_off = (wr * 64 + l15) * ROWB;
+    const int b_off = (wc * (BN_ / 2) + l15) * ROWB;
+
+    int s_i = 0, s_kt = 0, s_buf = 0;   // next (tile index, k-tile, ring slot) to stage
+    int c_i = 0, c_kt = 0, c_buf = 0;   // being computed
+    int done_tile = -1;                 // finished tile whose epilogue is still pending
+    // ---- prologue: STAGES-1 tiles in flight
+    set_sources(t0 + slot);
+#pragma unroll
+    for (int s0 = 0; s0 < STAGES - 1; ++s0) {
+        if (s0 < total) {
+            if (s0 > 0 && s_kt == 0) set_sources(t0 + slot + s_i * xblocks);
+            stage(s_buf, s_kt);
+            s_buf = (s_buf + 1 == STAGES) ? 0 : s_buf + 1;
+            if (++s_kt == nkt) { s_kt = 0; ++s_i; }
+        }
+    }
+    for (int it = 0; it < total; ++it) {
+        // tile `it` landed once at most (STAGES-2) younger stages are still outstanding
+        if (it + STAGES - 2 < total - 0 && STAGES > 2 && it + 1 < total) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * NL) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (done_tile >= 0) {           // epilogue of the previous tile: its stores are queued BEFORE the next DMA stage
+            int tm, tn;
+            tile_coords(done_tile, tiles_m, tiles_n, tm, tn);
+            const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN_;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int64_t m = m0 + wr * 64 + mi * 16 + l15;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int64_t n = n0 + wc * (BN_ / 2) + ni * 16 + g * 4;
+                    if (m < p.M && n < p.N) epilogue4<EPI, CDT>(p, m, n, acc[ni][mi], vec_ok);
+                    acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            done_tile = -1;
+        }
+        if (it + STAGES - 1 < total) {
+            if (s_kt == 0) set_sources(t0 + slot + s_i * xblocks);
+            stage(s_buf, s_kt);
+            s_buf = (s_buf + 1 == STAGES) ? 0 : s_buf + 1;
+            if (++s_kt == nkt) { s_kt = 0; ++s_i; }
+        }
+        const char* la = smem + c_buf * STAGE;
+        const char* lb = la + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int pc16 = ((ks * 4 + g) ^ sw) * 16;
+            bf16x8 af[4], bfr[NI];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(la + a_off + mi * 16 * ROWB + pc16);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8*>(lb + b_off + ni * 16 * ROWB + pc16);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
+        c_buf = (c_buf + 1 == STAGES) ? 0 : c_buf + 1;
+        if (++c_kt == nkt) {
+            done_tile = t0 + slot + c_i * xblocks;
+            c_kt = 0;
+            ++c_i;
+        }
+    }
+    if (done_tile >= 0) {
+        int tm, tn;
+        tile_coords(done_tile, tiles_m, tiles_n, tm, tn);
+        const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN_;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int64_t m = m0 + wr * 64 + mi * 16 + l15;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int64_t n = n0 + wc * (BN_ / 2) + ni * 16 + g * 4;
+                if (m < p.M && n < p.N) epilogue4<EPI, CDT>(p, m, n, acc[ni][mi], vec_ok);
+            }
+        }
+    }
+}
+
 template <int EPI, int CDT>
 __global__ void splitk_reduce_kernel(const mtl_gemm_args p, const int S, const int vec_ok_i) {
     const int64_t nq = (p.N + 3) / 4;
@@ -268,6 +453,19 @@ __global__ void splitk_reduce_kernel(const mtl_gemm_args p, const int S, const i
 }
 
 bool aligned(const void* ptr, size_t a) { return (reinterpret_cast<uintptr_t>(ptr) % a) == 0; }
+
+// experiment knobs (mtl_gemm_tune): mode 0 = one tile per workgroup, 1 = persistent flat-K; bn = 0 auto / 64 / 128
+struct Tuning { int mode = 1; int bn = 0; int stages = 2; int num_cu = 0; };
+Tuning& tuning() { static Tuning t; return t; }
+int num_cus() {
+    Tuning& t = tuning();
+    if (t.num_cu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        t.num_cu = n;
+    }
+    return t.num_cu;
+}
 
 template <int EPI, int CDT>
 int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
@@ -295,7 +493,28 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
             }
         }
     } closer{pf, rec, recording, st};
-    if (S == 1) {
+    if (S == 1 && tuning().mode == 1) {
+        const int ncu = num_cus();
+        int bn = tuning().bn;
+        const int stages = tuning().stages;
+        // measured on MI355X (tools/bench_gemm.py): the 128x64 tile (3 workgroups/CU) wins until the grid has >= 8 tiles of
+        // 128x128 per CU, from there the 128x128 tile's lower L1->LDS bytes per FLOP wins
+        if (bn == 0) bn = (tiles_m * tiles_n < 8 * ncu) ? 64 : 128;
+        const int tn = (int)((p.N + bn - 1) / bn), nt = tiles_m * tn;
+        const size_t lds = (size_t)stages * (BM + bn) * BK * 2;
+        const int per_cu = (int)(160 * 1024 / lds) < 1 ? 1 : (int)(160 * 1024 / lds);
+        const int grid = nt < per_cu * ncu ? nt : per_cu * ncu;
+#define MTL_PERSIST(BNV, STV)                                                                                          \
+    do {                                                                                                               \
+        auto kfn = gemm_nt_persist_kernel<EPI, CDT, BNV, STV>;                                                         \
+        static std::once_flag once;                                                                                    \
+        std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, p, vec_ok, tiles_m, tn);                               \
+    } while (0)
+        if (bn == 64) { if (stages == 2) MTL_PERSIST(64, 2); else if (stages == 3) MTL_PERSIST(64, 3); else MTL_PERSIST(64, 4); }
+        else { if (stages == 2) MTL_PERSIST(128, 2); else if (stages == 3) MTL_PERSIST(128, 3); else MTL_PERSIST(128, 4); }
+#undef MTL_PERSIST
+    } else if (S == 1) {
         hipLaunchKernelGGL((gemm_nt_kernel<EPI, CDT, false>), dim3(tiles_m * tiles_n, 1), dim3(256), 0, st, p, vec_ok);
     } else {
         const int ws_vec = (p.N % 4 == 0) && aligned(p.workspace, 16);
@@ -308,6 +527,14 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int mtl_gemm_tune(int mode, int bn, int stages) {
+    if ((mode != 0 && mode != 1) || (bn != 0 && bn != 64 && bn != 128) || stages < 2 || stages > 4) return MTL_ERR_ARG;
+    tuning().mode = mode;
+    tuning().bn = bn;
+    tuning().stages = stages;
+    return MTL_OK;
+}
 
 extern "C" int mtl_prof_enable(int on) {
     Profiler& pf = prof();

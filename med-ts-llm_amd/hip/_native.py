@@ -46,7 +46,7 @@ class AttnBwdArgs(C.Structure):
                 ("dq", vp), ("dq_bs", i64), ("dq_ts", i64), ("dq_hs", i64),
                 ("dk", vp), ("dk_bs", i64), ("dk_ts", i64), ("dk_hs", i64),
                 ("dv", vp), ("dv_bs", i64), ("dv_ts", i64), ("dv_hs", i64),
-                ("delta", vp)]
+                ("delta", vp), ("dkv_ws", vp), ("kv_splits", i64)]
 
 
 PP = C.POINTER(vp)
@@ -74,6 +74,7 @@ SIGNATURES = {
     "mtl_gemm_workspace_bytes": (C.c_size_t, [i64, i64, i32]),
     "mtl_gemm_nt": (i32, [C.POINTER(GemmArgs), vp]),
     "mtl_prof_enable": (i32, [i32]),
+    "mtl_gemm_tune": (i32, [i32, i32, i32]),
     "mtl_prof_read": (i32, [C.POINTER(i32), C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double), i32]),
     "mtl_cast_pad_f32_bf16": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, vp]),
     "mtl_transpose_bf16": (i32, [vp, i64, vp, i64, i64, i64, vp]),

@@ -195,6 +195,10 @@ def attention_bwd(q, k, v, o, lse, dout, Hq, Hkv, D, scale, causal, shared_kv=Fa
     b.dk, (b.dk_bs, b.dk_ts, b.dk_hs) = dk.data_ptr(), dks
     b.dv, (b.dv_bs, b.dv_ts, b.dv_hs) = dv.data_ptr(), dks
     b.delta = delta.data_ptr()
+    ws = None
+    if shared_kv and B > 1:
+        ws = torch.empty((2, Tk, Hkv * D), dtype=F32, device=q.device)
+        b.dkv_ws, b.kv_splits = ws.data_ptr(), max(1, min(B, 2048 // max(1, ((Tk + 63) // 64) * Hkv)))
     check(lib().mtl_attention_bwd(C.byref(b), stream()), "mtl_attention_bwd")
     return dq, dk, dv
 

@@ -1,0 +1,50 @@
+"""A/B microbenchmark of the GEMM variants on the GPT-2-small / Llama layer shapes (GPU box only)."""
+import sys, os, itertools
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from med_ts_llm_amd.hip import ops, _native as N
+
+lib = N.lib()
+BF16 = torch.bfloat16
+shapes = [("qkv   ", 8192, 2304, 768, N.EPI_STORE), ("aproj ", 8192, 768, 768, N.EPI_RESID), ("fc    ", 8192, 3072, 768, N.EPI_GELU),
+          ("mproj ", 8192, 768, 3072, N.EPI_RESID), ("dact  ", 8192, 3072, 768, N.EPI_DGELU), ("dx_fc ", 8192, 768, 3072, N.EPI_STORE),
+          ("dx_qkv", 8192, 768, 2304, N.EPI_STORE), ("llama_qkv", 8192, 12288, 4096, N.EPI_STORE), ("llama_down", 8192, 4096, 11008, N.EPI_RESID)]
+if len(sys.argv) > 1:
+    shapes = [s for s in shapes if s[0].strip() in sys.argv[1:]]
+variants = [(0, 0, 2), (1, 128, 2), (1, 64, 2), (1, 128, 3), (1, 64, 3), (1, 64, 4)]
+g = torch.Generator().manual_seed(0)
+for name, M, Nn, K, epi in shapes:
+    A = torch.randn(M, K, generator=g).to(BF16).cuda()
+    B = (torch.randn(Nn, K, generator=g) * 0.05).to(BF16).cuda()
+    bias = torch.randn(Nn, generator=g).cuda()
+    kw = {}
+    if epi == N.EPI_RESID:
+        kw = dict(out_dtype=torch.float32, aux_in=torch.randn(M, Nn, generator=g).cuda())
+    elif epi == N.EPI_GELU:
+        kw = dict(aux_out=torch.empty(M, Nn, dtype=BF16, device="cuda"))
+    elif epi == N.EPI_DGELU:
+        kw = dict(aux_in=torch.randn(M, Nn, generator=g).to(BF16).cuda())
+    outs, times = {}, {v: [] for v in variants}
+    for rnd in range(5):
+        for v in variants:
+            lib.mtl_gemm_tune(*v)
+            out = ops.gemm_nt(A, B, bias=bias, epilogue=epi, **kw)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                ops.gemm_nt(A, B, bias=bias, epilogue=epi, out=out, **{k: v_ for k, v_ in kw.items() if k != "out_dtype"})
+            e1.record()
+            torch.cuda.synchronize()
+            times[v].append(e0.elapsed_time(e1) / 20 * 1e3)
+            outs[v] = out.float().clone()
+    ref = outs[variants[0]]
+    fl = 2.0 * M * Nn * K
+    line = f"{name} M={M} N={Nn} K={K} epi={epi}: "
+    for v in variants:
+        t = sorted(times[v])[len(times[v]) // 2]
+        same = torch.equal(outs[v], ref)
+        line += f" mode{v}: {t:7.1f}us {fl / t / 1e6:7.1f}TF {'==' if same else '!='} |"
+    print(line)
+lib.mtl_gemm_tune(1, 0, 2)
