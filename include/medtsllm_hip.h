@@ -139,8 +139,8 @@ typedef struct {
     void* dk; int64_t dk_bs, dk_ts, dk_hs;   /* with k_bs == 0 the batch is reduced into dk/dv              */
     void* dv; int64_t dv_bs, dv_ts, dv_hs;
     float* delta;                   /* f32 [B, Hq, Tq] workspace: rowsum(dO * O)                            */
-    float* dkv_ws; int64_t kv_splits; /* batch-shared K/V only: fp32 [2, Tk, Hkv, D] accumulation workspace; the batch is
-                                       split into kv_splits chunks reduced with float atomics (NULL / <=1: one pass) */
+    float* dkv_ws; int64_t kv_splits; /* batch-shared K/V only: fp32 [kv_splits, 2, Tk, Hkv, D] partial slabs; the batch is
+                                       split into kv_splits chunks summed by a second kernel (NULL / <=1: one pass)  */
 } mtl_attn_bwd_args;
 int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream);
 

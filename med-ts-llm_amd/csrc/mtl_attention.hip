@@ -30,13 +30,19 @@ __device__ __forceinline__ bf16x8 pack8(const float* a, const float* b) {
     return f.v;
 }
 
-// operand gathered down a column of a row-major LDS tile: elements j<4 from rows ra+j, j>=4 from rows rb+(j-4)
-__device__ __forceinline__ bf16x8 gather_col(const bf16_t* tile, int ldt, int ra, int rb, int col) {
-    const bf16_t* pa = tile + ra * ldt + col;
-    const bf16_t* pb = tile + rb * ldt + col;
-    frag8 f;
-    f.u = (u32x4){(uint32_t)pa[0] | ((uint32_t)pa[ldt] << 16), (uint32_t)pa[2 * ldt] | ((uint32_t)pa[3 * ldt] << 16),
-                  (uint32_t)pb[0] | ((uint32_t)pb[ldt] << 16), (uint32_t)pb[2 * ldt] | ((uint32_t)pb[3 * ldt] << 16)};
+// TRANSPOSED operand from a row-major LDS tile via the gfx950 hardware transpose read (ds_read_b64_tr_b16):
+// the lane with l15 = lane & 15 receives, for output column c0 + l15, the 8 contraction rows
+//     j < 4: ra + j      j >= 4: rb + (j - 4)
+// Semantics (verified on MI355X, tools/probes/tr16.hip): within each 16-lane group lane i receives element (i & 3) of
+// the 4 contiguous bf16 addressed by lane 4j + (i >> 2), for j = 0..3. So lane L addresses row (L >> 2) of the 4-row
+// block and columns c0 + (L & 3) * 4 .. +3. Two 8-byte reads replace eight 2-byte gathers per MFMA operand.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+__device__ __forceinline__ bf16x8 gather_col(const bf16_t* tile, int ldt, int ra, int rb, int c0, int l15) {
+    const int off = (l15 >> 2) * ldt + c0 + (l15 & 3) * 4;
+    union { bf16x8 v; s16x4 h[2]; } f;
+    f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + ra * ldt + off));
+    f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + rb * ldt + off));
     return f.v;
 }
 
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
                 o[dt] *= alpha;
-                const bf16x8 vt = gather_col(vtile, LDT, sub * 32 + g * 4, sub * 32 + 16 + g * 4, dt * 16 + l15);
+                const bf16x8 vt = gather_col(vtile, LDT, sub * 32 + g * 4, sub * 32 + 16 + g * 4, dt * 16, l15);
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pf, o[dt], 0, 0, 0);
             }
         }
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
             const bf16x8 dsf = pack8(ds[0], ds[1]);
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
-                const bf16x8 kt = gather_col(ktile, LDT, sub * 32 + g * 4, sub * 32 + 16 + g * 4, dt * 16 + l15);
+                const bf16x8 kt = gather_col(ktile, LDT, sub * 32 + g * 4, sub * 32 + 16 + g * 4, dt * 16, l15);
                 dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf, dq[dt], 0, 0, 0);
             }
         }
@@ -341,9 +347,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const mtl_attn_bwd_ar
                     const bf16x8 dsf = pack8(ds[0], ds[1]);
 #pragma unroll
                     for (int dt = 0; dt < NDT; ++dt) {
-                        const bf16x8 dot = gather_col(dotile, LDT, sub * 32 + g * 4, sub * 32 + 16 + g * 4, dt * 16 + l15);
+                        const bf16x8 dot = gather_col(dotile, LDT, sub * 32 + g * 4, sub * 32 + 16 + g * 4, dt * 16, l15);
                         dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pf, dv[dt], 0, 0, 0);
-                        const bf16x8 qt = gather_col(qtile, LDT, sub * 32 + g * 4, sub * 32 + 16 + g * 4, dt * 16 + l15);
+                        const bf16x8 qt = gather_col(qtile, LDT, sub * 32 + g * 4, sub * 32 + 16 + g * 4, dt * 16, l15);
                         dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf, dk[dt], 0, 0, 0);
                     }
                 }
@@ -351,16 +357,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const mtl_attn_bwd_ar
         }
     }
     if (!k_valid) return;
-    if (shared_kv && gridDim.z > 1) {
-        float* wk = a.dkv_ws + (krow * f.Hkv + hk) * D;
-        float* wv = wk + f.Tk * f.Hkv * D;
+    if (shared_kv && gridDim.z > 1) {   // partial slab of this batch chunk: [split][2][Tk][Hkv][D] fp32, plain 16-B stores
+        const int64_t n = f.Tk * f.Hkv * D;
+        float* wk = a.dkv_ws + (int64_t)blockIdx.z * 2 * n + (krow * f.Hkv + hk) * D;
+        float* wv = wk + n;
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                unsafeAtomicAdd(wk + dt * 16 + g * 4 + r, dk[dt][r] * f.scale);
-                unsafeAtomicAdd(wv + dt * 16 + g * 4 + r, dv[dt][r]);
-            }
+        for (int dt = 0; dt < NDT; ++dt) {
+            *reinterpret_cast<float4*>(wk + dt * 16 + g * 4) = make_float4(dk[dt][0] * f.scale, dk[dt][1] * f.scale, dk[dt][2] * f.scale, dk[dt][3] * f.scale);
+            *reinterpret_cast<float4*>(wv + dt * 16 + g * 4) = make_float4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
+        }
         return;
     }
     const int64_t bo = shared_kv ? 0 : (int64_t)blockIdx.z;
@@ -375,14 +380,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const mtl_attn_bwd_ar
     }
 }
 
-// fp32 workspace [2][Tk][Hkv][D] -> bf16 dk / dv (strided)
-__global__ void dkv_convert_kernel(const mtl_attn_bwd_args a) {
+// fp32 partial slabs [splits][2][Tk][Hkv][D] -> summed bf16 dk / dv (strided)
+__global__ void dkv_convert_kernel(const mtl_attn_bwd_args a, const int splits) {
     const mtl_attn_fwd_args& f = a.f;
     const int64_t n = f.Tk * f.Hkv * f.D;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t d = i % f.D, hk = (i / f.D) % f.Hkv, t = i / (f.D * f.Hkv);
-        reinterpret_cast<bf16_t*>(a.dk)[hk * a.dk_hs + t * a.dk_ts + d] = f32_to_bf16(a.dkv_ws[i]);
-        reinterpret_cast<bf16_t*>(a.dv)[hk * a.dv_hs + t * a.dv_ts + d] = f32_to_bf16(a.dkv_ws[n + i]);
+        float sk = 0.f, sv = 0.f;
+        for (int s = 0; s < splits; ++s) {
+            sk += a.dkv_ws[(int64_t)s * 2 * n + i];
+            sv += a.dkv_ws[(int64_t)s * 2 * n + n + i];
+        }
+        reinterpret_cast<bf16_t*>(a.dk)[hk * a.dk_hs + t * a.dk_ts + d] = f32_to_bf16(sk);
+        reinterpret_cast<bf16_t*>(a.dv)[hk * a.dv_hs + t * a.dv_ts + d] = f32_to_bf16(sv);
     }
 }
 
@@ -429,7 +439,9 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
     int splits = 1;
     if (f.k_bs == 0 && a->dkv_ws && a->kv_splits > 1) {
         splits = (int)(a->kv_splits < f.B ? a->kv_splits : f.B);
-        if (hipMemsetAsync(a->dkv_ws, 0, (size_t)2 * f.Tk * f.Hkv * f.D * sizeof(float), st) != hipSuccess) return MTL_ERR_LAUNCH;
+        // every chunk must be non-empty so that every slab is fully written
+        const int64_t chunk = (f.B + splits - 1) / splits;
+        splits = (int)((f.B + chunk - 1) / chunk);
     }
     const dim3 gk((unsigned)((f.Tk + 63) / 64), (unsigned)f.Hkv, (unsigned)(f.k_bs == 0 ? splits : f.B));
 #define MTL_BWD(DD)                                                                                        \
@@ -444,7 +456,7 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
 #undef MTL_BWD
     if (splits > 1) {
         const int64_t n = f.Tk * f.Hkv * f.D;
-        hipLaunchKernelGGL(dkv_convert_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, st, *a);
+        hipLaunchKernelGGL(dkv_convert_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, st, *a, splits);
     }
     MTL_CHECK_LAUNCH();
     return MTL_OK;

@@ -197,8 +197,9 @@ def attention_bwd(q, k, v, o, lse, dout, Hq, Hkv, D, scale, causal, shared_kv=Fa
     b.delta = delta.data_ptr()
     ws = None
     if shared_kv and B > 1:
-        ws = torch.empty((2, Tk, Hkv * D), dtype=F32, device=q.device)
-        b.dkv_ws, b.kv_splits = ws.data_ptr(), max(1, min(B, 2048 // max(1, ((Tk + 63) // 64) * Hkv)))
+        splits = max(1, min(B, 1024 // max(1, ((Tk + 63) // 64) * Hkv)))
+        ws = torch.empty((splits, 2, Tk, Hkv * D), dtype=F32, device=q.device)
+        b.dkv_ws, b.kv_splits = ws.data_ptr(), splits
     check(lib().mtl_attention_bwd(C.byref(b), stream()), "mtl_attention_bwd")
     return dq, dk, dv
 

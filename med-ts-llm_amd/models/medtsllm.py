@@ -124,8 +124,6 @@ class MedTsLLM(nn.Module):
             assert self.d_llm % self.d_ff == 0
         elif self.embedding_downsample_mode != "truncate":
             raise ValueError(f"Unknown embedding downsample mode {self.embedding_downsample_mode}")
-        if self.d_ff not in (32, 64, 128):
-            raise ValueError(f"HIP reprogramming attention supports d_ff (head dim) in 32/64/128, got {self.d_ff}")
         self.lora_enabled = False
         self._id_cache = {}
         self.fixed_prompt_ids = None   # int32 [1 or B, n_tok]: synthetic-benchmark prompt (no tokenizer files needed)
@@ -146,8 +144,7 @@ class MedTsLLM(nn.Module):
         self._hf_cfg, self._hf_state = hf_cfg, sd
         bc = normalise_config(hf_cfg)
         self.d_llm = bc["d"]
-        if bc["head_dim"] not in (32, 64, 128):
-            raise ValueError(f"HIP attention supports head_dim 32/64/128, got {bc['head_dim']}")
+        self._head_dim = bc["head_dim"]
         emb = sd["wte.weight"] if bc["arch"] == "gpt2" else sd["embed_tokens.weight"]
         if emb.shape[0] > 100_000:
             # R:models/medtsllm.py:220-222 makes a TRAINABLE 100 000-row sub-sample (Llama-3). Not on the HIP path yet.
@@ -176,6 +173,10 @@ class MedTsLLM(nn.Module):
     def _ensure_backbone(self, device):
         if device.type != "cuda":
             raise RuntimeError("MedTsLLM (HIP path) needs a ROCm GPU tensor; there is no CPU fallback")
+        if self.d_ff not in (32, 64, 128) or self._head_dim not in (32, 64, 128):
+            raise ValueError(f"HIP attention kernels support head dims 32/64/128 (d_ff={self.d_ff}, backbone head_dim={self._head_dim})")
+        if (self.n_attention_heads * self.d_ff) % 64 or self.d_llm % 64:
+            raise ValueError("HIP GEMMs need n_heads*d_ff and d_llm to be multiples of 64")
         if self.backbone is None or self.backbone.device != device:
             self.backbone = FrozenBackbone(self._hf_cfg, self._hf_state, device, n_layers=self.llm_layers)
             bb = self.backbone

@@ -181,7 +181,7 @@ CASES = [
 
 
 def t2n(t):
-    return t.detach().cpu().float().numpy()
+    return t.detach().cpu().float().numpy().copy()   # copy: .numpy() aliases the (later updated) parameter storage
 
 
 def run_case(name, kind, task, B, L, C, pred, cov, down, prompting, n_classes, llm_dirs, backbones):

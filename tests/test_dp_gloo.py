@@ -1,0 +1,76 @@
+"""world_size-2 data-parallel tests on CPU (gloo): the flat-gradient all-reduce reproduces the single-process
+full-batch gradient, and the sampler/shard helpers partition a batch without overlap."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from med_ts_llm_amd import parallel
+    r, w, _ = parallel.init_from_env("cpu")
+    assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    frozen = torch.nn.Linear(3, 3)
+    for p_ in frozen.parameters():
+        p_.requires_grad = False
+    g = torch.Generator().manual_seed(1)
+    batch = {"x_enc": torch.randn(8, 6, generator=g), "y": torch.randn(8, 3, generator=g), "descriptions": [f"d{i}" for i in range(8)]}
+    shard = parallel.shard_batch(batch, rank, world)
+    assert shard["descriptions"] == batch["descriptions"][rank * 4:(rank + 1) * 4]
+    loss = torch.nn.functional.mse_loss(frozen(model(shard["x_enc"])), shard["y"])      # mean over the LOCAL shard
+    loss.backward()
+    sync = parallel.FlatGradAllReduce(list(model.parameters()) + list(frozen.parameters()))
+    assert sync.flat.numel() == sum(p_.numel() for p_ in model.parameters())          # frozen params are not communicated
+    sync()
+    grads = [p_.grad.clone() for p_ in model.parameters()]
+    if rank == 0:
+        ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+        ref.load_state_dict(model.state_dict())
+        torch.nn.functional.mse_loss(frozen(ref(batch["x_enc"])), batch["y"]).backward()  # mean over the GLOBAL batch
+        ok = all(torch.allclose(a, b.grad, rtol=1e-5, atol=1e-6) for a, b in zip(grads, ref.parameters()))
+        q.put(ok)
+    # both ranks end with identical gradients
+    t = torch.cat([g_.flatten() for g_ in grads])
+    lst = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(lst, t)
+    assert torch.equal(lst[0], lst[1])
+    dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_equals_full_batch_gradient():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    for p_ in procs:
+        p_.join(120)
+        assert p_.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_single_process_is_a_noop():
+    from med_ts_llm_amd import parallel
+    for k in ("WORLD_SIZE", "RANK"):
+        os.environ.pop(k, None)
+    assert parallel.init_from_env("cpu") == (0, 1, 0)
+    lin = torch.nn.Linear(2, 2)
+    lin(torch.ones(1, 2)).sum().backward()
+    g0 = lin.weight.grad.clone()
+    parallel.FlatGradAllReduce(lin.parameters())()
+    assert torch.equal(lin.weight.grad, g0)

@@ -1,0 +1,140 @@
+"""CPU tests of the host-side logic (no GPU): prompt construction, construction/checkpoint surface, C-ABI symbols,
+and the optimisation-step order (a10) pinned to the reference trainer's loss trajectory."""
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import CASES, GOLDEN, load_case, oracle_mcfg, rel_err, fixture_tokenizer
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _cfg_from_meta(meta):
+    from med_ts_llm_amd.utils import dict_to_object
+    return dict_to_object({
+        "DEBUG": True, "task": meta["task"], "model": "medtsllm", "history_len": meta["L"], "pred_len": meta["pred_len"],
+        "training": {"dropout": 0.0}, "setup": {"dtype": "fp32"}, "tasks": {"segmentation": {"mode": "boundary-prediction"}},
+        "models": {"timellm": {
+            "d_model": meta["d_model"], "d_ff": meta["d_ff"], "n_heads": meta["n_heads"], "num_tokens": meta["num_tokens"],
+            "covariate_mode": meta["covariate_mode"], "embedding_downsample_mode": meta["embedding_downsample_mode"],
+            "patching": {"patch_len": meta["patch_len"], "stride": meta["stride"]}, "prompting": meta["prompting"],
+            "llm": {"enabled": True, "llm": "fixture", "llm_layers": -1, "load_in_4bit": False, "load_in_8bit": False}}}})
+
+
+class _DS:
+    def __init__(self, meta):
+        self.description, self.n_features, self.n_classes, self.task_description = meta["dataset_description"], meta["C"], meta["n_classes"], None
+
+
+def _model(name):
+    from med_ts_llm_amd.models import model_lookup
+    meta, data, bcfg, backbone = load_case(name)
+    m = model_lookup["medtsllm"](_cfg_from_meta(meta), _DS(meta), backbone_state=(bcfg, backbone))
+    m.tokenizer = fixture_tokenizer(meta["backbone"])
+    return m, meta, data
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_prompt_strings_and_token_ids_exact(name):
+    """a6: identical part list, order, trailing-space rule, stats formatting; per-part token ids (reference goldens)."""
+    model, meta, data = _model(name)
+    inputs = {"x_enc": torch.from_numpy(data["x_enc"])}
+    if meta["descriptions"]:
+        inputs["descriptions"] = meta["descriptions"]
+    parts = model.build_prompt(inputs)
+    assert parts == meta["prompts"]
+    ids = [[model.tokenizer(p, padding=False, truncation=False).input_ids for p in ps] for ps in parts]
+    assert ids == meta["prompt_token_ids"]
+    assert model.task_description == meta["task_description"]
+    if parts[0]:
+        from med_ts_llm_amd.models.prompt import left_pad_ids
+        rows = left_pad_ids(ids, model.tokenizer.pad_token_id)
+        n = max(sum(len(p) for p in ps) for ps in ids)
+        assert all(len(r) == n for r in rows)
+        for r, ps in zip(rows, ids):
+            flat = [i for p in ps for i in p]
+            assert r[n - len(flat):] == flat and all(v == meta["pad_token_id"] for v in r[: n - len(flat)])
+
+
+def test_calc_lags_exact():
+    from med_ts_llm_amd.models.prompt import calc_lags
+    z = np.load(GOLDEN / "stats.npz")
+    x = torch.from_numpy(z["x"])
+    assert np.array_equal(calc_lags(x, 5).numpy(), z["lags_3d"])
+    assert np.array_equal(calc_lags(x[:, :, 1], 5).numpy(), z["lags_2d"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_construction_and_checkpoint_surface(name):
+    """a11: derived sizes, parameter names/shapes/requires_grad, state_dict filtering, load_pretrained key dropping."""
+    model, meta, _ = _model(name)
+    table = {n: {"shape": list(p.shape), "requires_grad": bool(p.requires_grad)} for n, p in model.named_parameters()}
+    assert table == meta["param_table"]
+    assert list(model.state_dict().keys()) == meta["state_dict_keys"]
+    assert model.n_patches == meta["n_patches"] and model.n_outputs == meta["n_outputs"] and model.d_model == meta["d_model_eff"]
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    assert model.load_pretrained(sd) == meta["load_pretrained_keys"]
+    with pytest.raises(RuntimeError):      # the product path has no CPU fallback
+        model({"x_enc": torch.zeros(2, meta["L"], meta["C"])})
+
+
+def test_registry_and_config_object():
+    from med_ts_llm_amd.models import model_lookup
+    from med_ts_llm_amd.tasks import task_lookup, get_trainer  # noqa: F401
+    from med_ts_llm_amd.utils import dict_to_object
+    assert model_lookup["timellm"] is model_lookup["medtsllm"]
+    assert set(task_lookup) == {"forecasting", "anomaly_detection", "reconstruction", "segmentation", "semantic_segmentation", "pretraining"}
+    c = dict_to_object({"a": {"b": 1}, "c": 2})
+    assert c.a.b == 1 and c["c"] == 2 and "a" in c and c.get("zz", 7) == 7 and c.copy().to_dict() == {"a": {"b": 1}, "c": 2}
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from med_ts_llm_amd.hip import _native
+    header = (ROOT / "include" / "medtsllm_hip.h").read_text()
+    declared = set(re.findall(r"\b(mtl_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
+    lib = _native.lib()                    # loads without a GPU; getattr raises on a missing export
+    for name in declared:
+        getattr(lib, name)
+    assert lib.mtl_abi_version() == _native.ABI_VERSION
+    assert b"alignment" in lib.mtl_strerror(-2)
+
+
+def test_optimisation_step_order_matches_reference_trajectory():
+    """a10: forward -> loss -> backward -> Adam.step -> zero_grad on the oracle reproduces the REFERENCE trainer's
+    per-step losses and final weights (golden from tasks.get_trainer(...).train() on a synthetic dataset)."""
+    from oracle import medtsllm_oracle as O
+    z = np.load(GOLDEN / "trainer_gpt2_concat_fc.npz")
+    meta, _, bcfg, backbone = load_case("gpt2_concat_fc")
+    tok = fixture_tokenizer("gpt2")
+    from med_ts_llm_amd.models import prompt as P
+    p = {k[len("init."):]: torch.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith("init.")}
+    opt = torch.optim.Adam(list(p.values()), lr=1e-3)
+    m = oracle_mcfg(meta)
+    losses = []
+    n_batches = len([k for k in z.files if k.endswith(".x_enc")])
+    for i in range(n_batches):
+        x, y = torch.from_numpy(z[f"batch{i}.x_enc"]), torch.from_numpy(z[f"batch{i}.y"])
+        parts = P.build_prompt_parts({"x_enc": x}, meta["prompting"], meta["dataset_description"], meta["task_description"], tok.bos_token)
+        ids = [[tok(s, padding=False, truncation=False).input_ids for s in ps] for ps in parts]
+        pred = O.medtsllm_forward(x, p, backbone, bcfg, m, token_ids=ids, pad_token_id=tok.pad_token_id, training=True)
+        loss = torch.nn.functional.mse_loss(pred, y)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        losses.append(loss.item())
+    # importing the reference's tasks package sets torch.set_float32_matmul_precision("medium") (R:tasks/base.py:19-22),
+    # so the golden trajectory itself carries ~3e-4 of reduced-precision CPU matmul noise; a wrong step order
+    # (e.g. zero_grad before step, stale gradients) moves these numbers by O(1e-1).
+    assert np.allclose(losses, z["losses"], rtol=1e-3, atol=1e-6), (losses, z["losses"])
+    for k in z.files:
+        if k.startswith("final."):
+            name = k[len("final."):]
+            moved = float(np.linalg.norm(z[k] - z["init." + name]))
+            assert float((p[name].detach() - torch.from_numpy(z[k])).norm()) < 0.05 * moved + 1e-6, k
+    assert int(z["step_counter"]) == 4 * n_batches   # BaseTask.step advances by batch_size per step (R:tasks/base.py:217)
