@@ -135,6 +135,8 @@ def test_optimisation_step_order_matches_reference_trajectory():
     for k in z.files:
         if k.startswith("final."):
             name = k[len("final."):]
+            if name.endswith("key_projection.bias"):
+                continue   # analytically-zero gradient: Adam normalises pure round-off noise into +-lr steps (not reproducible)
             moved = float(np.linalg.norm(z[k] - z["init." + name]))
             assert float((p[name].detach() - torch.from_numpy(z[k])).norm()) < 0.05 * moved + 1e-6, k
     assert int(z["step_counter"]) == 4 * n_batches   # BaseTask.step advances by batch_size per step (R:tasks/base.py:217)
