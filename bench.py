@@ -165,6 +165,7 @@ def main():
     ap.add_argument("--workload", default="gpt2s_B32_L1024_C12", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--full-backward", action="store_true", help="also compute the (unused) prompt-row input gradients")
     args = ap.parse_args()
 
     from med_ts_llm_amd import parallel
@@ -187,9 +188,10 @@ def main():
     model = model_lookup["medtsllm"](dict_to_object(model_cfg(L, pred)), DS(C_), backbone_state=(hf_cfg, sd)).to(device)
     prompt_ids = torch.randint(0, hf_cfg["vocab_size"], (1, n_tok), generator=torch.Generator().manual_seed(1), dtype=torch.int32)
     model.fixed_prompt_ids = prompt_ids
+    model.prune_dead_prompt_grads = not args.full_backward
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=1e-4)
+    opt = torch.optim.Adam(params, lr=1e-4, fused=True)
     sync = parallel.FlatGradAllReduce(params) if world > 1 else None
     loss_fn = torch.nn.MSELoss()
     batches = [make_batch(B, L, C_, pred, 1000 + rank * 97 + i, device) for i in range(4)]
@@ -264,6 +266,8 @@ def main():
                                    f"step = fwd+loss+bwd+{'allreduce+' if world > 1 else ''}Adam", "global_batch": B * world,
                        "parallelism": f"dp{world}"},
             "final_loss": final_loss,
+            "backward": "full (incl. unused prompt-row input gradients)" if args.full_backward else
+                        "exact dead-gradient elimination: prompt rows never depend on a trainable parameter, their input gradient is not computed",
             "algorithmic_tflop_per_step_per_gpu": round(fl / 1e12, 3),
             "step_mfma_frac": round(fl / (elapsed / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
             "roofline": roofline, "cpu_baseline": cpu,

@@ -130,6 +130,8 @@ typedef struct {
     int64_t B, Hq, Hkv, Tq, Tk, D;
     float scale;
     int causal;
+    int64_t causal_off;   /* causal: key k is visible to query q iff k <= q + causal_off (0 for Tq == Tk; Tk - Tq aligns bottom-right) */
+    int64_t stat_stride;  /* elements between consecutive (batch, head) rows of lse / delta; 0 -> Tq                          */
 } mtl_attn_fwd_args;
 int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream);
 typedef struct {
@@ -139,6 +141,7 @@ typedef struct {
     void* dk; int64_t dk_bs, dk_ts, dk_hs;   /* with k_bs == 0 the batch is reduced into dk/dv              */
     void* dv; int64_t dv_bs, dv_ts, dv_hs;
     float* delta;                   /* f32 [B, Hq, Tq] workspace: rowsum(dO * O)                            */
+    int64_t kv_row0;                /* dK/dV are produced only for keys >= kv_row0 (keys whose gradient is dead are skipped) */
     float* dkv_ws; int64_t kv_splits; /* batch-shared K/V only: fp32 [kv_splits, 2, Tk, Hkv, D] partial slabs; the batch is
                                        split into kv_splits chunks summed by a second kernel (NULL / <=1: one pass)  */
 } mtl_attn_bwd_args;
@@ -153,10 +156,12 @@ int mtl_norm_fwd(const float* x, const float* gamma, const float* beta, void* y,
                  int64_t M, int64_t d, float eps, int rms, int64_t group_rows, int64_t group_stride,
                  int64_t row_offset, void* stream);
 /* dX only (gamma/beta are frozen). dres_out[m] = (dres_in ? dres_in[m] : 0) + LN'(dy[m]); optionally also
- * a bf16 copy of dres_out (A operand of the next dX GEMM). dres_in may alias dres_out. */
+ * a bf16 copy of dres_out (A operand of the next dX GEMM). dres_in may alias dres_out. dy rows are compact (logical);
+ * x / dres rows are physical (gathered); stats rows are physical when stats_physical != 0 (statistics saved by a
+ * full-size forward), logical otherwise (statistics saved by a gathered forward). */
 int mtl_norm_bwd(const void* dy, int64_t ld_dy, const float* x, const float* gamma, const float* stats,
                  const float* dres_in, float* dres_out, void* dres_out_bf16, int64_t M, int64_t d, int rms,
-                 int64_t group_rows, int64_t group_stride, int64_t row_offset, void* stream);
+                 int64_t group_rows, int64_t group_stride, int64_t row_offset, int stats_physical, void* stream);
 
 /* ------------------------------------------------------------------ Llama elementwise
  * RoPE, half-split rotate_half form (HF:models/llama/modeling_llama.py:130-160), in place on the q and k
@@ -168,6 +173,13 @@ int mtl_rope_inplace(void* qkv, int64_t ld, const float* cos_t, const float* sin
  * bwd: dgu[M, 2F] from dh[M, F] and the saved gu. */
 int mtl_swiglu_fwd(const void* gu, void* h, int64_t M, int64_t F, void* stream);
 int mtl_swiglu_bwd(const void* gu, const void* dh, void* dgu, int64_t M, int64_t F, void* stream);
+/* row-gathered variants used by the pruned backbone backward: logical row m of the M processed rows is physical row
+ * (m / group_rows)*group_stride + row_offset + m % group_rows of qkv / gu (group_rows == 0: identity); dh, dgu compact. */
+int mtl_rope_inplace_rows(void* qkv, int64_t ld, const float* cos_t, const float* sin_t, int64_t M, int64_t T,
+                          int64_t n_rot_heads, int64_t D, int inverse, int64_t group_rows, int64_t group_stride,
+                          int64_t row_offset, void* stream);
+int mtl_swiglu_bwd_rows(const void* gu, const void* dh, void* dgu, int64_t M, int64_t F, int64_t group_rows,
+                        int64_t group_stride, int64_t row_offset, void* stream);
 
 /* ------------------------------------------------------------------ LLM input assembly (a6 tail, K10/K11)
  * h0[b, t, :] = (t < n_tok ? embed[ids[b, t]] : x_tok[b, t - n_tok, :]) + (wpe ? wpe[t] : 0)   -> f32 [B, T, d]
@@ -207,9 +219,13 @@ size_t mtl_backbone_work_bytes(const mtl_backbone_weights* w, int64_t B, int64_t
  * to the last n_last tokens of every sample (only those are consumed downstream, R:models/medtsllm.py:353). */
 int mtl_backbone_fwd(const mtl_backbone_weights* w, const float* h0, void* out, void* saved, void* work,
                      int64_t B, int64_t T, int64_t n_last, void* stream);
-/* dout bf16 [B, n_last, d] -> dh0 f32 [B, T, d]. `saved` from the matching forward. */
+/* dout bf16 [B, n_last, d] -> dh0 f32 [B, T, d]. `saved` from the matching forward.
+ * n_grad (n_last <= n_grad <= T): only the LAST n_grad tokens of every sample receive a gradient; rows before that are
+ * left zero. The leading tokens are the text prompt: causal attention never lets them see a patch token, so they are
+ * independent of every trainable parameter and their gradient is never consumed (SURVEY.md §7 "legal shortcut ii").
+ * All backward GEMMs / norms / attention then run on B*n_grad rows. n_grad = T computes the full dh0. */
 int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, const void* dout, float* dh0, void* saved,
-                     void* work, int64_t B, int64_t T, int64_t n_last, void* stream);
+                     void* work, int64_t B, int64_t T, int64_t n_last, int64_t n_grad, void* stream);
 
 #ifdef __cplusplus
 }

@@ -87,12 +87,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a
     for (int i = 0; i < NDT; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run = NEG_BIG, l_run = 0.f;
 
+    // causal: key visible to query q iff key <= q + causal_off (causal_off = Tk - Tq aligns the diagonal bottom-right)
+    const int64_t coff = a.causal_off;
     int64_t k_end = a.Tk;
     if (CAUSAL) {
-        const int64_t lim = qblk0 + 64 < a.Tq ? qblk0 + 64 : a.Tq;  // keys <= last query of the block
+        const int64_t lim = (qblk0 + 64 < a.Tq ? qblk0 + 64 : a.Tq) + coff;  // keys <= last query of the block
         k_end = lim < a.Tk ? lim : a.Tk;
     }
-    const int64_t wave_qmax = (q0 + 15 < a.Tq - 1) ? q0 + 15 : a.Tq - 1;
+    const int64_t wave_qmax = ((q0 + 15 < a.Tq - 1) ? q0 + 15 : a.Tq - 1) + coff;
 
     for (int64_t kc0 = 0; kc0 < k_end; kc0 += KC) {
         __syncthreads();
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a
                 for (int r = 0; r < 4; ++r) {
                     const int64_t key = kb + t * 16 + g * 4 + r;
                     float v = s[t][r] * a.scale;
-                    if (key >= a.Tk || (CAUSAL && key > qrow)) v = NEG_BIG;
+                    if (key >= a.Tk || (CAUSAL && key > qrow + coff)) v = NEG_BIG;
                     p[t][r] = v;
                     mx = fmaxf(mx, v);
                 }
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a
         u32x2 pk = {pack_bf16x2(o[dt][0] * inv_l, o[dt][1] * inv_l), pack_bf16x2(o[dt][2] * inv_l, o[dt][3] * inv_l)};
         *reinterpret_cast<u32x2*>(O + dt * 16 + g * 4) = pk;
     }
-    if (g == 0 && a.lse) a.lse[(b * a.Hq + h) * a.Tq + qrow] = m_run + __logf(l_run);
+    if (g == 0 && a.lse) a.lse[(b * a.Hq + h) * (a.stat_stride ? a.stat_stride : a.Tq) + qrow] = m_run + __logf(l_run);
 }
 
 // =============================================================================================== backward: dQ (+ delta)
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
     }
     dl += __shfl_xor(dl, 16, 64);
     dl += __shfl_xor(dl, 32, 64);
-    const int64_t stat_idx = (b * f.Hq + h) * f.Tq + qrow;
+    const int64_t stat_idx = (b * f.Hq + h) * (f.stat_stride ? f.stat_stride : f.Tq) + qrow;
     if (g == 0 && q_valid) a.delta[stat_idx] = dl;
     const float lse = f.lse[stat_idx];
 
@@ -206,12 +208,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
 #pragma unroll
     for (int i = 0; i < NDT; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    const int64_t coff = f.causal_off;
     int64_t k_end = f.Tk;
     if (CAUSAL) {
-        const int64_t lim = qblk0 + 64 < f.Tq ? qblk0 + 64 : f.Tq;
+        const int64_t lim = (qblk0 + 64 < f.Tq ? qblk0 + 64 : f.Tq) + coff;
         k_end = lim < f.Tk ? lim : f.Tk;
     }
-    const int64_t wave_qmax = (q0 + 15 < f.Tq - 1) ? q0 + 15 : f.Tq - 1;
+    const int64_t wave_qmax = ((q0 + 15 < f.Tq - 1) ? q0 + 15 : f.Tq - 1) + coff;
 
     for (int64_t kc0 = 0; kc0 < k_end; kc0 += KC) {
         __syncthreads();
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t key = kb + t * 16 + g * 4 + r;
-                    const bool masked = key >= f.Tk || (CAUSAL && key > qrow);
+                    const bool masked = key >= f.Tk || (CAUSAL && key > qrow + coff);
                     const float p = masked ? 0.f : __expf(s[r] * f.scale - lse);
                     ds[t][r] = p * (dp[r] - dl);
                 }
@@ -278,7 +281,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const mtl_attn_bwd_ar
     const int64_t chunk = shared_kv ? (f.B + gridDim.z - 1) / gridDim.z : 1;
     const int64_t b_begin = shared_kv ? (int64_t)blockIdx.z * chunk : blockIdx.z;
     const int64_t b_end = shared_kv ? ((b_begin + chunk < f.B) ? b_begin + chunk : f.B) : blockIdx.z + 1;
-    const int64_t kblk0 = (int64_t)blockIdx.x * 64;
+    const int64_t coff = f.causal_off;
+    const int64_t kblk0 = a.kv_row0 + (int64_t)blockIdx.x * 64;   // keys below kv_row0 need no gradient (pruned)
     const int64_t k0 = kblk0 + wave * 16;
     int64_t krow = k0 + l15;
     const bool k_valid = krow < f.Tk;
@@ -304,8 +308,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const mtl_attn_bwd_ar
             const int64_t h = hk * group + hg;
             const bf16_t* Q = reinterpret_cast<const bf16_t*>(f.q) + b * f.q_bs + h * f.q_hs;
             const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dout) + b * a.do_bs + h * a.do_hs;
-            const int64_t stat0 = (b * f.Hq + h) * f.Tq;
-            const int64_t qc_begin = CAUSAL ? (kblk0 / KC) * KC : 0;  // queries before the key tile never see it
+            const int64_t stat0 = (b * f.Hq + h) * (f.stat_stride ? f.stat_stride : f.Tq);
+            // queries q with q + coff < kblk0 never see this key tile
+            const int64_t qc_begin = (CAUSAL && kblk0 > coff) ? ((kblk0 - coff) / KC) * KC : 0;
             for (int64_t qc0 = qc_begin; qc0 < f.Tq; qc0 += KC) {
                 __syncthreads();
                 load_tile<D>(qtile, Q, f.q_ts, qc0, f.Tq);
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const mtl_attn_bwd_ar
                 for (int sub = 0; sub < 2; ++sub) {
                     const int64_t qb = qc0 + sub * 32;
                     if (qb >= f.Tq) continue;
-                    if (CAUSAL && qb + 31 < k0) continue;  // every query of the slab precedes this wave's keys
+                    if (CAUSAL && qb + 31 + coff < k0) continue;  // every query of the slab precedes this wave's keys
                     float p[2][4], ds[2][4];
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const mtl_attn_bwd_ar
                         for (int r = 0; r < 4; ++r) {
                             const int ql = sub * 32 + t * 16 + g * 4 + r;
                             const int64_t q = qc0 + ql;
-                            const bool masked = q >= f.Tq || (CAUSAL && krow > q);
+                            const bool masked = q >= f.Tq || (CAUSAL && krow > q + coff);
                             const float pv = masked ? 0.f : __expf(s[r] * f.scale - lse_s[ql]);
                             p[t][r] = pv;
                             ds[t][r] = pv * (dp[r] - delta_s[ql]);
@@ -443,7 +448,8 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
         const int64_t chunk = (f.B + splits - 1) / splits;
         splits = (int)((f.B + chunk - 1) / chunk);
     }
-    const dim3 gk((unsigned)((f.Tk + 63) / 64), (unsigned)f.Hkv, (unsigned)(f.k_bs == 0 ? splits : f.B));
+    if (a->kv_row0 < 0 || a->kv_row0 >= f.Tk) return MTL_ERR_ARG;
+    const dim3 gk((unsigned)((f.Tk - a->kv_row0 + 63) / 64), (unsigned)f.Hkv, (unsigned)(f.k_bs == 0 ? splits : f.B));
 #define MTL_BWD(DD)                                                                                        \
     if (f.causal) {                                                                                        \
         hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, true>), gq, block, 0, st, *a);                          \

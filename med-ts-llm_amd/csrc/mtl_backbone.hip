@@ -71,9 +71,15 @@ WorkLayout work_layout(const Dims& D) {
     return w;
 }
 
+struct RowMap { int64_t rows, stride, offset; };   // logical row m -> (m / rows) * stride + offset + m % rows; rows == 0: identity
+const RowMap kIdentity = {0, 0, 0};
+
 int gemm(const void* A, int64_t lda, const void* Bm, int64_t ldb, void* C, int64_t ldc, int cdt, int64_t M, int64_t N, int64_t K,
-         const float* bias, int epi, const void* aux_in, int64_t ld_aux_in, void* aux_out, int64_t ld_aux_out, void* stream) {
+         const float* bias, int epi, const void* aux_in, int64_t ld_aux_in, void* aux_out, int64_t ld_aux_out, void* stream,
+         RowMap am = kIdentity, RowMap cm = kIdentity) {
     mtl_gemm_args g = {};
+    g.a_group_rows = am.rows; g.a_group_stride = am.stride; g.a_row_offset = am.offset;
+    g.c_group_rows = cm.rows; g.c_group_stride = cm.stride; g.c_row_offset = cm.offset;
     g.A = A; g.lda = lda; g.B = Bm; g.ldb = ldb; g.C = C; g.ldc = ldc; g.c_dtype = cdt;
     g.M = M; g.N = N; g.K = K; g.bias = bias; g.epilogue = epi;
     g.aux_in = aux_in; g.ld_aux_in = ld_aux_in; g.aux_out = aux_out; g.ld_aux_out = ld_aux_out;
@@ -97,6 +103,8 @@ void attn_args(const Dims& D, char* qkv, char* attn, float* lse, mtl_attn_fwd_ar
     f->B = D.B; f->Hq = D.Hq; f->Hkv = D.Hkv; f->Tq = D.T; f->Tk = D.T; f->D = D.hd;
     f->scale = 1.0f / sqrtf((float)D.hd);
     f->causal = 1;
+    f->causal_off = 0;
+    f->stat_stride = 0;
 }
 
 int check_weights(const mtl_backbone_weights* w) {
@@ -150,7 +158,7 @@ extern "C" int mtl_backbone_fwd(const mtl_backbone_weights* w, const float* h0, 
         MTL_TRY(mtl_norm_fwd(H(2 * i), w->ln1_w[i], w->ln1_b ? w->ln1_b[i] : nullptr, wk + W.xln, D.d, st1, D.M, D.d, w->eps, rms, 0, 0, 0, stream));
         MTL_TRY(gemm(wk + W.xln, D.d, w->w_qkv[i], D.d, qkv, D.Nqkv, MTL_BF16, D.M, D.Nqkv, D.d, bq, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream));
         if (D.llama) MTL_TRY(mtl_rope_inplace(qkv, D.Nqkv, w->rope_cos, w->rope_sin, D.M, D.T, D.Hq + D.Hkv, D.hd, 0, stream));
-        mtl_attn_fwd_args fa;
+        mtl_attn_fwd_args fa = {};
         attn_args(D, qkv, attn, lse, &fa);
         MTL_TRY(mtl_attention_fwd(&fa, stream));
         MTL_TRY(gemm(attn, D.No, w->w_o[i], D.No, H(2 * i + 1), D.d, MTL_F32, D.M, D.d, D.No, bo, MTL_EPI_RESID, H(2 * i), D.d, nullptr, 0, stream));
@@ -169,9 +177,10 @@ extern "C" int mtl_backbone_fwd(const mtl_backbone_weights* w, const float* h0, 
 }
 
 extern "C" int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, const void* dout, float* dh0, void* saved, void* work,
-                                int64_t B, int64_t T, int64_t n_last, void* stream) {
+                                int64_t B, int64_t T, int64_t n_last, int64_t n_grad, void* stream) {
     MTL_TRY(check_weights(w));
     if (!h0 || !dout || !dh0 || !saved || !work || B <= 0 || T <= 0 || n_last <= 0 || n_last > T) return MTL_ERR_ARG;
+    if (n_grad < n_last || n_grad > T) return MTL_ERR_ARG;
     const Dims D = dims_of(w, B, T);
     const SavedLayout S = saved_layout(D, T);
     const WorkLayout W = work_layout(D);
@@ -182,13 +191,17 @@ extern "C" int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, 
     auto H = [&](int idx) -> float* {
         return idx == 0 ? const_cast<float*>(h0) : reinterpret_cast<float*>(sv + S.h + S.h_stride * (size_t)(idx - 1));
     };
-    // final norm: only the last n_last rows of each sample carry gradient; everything else starts at zero
-    if (n_last < T) {
+    // rows that receive a gradient: the last n_grad tokens of every sample (see header). Buffers addressed by (b, t)
+    // keep their full-size physical layout and are touched through the row map; dx / dact(llama) scratch is compact.
+    const int64_t r0 = D.T - n_grad;
+    const int64_t Mg = D.B * n_grad;
+    const RowMap rm = (n_grad == D.T) ? kIdentity : RowMap{n_grad, D.T, r0};
+    if (n_last < T) {   // rows without incoming gradient start at zero
         if (hipMemsetAsync(dh0, 0, (size_t)D.M * D.d * 4, st) != hipSuccess) return MTL_ERR_LAUNCH;
         if (hipMemsetAsync(wk + W.dres_b, 0, (size_t)D.M * D.d * 2, st) != hipSuccess) return MTL_ERR_LAUNCH;
     }
     const float* stf = reinterpret_cast<const float*>(sv + S.stats_f);
-    MTL_TRY(mtl_norm_bwd(dout, D.d, H(2 * D.L), w->lnf_w, stf, nullptr, dh0, wk + W.dres_b, D.B * n_last, D.d, rms, n_last, D.T, D.T - n_last, stream));
+    MTL_TRY(mtl_norm_bwd(dout, D.d, H(2 * D.L), w->lnf_w, stf, nullptr, dh0, wk + W.dres_b, D.B * n_last, D.d, rms, n_last, D.T, D.T - n_last, 0, stream));
     for (int i = D.L - 1; i >= 0; --i) {
         const float* st1 = reinterpret_cast<const float*>(sv + S.stats + S.stats_stride * (size_t)(2 * i));
         const float* st2 = reinterpret_cast<const float*>(sv + S.stats + S.stats_stride * (size_t)(2 * i + 1));
@@ -198,27 +211,35 @@ extern "C" int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, 
         char* fc = sv + S.fc + S.fc_stride * (size_t)i;
         // --- MLP block backward: h_out = h_mid + proj(act(fc(norm2(h_mid))))
         if (D.llama) {
-            MTL_TRY(gemm(wk + W.dres_b, D.d, w->w_proj_t[i], D.d, wk + W.dhact, D.ffn, MTL_BF16, D.M, D.ffn, D.d, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream));
-            MTL_TRY(mtl_swiglu_bwd(fc, wk + W.dhact, wk + W.dact, D.M, D.ffn, stream));
+            MTL_TRY(gemm(wk + W.dres_b, D.d, w->w_proj_t[i], D.d, wk + W.dhact, D.ffn, MTL_BF16, Mg, D.ffn, D.d, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream, rm));
+            MTL_TRY(mtl_swiglu_bwd_rows(fc, wk + W.dhact, wk + W.dact, Mg, D.ffn, rm.rows, rm.stride, rm.offset, stream));
         } else {
-            MTL_TRY(gemm(wk + W.dres_b, D.d, w->w_proj_t[i], D.d, wk + W.dact, D.ffn, MTL_BF16, D.M, D.ffn, D.d, nullptr, MTL_EPI_DGELU, fc, D.ffn, nullptr, 0, stream));
+            // C (and the saved pre-activation read by the dgelu epilogue) keep physical rows; the next GEMM gathers them
+            MTL_TRY(gemm(wk + W.dres_b, D.d, w->w_proj_t[i], D.d, wk + W.dact, D.ffn, MTL_BF16, Mg, D.ffn, D.d, nullptr, MTL_EPI_DGELU, fc, D.ffn, nullptr, 0, stream, rm, rm));
         }
-        MTL_TRY(gemm(wk + W.dact, D.Nfc, w->w_fc_t[i], D.Nfc, wk + W.dx, D.d, MTL_BF16, D.M, D.d, D.Nfc, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream));
-        MTL_TRY(mtl_norm_bwd(wk + W.dx, D.d, H(2 * i + 1), w->ln2_w[i], st2, dh0, dh0, wk + W.dres_b, D.M, D.d, rms, 0, 0, 0, stream));
+        MTL_TRY(gemm(wk + W.dact, D.Nfc, w->w_fc_t[i], D.Nfc, wk + W.dx, D.d, MTL_BF16, Mg, D.d, D.Nfc, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream,
+                     D.llama ? kIdentity : rm));
+        MTL_TRY(mtl_norm_bwd(wk + W.dx, D.d, H(2 * i + 1), w->ln2_w[i], st2, dh0, dh0, wk + W.dres_b, Mg, D.d, rms, rm.rows, rm.stride, rm.offset, 1, stream));
         // --- attention block backward: h_mid = h_in + o_proj(attn(qkv(norm1(h_in))))
-        MTL_TRY(gemm(wk + W.dres_b, D.d, w->w_o_t[i], D.d, wk + W.dO, D.No, MTL_BF16, D.M, D.No, D.d, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream));
+        MTL_TRY(gemm(wk + W.dres_b, D.d, w->w_o_t[i], D.d, wk + W.dO, D.No, MTL_BF16, Mg, D.No, D.d, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream, rm, rm));
         mtl_attn_bwd_args ba = {};
         attn_args(D, qkv, attn, lse, &ba.f);
         bf16_t* dq = reinterpret_cast<bf16_t*>(wk + W.dqkv);
-        ba.dout = wk + W.dO; ba.do_bs = D.T * D.No; ba.do_ts = D.No; ba.do_hs = D.hd;
-        ba.dq = dq; ba.dq_bs = D.T * D.Nqkv; ba.dq_ts = D.Nqkv; ba.dq_hs = D.hd;
+        // queries = the last n_grad rows (they see every key); dK/dV only for keys >= r0, fed by those queries only
+        ba.f.q = reinterpret_cast<const bf16_t*>(ba.f.q) + r0 * ba.f.q_ts;
+        ba.f.o = reinterpret_cast<bf16_t*>(ba.f.o) + r0 * ba.f.o_ts;
+        ba.f.lse = lse + r0;
+        ba.f.Tq = n_grad; ba.f.causal_off = r0; ba.f.stat_stride = D.T;
+        ba.kv_row0 = r0;
+        ba.dout = reinterpret_cast<bf16_t*>(wk + W.dO) + r0 * D.No; ba.do_bs = D.T * D.No; ba.do_ts = D.No; ba.do_hs = D.hd;
+        ba.dq = dq + r0 * D.Nqkv; ba.dq_bs = D.T * D.Nqkv; ba.dq_ts = D.Nqkv; ba.dq_hs = D.hd;
         ba.dk = dq + D.Hq * D.hd; ba.dk_bs = D.T * D.Nqkv; ba.dk_ts = D.Nqkv; ba.dk_hs = D.hd;
         ba.dv = dq + (D.Hq + D.Hkv) * D.hd; ba.dv_bs = D.T * D.Nqkv; ba.dv_ts = D.Nqkv; ba.dv_hs = D.hd;
-        ba.delta = reinterpret_cast<float*>(wk + W.delta);
+        ba.delta = reinterpret_cast<float*>(wk + W.delta) + r0;
         MTL_TRY(mtl_attention_bwd(&ba, stream));
-        if (D.llama) MTL_TRY(mtl_rope_inplace(wk + W.dqkv, D.Nqkv, w->rope_cos, w->rope_sin, D.M, D.T, D.Hq + D.Hkv, D.hd, 1, stream));
-        MTL_TRY(gemm(wk + W.dqkv, D.Nqkv, w->w_qkv_t[i], D.Nqkv, wk + W.dx, D.d, MTL_BF16, D.M, D.d, D.Nqkv, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream));
-        MTL_TRY(mtl_norm_bwd(wk + W.dx, D.d, H(2 * i), w->ln1_w[i], st1, dh0, dh0, wk + W.dres_b, D.M, D.d, rms, 0, 0, 0, stream));
+        if (D.llama) MTL_TRY(mtl_rope_inplace_rows(wk + W.dqkv, D.Nqkv, w->rope_cos, w->rope_sin, Mg, D.T, D.Hq + D.Hkv, D.hd, 1, rm.rows, rm.stride, rm.offset, stream));
+        MTL_TRY(gemm(wk + W.dqkv, D.Nqkv, w->w_qkv_t[i], D.Nqkv, wk + W.dx, D.d, MTL_BF16, Mg, D.d, D.Nqkv, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream, rm));
+        MTL_TRY(mtl_norm_bwd(wk + W.dx, D.d, H(2 * i), w->ln1_w[i], st1, dh0, dh0, wk + W.dres_b, Mg, D.d, rms, rm.rows, rm.stride, rm.offset, 1, stream));
     }
     return MTL_OK;
 }

@@ -94,13 +94,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 }
 
 // ---------------------------------------------------------------- RoPE (half-split), in place on q|k heads
+__device__ __forceinline__ int64_t remap_row(int64_t m, int64_t group_rows, int64_t group_stride, int64_t off) {
+    if (group_rows == 0) return m;
+    return (m / group_rows) * group_stride + off + (m % group_rows);
+}
+
 __global__ void rope_kernel(bf16_t* __restrict__ qkv, int64_t ld, const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-                            int64_t M, int64_t T, int n_heads, int D, int inverse) {
+                            int64_t M, int64_t T, int n_heads, int D, int inverse, int64_t gr, int64_t gs, int64_t ro) {
     const int half = D >> 1;
     const int pairs_per_row = n_heads * (half >> 1);  // two rotation pairs (i, i+1) per thread -> 4-byte accesses
     const int64_t total = M * pairs_per_row;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t m = idx / pairs_per_row;
+        const int64_t m = remap_row(idx / pairs_per_row, gr, gs, ro);
         const int rem = (int)(idx % pairs_per_row);
         const int h = rem / (half >> 1), i = (rem % (half >> 1)) * 2;
         const int64_t pos = m % T;
@@ -134,13 +139,15 @@ __global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restr
     }
 }
 
+// gu rows may be gathered (saved activations keep their physical layout); dh / dgu are compact
 __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dh, bf16_t* __restrict__ dgu, int64_t M,
-                                  int64_t F) {
+                                  int64_t F, int64_t gr, int64_t gs, int64_t ro) {
     const int64_t total = M * (F >> 1);
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = idx / (F >> 1), f = (idx % (F >> 1)) * 2;
-        const uint32_t g = *reinterpret_cast<const uint32_t*>(gu + m * 2 * F + f);
-        const uint32_t u = *reinterpret_cast<const uint32_t*>(gu + m * 2 * F + F + f);
+        const int64_t pm = remap_row(m, gr, gs, ro);
+        const uint32_t g = *reinterpret_cast<const uint32_t*>(gu + pm * 2 * F + f);
+        const uint32_t u = *reinterpret_cast<const uint32_t*>(gu + pm * 2 * F + F + f);
         const uint32_t d = *reinterpret_cast<const uint32_t*>(dh + m * F + f);
         float gv[2] = {__uint_as_float(g << 16), __uint_as_float(g & 0xffff0000u)};
         float uv[2] = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
@@ -252,15 +259,21 @@ extern "C" int mtl_colsum_bf16(const void* src, int64_t ld_src, float* dst, int6
     return MTL_OK;
 }
 
-extern "C" int mtl_rope_inplace(void* qkv, int64_t ld, const float* cos_t, const float* sin_t, int64_t M, int64_t T,
-                                int64_t n_rot_heads, int64_t D, int inverse, void* stream) {
+extern "C" int mtl_rope_inplace_rows(void* qkv, int64_t ld, const float* cos_t, const float* sin_t, int64_t M, int64_t T,
+                                     int64_t n_rot_heads, int64_t D, int inverse, int64_t group_rows, int64_t group_stride,
+                                     int64_t row_offset, void* stream) {
     if (!qkv || !cos_t || !sin_t || M <= 0 || T <= 0 || n_rot_heads <= 0) return MTL_ERR_ARG;
     if (D % 4 != 0 || ld % 2 != 0) return MTL_ERR_ALIGN;
     const int64_t items = M * n_rot_heads * (D / 4);
     hipLaunchKernelGGL(rope_kernel, dim3(grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)qkv, ld, cos_t, sin_t, M, T,
-                       (int)n_rot_heads, (int)D, inverse);
+                       (int)n_rot_heads, (int)D, inverse, group_rows, group_stride, row_offset);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
+}
+
+extern "C" int mtl_rope_inplace(void* qkv, int64_t ld, const float* cos_t, const float* sin_t, int64_t M, int64_t T,
+                                int64_t n_rot_heads, int64_t D, int inverse, void* stream) {
+    return mtl_rope_inplace_rows(qkv, ld, cos_t, sin_t, M, T, n_rot_heads, D, inverse, 0, 0, 0, stream);
 }
 
 extern "C" int mtl_swiglu_fwd(const void* gu, void* h, int64_t M, int64_t F, void* stream) {
@@ -271,13 +284,18 @@ extern "C" int mtl_swiglu_fwd(const void* gu, void* h, int64_t M, int64_t F, voi
     return MTL_OK;
 }
 
-extern "C" int mtl_swiglu_bwd(const void* gu, const void* dh, void* dgu, int64_t M, int64_t F, void* stream) {
+extern "C" int mtl_swiglu_bwd_rows(const void* gu, const void* dh, void* dgu, int64_t M, int64_t F, int64_t group_rows,
+                                   int64_t group_stride, int64_t row_offset, void* stream) {
     if (!gu || !dh || !dgu || M <= 0 || F <= 0) return MTL_ERR_ARG;
     if (F % 2 != 0) return MTL_ERR_ALIGN;
     hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(M * F / 2, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gu,
-                       (const bf16_t*)dh, (bf16_t*)dgu, M, F);
+                       (const bf16_t*)dh, (bf16_t*)dgu, M, F, group_rows, group_stride, row_offset);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
+}
+
+extern "C" int mtl_swiglu_bwd(const void* gu, const void* dh, void* dgu, int64_t M, int64_t F, void* stream) {
+    return mtl_swiglu_bwd_rows(gu, dh, dgu, M, F, 0, 0, 0, stream);
 }
 
 extern "C" int mtl_assemble_llm_input(const int32_t* ids, int64_t ids_B, const float* embed, const void* x_tok, const float* wpe,

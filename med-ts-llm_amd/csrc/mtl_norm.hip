@@ -78,15 +78,16 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict_
                                                        const float* __restrict__ gamma, const float* __restrict__ stats,
                                                        const float* dres_in, float* dres_out, bf16_t* dres_out_bf16,
                                                        int64_t M, int d, int64_t group_rows, int64_t group_stride,
-                                                       int64_t row_offset) {
+                                                       int64_t row_offset, int stats_physical) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int64_t prow = remap_row(row, group_rows, group_stride, row_offset);
     const float* xr = x + prow * (int64_t)d;
     const bf16_t* dyr = dy + row * ld_dy;
-    const float mean = RMS ? 0.f : stats[row * 2];
-    const float rstd = stats[row * 2 + 1];
+    const int64_t srow = stats_physical ? prow : row;
+    const float mean = RMS ? 0.f : stats[srow * 2];
+    const float rstd = stats[srow * 2 + 1];
     float4 g[NV], xh[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -168,7 +169,7 @@ extern "C" int mtl_norm_fwd(const float* x, const float* gamma, const float* bet
 
 extern "C" int mtl_norm_bwd(const void* dy, int64_t ld_dy, const float* x, const float* gamma, const float* stats,
                             const float* dres_in, float* dres_out, void* dres_out_bf16, int64_t M, int64_t d, int rms,
-                            int64_t group_rows, int64_t group_stride, int64_t row_offset, void* stream) {
+                            int64_t group_rows, int64_t group_stride, int64_t row_offset, int stats_physical, void* stream) {
     if (!dy || !x || !gamma || !stats || !dres_out || M <= 0 || d <= 0) return MTL_ERR_ARG;
     if (d % 4 != 0 || ld_dy % 4 != 0) return MTL_ERR_ALIGN;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -177,10 +178,10 @@ extern "C" int mtl_norm_bwd(const void* dy, int64_t ld_dy, const float* x, const
         constexpr int NV = decltype(nv)::value;
         if (rms)
             hipLaunchKernelGGL((norm_bwd_kernel<NV, true>), grid, block, 0, st, (const bf16_t*)dy, ld_dy, x, gamma, stats, dres_in,
-                               dres_out, (bf16_t*)dres_out_bf16, M, (int)d, group_rows, group_stride, row_offset);
+                               dres_out, (bf16_t*)dres_out_bf16, M, (int)d, group_rows, group_stride, row_offset, stats_physical);
         else
             hipLaunchKernelGGL((norm_bwd_kernel<NV, false>), grid, block, 0, st, (const bf16_t*)dy, ld_dy, x, gamma, stats, dres_in,
-                               dres_out, (bf16_t*)dres_out_bf16, M, (int)d, group_rows, group_stride, row_offset);
+                               dres_out, (bf16_t*)dres_out_bf16, M, (int)d, group_rows, group_stride, row_offset, stats_physical);
         MTL_CHECK_LAUNCH();
         return MTL_OK;
     };

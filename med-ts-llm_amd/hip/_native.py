@@ -37,7 +37,7 @@ class AttnFwdArgs(C.Structure):
                 ("v", vp), ("v_bs", i64), ("v_ts", i64), ("v_hs", i64),
                 ("o", vp), ("o_bs", i64), ("o_ts", i64), ("o_hs", i64),
                 ("lse", vp), ("B", i64), ("Hq", i64), ("Hkv", i64), ("Tq", i64), ("Tk", i64), ("D", i64),
-                ("scale", f32), ("causal", i32)]
+                ("scale", f32), ("causal", i32), ("causal_off", i64), ("stat_stride", i64)]
 
 
 class AttnBwdArgs(C.Structure):
@@ -46,7 +46,7 @@ class AttnBwdArgs(C.Structure):
                 ("dq", vp), ("dq_bs", i64), ("dq_ts", i64), ("dq_hs", i64),
                 ("dk", vp), ("dk_bs", i64), ("dk_ts", i64), ("dk_hs", i64),
                 ("dv", vp), ("dv_bs", i64), ("dv_ts", i64), ("dv_hs", i64),
-                ("delta", vp), ("dkv_ws", vp), ("kv_splits", i64)]
+                ("delta", vp), ("kv_row0", i64), ("dkv_ws", vp), ("kv_splits", i64)]
 
 
 PP = C.POINTER(vp)
@@ -84,15 +84,17 @@ SIGNATURES = {
     "mtl_attention_fwd": (i32, [C.POINTER(AttnFwdArgs), vp]),
     "mtl_attention_bwd": (i32, [C.POINTER(AttnBwdArgs), vp]),
     "mtl_norm_fwd": (i32, [vp, vp, vp, vp, i64, vp, i64, i64, f32, i32, i64, i64, i64, vp]),
-    "mtl_norm_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, i64, i64, i32, i64, i64, i64, vp]),
+    "mtl_norm_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, i64, i64, i32, i64, i64, i64, i32, vp]),
     "mtl_rope_inplace": (i32, [vp, i64, vp, vp, i64, i64, i64, i64, i32, vp]),
+    "mtl_rope_inplace_rows": (i32, [vp, i64, vp, vp, i64, i64, i64, i64, i32, i64, i64, i64, vp]),
+    "mtl_swiglu_bwd_rows": (i32, [vp, vp, vp, i64, i64, i64, i64, i64, vp]),
     "mtl_swiglu_fwd": (i32, [vp, vp, i64, i64, vp]),
     "mtl_swiglu_bwd": (i32, [vp, vp, vp, i64, i64, vp]),
     "mtl_assemble_llm_input": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, vp]),
     "mtl_backbone_saved_bytes": (C.c_size_t, [C.POINTER(BackboneWeights), i64, i64]),
     "mtl_backbone_work_bytes": (C.c_size_t, [C.POINTER(BackboneWeights), i64, i64]),
     "mtl_backbone_fwd": (i32, [C.POINTER(BackboneWeights), vp, vp, vp, vp, i64, i64, i64, vp]),
-    "mtl_backbone_bwd": (i32, [C.POINTER(BackboneWeights), vp, vp, vp, vp, vp, i64, i64, i64, vp]),
+    "mtl_backbone_bwd": (i32, [C.POINTER(BackboneWeights), vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]),
 }
 
 _lib = None

@@ -225,7 +225,7 @@ def norm_bwd(dy, x, gamma, stats, dres_in=None, rms=False, rows=None, want_bf16=
               else torch.empty(x.shape, dtype=BF16, device=x.device)) if want_bf16 else None
     gr, gs, ro = rows if rows is not None else (0, 0, 0)
     check(lib().mtl_norm_bwd(ptr(dy), dy.stride(0), ptr(x), ptr(gamma), ptr(stats), ptr(dres_in), ptr(dres_out), ptr(dres_b),
-                             M, d, 1 if rms else 0, gr, gs, ro, stream()), "mtl_norm_bwd")
+                             M, d, 1 if rms else 0, gr, gs, ro, 0, stream()), "mtl_norm_bwd")
     return (dres_out, dres_b) if want_bf16 else dres_out
 
 
@@ -391,19 +391,22 @@ class BackboneFn(torch.autograd.Function):
     """Frozen decoder stack (R:models/medtsllm.py:350) fwd + activation-gradient-only bwd, one C call each."""
 
     @staticmethod
-    def forward(ctx, h0, backbone, n_last):
+    def forward(ctx, h0, backbone, n_last, n_grad=None):
+        """n_grad: number of trailing tokens per sample whose input gradient is consumed (the patch tokens). The text
+        prompt rows before them never depend on a trainable parameter (causal attention), so their gradient is dead and
+        the backward runs on B*n_grad rows only; dh0 is zero there. None -> full backward."""
         h0 = h0.contiguous()
         out, saved = backbone.run_forward(h0, n_last, keep=ctx.needs_input_grad[0])
-        ctx.backbone, ctx.n_last, ctx.saved = backbone, n_last, saved
+        ctx.backbone, ctx.n_last, ctx.saved, ctx.n_grad = backbone, n_last, saved, n_grad
         ctx.save_for_backward(h0)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         (h0,) = ctx.saved_tensors
-        dh0 = ctx.backbone.run_backward(h0, dout.contiguous(), ctx.saved, ctx.n_last)
+        dh0 = ctx.backbone.run_backward(h0, dout.contiguous(), ctx.saved, ctx.n_last, ctx.n_grad)
         ctx.saved = None
-        return dh0, None, None
+        return dh0, None, None, None
 
 
 class RevinDenormFn(torch.autograd.Function):

@@ -164,8 +164,10 @@ class FrozenBackbone:
                 "mtl_backbone_fwd")
         return out, (saved if keep else None)
 
-    def run_backward(self, h0, dout, saved, n_last):
+    def run_backward(self, h0, dout, saved, n_last, n_grad=None):
+        """n_grad: trailing tokens per sample that need a gradient (default all T); see mtl_backbone_bwd."""
         B, T, d = h0.shape
+        n_grad = T if n_grad is None else max(int(n_grad), n_last)
         if saved is None:
             raise RuntimeError("backbone backward without saved activations (forward ran under no_grad)")
         w = self._struct(T)
@@ -173,7 +175,7 @@ class FrozenBackbone:
         work = torch.empty(lib.mtl_backbone_work_bytes(C.byref(w), B, T), dtype=torch.uint8, device=h0.device)
         dh0 = torch.empty_like(h0)
         N.check(lib.mtl_backbone_bwd(C.byref(w), N.ptr(h0), N.ptr(dout), N.ptr(dh0), N.ptr(saved), N.ptr(work), B, T, n_last,
-                                     N.stream()), "mtl_backbone_bwd")
+                                     n_grad, N.stream()), "mtl_backbone_bwd")
         return dh0
 
     def state_tensors(self):

@@ -126,6 +126,7 @@ class MedTsLLM(nn.Module):
             raise ValueError(f"Unknown embedding downsample mode {self.embedding_downsample_mode}")
         self.lora_enabled = False
         self._id_cache = {}
+        self.prune_dead_prompt_grads = True   # exact: skips gradients nobody consumes (set False for the full dh0)
         self.fixed_prompt_ids = None   # int32 [1 or B, n_tok]: synthetic-benchmark prompt (no tokenizer files needed)
 
     # ------------------------------------------------------------------ construction (a11)
@@ -296,7 +297,9 @@ class MedTsLLM(nn.Module):
         if ids is not None and cm in ("independent", "merge-end") and ids.shape[0] != 1:
             ids = ids.repeat_interleave(C, dim=0)        # R:models/medtsllm.py:343-344
         h0 = AssembleFn.apply(x_tok, ids, bb.embed_f32, bb.wpe)
-        dec = BackboneFn.apply(h0, bb, self.n_patches)   # [B', n_patches, d_llm] (final norm on the consumed rows only)
+        # only the x_tok rows of h0 have a trainable ancestor: prompt-row gradients are dead
+        n_grad = x_tok.shape[1] if self.prune_dead_prompt_grads else None
+        dec = BackboneFn.apply(h0, bb, self.n_patches, n_grad)   # [B', n_patches, d_llm] (final norm on the consumed rows only)
         mode = self.embedding_downsample_mode
         if mode == "truncate":
             dec = dec[:, :, :self.d_ff]

@@ -40,6 +40,12 @@ def test_backbone_stack(kind, B, T, n_last):
     assert rel_err(out.float(), ref) < L3
     dh0 = bb.run_backward(h_in, dout.cuda(), saved, n_last)
     assert rel_err(dh0, h0r.grad) < 2 * L3
+    # pruned backward: only the last n_grad tokens get a gradient (causality makes it exact for those rows), rest stays 0
+    for n_grad in sorted({n_last, min(T, n_last + 23), T}):
+        dh0p = bb.run_backward(h_in, dout.cuda(), saved, n_last, n_grad).cpu()
+        assert rel_err(dh0p[:, T - n_grad:], h0r.grad[:, T - n_grad:]) < 2 * L3, n_grad
+        assert rel_err(dh0p[:, T - n_grad:], dh0.cpu()[:, T - n_grad:]) < 2e-3, n_grad     # same arithmetic as the full pass
+        assert torch.all(dh0p[:, : T - n_grad] == 0)
 
 
 CASES = [
