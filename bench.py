@@ -142,19 +142,32 @@ def cpu_baseline(hf_cfg, sd, L, C_, pred, n_tok, prompt_ids, max_seconds=30.0):
 
 
 def read_prof(lib):
-    cap = 32
+    """per kernel instance (named exactly as rocprofv3 prints it): launches, total ms, total algorithmic FLOPs"""
+    cap = 64
     keys = (C.c_int * cap)()
     launches = (C.c_int64 * cap)()
     ms = (C.c_double * cap)()
     fl = (C.c_double * cap)()
     n = lib.mtl_prof_read(keys, launches, ms, fl, cap)
-    names = {0: "store", 1: "gelu", 2: "resid", 3: "dgelu", 4: "accum"}
     rows = []
     for i in range(n):
         k = keys[i]
-        rows.append({"kernel": f"gemm_nt_kernel<{names[k // 4]},{'bf16' if (k // 2) % 2 else 'f32'},{'splitk' if k % 2 else 'direct'}>",
-                     "launches": int(launches[i]), "total_ms": ms[i], "flops": fl[i]})
+        epi, cdt, split = (k & 0xff) // 4, ((k & 0xff) // 2) % 2, k & 1
+        if k & (1 << 8):
+            name = f"gemm_nt_persist_kernel<{epi}, {cdt}, {128 if k & (1 << 9) else 64}, {(k >> 11) & 3}, {8 if k & (1 << 10) else 4}>"
+        else:
+            name = f"gemm_nt_kernel<{epi}, {cdt}, {'true' if split else 'false'}>"
+        rows.append({"kernel": name, "launches": int(launches[i]), "total_ms": ms[i], "flops": fl[i]})
     return rows
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get(kernel)
 
 
 def main():
@@ -238,13 +251,16 @@ def main():
         rows = read_prof(lib)
         lib.mtl_prof_enable(0)
         if rows:
+            gap_ms = lib.mtl_prof_calibrate(C.c_void_p(torch.cuda.current_stream().cuda_stream))   # empty event bracket
+            for r in rows:
+                r["total_ms"] = max(r["total_ms"] - gap_ms * r["launches"], 1e-9)
             dom = max(rows, key=lambda r: r["total_ms"])
             per_launch_ms = dom["total_ms"] / dom["launches"]
             achieved = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom["kernel"]),
                         "launches": dom["launches"], "avg_launch_us": round(per_launch_ms * 1e3, 2),
-                        "flops_per_launch": dom["flops"] / dom["launches"],
+                        "flops_per_launch": dom["flops"] / dom["launches"], "event_bracket_overhead_us": round(gap_ms * 1e3, 2),
                         "all_gemm_instances": [{"kernel": r["kernel"], "launches": r["launches"], "avg_us": round(r["total_ms"] / r["launches"] * 1e3, 2),
                                                 "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 1)} for r in rows]}
 

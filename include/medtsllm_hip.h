@@ -93,11 +93,15 @@ size_t mtl_gemm_workspace_bytes(int64_t M, int64_t N, int split_k);
 int mtl_gemm_nt(const mtl_gemm_args* args, void* stream);
 /* Measurement aid (bench.py roofline leg; off by default, no effect on results): while enabled every GEMM launch is
  * bracketed by HIP events on its launch stream. mtl_prof_read aggregates per kernel instance
- * key = epilogue*4 + c_dtype*2 + (split_k > 1): launches, total ms, total algorithmic FLOPs (2*M*N*K). */
+ * key: bits 0-7 = epilogue*4 + c_dtype*2 + (split_k > 1); bit 8 = persistent kernel, bit 9 = 128-wide tile (else 64),
+ * bit 10 = 8 waves (else 4), bits 11-12 = LDS stages: launches, total ms, total algorithmic FLOPs (2*M*N*K).
+ * mtl_prof_calibrate returns the duration (ms) of an empty event bracket on `stream` (fixed per-launch overhead). */
 int mtl_prof_enable(int on);
+double mtl_prof_calibrate(void* stream);
 /* Experiment knob for A/B runs: mode 0 = one output tile per workgroup, 1 = persistent flat-K (default);
- * bn 0 = automatic tile width, 64 or 128 forced; stages = depth of the LDS ring (2..4). Results are identical in every mode. */
-int mtl_gemm_tune(int mode, int bn, int stages);
+ * bn 0 = automatic tile width, 64 or 128 forced; stages = depth of the LDS ring (2..4); waves = 0 (auto) / 4 / 8 per
+ * workgroup. Results are identical in every mode. */
+int mtl_gemm_tune(int mode, int bn, int stages, int waves);
 int mtl_prof_read(int* keys, int64_t* launches, double* total_ms, double* total_flops, int cap);
 
 /* ------------------------------------------------------------------ layout / cast helpers

@@ -275,15 +275,20 @@ __device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int
 
 // STAGES-deep LDS ring, ONE raw s_barrier per K tile, counted s_waitcnt vmcnt: STAGES-1 tiles of LDS-DMA stay in
 // flight across the barrier (GUIDE §5 "Pipelining across barriers"); __syncthreads() would drain them (vmcnt(0)).
-template <int EPI, int CDT, int BN_, int STAGES>
-__global__ __launch_bounds__(256) void gemm_nt_persist_kernel(const mtl_gemm_args p, const int vec_ok_i, const int tiles_m,
+// NW waves per workgroup: 4 = 2(M) x 2(N), 8 = 2(M) x 4(N). 8 waves on the 128x128 tile keep the same LDS bytes per
+// stage while each stage feeds twice the MFMA work per resident workgroup slot (more waves per LDS byte).
+template <int EPI, int CDT, int BN_, int STAGES, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_nt_persist_kernel(const mtl_gemm_args p, const int vec_ok_i, const int tiles_m,
                                                              const int tiles_n) {
     constexpr int BK_ = 64;
-    constexpr int NI = BN_ / 32;               // 16-wide n tiles per wave (wave covers BN_/2 columns)
+    constexpr int NT = NW * 64;                // threads
+    constexpr int WN = NW / 2;                 // waves along N (2 along M)
+    constexpr int WCOLS = BN_ / WN;            // columns per wave
+    constexpr int NI = WCOLS / 16;             // 16-wide n tiles per wave
     constexpr int CPR = BK_ / 8;               // 16-B chunks per tile row
     constexpr int ROWB = BK_ * 2;              // bytes per tile row
-    constexpr int NA = BM * CPR / 256;         // 16-B staging slots per thread, A tile
-    constexpr int NB = BN_ * CPR / 256;        // ... B tile
+    constexpr int NA = BM * CPR / NT;          // 16-B staging slots per thread, A tile
+    constexpr int NB = BN_ * CPR / NT;         // ... B tile
     constexpr int NL = NA + NB;                // LDS-DMA instructions per wave per stage
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN_ * ROWB;
     constexpr int STAGE = A_BYTES + B_BYTES;
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(256) void gemm_nt_persist_kernel(const mtl_gemm_arg
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WN, wc = wave % WN;
     const int l15 = lane & 15, g = lane >> 4;
     const bool vec_ok = vec_ok_i != 0;
 
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(256) void gemm_nt_persist_kernel(const mtl_gemm_arg
         const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN_;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int sl = i * 256 + tid;
+            const int sl = i * NT + tid;
             const int rr = sl / CPR, pc = sl % CPR;
             const int c = pc ^ swz64(rr);
             int64_t am = m0 + rr; if (am > p.M - 1) am = p.M - 1;
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(256) void gemm_nt_persist_kernel(const mtl_gemm_arg
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int sl = i * 256 + tid;
+            const int sl = i * NT + tid;
             const int rr = sl / CPR, pc = sl % CPR;
             const int c = pc ^ swz64(rr);
             int64_t bn = n0 + rr; if (bn > p.N - 1) bn = p.N - 1;
@@ -335,10 +340,10 @@ __global__ __launch_bounds__(256) void gemm_nt_persist_kernel(const mtl_gemm_arg
         const int64_t koff = (int64_t)kt * BK_;
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[i] + koff), (lds_void_t*)(la + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[i] + koff), (lds_void_t*)(la + (i * NT + wave * 64) * 16), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < NB; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(bsrc[i] + koff), (lds_void_t*)(lb + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(bsrc[i] + koff), (lds_void_t*)(lb + (i * NT + wave * 64) * 16), 16, 0, 0);
     };
 
     f32x4 acc[NI][4];
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(256) void gemm_nt_persist_kernel(const mtl_gemm_arg
 
     const int sw = swz64(l15);                 // wave / mi / ni row offsets are multiples of 16: swz unchanged
     const int a_off = (wr * 64 + l15) * ROWB;
-    const int b_off = (wc * (BN_ / 2) + l15) * ROWB;
+    const int b_off = (wc * WCOLS + l15) * ROWB;
 
     int s_i = 0, s_kt = 0, s_buf = 0;   // next (tile index, k-tile, ring slot) to stage
     int c_i = 0, c_kt = 0, c_buf = 0;   // being computed
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(256) void gemm_nt_persist_kernel(const mtl_gemm_arg
                 const int64_t m = m0 + wr * 64 + mi * 16 + l15;
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    const int64_t n = n0 + wc * (BN_ / 2) + ni * 16 + g * 4;
+                    const int64_t n = n0 + wc * WCOLS + ni * 16 + g * 4;
                     if (m < p.M && n < p.N) epilogue4<EPI, CDT>(p, m, n, acc[ni][mi], vec_ok);
                     acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(256) void gemm_nt_persist_kernel(const mtl_gemm_arg
             const int64_t m = m0 + wr * 64 + mi * 16 + l15;
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                const int64_t n = n0 + wc * (BN_ / 2) + ni * 16 + g * 4;
+                const int64_t n = n0 + wc * WCOLS + ni * 16 + g * 4;
                 if (m < p.M && n < p.N) epilogue4<EPI, CDT>(p, m, n, acc[ni][mi], vec_ok);
             }
         }
@@ -455,7 +460,7 @@ __global__ void splitk_reduce_kernel(const mtl_gemm_args p, const int S, const i
 bool aligned(const void* ptr, size_t a) { return (reinterpret_cast<uintptr_t>(ptr) % a) == 0; }
 
 // experiment knobs (mtl_gemm_tune): mode 0 = one tile per workgroup, 1 = persistent flat-K; bn = 0 auto / 64 / 128
-struct Tuning { int mode = 1; int bn = 0; int stages = 2; int num_cu = 0; };
+struct Tuning { int mode = 1; int bn = 0; int stages = 2; int waves = 0; int num_cu = 0; };
 Tuning& tuning() { static Tuning t; return t; }
 int num_cus() {
     Tuning& t = tuning();
@@ -477,7 +482,7 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
     if (pf.on) {
         std::lock_guard<std::mutex> lk(pf.mu);
         if (pf.on && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess) {
-            rec.key = EPI * 4 + CDT * 2 + (S > 1 ? 1 : 0);
+            rec.key = EPI * 4 + CDT * 2 + (S > 1 ? 1 : 0);   // variant bits are OR-ed in below once the tile shape is chosen
             rec.flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
             recording = true;
             hipEventRecord(rec.e0, st);
@@ -497,22 +502,32 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         const int ncu = num_cus();
         int bn = tuning().bn;
         const int stages = tuning().stages;
-        // measured on MI355X (tools/bench_gemm.py): the 128x64 tile (3 workgroups/CU) wins until the grid has >= 8 tiles of
-        // 128x128 per CU, from there the 128x128 tile's lower L1->LDS bytes per FLOP wins
-        if (bn == 0) bn = (tiles_m * tiles_n < 8 * ncu) ? 64 : 128;
+        // measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_ab.txt): with >= 2 tiles of 128x128 per CU the
+        // 128x128 tile run by 8 waves wins (same LDS bytes per stage feed twice the MFMA work per resident workgroup);
+        // below that the 128x64 / 4-wave tile fills the chip more evenly (3 workgroups per CU).
+        int nw = tuning().waves;
+        if (bn == 0) bn = (tiles_m * tiles_n >= 2 * ncu) ? 128 : 64;
+        if (nw == 0) nw = (bn == 128 && stages <= 3) ? 8 : 4;
         const int tn = (int)((p.N + bn - 1) / bn), nt = tiles_m * tn;
+        if (recording) rec.key |= (1 << 8) | ((bn == 128 ? 1 : 0) << 9) | ((nw == 8 ? 1 : 0) << 10) | (stages << 11);
         const size_t lds = (size_t)stages * (BM + bn) * BK * 2;
         const int per_cu = (int)(160 * 1024 / lds) < 1 ? 1 : (int)(160 * 1024 / lds);
         const int grid = nt < per_cu * ncu ? nt : per_cu * ncu;
-#define MTL_PERSIST(BNV, STV)                                                                                          \
+#define MTL_PERSIST(BNV, STV, NWV)                                                                                     \
     do {                                                                                                               \
-        auto kfn = gemm_nt_persist_kernel<EPI, CDT, BNV, STV>;                                                         \
+        auto kfn = gemm_nt_persist_kernel<EPI, CDT, BNV, STV, NWV>;                                                    \
         static std::once_flag once;                                                                                    \
         std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, p, vec_ok, tiles_m, tn);                               \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(NWV * 64), lds, st, p, vec_ok, tiles_m, tn);                          \
     } while (0)
-        if (bn == 64) { if (stages == 2) MTL_PERSIST(64, 2); else if (stages == 3) MTL_PERSIST(64, 3); else MTL_PERSIST(64, 4); }
-        else { if (stages == 2) MTL_PERSIST(128, 2); else if (stages == 3) MTL_PERSIST(128, 3); else MTL_PERSIST(128, 4); }
+        if (bn == 64) {
+            if (stages == 2) { if (nw == 8) MTL_PERSIST(64, 2, 8); else MTL_PERSIST(64, 2, 4); }
+            else if (stages == 3) MTL_PERSIST(64, 3, 4); else MTL_PERSIST(64, 4, 4);
+        } else {
+            if (stages == 2) { if (nw == 8) MTL_PERSIST(128, 2, 8); else MTL_PERSIST(128, 2, 4); }
+            else if (stages == 3) { if (nw == 8) MTL_PERSIST(128, 3, 8); else MTL_PERSIST(128, 3, 4); }
+            else MTL_PERSIST(128, 4, 4);
+        }
 #undef MTL_PERSIST
     } else if (S == 1) {
         hipLaunchKernelGGL((gemm_nt_kernel<EPI, CDT, false>), dim3(tiles_m * tiles_n, 1), dim3(256), 0, st, p, vec_ok);
@@ -528,12 +543,33 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int mtl_gemm_tune(int mode, int bn, int stages) {
-    if ((mode != 0 && mode != 1) || (bn != 0 && bn != 64 && bn != 128) || stages < 2 || stages > 4) return MTL_ERR_ARG;
+extern "C" int mtl_gemm_tune(int mode, int bn, int stages, int waves) {
+    if ((mode != 0 && mode != 1) || (bn != 0 && bn != 64 && bn != 128) || stages < 2 || stages > 4 || (waves != 0 && waves != 4 && waves != 8))
+        return MTL_ERR_ARG;
     tuning().mode = mode;
     tuning().bn = bn;
     tuning().stages = stages;
+    tuning().waves = waves;
     return MTL_OK;
+}
+
+// average duration (ms) of an EMPTY event bracket on `stream`: the fixed cost included in every bracketed launch
+extern "C" double mtl_prof_calibrate(void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int n = 64;
+    double tot = 0;
+    int ok = 0;
+    for (int i = 0; i < n; ++i) {
+        hipEvent_t e0, e1;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) continue;
+        (void)hipEventRecord(e0, st);
+        (void)hipEventRecord(e1, st);
+        float ms = 0.f;
+        if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { tot += ms; ++ok; }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    return ok ? tot / ok : 0.0;
 }
 
 extern "C" int mtl_prof_enable(int on) {

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Turn the FETCH_SIZE / WRITE_SIZE rocprofv3 passes (tools/pmc_run.sh) into HBM bytes per launch per kernel.
+
+GUIDE MI355X_MICROARCH §HBM: the counters are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream
+(TCC_EA0_RDREQ tallied at 64 B for 128-B requests) -> x2 on the read side. WRITE_SIZE is taken as reported."""
+import glob
+import json
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def per_kernel(db, counter):
+    c = sqlite3.connect(db)
+    per_disp = defaultdict(float)
+    name = {}
+    for kn, cn, v, did in c.execute("select kernel_name, counter_name, value, dispatch_id from counters_collection"):
+        if cn == counter:
+            per_disp[did] += v
+            name[did] = kn
+    agg = defaultdict(lambda: [0.0, 0])
+    for did, v in per_disp.items():
+        a = agg[name[did]]
+        a[0] += v
+        a[1] += 1
+    return {k: (t / n, n) for k, (t, n) in agg.items()}
+
+
+def clean(kn):
+    kn = kn.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+    return kn.split("(")[0]
+
+
+def main(tag, out):
+    f = glob.glob(f"gpurun_out/pmc_{tag}_fetch/**/*.db", recursive=True)
+    w = glob.glob(f"gpurun_out/pmc_{tag}_write/**/*.db", recursive=True)
+    fetch = per_kernel(f[0], "FETCH_SIZE") if f else {}
+    write = per_kernel(w[0], "WRITE_SIZE") if w else {}
+    res, lines = {}, []
+    for kn in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, (0, 0))[0] * fetch.get(k, (0, 0))[1])):
+        fk, n = fetch.get(kn, (0.0, 0))
+        wk, _ = write.get(kn, (0.0, 0))
+        rd, wr = 2.0 * fk * 1024.0, wk * 1024.0
+        res[clean(kn)] = {"hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr, "dispatches": n}
+        lines.append(f"{rd / 1e6:12.2f} MB read (2x FETCH_SIZE) {wr / 1e6:12.2f} MB written  per launch over {n:5d} launches  {clean(kn)[:110]}")
+    json.dump(res, open(out, "w"), indent=1)
+    print("\n".join(lines[:40]))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
