@@ -94,14 +94,15 @@ int mtl_gemm_nt(const mtl_gemm_args* args, void* stream);
 /* Measurement aid (bench.py roofline leg; off by default, no effect on results): while enabled every GEMM launch is
  * bracketed by HIP events on its launch stream. mtl_prof_read aggregates per kernel instance
  * key: bits 0-7 = epilogue*4 + c_dtype*2 + (split_k > 1); bit 8 = persistent kernel, bit 9 = 128-wide tile (else 64),
- * bit 10 = 8 waves (else 4), bits 11-12 = LDS stages: launches, total ms, total algorithmic FLOPs (2*M*N*K).
+ * bits 10-11 = waves (0: 4, 1: 8, 2: 16), bits 12-13 = LDS stages, bit 14 = 256-row tile (else 128): launches, total ms, total algorithmic FLOPs (2*M*N*K).
  * mtl_prof_calibrate returns the duration (ms) of an empty event bracket on `stream` (fixed per-launch overhead). */
 int mtl_prof_enable(int on);
 double mtl_prof_calibrate(void* stream);
 /* Experiment knob for A/B runs: mode 0 = one output tile per workgroup, 1 = persistent flat-K (default);
- * bn 0 = automatic tile width, 64 or 128 forced; stages = depth of the LDS ring (2..4); waves = 0 (auto) / 4 / 8 per
- * workgroup. Results are identical in every mode. */
-int mtl_gemm_tune(int mode, int bn, int stages, int waves);
+ * bm / bn = tile rows (128, 256) / columns (64, 128), stages = LDS ring depth (2, 3), waves per workgroup (4, 8, 16);
+ * 0 = automatic. Supported combinations: 128x64/4w/2, 128x128/{4,8}w/2, 128x128/8w/3, 256x128/16w/{2,3}; anything else
+ * makes mtl_gemm_nt return MTL_ERR_UNSUPPORTED. Results are identical in every mode. */
+int mtl_gemm_tune(int mode, int bm, int bn, int stages, int waves);
 int mtl_prof_read(int* keys, int64_t* launches, double* total_ms, double* total_flops, int cap);
 
 /* ------------------------------------------------------------------ layout / cast helpers

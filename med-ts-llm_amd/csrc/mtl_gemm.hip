@@ -275,22 +275,26 @@ __device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int
 
 // STAGES-deep LDS ring, ONE raw s_barrier per K tile, counted s_waitcnt vmcnt: STAGES-1 tiles of LDS-DMA stay in
 // flight across the barrier (GUIDE §5 "Pipelining across barriers"); __syncthreads() would drain them (vmcnt(0)).
-// NW waves per workgroup: 4 = 2(M) x 2(N), 8 = 2(M) x 4(N). 8 waves on the 128x128 tile keep the same LDS bytes per
-// stage while each stage feeds twice the MFMA work per resident workgroup slot (more waves per LDS byte).
-template <int EPI, int CDT, int BN_, int STAGES, int NW>
+// BM_ x BN_ tile, NW waves = (BM_/64)(M) x rest(N); every wave owns a 64-row x (BN_/WN)-column sub-tile.
+//   128x64 / 4 waves  (3 workgroups/CU)  small grids
+//   128x128 / 8 waves (2 workgroups/CU)  same LDS bytes per stage feed twice the MFMA work per resident slot
+//   256x128 / 16 waves, 3 stages (1 workgroup/CU): two 48-KiB stages in flight cover the loaded L2 latency with
+//   4.2 MFLOP of MFMA work each and halve the L1->LDS bytes per FLOP again
+template <int EPI, int CDT, int BM_, int BN_, int STAGES, int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_nt_persist_kernel(const mtl_gemm_args p, const int vec_ok_i, const int tiles_m,
                                                              const int tiles_n) {
     constexpr int BK_ = 64;
     constexpr int NT = NW * 64;                // threads
-    constexpr int WN = NW / 2;                 // waves along N (2 along M)
+    constexpr int WM = BM_ / 64;               // waves along M
+    constexpr int WN = NW / WM;                // waves along N
     constexpr int WCOLS = BN_ / WN;            // columns per wave
     constexpr int NI = WCOLS / 16;             // 16-wide n tiles per wave
     constexpr int CPR = BK_ / 8;               // 16-B chunks per tile row
     constexpr int ROWB = BK_ * 2;              // bytes per tile row
-    constexpr int NA = BM * CPR / NT;          // 16-B staging slots per thread, A tile
+    constexpr int NA = BM_ * CPR / NT;         // 16-B staging slots per thread, A tile
     constexpr int NB = BN_ * CPR / NT;         // ... B tile
     constexpr int NL = NA + NB;                // LDS-DMA instructions per wave per stage
-    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN_ * ROWB;
+    constexpr int A_BYTES = BM_ * ROWB, B_BYTES = BN_ * ROWB;
     constexpr int STAGE = A_BYTES + B_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_persist_kernel(const mtl_gemm
     auto set_sources = [&](int tile) {
         int tm, tn;
         tile_coords(tile, tiles_m, tiles_n, tm, tn);
-        const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN_;
+        const int64_t m0 = (int64_t)tm * BM_, n0 = (int64_t)tn * BN_;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int sl = i * NT + tid;
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_persist_kernel(const mtl_gemm
         if (done_tile >= 0) {           // epilogue of the previous tile: its stores are queued BEFORE the next DMA stage
             int tm, tn;
             tile_coords(done_tile, tiles_m, tiles_n, tm, tn);
-            const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN_;
+            const int64_t m0 = (int64_t)tm * BM_, n0 = (int64_t)tn * BN_;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 const int64_t m = m0 + wr * 64 + mi * 16 + l15;
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_persist_kernel(const mtl_gemm
     if (done_tile >= 0) {
         int tm, tn;
         tile_coords(done_tile, tiles_m, tiles_n, tm, tn);
-        const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN_;
+        const int64_t m0 = (int64_t)tm * BM_, n0 = (int64_t)tn * BN_;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             const int64_t m = m0 + wr * 64 + mi * 16 + l15;
@@ -460,7 +464,7 @@ __global__ void splitk_reduce_kernel(const mtl_gemm_args p, const int S, const i
 bool aligned(const void* ptr, size_t a) { return (reinterpret_cast<uintptr_t>(ptr) % a) == 0; }
 
 // experiment knobs (mtl_gemm_tune): mode 0 = one tile per workgroup, 1 = persistent flat-K; bn = 0 auto / 64 / 128
-struct Tuning { int mode = 1; int bn = 0; int stages = 2; int waves = 0; int num_cu = 0; };
+struct Tuning { int mode = 1; int bn = 0; int stages = 0; int waves = 0; int bm = 0; int num_cu = 0; };
 Tuning& tuning() { static Tuning t; return t; }
 int num_cus() {
     Tuning& t = tuning();
@@ -500,34 +504,32 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
     } closer{pf, rec, recording, st};
     if (S == 1 && tuning().mode == 1) {
         const int ncu = num_cus();
-        int bn = tuning().bn;
-        const int stages = tuning().stages;
-        // measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_ab.txt): with >= 2 tiles of 128x128 per CU the
-        // 128x128 tile run by 8 waves wins (same LDS bytes per stage feed twice the MFMA work per resident workgroup);
-        // below that the 128x64 / 4-wave tile fills the chip more evenly (3 workgroups per CU).
-        int nw = tuning().waves;
-        if (bn == 0) bn = (tiles_m * tiles_n >= 2 * ncu) ? 128 : 64;
-        if (nw == 0) nw = (bn == 128 && stages <= 3) ? 8 : 4;
-        const int tn = (int)((p.N + bn - 1) / bn), nt = tiles_m * tn;
-        if (recording) rec.key |= (1 << 8) | ((bn == 128 ? 1 : 0) << 9) | ((nw == 8 ? 1 : 0) << 10) | (stages << 11);
-        const size_t lds = (size_t)stages * (BM + bn) * BK * 2;
+        // tile choice, measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_ab*.txt)
+        int bm = tuning().bm, bn = tuning().bn, stages = tuning().stages, nw = tuning().waves;
+        const int t128 = tiles_m * tiles_n;            // grid size in 128x128 tiles
+        if (bm == 0) bm = (t128 >= 8 * ncu) ? 256 : 128;   // Llama-class grids: 256x128 / 16 waves / 3 stages reaches 1.04-1.06 PF/s
+        if (bn == 0) bn = (bm == 256 || t128 >= 2 * ncu) ? 128 : 64;
+        if (nw == 0) nw = bm == 256 ? 16 : (bn == 128 ? 8 : 4);
+        if (stages == 0) stages = bm == 256 ? 3 : 2;
+        const int tm = (int)((p.M + bm - 1) / bm), tn = (int)((p.N + bn - 1) / bn), nt = tm * tn;
+        const size_t lds = (size_t)stages * (bm + bn) * BK * 2;
         const int per_cu = (int)(160 * 1024 / lds) < 1 ? 1 : (int)(160 * 1024 / lds);
         const int grid = nt < per_cu * ncu ? nt : per_cu * ncu;
-#define MTL_PERSIST(BNV, STV, NWV)                                                                                     \
+        if (recording) rec.key |= (1 << 8) | ((bn == 128 ? 1 : 0) << 9) | ((nw == 8 ? 1 : (nw == 16 ? 2 : 0)) << 10) | (stages << 12) | ((bm == 256 ? 1 : 0) << 14);
+#define MTL_PERSIST(BMV, BNV, STV, NWV)                                                                                \
     do {                                                                                                               \
-        auto kfn = gemm_nt_persist_kernel<EPI, CDT, BNV, STV, NWV>;                                                    \
+        auto kfn = gemm_nt_persist_kernel<EPI, CDT, BMV, BNV, STV, NWV>;                                               \
         static std::once_flag once;                                                                                    \
         std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(NWV * 64), lds, st, p, vec_ok, tiles_m, tn);                          \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(NWV * 64), lds, st, p, vec_ok, tm, tn);                               \
     } while (0)
-        if (bn == 64) {
-            if (stages == 2) { if (nw == 8) MTL_PERSIST(64, 2, 8); else MTL_PERSIST(64, 2, 4); }
-            else if (stages == 3) MTL_PERSIST(64, 3, 4); else MTL_PERSIST(64, 4, 4);
-        } else {
-            if (stages == 2) { if (nw == 8) MTL_PERSIST(128, 2, 8); else MTL_PERSIST(128, 2, 4); }
-            else if (stages == 3) { if (nw == 8) MTL_PERSIST(128, 3, 8); else MTL_PERSIST(128, 3, 4); }
-            else MTL_PERSIST(128, 4, 4);
-        }
+        if (bm == 256 && bn == 128 && nw == 16 && stages == 3) MTL_PERSIST(256, 128, 3, 16);
+        else if (bm == 256 && bn == 128 && nw == 16 && stages == 2) MTL_PERSIST(256, 128, 2, 16);
+        else if (bm == 128 && bn == 128 && nw == 8 && stages == 2) MTL_PERSIST(128, 128, 2, 8);
+        else if (bm == 128 && bn == 128 && nw == 8 && stages == 3) MTL_PERSIST(128, 128, 3, 8);
+        else if (bm == 128 && bn == 128 && nw == 4 && stages == 2) MTL_PERSIST(128, 128, 2, 4);
+        else if (bm == 128 && bn == 64 && nw == 4 && stages == 2) MTL_PERSIST(128, 64, 2, 4);
+        else return MTL_ERR_UNSUPPORTED;
 #undef MTL_PERSIST
     } else if (S == 1) {
         hipLaunchKernelGGL((gemm_nt_kernel<EPI, CDT, false>), dim3(tiles_m * tiles_n, 1), dim3(256), 0, st, p, vec_ok);
@@ -543,10 +545,12 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int mtl_gemm_tune(int mode, int bn, int stages, int waves) {
-    if ((mode != 0 && mode != 1) || (bn != 0 && bn != 64 && bn != 128) || stages < 2 || stages > 4 || (waves != 0 && waves != 4 && waves != 8))
+extern "C" int mtl_gemm_tune(int mode, int bm, int bn, int stages, int waves) {
+    if ((mode != 0 && mode != 1) || (bm != 0 && bm != 128 && bm != 256) || (bn != 0 && bn != 64 && bn != 128) ||
+        (stages != 0 && stages != 2 && stages != 3) || (waves != 0 && waves != 4 && waves != 8 && waves != 16))
         return MTL_ERR_ARG;
     tuning().mode = mode;
+    tuning().bm = bm;
     tuning().bn = bn;
     tuning().stages = stages;
     tuning().waves = waves;
