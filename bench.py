@@ -32,17 +32,21 @@ sys.path.insert(0, ROOT)
 
 GPT2_SMALL = {"model_type": "gpt2", "vocab_size": 50257, "n_positions": 1024, "n_embd": 768, "n_layer": 12, "n_head": 12,
               "layer_norm_epsilon": 1e-5}
+LLAMA2_7B = {"model_type": "llama", "vocab_size": 32000, "hidden_size": 4096, "intermediate_size": 11008, "num_hidden_layers": 32,
+             "num_attention_heads": 32, "num_key_value_heads": 32, "rms_norm_eps": 1e-5, "rope_theta": 10000.0}
 WORKLOADS = {
-    # name: (hf cfg, B per GPU, L, C, pred_len, n_tok)
-    "gpt2s_B32_L1024_C12": (GPT2_SMALL, 32, 1024, 12, 96, 128),
-    "gpt2s_etth1_B32_L512_C7": (GPT2_SMALL, 32, 512, 7, 96, 128),
+    # name: (hf cfg, B per GPU, L, C, pred_len, n_tok, task)
+    "gpt2s_B32_L1024_C12": (GPT2_SMALL, 32, 1024, 12, 96, 128, "forecasting"),
+    "gpt2s_etth1_B32_L512_C7": (GPT2_SMALL, 32, 512, 7, 96, 128, "forecasting"),
+    # BASELINE.json configs[2]: LUDB-shaped semantic segmentation (4 classes), frozen Llama-2-7B (random init, generated on the GPU)
+    "llama2_7b_semseg_B32_L1024_C12": (LLAMA2_7B, 32, 1024, 12, 1024, 128, "semantic_segmentation"),
 }
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md
 
 
-def model_cfg(L, pred):
+def model_cfg(L, pred, task="forecasting"):
     return {
-        "DEBUG": True, "task": "forecasting", "model": "medtsllm", "history_len": L, "pred_len": pred,
+        "DEBUG": True, "task": task, "model": "medtsllm", "history_len": L, "pred_len": pred,
         "training": {"dropout": 0.0}, "setup": {"dtype": "mixed"},
         "models": {"timellm": {
             "d_model": 32, "d_ff": 128, "n_heads": 8, "num_tokens": 1024, "covariate_mode": "concat",
@@ -55,28 +59,37 @@ def model_cfg(L, pred):
 
 
 class DS:
-    def __init__(self, C_):
-        self.description, self.n_features, self.n_classes, self.task_description = "synthetic", C_, 0, None
+    def __init__(self, C_, n_classes=0):
+        self.description, self.n_features, self.n_classes, self.task_description = "synthetic", C_, n_classes, None
 
 
-def make_batch(B, L, C_, pred, seed, device):
+def make_batch(B, L, C_, pred, seed, device, task="forecasting"):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, L, C_, generator=g) + (torch.rand(C_, generator=g) * 4 - 2)
-    y = torch.randn(B, pred, C_, generator=g)
+    y = torch.randn(B, pred, C_, generator=g) if task == "forecasting" else torch.randint(0, 4, (B, pred), generator=g)
     return {"x_enc": x.to(device), "y": y.to(device)}
 
 
 def flops_per_step(cfg, B, T, P, C_, n_out, V, S=1024, d_model=32, d_ff=128, H=8):
     """Algorithmic fwd+bwd FLOPs: frozen GEMMs 2x fwd, attention 3x fwd, trainables 3x fwd, mapping 2x."""
-    d, L_, ffn = cfg["n_embd"], cfg["n_layer"], 4 * cfg["n_embd"]
-    M = B * T
-    gemm_fwd = L_ * 2 * M * (d * 3 * d + d * d + 2 * d * ffn)
+    if cfg["model_type"] == "llama":
+        d, L_, ffn = cfg["hidden_size"], cfg["num_hidden_layers"], cfg["intermediate_size"]
+        M = B * T
+        gemm_fwd = L_ * 2 * M * (4 * d * d + 3 * d * ffn)
+    else:
+        d, L_, ffn = cfg["n_embd"], cfg["n_layer"], 4 * cfg["n_embd"]
+        M = B * T
+        gemm_fwd = L_ * 2 * M * (d * 3 * d + d * d + 2 * d * ffn)
     attn_fwd = L_ * 4 * B * T * T * d
     HE = H * d_ff
     front = 2 * B * P * (C_ * d_model) * HE + 2 * 2 * S * d * HE + 4 * B * P * S * HE + 2 * B * P * HE * d
     tail = 2 * B * P * d * d_ff + 2 * B * d_ff * P * n_out
     mapping = 2 * S * V * d
-    return 2 * gemm_fwd + 3 * attn_fwd + 3 * (front + tail) + 2 * mapping
+    algorithmic = 2 * gemm_fwd + 3 * attn_fwd + 3 * (front + tail) + 2 * mapping
+    # executed with the exact dead-gradient elimination: backward GEMMs on the P patch rows only; attention backward keeps
+    # dQ of the patch queries (3/4 of the causal area) and dK/dV of the patch keys (1/4) -> about half of its FLOPs
+    executed = gemm_fwd * (1 + P / T) + attn_fwd * (1 + 2 * 0.5) + 3 * (front + tail) + 2 * mapping
+    return algorithmic, executed
 
 
 def cpu_baseline(hf_cfg, sd, L, C_, pred, n_tok, prompt_ids, max_seconds=30.0):
@@ -84,7 +97,7 @@ def cpu_baseline(hf_cfg, sd, L, C_, pred, n_tok, prompt_ids, max_seconds=30.0):
     from oracle import medtsllm_oracle as O
     Bs = 4
     g = torch.Generator().manual_seed(123)
-    d = hf_cfg["n_embd"]
+    d = hf_cfg["n_embd"]   # CPU baseline is only run for the GPT-2 workloads
     p = {
         "patch_embedding.value_embedding.tokenConv.weight": torch.randn(32, 16, 3, generator=g) * 0.2,
         "mapping_layer.weight": torch.randn(1024, hf_cfg["vocab_size"], generator=g) * 0.01,
@@ -196,10 +209,12 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    hf_cfg, B, L, C_, pred, n_tok = WORKLOADS[args.workload]
-    sd = random_state_dict(hf_cfg, seed=0, std=0.02)
+    hf_cfg, B, L, C_, pred, n_tok, task = WORKLOADS[args.workload]
+    big = hf_cfg["model_type"] == "llama"
+    sd = random_state_dict(hf_cfg, seed=0, std=0.02, device=device if big else "cpu", dtype=torch.bfloat16 if big else torch.float32)
     torch.manual_seed(0)
-    model = model_lookup["medtsllm"](dict_to_object(model_cfg(L, pred)), DS(C_), backbone_state=(hf_cfg, sd)).to(device)
+    model = model_lookup["medtsllm"](dict_to_object(model_cfg(L, pred, task)), DS(C_, 4 if task == "semantic_segmentation" else 0),
+                                     backbone_state=(hf_cfg, sd)).to(device)
     prompt_ids = torch.randint(0, hf_cfg["vocab_size"], (1, n_tok), generator=torch.Generator().manual_seed(1), dtype=torch.int32)
     model.fixed_prompt_ids = prompt_ids
     model.prune_dead_prompt_grads = not args.full_backward
@@ -207,13 +222,14 @@ def main():
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-4, fused=True)
     sync = parallel.FlatGradAllReduce(params) if world > 1 else None
-    loss_fn = torch.nn.MSELoss()
-    batches = [make_batch(B, L, C_, pred, 1000 + rank * 97 + i, device) for i in range(4)]
+    loss_fn = torch.nn.MSELoss() if task == "forecasting" else torch.nn.CrossEntropyLoss()
+    batches = [make_batch(B, L, C_, pred, 1000 + rank * 97 + i, device, task) for i in range(4)]
 
     def step(i):
         inputs = batches[i % len(batches)]
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=True):
-            loss = loss_fn(model(inputs), inputs["y"])
+            pred_ = model(inputs)
+            loss = loss_fn(pred_ if task == "forecasting" else pred_.permute(0, 2, 1), inputs["y"])
         loss.backward()
         if sync is not None:
             sync()
@@ -266,27 +282,29 @@ def main():
                                                 "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 1)} for r in rows]}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not big:
         cpu = cpu_baseline(hf_cfg, sd, L, C_, pred, n_tok, prompt_ids[0].tolist())
 
     if rank == 0:
         P = (L + 8 - 16) // 8 + 1
         T = n_tok + P
-        fl = flops_per_step(hf_cfg, B, T, P, C_, pred * C_, hf_cfg["vocab_size"])
+        fl, fl_exec = flops_per_step(hf_cfg, B, T, P, C_, pred * (C_ if task == "forecasting" else 4), hf_cfg["vocab_size"])
+        if args.full_backward:
+            fl_exec = fl
         value = B * world * args.steps / elapsed
         out = {
             "metric": "samples/sec (1024-step, 12-ch windows) through MedTsLLM fwd+bwd", "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.workload}: [B={B}/GPU, L={L}, C={C_}] windows, P={P}, prompt {n_tok} tok -> T={T}, "
-                                   f"frozen GPT-2-small (random init) backbone, concat covariates, forecasting pred_len={pred}, "
+                                   f"frozen {'Llama-2-7B' if big else 'GPT-2-small'} (random init) backbone, concat covariates, {task} pred_len={pred}, "
                                    f"step = fwd+loss+bwd+{'allreduce+' if world > 1 else ''}Adam", "global_batch": B * world,
                        "parallelism": f"dp{world}"},
             "final_loss": final_loss,
             "backward": "full (incl. unused prompt-row input gradients)" if args.full_backward else
                         "exact dead-gradient elimination: prompt rows never depend on a trainable parameter, their input gradient is not computed",
-            "algorithmic_tflop_per_step_per_gpu": round(fl / 1e12, 3),
-            "step_mfma_frac": round(fl / (elapsed / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "algorithmic_tflop_per_step_per_gpu": round(fl / 1e12, 3), "executed_tflop_per_step_per_gpu": round(fl_exec / 1e12, 3),
+            "step_mfma_frac": round(fl_exec / (elapsed / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -182,13 +182,14 @@ class FrozenBackbone:
         return self._t
 
 
-def random_state_dict(cfg, seed=0, std=0.02):
-    """Seeded random-init weights of the given architecture (bench / tests: no checkpoints are downloadable)."""
+def random_state_dict(cfg, seed=0, std=0.02, device="cpu", dtype=torch.float32):
+    """Seeded random-init weights of the given architecture (bench / tests: no checkpoints are downloadable).
+    `device`/`dtype` let multi-billion-parameter backbones be generated directly in HBM in bf16."""
     c = normalise_config(cfg)
-    g = torch.Generator().manual_seed(seed)
+    g = torch.Generator(device=device).manual_seed(seed)
 
     def rn(*shape, s=std):
-        return torch.randn(*shape, generator=g) * s
+        return (torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * s).to(dtype)
 
     sd = {}
     d, L, ffn = c["d"], c["n_layers"], c["ffn"]
