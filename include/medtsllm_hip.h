@@ -137,6 +137,9 @@ typedef struct {
     int causal;
     int64_t causal_off;   /* causal: key k is visible to query q iff k <= q + causal_off (0 for Tq == Tk; Tk - Tq aligns bottom-right) */
     int64_t stat_stride;  /* elements between consecutive (batch, head) rows of lse / delta; 0 -> Tq                          */
+    /* attention dropout A = dropout(softmax(.)) of the reprogramming layer (R:models/medtsllm.py:588, p = training.dropout);
+     * non-causal only. keep(b*Hq+h, q, key) is a counter-based hash of dropout_seed, regenerated identically in the backward. */
+    float dropout_p; uint32_t dropout_seed;
 } mtl_attn_fwd_args;
 int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream);
 typedef struct {

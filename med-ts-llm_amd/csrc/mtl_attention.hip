@@ -60,9 +60,21 @@ __device__ __forceinline__ void load_tile(bf16_t* tile, const bf16_t* src, int64
 }
 
 #define NEG_BIG (-1.0e30f)
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+
+// attention dropout: counter-based keep mask, a pure function of (seed, batch*head, query, key) so the backward kernels
+// regenerate exactly the forward's mask (tests/test_gpu_kernels.py replicates the hash on the host).
+__device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint32_t bh, uint32_t q, uint32_t key) {
+    uint32_t h = seed ^ (bh * 0x9E3779B1u);
+    h = (h ^ (q * 0x85EBCA77u)) * 0xC2B2AE3Du;
+    h = (h ^ (h >> 15) ^ (key * 0x27D4EB2Fu)) * 0x165667B1u;
+    h ^= h >> 13; h *= 0x85EBCA6Bu; h ^= h >> 16;
+    return h;
+}
 
 // =============================================================================================== forward
-template <int D, bool CAUSAL>
+template <int D, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a) {
     constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
     __shared__ __attribute__((aligned(16))) bf16_t ktile[KC * LDT];
@@ -85,7 +97,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a
     f32x4 o[NDT];
 #pragma unroll
     for (int i = 0; i < NDT; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // running max is kept in the exp2 domain: m2 = max(score) * scale * log2(e); p = exp2(s * c - m2): one FMA + v_exp_f32
+    const float c = a.scale * LOG2E;
     float m_run = NEG_BIG, l_run = 0.f;
+    const uint32_t drop_thr = DROP ? (uint32_t)fminf(a.dropout_p * 4294967296.0f, 4294967040.0f) : 0u;
+    const float drop_scale = DROP ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
+    const uint32_t bh = (uint32_t)(b * a.Hq + h);
 
     // causal: key visible to query q iff key <= q + causal_off (causal_off = Tk - Tq aligns the diagonal bottom-right)
     const int64_t coff = a.causal_off;
@@ -94,6 +111,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a
         const int64_t lim = (qblk0 + 64 < a.Tq ? qblk0 + 64 : a.Tq) + coff;  // keys <= last query of the block
         k_end = lim < a.Tk ? lim : a.Tk;
     }
+    const int64_t wave_qmin = q0 + coff;
     const int64_t wave_qmax = ((q0 + 15 < a.Tq - 1) ? q0 + 15 : a.Tq - 1) + coff;
 
     for (int64_t kc0 = 0; kc0 < k_end; kc0 += KC) {
@@ -116,35 +134,54 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a
                     s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kr + ks * 32), qf[ks], s[t], 0, 0, 0);
             }
             float p[2][4];
-            float mx = NEG_BIG;
+            // masking is needed only on slabs that touch the diagonal or the end of the key range (wave-uniform test)
+            const bool need_mask = (kb + 32 > a.Tk) || (CAUSAL && kb + 31 > wave_qmin);
+            if (need_mask) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t key = kb + t * 16 + g * 4 + r;
-                    float v = s[t][r] * a.scale;
-                    if (key >= a.Tk || (CAUSAL && key > qrow + coff)) v = NEG_BIG;
-                    p[t][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t key = kb + t * 16 + g * 4 + r;
+                        p[t][r] = (key >= a.Tk || (CAUSAL && key > qrow + coff)) ? NEG_BIG : s[t][r] * c;
+                    }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p[t][r] = s[t][r] * c;
+            }
+            float mx = fmaxf(fmaxf(fmaxf(p[0][0], p[0][1]), fmaxf(p[0][2], p[0][3])), fmaxf(fmaxf(p[1][0], p[1][1]), fmaxf(p[1][2], p[1][3])));
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = __expf(m_run - m_new);
             float psum = 0.f;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    p[t][r] = __expf(p[t][r] - m_new);
+                    p[t][r] = __builtin_amdgcn_exp2f(p[t][r] - m_new);
                     psum += p[t][r];
                 }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
+            if (__any(m_new != m_run)) {   // rescale only when some row's running max moved (wave-uniform branch)
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
+                m_run = m_new;
+            }
+            l_run += psum;
+            if (DROP) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const uint32_t key = (uint32_t)(kb + t * 16 + g * 4 + r);
+                        p[t][r] = drop_hash(a.dropout_seed, bh, (uint32_t)qrow, key) >= drop_thr ? p[t][r] * drop_scale : 0.f;
+                    }
+            }
             const bf16x8 pf = pack8(p[0], p[1]);
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
-                o[dt] *= alpha;
                 const bf16x8 vt = gather_col(vtile, LDT, sub * 32 + g * 4, sub * 32 + 16 + g * 4, dt * 16, l15);
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pf, o[dt], 0, 0, 0);
             }
@@ -160,11 +197,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a
         u32x2 pk = {pack_bf16x2(o[dt][0] * inv_l, o[dt][1] * inv_l), pack_bf16x2(o[dt][2] * inv_l, o[dt][3] * inv_l)};
         *reinterpret_cast<u32x2*>(O + dt * 16 + g * 4) = pk;
     }
-    if (g == 0 && a.lse) a.lse[(b * a.Hq + h) * (a.stat_stride ? a.stat_stride : a.Tq) + qrow] = m_run + __logf(l_run);
+    // natural-log sum-exp of the scaled scores
+    if (g == 0 && a.lse) a.lse[(b * a.Hq + h) * (a.stat_stride ? a.stat_stride : a.Tq) + qrow] = (m_run + __builtin_amdgcn_logf(l_run)) * LN2;
 }
 
 // =============================================================================================== backward: dQ (+ delta)
-template <int D, bool CAUSAL>
+template <int D, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_args a) {
     constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
     __shared__ __attribute__((aligned(16))) bf16_t ktile[KC * LDT];
@@ -202,7 +240,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
     dl += __shfl_xor(dl, 32, 64);
     const int64_t stat_idx = (b * f.Hq + h) * (f.stat_stride ? f.stat_stride : f.Tq) + qrow;
     if (g == 0 && q_valid) a.delta[stat_idx] = dl;
-    const float lse = f.lse[stat_idx];
+    const float c = f.scale * LOG2E;
+    const float lse2 = f.lse[stat_idx] * LOG2E;   // exp(s*scale - lse) == exp2(s*c - lse2)
+    const uint32_t drop_thr = DROP ? (uint32_t)fminf(f.dropout_p * 4294967296.0f, 4294967040.0f) : 0u;
+    const float drop_scale = DROP ? 1.0f / (1.0f - f.dropout_p) : 1.0f;
+    const uint32_t bh = (uint32_t)(b * f.Hq + h);
 
     f32x4 dq[NDT];
 #pragma unroll
@@ -241,8 +283,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
                 for (int r = 0; r < 4; ++r) {
                     const int64_t key = kb + t * 16 + g * 4 + r;
                     const bool masked = key >= f.Tk || (CAUSAL && key > qrow + coff);
-                    const float p = masked ? 0.f : __expf(s[r] * f.scale - lse);
-                    ds[t][r] = p * (dp[r] - dl);
+                    const float p = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse2);
+                    float dpv = dp[r];
+                    if (DROP) dpv = drop_hash(f.dropout_seed, bh, (uint32_t)qrow, (uint32_t)key) >= drop_thr ? dpv * drop_scale : 0.f;
+                    ds[t][r] = p * (dpv - dl);
                 }
             }
             const bf16x8 dsf = pack8(ds[0], ds[1]);
@@ -265,7 +309,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
 // =============================================================================================== backward: dK, dV
 // One workgroup per (64-key tile, kv head, batch or ALL batches when K/V are batch-shared); loops over the query
 // heads of the GQA group and over 64-query chunks. Lane owns key = lane & 15 of its wave's 16 keys.
-template <int D, bool CAUSAL>
+template <int D, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const mtl_attn_bwd_args a) {
     constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
     __shared__ __attribute__((aligned(16))) bf16_t qtile[KC * LDT];
@@ -288,6 +332,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const mtl_attn_bwd_ar
     const bool k_valid = krow < f.Tk;
     if (krow > f.Tk - 1) krow = f.Tk - 1;
 
+    const float c = f.scale * LOG2E;
+    const uint32_t drop_thr = DROP ? (uint32_t)fminf(f.dropout_p * 4294967296.0f, 4294967040.0f) : 0u;
+    const float drop_scale = DROP ? 1.0f / (1.0f - f.dropout_p) : 1.0f;
     f32x4 dk[NDT], dv[NDT];
 #pragma unroll
     for (int i = 0; i < NDT; ++i) {
@@ -318,7 +365,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const mtl_attn_bwd_ar
                 if (threadIdx.x < KC) {
                     int64_t qq = qc0 + threadIdx.x;
                     if (qq > f.Tq - 1) qq = f.Tq - 1;
-                    lse_s[threadIdx.x] = f.lse[stat0 + qq];
+                    lse_s[threadIdx.x] = f.lse[stat0 + qq] * LOG2E;
                     delta_s[threadIdx.x] = a.delta[stat0 + qq];
                 }
                 __syncthreads();
@@ -343,9 +390,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const mtl_attn_bwd_ar
                             const int ql = sub * 32 + t * 16 + g * 4 + r;
                             const int64_t q = qc0 + ql;
                             const bool masked = q >= f.Tq || (CAUSAL && krow > q + coff);
-                            const float pv = masked ? 0.f : __expf(s[r] * f.scale - lse_s[ql]);
-                            p[t][r] = pv;
-                            ds[t][r] = pv * (dp[r] - delta_s[ql]);
+                            const float pv = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse_s[ql]);
+                            float keep = 1.0f;
+                            if (DROP) keep = drop_hash(f.dropout_seed, (uint32_t)(b * f.Hq + h), (uint32_t)q, (uint32_t)krow) >= drop_thr ? drop_scale : 0.f;
+                            p[t][r] = pv * keep;                               // feeds dV = (dropped P)^T dO
+                            ds[t][r] = pv * (dp[r] * keep - delta_s[ql]);      // feeds dK
                         }
                     }
                     const bf16x8 pf = pack8(p[0], p[1]);
@@ -419,9 +468,12 @@ extern "C" int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream) {
     if (rc != MTL_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)((a->Tq + 63) / 64), (unsigned)a->Hq, (unsigned)a->B), block(256);
+    const bool drop = a->dropout_p > 0.f;
+    if (drop && (a->dropout_p >= 1.f || a->causal)) return MTL_ERR_UNSUPPORTED;   // dropout: reprogramming (non-causal) attention only
 #define MTL_FWD(DD)                                                                                        \
-    if (a->causal) hipLaunchKernelGGL((attn_fwd_kernel<DD, true>), grid, block, 0, st, *a);                \
-    else hipLaunchKernelGGL((attn_fwd_kernel<DD, false>), grid, block, 0, st, *a)
+    if (a->causal) hipLaunchKernelGGL((attn_fwd_kernel<DD, true, false>), grid, block, 0, st, *a);         \
+    else if (drop) hipLaunchKernelGGL((attn_fwd_kernel<DD, false, true>), grid, block, 0, st, *a);         \
+    else hipLaunchKernelGGL((attn_fwd_kernel<DD, false, false>), grid, block, 0, st, *a)
     if (a->D == 32) { MTL_FWD(32); } else if (a->D == 64) { MTL_FWD(64); } else { MTL_FWD(128); }
 #undef MTL_FWD
     MTL_CHECK_LAUNCH();
@@ -450,13 +502,18 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
     }
     if (a->kv_row0 < 0 || a->kv_row0 >= f.Tk) return MTL_ERR_ARG;
     const dim3 gk((unsigned)((f.Tk - a->kv_row0 + 63) / 64), (unsigned)f.Hkv, (unsigned)(f.k_bs == 0 ? splits : f.B));
+    const bool drop = f.dropout_p > 0.f;
+    if (drop && (f.dropout_p >= 1.f || f.causal)) return MTL_ERR_UNSUPPORTED;
 #define MTL_BWD(DD)                                                                                        \
     if (f.causal) {                                                                                        \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, true>), gq, block, 0, st, *a);                          \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<DD, true>), gk, block, 0, st, *a);                         \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, true, false>), gq, block, 0, st, *a);                   \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<DD, true, false>), gk, block, 0, st, *a);                  \
+    } else if (drop) {                                                                                     \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, false, true>), gq, block, 0, st, *a);                   \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<DD, false, true>), gk, block, 0, st, *a);                  \
     } else {                                                                                               \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, false>), gq, block, 0, st, *a);                         \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<DD, false>), gk, block, 0, st, *a);                        \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, false, false>), gq, block, 0, st, *a);                  \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<DD, false, false>), gk, block, 0, st, *a);                 \
     }
     if (f.D == 32) { MTL_BWD(32) } else if (f.D == 64) { MTL_BWD(64) } else { MTL_BWD(128) }
 #undef MTL_BWD

@@ -37,7 +37,8 @@ class AttnFwdArgs(C.Structure):
                 ("v", vp), ("v_bs", i64), ("v_ts", i64), ("v_hs", i64),
                 ("o", vp), ("o_bs", i64), ("o_ts", i64), ("o_hs", i64),
                 ("lse", vp), ("B", i64), ("Hq", i64), ("Hkv", i64), ("Tq", i64), ("Tk", i64), ("D", i64),
-                ("scale", f32), ("causal", i32), ("causal_off", i64), ("stat_stride", i64)]
+                ("scale", f32), ("causal", i32), ("causal_off", i64), ("stat_stride", i64),
+                ("dropout_p", f32), ("dropout_seed", C.c_uint32)]
 
 
 class AttnBwdArgs(C.Structure):

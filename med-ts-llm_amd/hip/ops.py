@@ -150,8 +150,9 @@ def revin_denorm(y, mean, stdev):
     return out
 
 
-def _attn_fwd_args(q, k, v, o, lse, B, Hq, Hkv, Tq, Tk, D, scale, causal, qs, ks, vs, os_):
+def _attn_fwd_args(q, k, v, o, lse, B, Hq, Hkv, Tq, Tk, D, scale, causal, qs, ks, vs, os_, dropout=(0.0, 0)):
     a = N.AttnFwdArgs()
+    a.dropout_p, a.dropout_seed = float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF
     a.q, (a.q_bs, a.q_ts, a.q_hs) = q.data_ptr(), qs
     a.k, (a.k_bs, a.k_ts, a.k_hs) = k.data_ptr(), ks
     a.v, (a.v_bs, a.v_ts, a.v_hs) = v.data_ptr(), vs
@@ -162,7 +163,7 @@ def _attn_fwd_args(q, k, v, o, lse, B, Hq, Hkv, Tq, Tk, D, scale, causal, qs, ks
     return a
 
 
-def attention_fwd(q, k, v, Hq, Hkv, D, scale, causal, shared_kv=False):
+def attention_fwd(q, k, v, Hq, Hkv, D, scale, causal, shared_kv=False, dropout=(0.0, 0)):
     """q [B,Tq,Hq*D] bf16; k, v [B,Tk,Hkv*D] (or [Tk,Hkv*D] when shared_kv). Views with unit inner stride allowed."""
     B, Tq = q.shape[0], q.shape[1]
     Tk = k.shape[-2]
@@ -171,12 +172,12 @@ def attention_fwd(q, k, v, Hq, Hkv, D, scale, causal, shared_kv=False):
     ks = (0, k.stride(-2), D) if shared_kv else (k.stride(0), k.stride(1), D)
     vs = (0, v.stride(-2), D) if shared_kv else (v.stride(0), v.stride(1), D)
     a = _attn_fwd_args(q, k, v, o, lse, B, Hq, Hkv, Tq, Tk, D, scale, causal, (q.stride(0), q.stride(1), D), ks, vs,
-                       (o.stride(0), o.stride(1), D))
+                       (o.stride(0), o.stride(1), D), dropout)
     check(lib().mtl_attention_fwd(C.byref(a), stream()), "mtl_attention_fwd")
     return o, lse
 
 
-def attention_bwd(q, k, v, o, lse, dout, Hq, Hkv, D, scale, causal, shared_kv=False):
+def attention_bwd(q, k, v, o, lse, dout, Hq, Hkv, D, scale, causal, shared_kv=False, dropout=(0.0, 0)):
     B, Tq = q.shape[0], q.shape[1]
     Tk = k.shape[-2]
     dout = dout.contiguous()
@@ -188,7 +189,7 @@ def attention_bwd(q, k, v, o, lse, dout, Hq, Hkv, D, scale, causal, shared_kv=Fa
     vs = (0, v.stride(-2), D) if shared_kv else (v.stride(0), v.stride(1), D)
     b = N.AttnBwdArgs()
     b.f = _attn_fwd_args(q, k, v, o, lse, B, Hq, Hkv, Tq, Tk, D, scale, causal, (q.stride(0), q.stride(1), D), ks, vs,
-                         (o.stride(0), o.stride(1), D))
+                         (o.stride(0), o.stride(1), D), dropout)
     b.dout, (b.do_bs, b.do_ts, b.do_hs) = dout.data_ptr(), (dout.stride(0), dout.stride(1), D)
     b.dq, (b.dq_bs, b.dq_ts, b.dq_hs) = dq.data_ptr(), (dq.stride(0), dq.stride(1), D)
     dks = (0, dk.stride(-2), D) if shared_kv else (dk.stride(0), dk.stride(1), D)
@@ -357,20 +358,22 @@ class CrossAttnFn(torch.autograd.Function):
     """Reprogramming attention (R:models/medtsllm.py:581-591): q [B,L,H*E], k/v [S,H*E] shared by every sample."""
 
     @staticmethod
-    def forward(ctx, q, k, v, H, E):
+    def forward(ctx, q, k, v, H, E, dropout_p=0.0, dropout_seed=0):
+        """dropout_p > 0: A = dropout(softmax(.)) with a counter-based keep mask (seed chosen by the caller per step)."""
         scale = 1.0 / math.sqrt(E)
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-        o, lse = attention_fwd(q, k, v, H, H, E, scale, causal=False, shared_kv=True)
+        drop = (float(dropout_p), int(dropout_seed))
+        o, lse = attention_fwd(q, k, v, H, H, E, scale, causal=False, shared_kv=True, dropout=drop)
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.meta = (H, E, scale)
+        ctx.meta = (H, E, scale, drop)
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, lse = ctx.saved_tensors
-        H, E, scale = ctx.meta
-        dq, dk, dv = attention_bwd(q, k, v, o, lse, do, H, H, E, scale, causal=False, shared_kv=True)
-        return dq, dk, dv, None, None
+        H, E, scale, drop = ctx.meta
+        dq, dk, dv = attention_bwd(q, k, v, o, lse, do, H, H, E, scale, causal=False, shared_kv=True, dropout=drop)
+        return dq, dk, dv, None, None, None, None
 
 
 class AssembleFn(torch.autograd.Function):

@@ -270,9 +270,11 @@ class MedTsLLM(nn.Module):
         q = LinearFn.apply(tokens, rl.query_projection.weight, rl.query_projection.bias)
         k = LinearFn.apply(source, rl.key_projection.weight, rl.key_projection.bias)
         v = LinearFn.apply(source, rl.value_projection.weight, rl.value_projection.bias)
-        if self.training and self.dropout > 0:
-            raise NotImplementedError("attention dropout inside the fused reprogramming kernel is a 'next' row; use training.dropout = 0")
-        a = CrossAttnFn.apply(q, k, v, self.n_attention_heads, self.d_ff)
+        if self.training and self.dropout > 0:   # A = dropout(softmax(.)), R:models/medtsllm.py:588 (own RNG stream)
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+            a = CrossAttnFn.apply(q, k, v, self.n_attention_heads, self.d_ff, float(self.dropout), seed)
+        else:
+            a = CrossAttnFn.apply(q, k, v, self.n_attention_heads, self.d_ff)
         enc = LinearFn.apply(a, rl.out_projection.weight, rl.out_projection.bias)     # [B', P, d_llm]
         n_patches, d_llm = enc.shape[1], self.d_llm
         cm = self.covariate_mode

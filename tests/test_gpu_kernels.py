@@ -174,6 +174,46 @@ def test_attention_cross_shared_kv(ops, B, L, S, H, E):
     assert rel_err(dv.float(), vf.grad) < 1e-2
 
 
+def _drop_hash(seed, bh, q, key):
+    """host replica of drop_hash() in csrc/mtl_attention.hip (uint32 arithmetic)"""
+    M = 0xFFFFFFFF
+    h = (seed ^ ((bh * 0x9E3779B1) & M)) & M
+    h = ((h ^ ((q * 0x85EBCA77) & M)) * 0xC2B2AE3D) & M
+    h = ((h ^ (h >> 15) ^ ((key * 0x27D4EB2F) & M)) * 0x165667B1) & M
+    h ^= h >> 13
+    h = (h * 0x85EBCA6B) & M
+    h ^= h >> 16
+    return h
+
+
+@pytest.mark.parametrize("pdrop", [0.1, 0.5])
+def test_attention_cross_dropout(ops, pdrop):
+    """A = dropout(softmax(.)) (R:models/medtsllm.py:588): the kernel's counter-based keep mask is replicated on the host,
+    so forward and all three gradients are compared exactly like the no-dropout case; keep rate ~ 1 - p."""
+    B, L, S, H, E, seed = 2, 40, 200, 2, 64, 12345
+    q = torch.randn(B, L, H * E, generator=g(1)).to(BF16)
+    k = torch.randn(S, H * E, generator=g(2)).to(BF16)
+    v = torch.randn(S, H * E, generator=g(3)).to(BF16)
+    do = torch.randn(B, L, H * E, generator=g(4)).to(BF16)
+    scale = 1.0 / math.sqrt(E)
+    thr = min(int(np.float32(pdrop) * np.float32(4294967296.0)), 4294967040)
+    bh, qq, kk = np.meshgrid(np.arange(B * H, dtype=np.uint64), np.arange(L, dtype=np.uint64), np.arange(S, dtype=np.uint64), indexing="ij")
+    keep = (_drop_hash(seed, bh, qq, kk) >= thr)
+    assert abs(keep.mean() - (1 - pdrop)) < 0.02
+    keep = torch.from_numpy(keep.reshape(B, H, L, S)).float() / (1.0 - float(np.float32(pdrop)))
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    scores = torch.einsum("blhe,she->bhls", qf.view(B, L, H, E), kf.view(S, H, E))
+    A = torch.softmax(scale * scores, dim=-1) * keep
+    ref = torch.einsum("bhls,she->blhe", A, vf.view(S, H, E)).reshape(B, L, H * E)
+    ref.backward(do.float())
+    o, lse = ops.attention_fwd(dev(q), dev(k), dev(v), H, H, E, scale, False, shared_kv=True, dropout=(pdrop, seed))
+    assert rel_err(o.float(), ref) < TOL_BF16
+    dq, dk, dv = ops.attention_bwd(dev(q), dev(k), dev(v), o, lse, dev(do), H, H, E, scale, False, shared_kv=True, dropout=(pdrop, seed))
+    assert rel_err(dq.float(), qf.grad) < 1e-2
+    assert rel_err(dk.float(), kf.grad) < 1e-2
+    assert rel_err(dv.float(), vf.grad) < 1e-2
+
+
 def test_attention_online_softmax_rescale(ops):
     """force the running-max rescale branch: one key far above the rest, placed in the LAST chunk"""
     B, T, H, D = 1, 192, 1, 64
