@@ -34,12 +34,16 @@ GPT2_SMALL = {"model_type": "gpt2", "vocab_size": 50257, "n_positions": 1024, "n
               "layer_norm_epsilon": 1e-5}
 LLAMA2_7B = {"model_type": "llama", "vocab_size": 32000, "hidden_size": 4096, "intermediate_size": 11008, "num_hidden_layers": 32,
              "num_attention_heads": 32, "num_key_value_heads": 32, "rms_norm_eps": 1e-5, "rope_theta": 10000.0}
+LLAMA3_8B = {"model_type": "llama", "vocab_size": 128256, "hidden_size": 4096, "intermediate_size": 14336, "num_hidden_layers": 32,
+             "num_attention_heads": 32, "num_key_value_heads": 8, "rms_norm_eps": 1e-5, "rope_theta": 500000.0}
 WORKLOADS = {
     # name: (hf cfg, B per GPU, L, C, pred_len, n_tok, task)
     "gpt2s_B32_L1024_C12": (GPT2_SMALL, 32, 1024, 12, 96, 128, "forecasting"),
     "gpt2s_etth1_B32_L512_C7": (GPT2_SMALL, 32, 512, 7, 96, 128, "forecasting"),
     # BASELINE.json configs[2]: LUDB-shaped semantic segmentation (4 classes), frozen Llama-2-7B (random init, generated on the GPU)
     "llama2_7b_semseg_B32_L1024_C12": (LLAMA2_7B, 32, 1024, 12, 1024, 128, "semantic_segmentation"),
+    # BASELINE.json configs[4] shape: reconstruction, frozen Llama-3-8B (GQA 32/8, vocab 128256 -> 100 000 TRAINABLE sub-sampled rows)
+    "llama3_8b_recon_B32_L1024_C12": (LLAMA3_8B, 32, 1024, 12, 1024, 128, "reconstruction"),
 }
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md
 
@@ -66,7 +70,7 @@ class DS:
 def make_batch(B, L, C_, pred, seed, device, task="forecasting"):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, L, C_, generator=g) + (torch.rand(C_, generator=g) * 4 - 2)
-    y = torch.randn(B, pred, C_, generator=g) if task == "forecasting" else torch.randint(0, 4, (B, pred), generator=g)
+    y = torch.randn(B, pred, C_, generator=g) if task != "semantic_segmentation" else torch.randint(0, 4, (B, pred), generator=g)
     return {"x_enc": x.to(device), "y": y.to(device)}
 
 
@@ -75,7 +79,8 @@ def flops_per_step(cfg, B, T, P, C_, n_out, V, S=1024, d_model=32, d_ff=128, H=8
     if cfg["model_type"] == "llama":
         d, L_, ffn = cfg["hidden_size"], cfg["num_hidden_layers"], cfg["intermediate_size"]
         M = B * T
-        gemm_fwd = L_ * 2 * M * (4 * d * d + 3 * d * ffn)
+        kv = cfg["num_key_value_heads"] * (d // cfg["num_attention_heads"])
+        gemm_fwd = L_ * 2 * M * (2 * d * d + 2 * d * kv + 3 * d * ffn)
     else:
         d, L_, ffn = cfg["n_embd"], cfg["n_layer"], 4 * cfg["n_embd"]
         M = B * T
@@ -222,14 +227,14 @@ def main():
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-4, fused=True)
     sync = parallel.FlatGradAllReduce(params) if world > 1 else None
-    loss_fn = torch.nn.MSELoss() if task == "forecasting" else torch.nn.CrossEntropyLoss()
+    loss_fn = torch.nn.MSELoss() if task != "semantic_segmentation" else torch.nn.CrossEntropyLoss()
     batches = [make_batch(B, L, C_, pred, 1000 + rank * 97 + i, device, task) for i in range(4)]
 
     def step(i):
         inputs = batches[i % len(batches)]
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=True):
             pred_ = model(inputs)
-            loss = loss_fn(pred_ if task == "forecasting" else pred_.permute(0, 2, 1), inputs["y"])
+            loss = loss_fn(pred_ if task != "semantic_segmentation" else pred_.permute(0, 2, 1), inputs["y"])
         loss.backward()
         if sync is not None:
             sync()
@@ -288,7 +293,7 @@ def main():
     if rank == 0:
         P = (L + 8 - 16) // 8 + 1
         T = n_tok + P
-        fl, fl_exec = flops_per_step(hf_cfg, B, T, P, C_, pred * (C_ if task == "forecasting" else 4), hf_cfg["vocab_size"])
+        fl, fl_exec = flops_per_step(hf_cfg, B, T, P, C_, pred * (C_ if task != "semantic_segmentation" else 4), min(hf_cfg["vocab_size"], 100_000))
         if args.full_backward:
             fl_exec = fl
         value = B * world * args.steps / elapsed
@@ -297,7 +302,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.workload}: [B={B}/GPU, L={L}, C={C_}] windows, P={P}, prompt {n_tok} tok -> T={T}, "
-                                   f"frozen {'Llama-2-7B' if big else 'GPT-2-small'} (random init) backbone, concat covariates, {task} pred_len={pred}, "
+                                   f"frozen {args.workload.split('_B32')[0] if big else 'GPT-2-small'} (random init) backbone, concat covariates, {task} pred_len={pred}, "
                                    f"step = fwd+loss+bwd+{'allreduce+' if world > 1 else ''}Adam", "global_batch": B * world,
                        "parallelism": f"dp{world}"},
             "final_loss": final_loss,

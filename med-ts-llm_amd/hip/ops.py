@@ -354,6 +354,42 @@ class MappingFn(torch.autograd.Function):
         return dW, db, None, None, None
 
 
+class MappingTrainableFn(torch.autograd.Function):
+    """MappingFn for vocabularies > 100 000, where the reference turns the (linspace sub-sampled) word-embedding table
+    into a TRAINABLE parameter (R:models/medtsllm.py:220-222): source = Wmap @ Wemb + b with gradients for all three.
+    dWemb[V, d] = Wmap^T[V, S] @ dsource[S, d] — one more NT GEMM with fp32 output."""
+
+    @staticmethod
+    def forward(ctx, Wmap, b, Wemb, split_k):
+        S, V = Wmap.shape
+        d = Wemb.shape[1]
+        Vp, Sp = pad64(V + 1), pad64(S)
+        dev = Wmap.device
+        wm = torch.empty((S, Vp), dtype=BF16, device=dev)
+        wmT = torch.empty((V, Sp), dtype=BF16, device=dev)
+        cast_pad(Wmap.detach().contiguous().float(), dst=wm, dst_t=wmT)
+        wm[:, V] = b.detach().to(BF16)
+        we = torch.empty((V, d), dtype=BF16, device=dev)
+        weT = torch.zeros((d, Vp), dtype=BF16, device=dev)
+        cast_pad(Wemb.detach().contiguous().float(), dst=we, dst_t=weT)
+        weT[:, V] = 1.0
+        src = gemm_nt(wm, weT, split_k=split_k)
+        ctx.save_for_backward(we, wmT)
+        ctx.meta = (S, V, d)
+        return src
+
+    @staticmethod
+    def backward(ctx, dsrc):
+        we, wmT = ctx.saved_tensors
+        S, V, d = ctx.meta
+        dsrc = dsrc.contiguous()
+        dW = gemm_nt(dsrc, we, out_dtype=F32) if ctx.needs_input_grad[0] else None          # [S, V]
+        dsT = transpose_bf16(dsrc, wmT.shape[1])                                               # [d, Sp]
+        db = colsum(transpose_bf16(dsrc)) if ctx.needs_input_grad[1] else None              # row sums of dsrc
+        dE = gemm_nt(wmT, dsT, out_dtype=F32) if ctx.needs_input_grad[2] else None            # [V, d]
+        return dW, db, dE, None
+
+
 class CrossAttnFn(torch.autograd.Function):
     """Reprogramming attention (R:models/medtsllm.py:581-591): q [B,L,H*E], k/v [S,H*E] shared by every sample."""
 

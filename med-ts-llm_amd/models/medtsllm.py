@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..hip import ops
-from ..hip.ops import (PatchTokenizeFn, LinearFn, MappingFn, CrossAttnFn, AssembleFn, BackboneFn, RevinDenormFn, pad64)
+from ..hip.ops import (PatchTokenizeFn, LinearFn, MappingFn, MappingTrainableFn, CrossAttnFn, AssembleFn, BackboneFn, RevinDenormFn, pad64)
 from . import prompt as P
 from .backbone import FrozenBackbone, load_hf_dir, normalise_config
 
@@ -148,11 +148,13 @@ class MedTsLLM(nn.Module):
         self._head_dim = bc["head_dim"]
         emb = sd["wte.weight"] if bc["arch"] == "gpt2" else sd["embed_tokens.weight"]
         if emb.shape[0] > 100_000:
-            # R:models/medtsllm.py:220-222 makes a TRAINABLE 100 000-row sub-sample (Llama-3). Not on the HIP path yet.
-            raise NotImplementedError("vocabularies > 100 000 (trainable sub-sampled word_embeddings) are a 'next' row (DESIGN.md)")
-        # registered like the reference (alias of the frozen input-embedding table; filtered from state_dict)
-        self.word_embeddings = nn.Parameter(emb.detach().float().clone(), requires_grad=False)
-        self.vocab_size = emb.shape[0]
+            # R:models/medtsllm.py:220-222: 100 000 linspace-sampled rows become a fresh, TRAINABLE nn.Parameter (Llama-3)
+            inds = torch.linspace(0, emb.shape[0] - 1, 100_000, dtype=torch.long)
+            self.word_embeddings = nn.Parameter(emb.detach()[inds.to(emb.device), :].float().clone())
+        else:
+            # registered like the reference (alias of the frozen input-embedding table; filtered from state_dict)
+            self.word_embeddings = nn.Parameter(emb.detach().float().clone(), requires_grad=False)
+        self.vocab_size = self.word_embeddings.shape[0]
         self.backbone = None
         self.tokenizer = None
         self._tok_dir = self.llm_id if (isinstance(self.llm_id, str) and os.path.isdir(self.llm_id)) else None
@@ -183,10 +185,11 @@ class MedTsLLM(nn.Module):
             bb = self.backbone
             V, d = self.vocab_size, self.d_llm
             Vp = pad64(V + 1)
-            wT = torch.zeros((d, Vp), dtype=BF16, device=device)
-            wT[:, :V] = bb.embed_f32.t().to(BF16)
-            wT[:, V] = 1.0                                   # bias carrier (see MappingFn)
-            self._wT, self._w = wT, bb.embed_f32.to(BF16).contiguous()
+            if not self.word_embeddings.requires_grad:       # frozen table: bf16 operands prepared once
+                wT = torch.zeros((d, Vp), dtype=BF16, device=device)
+                wT[:, :V] = bb.embed_f32.t().to(BF16)
+                wT[:, V] = 1.0                               # bias carrier (see MappingFn)
+                self._wT, self._w = wT, bb.embed_f32.to(BF16).contiguous()
             nkt = Vp // 64
             tiles = ((self.num_tokens + 127) // 128) * ((d + 127) // 128)
             self._map_split_k = max(1, min(nkt, 16, (512 + tiles - 1) // tiles))
@@ -266,7 +269,10 @@ class MedTsLLM(nn.Module):
                                                     self.patch_len, self.stride, concat)
         if self.training and self.dropout > 0:
             tokens = F.dropout(tokens, self.dropout, True)
-        source = MappingFn.apply(self.mapping_layer.weight, self.mapping_layer.bias, self._wT, self._w, self._map_split_k)
+        if self.word_embeddings.requires_grad:
+            source = MappingTrainableFn.apply(self.mapping_layer.weight, self.mapping_layer.bias, self.word_embeddings, self._map_split_k)
+        else:
+            source = MappingFn.apply(self.mapping_layer.weight, self.mapping_layer.bias, self._wT, self._w, self._map_split_k)
         q = LinearFn.apply(tokens, rl.query_projection.weight, rl.query_projection.bias)
         k = LinearFn.apply(source, rl.key_projection.weight, rl.key_projection.bias)
         v = LinearFn.apply(source, rl.value_projection.weight, rl.value_projection.bias)

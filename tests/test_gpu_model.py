@@ -58,6 +58,8 @@ CASES = [
     ("llama", "forecasting", 2, 64, 3, 16, "weighted-average", "linear", False),
     ("llama", "forecasting", 2, 64, 3, 16, "merge-end", "linear", True),
     ("gpt2", "segmentation", 2, 64, 1, 64, "univariate", "linear", True),
+    # vocabulary > 100 000: the sub-sampled word-embedding table is a trainable parameter (Llama-3 quirk, R:models/medtsllm.py:220-222)
+    ("llama_gqa_bigvocab", "reconstruction", 2, 64, 2, 64, "concat", "linear", False),
 ]
 
 
@@ -68,7 +70,7 @@ def test_full_model_fwd_bwd(kind, task, B, L, C, pred, cov, down, prompt_on):
     from med_ts_llm_amd.utils import dict_to_object
     from oracle import medtsllm_oracle as O
 
-    cfg = hf_cfg(kind)
+    cfg = hf_cfg("llama_gqa", vocab=100_100) if kind == "llama_gqa_bigvocab" else hf_cfg(kind)
     sd = random_state_dict(cfg, seed=7, std=0.06)
     prompting = {"dataset": prompt_on, "task": prompt_on, "clip": False, "input_stats": prompt_on, "examples": False,
                  "input_stats_dim": 0, "input_stats_select": "all"}
@@ -90,7 +92,11 @@ def test_full_model_fwd_bwd(kind, task, B, L, C, pred, cov, down, prompt_on):
     pred_hip = model(inputs)
 
     # ---- oracle on the same weights / prompt ids
-    p = {n: t.detach().cpu().float().clone().requires_grad_(t.requires_grad) for n, t in model.named_parameters() if n != "word_embeddings"}
+    trainable_emb = model.word_embeddings.requires_grad
+    assert trainable_emb == (kind == "llama_gqa_bigvocab") and model.vocab_size == min(cfg["vocab_size"], 100_000)
+    p = {n: t.detach().cpu().float().clone().requires_grad_(t.requires_grad) for n, t in model.named_parameters()
+         if n != "word_embeddings" or trainable_emb}
+    we_kw = {"word_emb": p["word_embeddings"]} if trainable_emb else {}
     tok_ids = None
     if prompt_on:
         # input statistics (median / rFFT lags) are data dependent: take the strings the GPU model itself builds so that
@@ -100,13 +106,14 @@ def test_full_model_fwd_bwd(kind, task, B, L, C, pred, cov, down, prompt_on):
     meta = {"task": task, "pred_len": pred, "patch_len": 16, "stride": 8, "n_heads": 2, "d_ff": 64, "covariate_mode": cov,
             "embedding_downsample_mode": down, "n_classes": n_classes, "C": C}
     m = oracle_mcfg(meta)
-    ref = O.medtsllm_forward(x, p, sd, cfg, m, token_ids=tok_ids, pad_token_id=model.tokenizer.pad_token_id, training=True)
+    ref = O.medtsllm_forward(x, p, sd, cfg, m, token_ids=tok_ids, pad_token_id=model.tokenizer.pad_token_id, training=True, **we_kw)
     assert pred_hip.shape == ref.shape
     # L3 bar = 1.5 x the reference's OWN bf16-vs-fp32 deviation on THIS model: the oracle run under CPU bf16 autocast is
     # the reference's dtype="mixed" arithmetic (same ATen autocast policy: bf16 linear/matmul, fp32 norm/softmax).
     p16 = {n: t.detach().clone().requires_grad_(t.requires_grad) for n, t in p.items()}
+    we_kw16 = {"word_emb": p16["word_embeddings"]} if trainable_emb else {}
     with torch.autocast("cpu", dtype=torch.bfloat16):
-        ref16 = O.medtsllm_forward(x, p16, sd, cfg, m, token_ids=tok_ids, pad_token_id=model.tokenizer.pad_token_id, training=True)
+        ref16 = O.medtsllm_forward(x, p16, sd, cfg, m, token_ids=tok_ids, pad_token_id=model.tokenizer.pad_token_id, training=True, **we_kw16)
     self_err = rel_err(ref16.float(), ref)
     bar = 1.5 * max(self_err, 4e-3)
     e = rel_err(pred_hip, ref)
@@ -149,7 +156,7 @@ def test_full_model_fwd_bwd(kind, task, B, L, C, pred, cov, down, prompt_on):
     model.eval()
     with torch.no_grad():
         pe = model(inputs)
-        pr = O.medtsllm_forward(x, p, sd, cfg, m, token_ids=tok_ids, pad_token_id=model.tokenizer.pad_token_id, training=False)
+        pr = O.medtsllm_forward(x, p, sd, cfg, m, token_ids=tok_ids, pad_token_id=model.tokenizer.pad_token_id, training=False, **we_kw)
     assert rel_err(pe, pr) < bar
 
 
