@@ -37,7 +37,9 @@ class SyntheticWindows(Dataset):
         phase = torch.rand(self.n, 1, self.n_features, generator=g) * 6.28
         freq = 0.05 + 0.2 * torch.rand(self.n, 1, self.n_features, generator=g)
         self.data = torch.sin(t[None, :, None] * freq + phase) + 0.1 * torch.randn(self.n, T, self.n_features, generator=g)
-        self.labels = torch.randint(0, max(self.n_classes, 2), (self.n, self.pred), generator=g)
+        # learnable labels: the amplitude bucket of channel 0 at the same time step
+        nb = max(self.n_classes, 2)
+        self.labels = torch.clamp(((self.data[:, :self.pred, 0] + 1.2) / 2.4 * nb).long(), 0, nb - 1)
 
     def __len__(self):
         return self.n
