@@ -86,8 +86,75 @@ __global__ __launch_bounds__(256) void tokenize_fwd_kernel(const float* __restri
     }
 }
 
+// Fast path (patch_len == 16, stride % 4 == 0, 256 % d_patch == 0): every thread owns ONE output channel with its
+// 48 conv weights in registers and walks the patches; the patch windows are contiguous 64-B slices of the replicate-padded
+// normalised series in LDS (exactly the reference's pad + unfold), read as 16-B broadcasts.
+// dynamic LDS: xpad[L + stride] | red[4]
+__global__ __launch_bounds__(256) void tokenize_fwd_fast_kernel(const float* __restrict__ x, const float* __restrict__ conv_w,
+                                                                bf16_t* __restrict__ out, float* __restrict__ mean_out,
+                                                                float* __restrict__ stdev_out, int L, int C, int stride, int d_patch,
+                                                                int P, int64_t ld_out, int concat, float eps) {
+    constexpr int PL = 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xp = lds;
+    float* red = lds + ((L + stride + 3) & ~3);
+    const int bc = blockIdx.x, b = bc / C, c = bc % C;
+    const int tid = threadIdx.x;
+    const float* xs = x + (int64_t)b * L * C + c;
+    float s = 0.f;
+    for (int t = tid; t < L; t += 256) {
+        const float v = xs[(int64_t)t * C];
+        xp[t] = v;
+        s += v;
+    }
+    const int o = tid % d_patch, pg = tid / d_patch, npg = 256 / d_patch;
+    float w[3][PL];
+#pragma unroll
+    for (int j = 0; j < PL; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w[k][j] = conv_w[(o * PL + j) * 3 + k];
+    const float mean = block_sum(s, red) / (float)L;
+    float q = 0.f;
+    for (int t = tid; t < L; t += 256) {
+        const float dlt = xp[t] - mean;
+        q += dlt * dlt;
+    }
+    const float stdev = sqrtf(block_sum(q, red) / (float)L + eps);
+    if (tid == 0) {
+        mean_out[bc] = mean;
+        stdev_out[bc] = stdev;
+    }
+    for (int t = tid; t < L; t += 256) xp[t] = (xp[t] - mean) / stdev;
+    __syncthreads();
+    const float last = xp[L - 1];
+    for (int t = L + tid; t < L + stride; t += 256) xp[t] = last;   // ReplicationPad1d((0, stride))
+    __syncthreads();
+    const int64_t row0 = concat ? (int64_t)b * P : (int64_t)bc * P;
+    const int col0 = concat ? c * d_patch : 0;
+    for (int p = pg; p < P; p += npg) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int pp = p + k - 1;
+            pp = pp < 0 ? pp + P : (pp >= P ? pp - P : pp);
+            const float4* win = reinterpret_cast<const float4*>(xp + pp * stride);
+#pragma unroll
+            for (int j4 = 0; j4 < PL / 4; ++j4) {
+                const float4 v = win[j4];
+                acc += w[k][j4 * 4] * v.x + w[k][j4 * 4 + 1] * v.y + w[k][j4 * 4 + 2] * v.z + w[k][j4 * 4 + 3] * v.w;
+            }
+        }
+        out[(row0 + p) * ld_out + col0 + o] = f32_to_bf16(acc);
+    }
+    const int used = concat ? C * d_patch : d_patch;
+    const int pad = (int)ld_out - used;
+    if (pad > 0 && (!concat || c == 0)) {
+        for (int e = tid; e < P * pad; e += 256) out[(row0 + e / pad) * ld_out + used + e % pad] = 0;
+    }
+}
+
 // dW partial for one series: partial[bc][o][j][k] = sum_p dout[p][o] * patch[(p + k - 1) mod P][j]
-// dynamic LDS: xn[L] | red[4]
+// dynamic LDS: xn[L] | dout tile [P][d_patch] fp32
 __global__ __launch_bounds__(256) void tokenize_bwd_kernel(const float* __restrict__ x, const float* __restrict__ mean_in,
                                                            const float* __restrict__ stdev_in, const bf16_t* __restrict__ dout,
                                                            float* __restrict__ partial, int L, int C, int patch_len, int stride,
@@ -99,28 +166,36 @@ __global__ __launch_bounds__(256) void tokenize_bwd_kernel(const float* __restri
     const float* xs = x + (int64_t)b * L * C + c;
     const float mean = mean_in[bc], stdev = stdev_in[bc];
     for (int t = tid; t < L; t += 256) xn[t] = (xs[(int64_t)t * C] - mean) / stdev;
-    __syncthreads();
+    float* dt = lds + L;
     const int64_t row0 = concat ? (int64_t)b * P : (int64_t)bc * P;
     const int col0 = concat ? c * d_patch : 0;
+    for (int e = tid; e < P * d_patch; e += 256) dt[e] = bf16_to_f32(dout[(row0 + e / d_patch) * ld_out + col0 + e % d_patch]);
+    __syncthreads();
     const int nw = d_patch * patch_len * 3;
+    // consecutive threads -> consecutive output channels o (conflict-free dt reads, broadcast xn reads)
     for (int e = tid; e < nw; e += 256) {
-        const int o = e / (patch_len * 3), j = (e / 3) % patch_len, k = e % 3;
+        const int o = e % d_patch, jk = e / d_patch, j = jk / 3, k = jk % 3;
         float acc = 0.f;
         for (int p = 0; p < P; ++p) {
             int pp = p + k - 1;
             pp = pp < 0 ? pp + P : (pp >= P ? pp - P : pp);
-            acc += bf16_to_f32(dout[(row0 + p) * ld_out + col0 + o]) * xn[patch_src_index(pp, j, L, stride)];
+            acc += dt[p * d_patch + o] * xn[patch_src_index(pp, j, L, stride)];
         }
-        partial[(int64_t)bc * nw + e] = acc;
+        partial[(int64_t)bc * nw + (o * patch_len + j) * 3 + k] = acc;
     }
 }
 
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ dw, int n_series, int nw) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nw) return;
+// deterministic two-stage reduction: 64 outputs per block, 4 series lanes per output
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ dw, int n_series, int nw) {
+    __shared__ float part[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + tx;
     float s = 0.f;
-    for (int i = 0; i < n_series; ++i) s += partial[(int64_t)i * nw + e];
-    dw[e] = s;
+    if (e < nw)
+        for (int i = ty; i < n_series; i += 4) s += partial[(int64_t)i * nw + e];
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && e < nw) dw[e] = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
 }
 
 }  // namespace
@@ -142,6 +217,15 @@ extern "C" int mtl_patch_tokenize_fwd(const float* x, const float* conv_w, void*
         return MTL_ERR_ARG;
     const int P = (int)((L + stride - patch_len) / stride + 1);
     if (ld_out < (concat ? C * d_patch : d_patch)) return MTL_ERR_ARG;
+    if (patch_len == 16 && stride % 4 == 0 && d_patch <= 256 && 256 % d_patch == 0) {
+        const size_t fast_bytes = (size_t)(((L + stride + 3) & ~3) + 4) * sizeof(float);
+        if (fast_bytes <= 64 * 1024) {
+            hipLaunchKernelGGL(tokenize_fwd_fast_kernel, dim3((unsigned)(B * C)), dim3(256), fast_bytes, (hipStream_t)stream, x, conv_w,
+                               (bf16_t*)out, mean, stdev, (int)L, (int)C, (int)stride, (int)d_patch, P, ld_out, concat, eps);
+            MTL_CHECK_LAUNCH();
+            return MTL_OK;
+        }
+    }
     const size_t lds_bytes = (size_t)(L + d_patch * patch_len * 3 + 4) * sizeof(float);
     if (lds_bytes > 64 * 1024) return MTL_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(tokenize_fwd_kernel, dim3((unsigned)(B * C)), dim3(256), lds_bytes, (hipStream_t)stream, x, conv_w, (bf16_t*)out,
@@ -155,13 +239,13 @@ extern "C" int mtl_patch_tokenize_bwd(const float* x, const float* mean, const f
                                       int64_t ld_out, int concat, void* stream) {
     if (!x || !mean || !stdev || !dout || !partial || !dw || B <= 0 || C <= 0 || L < patch_len) return MTL_ERR_ARG;
     const int P = (int)((L + stride - patch_len) / stride + 1);
-    const size_t lds_bytes = (size_t)(L + 4) * sizeof(float);
+    const size_t lds_bytes = (size_t)(L + P * d_patch) * sizeof(float);
     if (lds_bytes > 64 * 1024) return MTL_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(tokenize_bwd_kernel, dim3((unsigned)(B * C)), dim3(256), lds_bytes, st, x, mean, stdev, (const bf16_t*)dout, partial,
                        (int)L, (int)C, (int)patch_len, (int)stride, (int)d_patch, P, ld_out, concat);
     const int nw = (int)(d_patch * patch_len * 3);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((nw + 255) / 256), dim3(256), 0, st, partial, dw, (int)(B * C), nw);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((nw + 63) / 64), dim3(256), 0, st, partial, dw, (int)(B * C), nw);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
