@@ -154,6 +154,9 @@ typedef struct {
                                        split into kv_splits chunks summed by a second kernel (NULL / <=1: one pass)  */
 } mtl_attn_bwd_args;
 int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream);
+/* A/B knob: 1 (default) lets causal self-attention use the resident-K/V kernels (whole head in LDS, no barrier in the
+ * key loop) whenever they fit, 0 forces the chunked kernels. Results agree to rounding. */
+int mtl_attention_tune(int resident);
 
 /* ------------------------------------------------------------------ norms (fp32 statistics)
  * LayerNorm eps 1e-5 (HF:models/gpt2/modeling_gpt2.py:252,254,497) and LlamaRMSNorm

@@ -15,6 +15,8 @@
 // (row stride D+8 bf16: conflict-free 16-B fragment reads), fp32 online softmax.
 #include "mtl_common.h"
 
+#include <mutex>
+
 namespace {
 
 constexpr int KC = 64;  // keys (or queries, in the dK/dV kernel) per LDS chunk
@@ -46,16 +48,25 @@ __device__ __forceinline__ bf16x8 gather_col(const bf16_t* tile, int ldt, int ra
     return f.v;
 }
 
-// cooperative load of `rows` x D bf16 (row stride src_ts elements) into a padded LDS tile; rows >= limit are clamped
+// cooperative load of KC rows x D bf16 (row stride src_ts elements) into a padded LDS tile; rows >= limit are clamped.
+// All global loads of a thread are issued BEFORE the first LDS store: a load->store->load loop costs one full memory
+// round trip per iteration (hipcc waits vmcnt(0) in front of every ds_write), which was most of these kernels' time.
 template <int D>
 __device__ __forceinline__ void load_tile(bf16_t* tile, const bf16_t* src, int64_t src_ts, int64_t row0, int64_t limit) {
-    constexpr int LDT = D + 8, CPR = D / 8;
-    for (int s = threadIdx.x; s < KC * CPR; s += 256) {
+    constexpr int LDT = D + 8, CPR = D / 8, NIT = KC * CPR / 256;
+    u32x4 v[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int s = threadIdx.x + i * 256;
         const int r = s / CPR, c = s % CPR;
         int64_t gr = row0 + r;
         if (gr > limit - 1) gr = limit - 1;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(src + gr * src_ts + c * 8);
-        *reinterpret_cast<u32x4*>(tile + r * LDT + c * 8) = v;
+        v[i] = *reinterpret_cast<const u32x4*>(src + gr * src_ts + c * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int s = threadIdx.x + i * 256;
+        *reinterpret_cast<u32x4*>(tile + (s / CPR) * LDT + (s % CPR) * 8) = v[i];
     }
 }
 
@@ -434,6 +445,336 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const mtl_attn_bwd_ar
     }
 }
 
+// =============================================================================================== resident variants
+// Causal self-attention of the backbone at T <= 256..512: the whole K and V of one (batch, head) fit in LDS, so a
+// workgroup pays the global-load latency ONCE, synchronises once, and every wave then streams through the keys with no
+// barrier at all (the chunked kernels above spend most of their time parked at the two barriers per 64-key chunk:
+// 32 us per layer for 3.2 GFLOP). Waves take PAIRS of 16-row query tiles (i, nt-1-i): with a causal mask every pair
+// costs the same, so waves and workgroups are balanced by construction.
+// dynamic LDS: K tile [Tk][D+8] | V tile [Tk][D+8]
+// rows [0, rows) are copied, rows [rows, ceil32(rows)) are ZERO-filled: every 32-row slab read below stays in bounds and
+// the masked (p == 0) rows contribute exact zeros instead of 0 * garbage.
+__device__ __forceinline__ int64_t ceil32(int64_t v) { return (v + 31) & ~(int64_t)31; }
+template <int D, int NT, int BATCH = 8>
+__device__ __forceinline__ void load_rows(bf16_t* tile, const bf16_t* src, int64_t src_ts, int64_t rows) {
+    constexpr int LDT = D + 8, CPR = D / 8;
+    const int64_t total = ceil32(rows) * CPR;
+    for (int64_t base = 0; base < total; base += (int64_t)BATCH * NT) {
+        u32x4 v[BATCH];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {       // 8 independent 16-B loads in flight per thread, then the stores
+            const int64_t s = base + threadIdx.x + (int64_t)i * NT;
+            const int64_t r = s / CPR;
+            v[i] = (u32x4){0u, 0u, 0u, 0u};
+            if (s < total && r < rows) v[i] = *reinterpret_cast<const u32x4*>(src + r * src_ts + (s % CPR) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            const int64_t s = base + threadIdx.x + (int64_t)i * NT;
+            if (s < total) *reinterpret_cast<u32x4*>(tile + (s / CPR) * LDT + (s % CPR) * 8) = v[i];
+        }
+    }
+}
+
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fwd_args a) {
+    constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t* ktile = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* vtile = ktile + ceil32(a.Tk) * LDT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+    const int64_t b = blockIdx.z, h = blockIdx.y, hk = h / (a.Hq / a.Hkv);
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * a.q_hs;
+    load_rows<D, NW * 64>(ktile, reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + hk * a.k_hs, a.k_ts, a.Tk);
+    load_rows<D, NW * 64>(vtile, reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + hk * a.v_hs, a.v_ts, a.Tk);
+    __syncthreads();
+    const float c = a.scale * LOG2E;
+    const int64_t coff = a.causal_off;
+    const int nt = (int)((a.Tq + 15) / 16), npairs = (nt + 1) / 2;
+    const int pi = blockIdx.x * NW + wave;
+    if (pi >= npairs) return;
+    for (int half = 0; half < 2; ++half) {
+        const int tile = half == 0 ? pi : nt - 1 - pi;
+        if (half == 1 && tile == pi) break;
+        const int64_t q0 = (int64_t)tile * 16;
+        int64_t qrow = q0 + l15;
+        const bool q_valid = qrow < a.Tq;
+        if (qrow > a.Tq - 1) qrow = a.Tq - 1;
+        bf16x8 qf[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + qrow * a.q_ts + ks * 32 + g * 8);
+        f32x4 o[NDT];
+#pragma unroll
+        for (int i = 0; i < NDT; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float m_run = NEG_BIG, l_run = 0.f;
+        const int64_t wave_qmin = q0 + coff;
+        const int64_t wave_qmax = ((q0 + 15 < a.Tq - 1) ? q0 + 15 : a.Tq - 1) + coff;
+        const int64_t k_end = (wave_qmax + 1 < a.Tk) ? wave_qmax + 1 : a.Tk;
+        for (int64_t kb = 0; kb < k_end; kb += 32) {
+            f32x4 s[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const bf16_t* kr = ktile + (kb + t * 16 + l15) * LDT + g * 8;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks)
+                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kr + ks * 32), qf[ks], s[t], 0, 0, 0);
+            }
+            float p[2][4];
+            const bool need_mask = (kb + 32 > a.Tk) || (kb + 31 > wave_qmin);
+            if (need_mask) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t key = kb + t * 16 + g * 4 + r;
+                        p[t][r] = (key >= a.Tk || key > qrow + coff) ? NEG_BIG : s[t][r] * c;
+                    }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p[t][r] = s[t][r] * c;
+            }
+            float mx = fmaxf(fmaxf(fmaxf(p[0][0], p[0][1]), fmaxf(p[0][2], p[0][3])), fmaxf(fmaxf(p[1][0], p[1][1]), fmaxf(p[1][2], p[1][3])));
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            float psum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[t][r] = __builtin_amdgcn_exp2f(p[t][r] - m_new);
+                    psum += p[t][r];
+                }
+            if (__any(m_new != m_run)) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
+                m_run = m_new;
+            }
+            l_run += psum;
+            const bf16x8 pf = pack8(p[0], p[1]);
+            const int ra = (int)(kb + g * 4), rb = (int)(kb + 16 + g * 4);   // rows >= Tk are zero-filled and carry p == 0
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const bf16x8 vt = gather_col(vtile, LDT, ra, rb, dt * 16, l15);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pf, o[dt], 0, 0, 0);
+            }
+        }
+        l_run += __shfl_xor(l_run, 16, 64);
+        l_run += __shfl_xor(l_run, 32, 64);
+        if (q_valid) {
+            const float inv_l = 1.0f / l_run;
+            bf16_t* O = reinterpret_cast<bf16_t*>(a.o) + b * a.o_bs + h * a.o_hs + qrow * a.o_ts;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                u32x2 pk = {pack_bf16x2(o[dt][0] * inv_l, o[dt][1] * inv_l), pack_bf16x2(o[dt][2] * inv_l, o[dt][3] * inv_l)};
+                *reinterpret_cast<u32x2*>(O + dt * 16 + g * 4) = pk;
+            }
+            if (g == 0 && a.lse) a.lse[(b * a.Hq + h) * (a.stat_stride ? a.stat_stride : a.Tq) + qrow] = (m_run + __builtin_amdgcn_logf(l_run)) * LN2;
+        }
+    }
+}
+
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn_bwd_args a) {
+    constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const mtl_attn_fwd_args& f = a.f;
+    bf16_t* ktile = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* vtile = ktile + ceil32(f.Tk) * LDT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+    const int64_t b = blockIdx.z, h = blockIdx.y, hk = h / (f.Hq / f.Hkv);
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(f.q) + b * f.q_bs + h * f.q_hs;
+    const bf16_t* O = reinterpret_cast<const bf16_t*>(f.o) + b * f.o_bs + h * f.o_hs;
+    const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dout) + b * a.do_bs + h * a.do_hs;
+    load_rows<D, NW * 64>(ktile, reinterpret_cast<const bf16_t*>(f.k) + b * f.k_bs + hk * f.k_hs, f.k_ts, f.Tk);
+    load_rows<D, NW * 64>(vtile, reinterpret_cast<const bf16_t*>(f.v) + b * f.v_bs + hk * f.v_hs, f.v_ts, f.Tk);
+    __syncthreads();
+    const float c = f.scale * LOG2E;
+    const int64_t coff = f.causal_off;
+    const int nt = (int)((f.Tq + 15) / 16), npairs = (nt + 1) / 2;
+    const int pi = blockIdx.x * NW + wave;
+    if (pi >= npairs) return;
+    for (int half = 0; half < 2; ++half) {
+        const int tile = half == 0 ? pi : nt - 1 - pi;
+        if (half == 1 && tile == pi) break;
+        const int64_t q0 = (int64_t)tile * 16;
+        int64_t qrow = q0 + l15;
+        const bool q_valid = qrow < f.Tq;
+        if (qrow > f.Tq - 1) qrow = f.Tq - 1;
+        bf16x8 qf[NKS], dof[NKS];
+        float dl = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            qf[ks] = *reinterpret_cast<const bf16x8*>(Q + qrow * f.q_ts + ks * 32 + g * 8);
+            frag8 d8, o8;
+            d8.v = *reinterpret_cast<const bf16x8*>(dO + qrow * a.do_ts + ks * 32 + g * 8);
+            o8.v = *reinterpret_cast<const bf16x8*>(O + qrow * f.o_ts + ks * 32 + g * 8);
+            dof[ks] = d8.v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dl += __uint_as_float(d8.u[e] << 16) * __uint_as_float(o8.u[e] << 16);
+                dl += __uint_as_float(d8.u[e] & 0xffff0000u) * __uint_as_float(o8.u[e] & 0xffff0000u);
+            }
+        }
+        dl += __shfl_xor(dl, 16, 64);
+        dl += __shfl_xor(dl, 32, 64);
+        const int64_t stat_idx = (b * f.Hq + h) * (f.stat_stride ? f.stat_stride : f.Tq) + qrow;
+        if (g == 0 && q_valid) a.delta[stat_idx] = dl;
+        const float lse2 = f.lse[stat_idx] * LOG2E;
+        f32x4 dq[NDT];
+#pragma unroll
+        for (int i = 0; i < NDT; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int64_t wave_qmax = ((q0 + 15 < f.Tq - 1) ? q0 + 15 : f.Tq - 1) + coff;
+        const int64_t k_end = (wave_qmax + 1 < f.Tk) ? wave_qmax + 1 : f.Tk;
+        for (int64_t kb = 0; kb < k_end; kb += 32) {
+            float ds[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                const bf16_t* kr = ktile + (kb + t * 16 + l15) * LDT + g * 8;
+                const bf16_t* vr = vtile + (kb + t * 16 + l15) * LDT + g * 8;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kr + ks * 32), qf[ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(vr + ks * 32), dof[ks], dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t key = kb + t * 16 + g * 4 + r;
+                    const bool masked = key >= f.Tk || key > qrow + coff;
+                    const float pv = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse2);
+                    ds[t][r] = pv * (dp[r] - dl);
+                }
+            }
+            const bf16x8 dsf = pack8(ds[0], ds[1]);
+            const int ra = (int)(kb + g * 4), rb = (int)(kb + 16 + g * 4);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const bf16x8 kt = gather_col(ktile, LDT, ra, rb, dt * 16, l15);
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf, dq[dt], 0, 0, 0);
+            }
+        }
+        if (q_valid) {
+            bf16_t* DQ = reinterpret_cast<bf16_t*>(a.dq) + b * a.dq_bs + h * a.dq_hs + qrow * a.dq_ts;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                u32x2 pk = {pack_bf16x2(dq[dt][0] * f.scale, dq[dt][1] * f.scale), pack_bf16x2(dq[dt][2] * f.scale, dq[dt][3] * f.scale)};
+                *reinterpret_cast<u32x2*>(DQ + dt * 16 + g * 4) = pk;
+            }
+        }
+    }
+}
+
+// dK/dV with every query row (Q, dO, lse, delta) of the head resident in LDS; waves take pairs of 16-key tiles.
+// dynamic LDS: Q tile [Tq][D+8] | dO tile [Tq][D+8] | lse2[Tq] | delta[Tq]
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(const mtl_attn_bwd_args a) {
+    constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const mtl_attn_fwd_args& f = a.f;
+    bf16_t* qtile = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* dotile = qtile + ceil32(f.Tq) * LDT;
+    float* lse_s = reinterpret_cast<float*>(dotile + ceil32(f.Tq) * LDT);
+    float* delta_s = lse_s + ceil32(f.Tq);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+    const int64_t b = blockIdx.z, hk = blockIdx.y;
+    const int group = (int)(f.Hq / f.Hkv);
+    const float c = f.scale * LOG2E;
+    const int64_t coff = f.causal_off;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(f.k) + b * f.k_bs + hk * f.k_hs;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(f.v) + b * f.v_bs + hk * f.v_hs;
+    const int nkt = (int)((f.Tk - a.kv_row0 + 15) / 16), npairs = (nkt + 1) / 2;
+    const int pi = blockIdx.x * NW + wave;
+    const bool active = pi < npairs;
+    // one accumulator set: the two key tiles of the pair are processed one after the other (for GQA the query heads of
+    // the group are re-staged per tile; group == 1 stages Q/dO exactly once)
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const int tile = half == 0 ? pi : nkt - 1 - pi;
+        const bool tile_on = active && !(half == 1 && tile == pi);
+        const int64_t k0 = a.kv_row0 + (int64_t)(tile_on ? tile : 0) * 16;
+        const int64_t krow = k0 + l15;
+        const int64_t krc = krow > f.Tk - 1 ? f.Tk - 1 : krow;
+        bf16x8 kf[NKS], vf[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            kf[ks] = *reinterpret_cast<const bf16x8*>(K + krc * f.k_ts + ks * 32 + g * 8);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(V + krc * f.v_ts + ks * 32 + g * 8);
+        }
+        f32x4 dk[NDT], dv[NDT];
+#pragma unroll
+        for (int i = 0; i < NDT; ++i) {
+            dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll 1
+        for (int hg = 0; hg < group; ++hg) {
+            if (half == 0 || group > 1) {
+                const int64_t h = hk * group + hg;
+                const int64_t stat0 = (b * f.Hq + h) * (f.stat_stride ? f.stat_stride : f.Tq);
+                __syncthreads();
+                load_rows<D, NW * 64, 4>(qtile, reinterpret_cast<const bf16_t*>(f.q) + b * f.q_bs + h * f.q_hs, f.q_ts, f.Tq);
+                load_rows<D, NW * 64, 4>(dotile, reinterpret_cast<const bf16_t*>(a.dout) + b * a.do_bs + h * a.do_hs, a.do_ts, f.Tq);
+                for (int64_t i = threadIdx.x; i < ceil32(f.Tq); i += NW * 64) {
+                    lse_s[i] = i < f.Tq ? f.lse[stat0 + i] * LOG2E : 0.f;
+                    delta_s[i] = i < f.Tq ? a.delta[stat0 + i] : 0.f;
+                }
+                __syncthreads();
+            }
+            if (!tile_on) continue;
+            // first query that can see key k0: q + coff >= k0
+            const int64_t qs = k0 > coff ? ((k0 - coff) / 32) * 32 : 0;
+            for (int64_t qb = qs; qb < f.Tq; qb += 32) {
+                float p[2][4], ds[2][4];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    const bf16_t* qr = qtile + (qb + t * 16 + l15) * LDT + g * 8;
+                    const bf16_t* dr = dotile + (qb + t * 16 + l15) * LDT + g * 8;
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(qr + ks * 32), kf[ks], s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(dr + ks * 32), vf[ks], dp, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t q = qb + t * 16 + g * 4 + r;
+                        const bool masked = q >= f.Tq || krow > q + coff;
+                        const float pv = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse_s[q]);
+                        p[t][r] = pv;
+                        ds[t][r] = pv * (dp[r] - delta_s[q]);
+                    }
+                }
+                const bf16x8 pf = pack8(p[0], p[1]);
+                const bf16x8 dsf = pack8(ds[0], ds[1]);
+                const int ra = (int)(qb + g * 4), rb = (int)(qb + 16 + g * 4);
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    const bf16x8 dot = gather_col(dotile, LDT, ra, rb, dt * 16, l15);
+                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pf, dv[dt], 0, 0, 0);
+                    const bf16x8 qt = gather_col(qtile, LDT, ra, rb, dt * 16, l15);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf, dk[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (!tile_on || krow >= f.Tk) continue;
+        bf16_t* DK = reinterpret_cast<bf16_t*>(a.dk) + b * a.dk_bs + hk * a.dk_hs + krow * a.dk_ts;
+        bf16_t* DV = reinterpret_cast<bf16_t*>(a.dv) + b * a.dv_bs + hk * a.dv_hs + krow * a.dv_ts;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            u32x2 pk = {pack_bf16x2(dk[dt][0] * f.scale, dk[dt][1] * f.scale), pack_bf16x2(dk[dt][2] * f.scale, dk[dt][3] * f.scale)};
+            *reinterpret_cast<u32x2*>(DK + dt * 16 + g * 4) = pk;
+            u32x2 pv2 = {pack_bf16x2(dv[dt][0], dv[dt][1]), pack_bf16x2(dv[dt][2], dv[dt][3])};
+            *reinterpret_cast<u32x2*>(DV + dt * 16 + g * 4) = pv2;
+        }
+    }
+}
+
 // fp32 partial slabs [splits][2][Tk][Hkv][D] -> summed bf16 dk / dv (strided)
 __global__ void dkv_convert_kernel(const mtl_attn_bwd_args a, const int splits) {
     const mtl_attn_fwd_args& f = a.f;
@@ -462,11 +803,47 @@ int check_fwd(const mtl_attn_fwd_args& f) {
 
 }  // namespace
 
+namespace {
+
+// resident-K/V path: causal, per-sample K/V, no dropout, >= 4 rows, and both tiles fit the 160 KiB LDS
+constexpr size_t kLdsBudget = 156 * 1024;
+int g_attn_mode = 1;   // 1 = use the resident kernels when they fit, 0 = always the chunked kernels (A/B knob)
+
+template <typename KernelT>
+void set_lds(KernelT k, size_t bytes) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); }
+
+}  // namespace
+
+extern "C" int mtl_attention_tune(int resident) { g_attn_mode = resident ? 1 : 0; return MTL_OK; }
+
+namespace {
+
+size_t pad32(int64_t v) { return (size_t)((v + 31) & ~(int64_t)31); }
+bool resident_ok(const mtl_attn_fwd_args& f, int64_t rows) {
+    return g_attn_mode == 1 && f.causal && f.k_bs != 0 && f.dropout_p <= 0.f && (f.D == 64 || f.D == 128) &&
+           2 * pad32(rows) * (f.D + 8) * 2 + 2 * pad32(rows) * 4 <= kLdsBudget;
+}
+
+}  // namespace
+
 extern "C" int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream) {
     if (!a) return MTL_ERR_ARG;
     const int rc = check_fwd(*a);
     if (rc != MTL_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (resident_ok(*a, a->Tk)) {
+        const size_t lds = 2 * pad32(a->Tk) * (a->D + 8) * 2;
+        const int npairs = (int)(((a->Tq + 15) / 16 + 1) / 2);
+        if (a->D == 64) {
+            static std::once_flag once; std::call_once(once, [&] { set_lds(attn_fwd_res_kernel<64, 8>, kLdsBudget); });
+            hipLaunchKernelGGL((attn_fwd_res_kernel<64, 8>), dim3((unsigned)((npairs + 7) / 8), (unsigned)a->Hq, (unsigned)a->B), dim3(512), lds, st, *a);
+        } else {
+            static std::once_flag once; std::call_once(once, [&] { set_lds(attn_fwd_res_kernel<128, 8>, kLdsBudget); });
+            hipLaunchKernelGGL((attn_fwd_res_kernel<128, 8>), dim3((unsigned)((npairs + 7) / 8), (unsigned)a->Hq, (unsigned)a->B), dim3(512), lds, st, *a);
+        }
+        MTL_CHECK_LAUNCH();
+        return MTL_OK;
+    }
     const dim3 grid((unsigned)((a->Tq + 63) / 64), (unsigned)a->Hq, (unsigned)a->B), block(256);
     const bool drop = a->dropout_p > 0.f;
     if (drop && (a->dropout_p >= 1.f || a->causal)) return MTL_ERR_UNSUPPORTED;   // dropout: reprogramming (non-causal) attention only
@@ -491,6 +868,25 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
     for (int64_t s : sts) if (s % 4 != 0) return MTL_ERR_ALIGN;
     if (a->do_ts % 8 != 0 || a->do_hs % 8 != 0 || a->do_bs % 8 != 0 || ((uintptr_t)a->dout % 16)) return MTL_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
+    if (resident_ok(f, f.Tk) && resident_ok(f, f.Tq)) {
+        if (a->kv_row0 < 0 || a->kv_row0 >= f.Tk) return MTL_ERR_ARG;
+        const size_t lds_q = 2 * pad32(f.Tk) * (f.D + 8) * 2;
+        const size_t lds_k = 2 * pad32(f.Tq) * (f.D + 8) * 2 + 2 * pad32(f.Tq) * 4;
+        const int npq = (int)(((f.Tq + 15) / 16 + 1) / 2), npk = (int)(((f.Tk - a->kv_row0 + 15) / 16 + 1) / 2);
+        if (f.D == 64) {
+            static std::once_flag once;
+            std::call_once(once, [&] { set_lds(attn_bwd_dq_res_kernel<64, 8>, kLdsBudget); set_lds(attn_bwd_dkv_res_kernel<64, 4>, kLdsBudget); });
+            hipLaunchKernelGGL((attn_bwd_dq_res_kernel<64, 8>), dim3((unsigned)((npq + 7) / 8), (unsigned)f.Hq, (unsigned)f.B), dim3(512), lds_q, st, *a);
+            hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<64, 4>), dim3((unsigned)((npk + 3) / 4), (unsigned)f.Hkv, (unsigned)f.B), dim3(256), lds_k, st, *a);
+        } else {
+            static std::once_flag once;
+            std::call_once(once, [&] { set_lds(attn_bwd_dq_res_kernel<128, 8>, kLdsBudget); set_lds(attn_bwd_dkv_res_kernel<128, 4>, kLdsBudget); });
+            hipLaunchKernelGGL((attn_bwd_dq_res_kernel<128, 8>), dim3((unsigned)((npq + 7) / 8), (unsigned)f.Hq, (unsigned)f.B), dim3(512), lds_q, st, *a);
+            hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<128, 4>), dim3((unsigned)((npk + 3) / 4), (unsigned)f.Hkv, (unsigned)f.B), dim3(256), lds_k, st, *a);
+        }
+        MTL_CHECK_LAUNCH();
+        return MTL_OK;
+    }
     const dim3 block(256);
     const dim3 gq((unsigned)((f.Tq + 63) / 64), (unsigned)f.Hq, (unsigned)f.B);
     int splits = 1;

@@ -84,6 +84,7 @@ SIGNATURES = {
     "mtl_cast_bf16_to_f32": (i32, [vp, vp, i64, vp]),
     "mtl_colsum_bf16": (i32, [vp, i64, vp, i64, i64, vp]),
     "mtl_attention_fwd": (i32, [C.POINTER(AttnFwdArgs), vp]),
+    "mtl_attention_tune": (i32, [i32]),
     "mtl_attention_bwd": (i32, [C.POINTER(AttnBwdArgs), vp]),
     "mtl_norm_fwd": (i32, [vp, vp, vp, vp, i64, vp, i64, i64, f32, i32, i64, i64, i64, vp]),
     "mtl_norm_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, i64, i64, i32, i64, i64, i64, i32, vp]),

@@ -140,6 +140,29 @@ def test_attention_self(ops, B, T, Hq, Hkv, D, causal):
     assert rel_err(dv.float(), vf.grad) < 1e-2
 
 
+@pytest.mark.parametrize("B,T,Hq,Hkv,D", [(2, 173, 4, 4, 64), (2, 256, 4, 2, 128), (1, 40, 2, 1, 64)])
+def test_attention_chunked_equals_resident(ops, B, T, Hq, Hkv, D):
+    """the chunked (64-key LDS tiles) and the resident (whole head in LDS) causal kernels are two schedules of one algorithm"""
+    from med_ts_llm_amd.hip import _native
+    q = torch.randn(B, T, Hq * D, generator=g(1)).to(BF16).cuda()
+    k = torch.randn(B, T, Hkv * D, generator=g(2)).to(BF16).cuda()
+    v = torch.randn(B, T, Hkv * D, generator=g(3)).to(BF16).cuda()
+    do = torch.randn(B, T, Hq * D, generator=g(4)).to(BF16).cuda()
+    scale = 1.0 / math.sqrt(D)
+    res = {}
+    try:
+        for mode in (1, 0):
+            _native.lib().mtl_attention_tune(mode)
+            o, lse = ops.attention_fwd(q, k, v, Hq, Hkv, D, scale, True)
+            res[mode] = (o, lse) + ops.attention_bwd(q, k, v, o, lse, do, Hq, Hkv, D, scale, True)
+    finally:
+        _native.lib().mtl_attention_tune(1)
+    for a, b in zip(res[0], res[1]):
+        assert rel_err(a.float(), b.float()) < 5e-3
+    ref = ref_attention(q.float().cpu(), k.float().cpu(), v.float().cpu(), Hq, Hkv, D, scale, True)
+    assert rel_err(res[0][0].float(), ref) < TOL_BF16 and rel_err(res[1][0].float(), ref) < TOL_BF16
+
+
 def test_attention_fused_qkv_views(ops):
     """strided q/k/v views into one fused [B,T,(Hq+2Hkv)*D] buffer, as the backbone uses them"""
     B, T, Hq, Hkv, D = 2, 80, 4, 2, 64
