@@ -21,6 +21,26 @@ namespace {
 
 constexpr int KC = 64;  // keys (or queries, in the dK/dV kernel) per LDS chunk
 
+// reductions across the four 16-lane rows of a wave (lanes with equal lane & 15) without touching the LDS crossbar:
+// v_permlane16_swap / v_permlane32_swap exchange whole rows / halves in one VALU instruction (ds_bpermute costs an LDS
+// round trip and these sit on the serial softmax critical path).
+__device__ __forceinline__ float rows_max(float v) {
+    const uint32_t u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float m = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    const uint32_t w = __float_as_uint(m);
+    auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+__device__ __forceinline__ float rows_sum(float v) {
+    const uint32_t u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float m = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const uint32_t w = __float_as_uint(m);
+    auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
 union frag8 {
     bf16x8 v;
     u32x4 u;
@@ -162,8 +182,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a
                     for (int r = 0; r < 4; ++r) p[t][r] = s[t][r] * c;
             }
             float mx = fmaxf(fmaxf(fmaxf(p[0][0], p[0][1]), fmaxf(p[0][2], p[0][3])), fmaxf(fmaxf(p[1][0], p[1][1]), fmaxf(p[1][2], p[1][3])));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = rows_max(mx);
             const float m_new = fmaxf(m_run, mx);
             float psum = 0.f;
 #pragma unroll
@@ -198,8 +217,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a
             }
         }
     }
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
+    l_run = rows_sum(l_run);
     if (!q_valid) return;
     const float inv_l = 1.0f / l_run;
     bf16_t* O = reinterpret_cast<bf16_t*>(a.o) + b * a.o_bs + h * a.o_hs + qrow * a.o_ts;
@@ -247,8 +265,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
             dl += __uint_as_float(d8.u[e] & 0xffff0000u) * __uint_as_float(o8.u[e] & 0xffff0000u);
         }
     }
-    dl += __shfl_xor(dl, 16, 64);
-    dl += __shfl_xor(dl, 32, 64);
+    dl = rows_sum(dl);
     const int64_t stat_idx = (b * f.Hq + h) * (f.stat_stride ? f.stat_stride : f.Tq) + qrow;
     if (g == 0 && q_valid) a.delta[stat_idx] = dl;
     const float c = f.scale * LOG2E;
@@ -537,8 +554,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fw
                     for (int r = 0; r < 4; ++r) p[t][r] = s[t][r] * c;
             }
             float mx = fmaxf(fmaxf(fmaxf(p[0][0], p[0][1]), fmaxf(p[0][2], p[0][3])), fmaxf(fmaxf(p[1][0], p[1][1]), fmaxf(p[1][2], p[1][3])));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = rows_max(mx);
             const float m_new = fmaxf(m_run, mx);
             float psum = 0.f;
 #pragma unroll
@@ -564,8 +580,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fw
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pf, o[dt], 0, 0, 0);
             }
         }
-        l_run += __shfl_xor(l_run, 16, 64);
-        l_run += __shfl_xor(l_run, 32, 64);
+        l_run = rows_sum(l_run);
         if (q_valid) {
             const float inv_l = 1.0f / l_run;
             bf16_t* O = reinterpret_cast<bf16_t*>(a.o) + b * a.o_bs + h * a.o_hs + qrow * a.o_ts;
@@ -621,8 +636,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn
                 dl += __uint_as_float(d8.u[e] & 0xffff0000u) * __uint_as_float(o8.u[e] & 0xffff0000u);
             }
         }
-        dl += __shfl_xor(dl, 16, 64);
-        dl += __shfl_xor(dl, 32, 64);
+        dl = rows_sum(dl);
         const int64_t stat_idx = (b * f.Hq + h) * (f.stat_stride ? f.stat_stride : f.Tq) + qrow;
         if (g == 0 && q_valid) a.delta[stat_idx] = dl;
         const float lse2 = f.lse[stat_idx] * LOG2E;
