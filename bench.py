@@ -172,8 +172,8 @@ def read_prof(lib):
         k = keys[i]
         epi, cdt, split = (k & 0xff) // 4, ((k & 0xff) // 2) % 2, k & 1
         if k & (1 << 8):
-            name = (f"gemm_nt_persist_kernel<{epi}, {cdt}, {256 if k & (1 << 14) else 128}, {128 if k & (1 << 9) else 64}, "
-                    f"{(k >> 12) & 3}, {(4, 8, 16)[(k >> 10) & 3]}>")
+            name = (f"gemm_nt_persist_kernel<{epi}, {cdt}, {256 if k & (1 << 15) else 128}, {128 if k & (1 << 9) else 64}, "
+                    f"{(k >> 12) & 7}, {(4, 8, 16)[(k >> 10) & 3]}>")
         else:
             name = f"gemm_nt_kernel<{epi}, {cdt}, {'true' if split else 'false'}>"
         rows.append({"kernel": name, "launches": int(launches[i]), "total_ms": ms[i], "flops": fl[i]})

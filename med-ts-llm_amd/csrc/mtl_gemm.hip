@@ -124,6 +124,87 @@ __device__ __forceinline__ void epilogue4(const mtl_gemm_args& p, int64_t m, int
     }
 }
 
+// Wave-level epilogue of a 64 x (NI*16) sub-tile, vector path: ALL auxiliary loads (bias, residual, saved
+// pre-activation) are issued first, then the math and the stores. Calling epilogue4 per 16x16 tile interleaves
+// load -> use -> store; the compiler may not move a later tile's load above an earlier tile's store (C may alias the
+// residual), so every tile paid a full memory round trip: ~14 us of fixed cost on the N = 768 residual GEMMs.
+// FULL = the whole tile lies inside C: no per-lane predicate at all, so the loads, the single wait and the stores come
+// out as straight-line code. (With predicates every use sits in its own branch and hipcc waits vmcnt(0) in each, i.e.
+// every store waits for the previous store to complete, and the still-"pending" bias registers force a vmcnt(0) in
+// front of the next k-step's first ds_read, draining the LDS-DMA pipeline.)
+template <int EPI, int CDT, int NI, bool FULL>
+__device__ __forceinline__ void epilogue_wave(const mtl_gemm_args& p, int64_t m_first, int64_t n_first, f32x4 (&acc)[NI][4]) {
+    // lane owns rows m_first + mi*16 (mi = 0..3) and columns n_first + ni*16 .. +3.  Edge tiles (!FULL) LOAD from
+    // clamped (always valid) addresses and predicate only the stores: no load result is ever consumed inside a branch.
+    int64_t crow[4];
+    bool mok[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int64_t m = m_first + mi * 16;
+        mok[mi] = FULL || m < p.M;
+        crow[mi] = remap_row(mok[mi] ? m : p.M - 1, p.c_group_rows, p.c_group_stride, p.c_row_offset);
+    }
+    bool nok[NI];
+    int64_t ncol[NI];
+    float4 b4[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int64_t n = n_first + ni * 16;
+        nok[ni] = FULL || n < p.N;  // vector path: N % 4 == 0, so the 4 columns are valid together
+        ncol[ni] = nok[ni] ? n : p.N - 4;
+        b4[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (p.bias) {                   // uniform branch around ALL bias loads
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b4[ni] = *reinterpret_cast<const float4*>(p.bias + ncol[ni]);
+    }
+    float4 res[EPI == MTL_EPI_RESID || EPI == MTL_EPI_ACCUM ? NI : 1][4];
+    u32x2 hk[EPI == MTL_EPI_DGELU ? NI : 1][4];
+    if constexpr (EPI == MTL_EPI_RESID || EPI == MTL_EPI_ACCUM || EPI == MTL_EPI_DGELU) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                if constexpr (EPI == MTL_EPI_RESID) res[ni][mi] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.aux_in) + crow[mi] * p.ld_aux_in + ncol[ni]);
+                if constexpr (EPI == MTL_EPI_ACCUM) res[ni][mi] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.C) + crow[mi] * p.ldc + ncol[ni]);
+                if constexpr (EPI == MTL_EPI_DGELU) hk[ni][mi] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.aux_in) + crow[mi] * p.ld_aux_in + ncol[ni]);
+            }
+    }
+    // edge tiles: hipcc sinks the bias/residual math into the predicated store blocks, which leaves the load results
+    // "pending" at the merge and costs a vmcnt(0) before every later ds_read; a compiler-visible wait here settles it.
+    if constexpr (!FULL) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0) only (gfx9 encoding)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const bool ok = mok[mi] && nok[ni];
+            const int64_t n = ncol[ni];
+            float o[4] = {acc[ni][mi][0] * p.alpha + b4[ni].x, acc[ni][mi][1] * p.alpha + b4[ni].y, acc[ni][mi][2] * p.alpha + b4[ni].z,
+                          acc[ni][mi][3] * p.alpha + b4[ni].w};
+            if constexpr (EPI == MTL_EPI_GELU) {
+                const u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                if (ok) *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.aux_out) + crow[mi] * p.ld_aux_out + n) = pk;
+                o[0] = gelu_new_f(__uint_as_float(pk[0] << 16)); o[1] = gelu_new_f(__uint_as_float(pk[0] & 0xffff0000u));
+                o[2] = gelu_new_f(__uint_as_float(pk[1] << 16)); o[3] = gelu_new_f(__uint_as_float(pk[1] & 0xffff0000u));
+            } else if constexpr (EPI == MTL_EPI_RESID) {
+                const u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};   // bf16 Linear output, then fp32 add
+                o[0] = res[ni][mi].x + __uint_as_float(pk[0] << 16); o[1] = res[ni][mi].y + __uint_as_float(pk[0] & 0xffff0000u);
+                o[2] = res[ni][mi].z + __uint_as_float(pk[1] << 16); o[3] = res[ni][mi].w + __uint_as_float(pk[1] & 0xffff0000u);
+            } else if constexpr (EPI == MTL_EPI_DGELU) {
+                o[0] *= dgelu_new_f(__uint_as_float(hk[ni][mi][0] << 16)); o[1] *= dgelu_new_f(__uint_as_float(hk[ni][mi][0] & 0xffff0000u));
+                o[2] *= dgelu_new_f(__uint_as_float(hk[ni][mi][1] << 16)); o[3] *= dgelu_new_f(__uint_as_float(hk[ni][mi][1] & 0xffff0000u));
+            } else if constexpr (EPI == MTL_EPI_ACCUM) {
+                o[0] += res[ni][mi].x; o[1] += res[ni][mi].y; o[2] += res[ni][mi].z; o[3] += res[ni][mi].w;
+            }
+            if constexpr (CDT == MTL_BF16) {
+                const u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                if (ok) *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + crow[mi] * p.ldc + n) = pk;
+            } else {
+                if (ok) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + crow[mi] * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+}
+
 // SPLIT: raw fp32 partial sums go to workspace slab [split][M][N]; epilogue runs in splitk_reduce_kernel.
 template <int EPI, int CDT, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const mtl_gemm_args p, const int vec_ok_i) {
@@ -387,16 +468,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_persist_kernel(const mtl_gemm
             int tm, tn;
             tile_coords(done_tile, tiles_m, tiles_n, tm, tn);
             const int64_t m0 = (int64_t)tm * BM_, n0 = (int64_t)tn * BN_;
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int64_t m = m0 + wr * 64 + mi * 16 + l15;
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const int64_t n = n0 + wc * WCOLS + ni * 16 + g * 4;
-                    if (m < p.M && n < p.N) epilogue4<EPI, CDT>(p, m, n, acc[ni][mi], vec_ok);
-                    acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
+            if (m0 + BM_ <= p.M && n0 + BN_ <= p.N) {
+                epilogue_wave<EPI, CDT, NI, true>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * 4, acc);
+            } else {
+                epilogue_wave<EPI, CDT, NI, false>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * 4, acc);
             }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
             done_tile = -1;
         }
         if (it + STAGES - 1 < total) {
@@ -432,14 +512,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_persist_kernel(const mtl_gemm
         int tm, tn;
         tile_coords(done_tile, tiles_m, tiles_n, tm, tn);
         const int64_t m0 = (int64_t)tm * BM_, n0 = (int64_t)tn * BN_;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int64_t m = m0 + wr * 64 + mi * 16 + l15;
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int64_t n = n0 + wc * WCOLS + ni * 16 + g * 4;
-                if (m < p.M && n < p.N) epilogue4<EPI, CDT>(p, m, n, acc[ni][mi], vec_ok);
-            }
+        if (m0 + BM_ <= p.M && n0 + BN_ <= p.N) {
+            epilogue_wave<EPI, CDT, NI, true>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * 4, acc);
+        } else {
+            epilogue_wave<EPI, CDT, NI, false>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * 4, acc);
         }
     }
 }
@@ -502,7 +578,7 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
             }
         }
     } closer{pf, rec, recording, st};
-    if (S == 1 && tuning().mode == 1) {
+    if (S == 1 && tuning().mode == 1 && vec_ok && p.N >= 4) {   // the persistent kernel has the vector epilogue only
         const int ncu = num_cus();
         // tile choice, measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_ab*.txt)
         int bm = tuning().bm, bn = tuning().bn, stages = tuning().stages, nw = tuning().waves;
@@ -515,7 +591,7 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         const size_t lds = (size_t)stages * (bm + bn) * BK * 2;
         const int per_cu = (int)(160 * 1024 / lds) < 1 ? 1 : (int)(160 * 1024 / lds);
         const int grid = nt < per_cu * ncu ? nt : per_cu * ncu;
-        if (recording) rec.key |= (1 << 8) | ((bn == 128 ? 1 : 0) << 9) | ((nw == 8 ? 1 : (nw == 16 ? 2 : 0)) << 10) | (stages << 12) | ((bm == 256 ? 1 : 0) << 14);
+        if (recording) rec.key |= (1 << 8) | ((bn == 128 ? 1 : 0) << 9) | ((nw == 8 ? 1 : (nw == 16 ? 2 : 0)) << 10) | (stages << 12) | ((bm == 256 ? 1 : 0) << 15);
 #define MTL_PERSIST(BMV, BNV, STV, NWV)                                                                                \
     do {                                                                                                               \
         auto kfn = gemm_nt_persist_kernel<EPI, CDT, BMV, BNV, STV, NWV>;                                               \
@@ -529,6 +605,8 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         else if (bm == 128 && bn == 128 && nw == 8 && stages == 3) MTL_PERSIST(128, 128, 3, 8);
         else if (bm == 128 && bn == 128 && nw == 4 && stages == 2) MTL_PERSIST(128, 128, 2, 4);
         else if (bm == 128 && bn == 64 && nw == 4 && stages == 2) MTL_PERSIST(128, 64, 2, 4);
+        else if (bm == 128 && bn == 64 && nw == 4 && stages == 3) MTL_PERSIST(128, 64, 3, 4);
+        else if (bm == 128 && bn == 64 && nw == 4 && stages == 4) MTL_PERSIST(128, 64, 4, 4);
         else return MTL_ERR_UNSUPPORTED;
 #undef MTL_PERSIST
     } else if (S == 1) {
@@ -547,7 +625,7 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
 
 extern "C" int mtl_gemm_tune(int mode, int bm, int bn, int stages, int waves) {
     if ((mode != 0 && mode != 1) || (bm != 0 && bm != 128 && bm != 256) || (bn != 0 && bn != 64 && bn != 128) ||
-        (stages != 0 && stages != 2 && stages != 3) || (waves != 0 && waves != 4 && waves != 8 && waves != 16))
+        (stages != 0 && stages != 2 && stages != 3 && stages != 4) || (waves != 0 && waves != 4 && waves != 8 && waves != 16))
         return MTL_ERR_ARG;
     tuning().mode = mode;
     tuning().bm = bm;
