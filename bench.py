@@ -198,6 +198,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--full-backward", action="store_true", help="also compute the (unused) prompt-row input gradients")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the HIP multi-tensor Adam")
     args = ap.parse_args()
 
     from med_ts_llm_amd import parallel
@@ -225,7 +226,13 @@ def main():
     model.prune_dead_prompt_grads = not args.full_backward
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=1e-4, fused=True)
+    if args.torch_adam:
+        opt = torch.optim.Adam(params, lr=1e-4, fused=True)
+    else:
+        from med_ts_llm_amd.hip.optim import HipAdam
+        opt = HipAdam(params, lr=1e-4)
+        for sh in model.bf16_shadows():
+            opt.register_shadow(sh)
     sync = parallel.FlatGradAllReduce(params) if world > 1 else None
     loss_fn = torch.nn.MSELoss() if task != "semantic_segmentation" else torch.nn.CrossEntropyLoss()
     batches = [make_batch(B, L, C_, pred, 1000 + rank * 97 + i, device, task) for i in range(4)]

@@ -94,7 +94,7 @@ int mtl_gemm_nt(const mtl_gemm_args* args, void* stream);
 /* Measurement aid (bench.py roofline leg; off by default, no effect on results): while enabled every GEMM launch is
  * bracketed by HIP events on its launch stream. mtl_prof_read aggregates per kernel instance
  * key: bits 0-7 = epilogue*4 + c_dtype*2 + (split_k > 1); bit 8 = persistent kernel, bit 9 = 128-wide tile (else 64),
- * bits 10-11 = waves (0: 4, 1: 8, 2: 16), bits 12-13 = LDS stages, bit 14 = 256-row tile (else 128): launches, total ms, total algorithmic FLOPs (2*M*N*K).
+ * bits 10-11 = waves (0: 4, 1: 8, 2: 16), bits 12-14 = LDS stages, bit 15 = 256-row tile (else 128): launches, total ms, total algorithmic FLOPs (2*M*N*K).
  * mtl_prof_calibrate returns the duration (ms) of an empty event bracket on `stream` (fixed per-launch overhead). */
 int mtl_prof_enable(int on);
 double mtl_prof_calibrate(void* stream);
@@ -118,6 +118,26 @@ int mtl_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int mtl_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 /* column sums of a bf16 [R, Cc] matrix into f32 [Cc] (bias gradients) */
 int mtl_colsum_bf16(const void* src, int64_t ld_src, float* dst, int64_t R, int64_t Cc, void* stream);
+
+/* ------------------------------------------------------------------ optimiser step
+ * torch.optim.Adam / AdamW (R:tasks/base.py:97,99; stepped at R:tasks/forecasting.py:27 and the 4 other task loops)
+ * for every trainable tensor in one launch per MTL_ADAM_MAX_TENSORS tensors: fp32 p/g/m/v, bias-corrected with
+ * `step` (1-based, after increment, as torch does). weight_decay: decoupled = 0 -> Adam's L2 (g += wd*p),
+ * 1 -> AdamW (p *= 1 - lr*wd). `shadow` (optional) receives the bf16 copy of the UPDATED p viewed as
+ * [n / cols, cols] with row stride ld_shadow (the autocast weight copy the next forward needs). */
+#define MTL_ADAM_MAX_TENSORS 24
+typedef struct mtl_adam_tensor {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    int64_t n;
+    void* shadow;        /* bf16 or NULL */
+    int64_t cols;        /* used with shadow */
+    int64_t ld_shadow;
+} mtl_adam_tensor;
+int mtl_adam_step(const mtl_adam_tensor* tensors, int count, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int decoupled, int64_t step, void* stream);
 
 /* ------------------------------------------------------------------ attention (flash-style, never materialises scores)
  * O = softmax(scale * Q K^T [+ causal mask]) V per (batch, head); fp32 softmax statistics, bf16 I/O.

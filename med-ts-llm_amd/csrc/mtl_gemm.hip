@@ -38,7 +38,10 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 __device__ __forceinline__ int64_t remap_row(int64_t m, int64_t group_rows, int64_t group_stride, int64_t off) {
     if (group_rows == 0) return m;
-    return (m / group_rows) * group_stride + off + (m % group_rows);
+    // 32-bit divide (mtl_gemm_nt rejects M or group_rows >= 2^31): the 64-bit one is a ~100-instruction branchy
+    // expansion, paid 8-12 times per lane per tile by the row-mapped (pruned backward) GEMMs
+    const uint32_t mm = (uint32_t)m, gr = (uint32_t)group_rows, q = mm / gr;
+    return (int64_t)q * group_stride + off + (int64_t)(mm - q * gr);
 }
 
 template <int EPI, int CDT>
@@ -301,8 +304,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const mtl_gemm_args p, 
                     for (int mi = 0; mi < 4; ++mi)
                         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            // raw barrier: __syncthreads() in a loop with LDS-DMA in flight makes hipcc drain vmcnt(0) in front of the
+            // k-step's first ds_read as well (tools/asm_waits.py), i.e. no load/compute overlap at all
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
     }
 
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_persist_kernel(const mtl_gemm
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;
     const int l15 = lane & 15, g = lane >> 4;
-    const bool vec_ok = vec_ok_i != 0;
+    (void)vec_ok_i;                            // the persistent kernel is only launched when the vector epilogue applies
 
     const int ntiles = tiles_m * tiles_n;
     const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
@@ -565,14 +571,14 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
             rec.key = EPI * 4 + CDT * 2 + (S > 1 ? 1 : 0);   // variant bits are OR-ed in below once the tile shape is chosen
             rec.flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
             recording = true;
-            hipEventRecord(rec.e0, st);
+            (void)hipEventRecord(rec.e0, st);
         }
     }
     struct Closer {
         Profiler& pf; ProfRec& rec; bool& recording; hipStream_t st;
         ~Closer() {
             if (recording) {
-                hipEventRecord(rec.e1, st);
+                (void)hipEventRecord(rec.e1, st);
                 std::lock_guard<std::mutex> lk(pf.mu);
                 pf.recs.push_back(rec);
             }
@@ -659,7 +665,7 @@ extern "C" int mtl_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(pf.mu);
     pf.on = on != 0;
     if (on) {
-        for (auto& r : pf.recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+        for (auto& r : pf.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
         pf.recs.clear();
     }
     return MTL_OK;
@@ -692,6 +698,7 @@ extern "C" int mtl_gemm_nt(const mtl_gemm_args* a, void* stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MTL_ERR_ARG;
     if (p.K % BK != 0 || p.lda % 8 != 0 || p.ldb % 8 != 0) return MTL_ERR_ALIGN;
     if (!aligned(p.A, 16) || !aligned(p.B, 16)) return MTL_ERR_ALIGN;
+    if (p.M >= (int64_t)1 << 31 || p.a_group_rows >= (int64_t)1 << 31 || p.c_group_rows >= (int64_t)1 << 31) return MTL_ERR_ARG;
     if (p.c_dtype != MTL_F32 && p.c_dtype != MTL_BF16) return MTL_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int S = p.split_k > 1 ? p.split_k : 1;

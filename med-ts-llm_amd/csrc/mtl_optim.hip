@@ -1,0 +1,116 @@
+// Adam / AdamW step of every trainable tensor in ONE streaming launch (R:tasks/base.py:97,99 builds torch.optim.Adam /
+// AdamW; the loop bodies call optimizer.step(), R:tasks/forecasting.py:27). HBM-bound: 28 B/element (read p,g,m,v;
+// write p,m,v) + 2 B for the optional bf16 shadow of the updated weight, which replaces the separate
+// f32 -> bf16 re-cast (another 4 B read) the next forward would otherwise do.
+#include "mtl_common.h"
+
+namespace {
+
+constexpr int MAX_T = MTL_ADAM_MAX_TENSORS;
+constexpr int THREADS = 256;
+constexpr int VEC_PER_THREAD = 4;                          // float4 per thread
+constexpr int64_t CHUNK = (int64_t)THREADS * 4 * VEC_PER_THREAD;   // elements per block
+
+struct AdamTable {
+    mtl_adam_tensor t[MAX_T];
+    int first_block[MAX_T + 1];
+    int count;
+};
+
+struct AdamHyper { float lr, beta1, beta2, eps, wd, bc1, bc2_sqrt; int decoupled; };
+
+__device__ __forceinline__ float adam_one(float p, float g, float& m, float& v, const AdamHyper& h) {
+    if (h.wd != 0.f) {
+        if (h.decoupled) p *= 1.f - h.lr * h.wd;           // AdamW
+        else g += h.wd * p;                                // Adam L2
+    }
+    m += (g - m) * (1.f - h.beta1);                        // torch: exp_avg.lerp_(grad, 1 - beta1)
+    v = v * h.beta2 + (1.f - h.beta2) * g * g;
+    const float denom = sqrtf(v) / h.bc2_sqrt + h.eps;
+    return p - (h.lr / h.bc1) * (m / denom);
+}
+
+__global__ __launch_bounds__(THREADS) void adam_multi_kernel(const AdamTable tab, const AdamHyper h) {
+    // block -> tensor: linear search over <= MAX_T prefix entries (wave-uniform)
+    int ti = 0;
+    const int b = blockIdx.x;
+    while (ti + 1 < tab.count && b >= tab.first_block[ti + 1]) ++ti;
+    const mtl_adam_tensor t = tab.t[ti];
+    const int64_t base = (int64_t)(b - tab.first_block[ti]) * CHUNK;
+    const bool vec = (((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0;
+    bf16_t* sh = reinterpret_cast<bf16_t*>(t.shadow);
+#pragma unroll
+    for (int i = 0; i < VEC_PER_THREAD; ++i) {
+        const int64_t e0 = base + ((int64_t)i * THREADS + threadIdx.x) * 4;
+        if (e0 >= t.n) break;
+        float pp[4], gg[4], mm[4], vv[4];
+        const int nv = (t.n - e0) >= 4 ? 4 : (int)(t.n - e0);
+        if (vec && nv == 4) {
+            const float4 p4 = *reinterpret_cast<const float4*>(t.p + e0), g4 = *reinterpret_cast<const float4*>(t.g + e0);
+            const float4 m4 = *reinterpret_cast<const float4*>(t.m + e0), v4 = *reinterpret_cast<const float4*>(t.v + e0);
+            pp[0] = p4.x; pp[1] = p4.y; pp[2] = p4.z; pp[3] = p4.w;
+            gg[0] = g4.x; gg[1] = g4.y; gg[2] = g4.z; gg[3] = g4.w;
+            mm[0] = m4.x; mm[1] = m4.y; mm[2] = m4.z; mm[3] = m4.w;
+            vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = e < nv;
+                pp[e] = ok ? t.p[e0 + e] : 0.f; gg[e] = ok ? t.g[e0 + e] : 0.f;
+                mm[e] = ok ? t.m[e0 + e] : 0.f; vv[e] = ok ? t.v[e0 + e] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pp[e] = adam_one(pp[e], gg[e], mm[e], vv[e], h);
+        if (vec && nv == 4) {
+            *reinterpret_cast<float4*>(t.p + e0) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+            *reinterpret_cast<float4*>(t.m + e0) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+            *reinterpret_cast<float4*>(t.v + e0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < nv) { t.p[e0 + e] = pp[e]; t.m[e0 + e] = mm[e]; t.v[e0 + e] = vv[e]; }
+        }
+        if (sh) {   // bf16 shadow [rows, ld_shadow] of the fp32 [rows, cols] weight (n < 2^32 checked on the host)
+            const uint32_t cols = (uint32_t)t.cols;
+            uint32_t row = (uint32_t)e0 / cols, col = (uint32_t)e0 - row * cols;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (e < nv) sh[(int64_t)row * t.ld_shadow + col] = f32_to_bf16(pp[e]);
+                if (++col == cols) { col = 0; ++row; }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mtl_adam_step(const mtl_adam_tensor* tensors, int count, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int decoupled, int64_t step, void* stream) {
+    if (count < 0 || (count > 0 && !tensors) || step < 1) return MTL_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    AdamHyper h;
+    h.lr = lr; h.beta1 = beta1; h.beta2 = beta2; h.eps = eps; h.wd = weight_decay; h.decoupled = decoupled;
+    h.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    h.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    for (int i0 = 0; i0 < count; i0 += MAX_T) {
+        AdamTable tab;
+        tab.count = 0;
+        int blocks = 0;
+        for (int i = i0; i < count && tab.count < MAX_T; ++i) {
+            const mtl_adam_tensor& t = tensors[i];
+            if (t.n == 0) continue;
+            if (!t.p || !t.g || !t.m || !t.v || t.n < 0) return MTL_ERR_ARG;
+            if (t.shadow && (t.cols <= 0 || t.ld_shadow < t.cols || t.n % t.cols != 0 || t.n >= ((int64_t)1 << 32))) return MTL_ERR_ARG;
+            tab.t[tab.count] = t;
+            tab.first_block[tab.count] = blocks;
+            blocks += (int)((t.n + CHUNK - 1) / CHUNK);
+            ++tab.count;
+        }
+        tab.first_block[tab.count] = blocks;
+        if (blocks == 0) continue;
+        hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(THREADS), 0, st, tab, h);
+        MTL_CHECK_LAUNCH();
+    }
+    return MTL_OK;
+}

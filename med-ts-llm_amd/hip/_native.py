@@ -31,6 +31,13 @@ class GemmArgs(C.Structure):
                 ("alpha", f32), ("split_k", i32), ("workspace", vp), ("workspace_bytes", C.c_size_t)]
 
 
+class AdamTensor(C.Structure):
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("n", i64), ("shadow", vp), ("cols", i64), ("ld_shadow", i64)]
+
+
+ADAM_MAX_TENSORS = 24
+
+
 class AttnFwdArgs(C.Structure):
     _fields_ = [("q", vp), ("q_bs", i64), ("q_ts", i64), ("q_hs", i64),
                 ("k", vp), ("k_bs", i64), ("k_ts", i64), ("k_hs", i64),
@@ -83,6 +90,7 @@ SIGNATURES = {
     "mtl_cast_f32_to_bf16": (i32, [vp, vp, i64, vp]),
     "mtl_cast_bf16_to_f32": (i32, [vp, vp, i64, vp]),
     "mtl_colsum_bf16": (i32, [vp, i64, vp, i64, i64, vp]),
+    "mtl_adam_step": (i32, [C.POINTER(AdamTensor), i32, f32, f32, f32, f32, f32, i32, i64, vp]),
     "mtl_attention_fwd": (i32, [C.POINTER(AttnFwdArgs), vp]),
     "mtl_attention_tune": (i32, [i32]),
     "mtl_attention_bwd": (i32, [C.POINTER(AttnBwdArgs), vp]),

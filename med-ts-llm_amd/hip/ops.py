@@ -333,11 +333,17 @@ class MappingFn(torch.autograd.Function):
     `emb` = FrozenEmbedding-like object with .wT bf16 [d, Vp] (ones at column V) and .w bf16 [V, d]."""
 
     @staticmethod
-    def forward(ctx, Wmap, b, wT, w, split_k):
+    def forward(ctx, Wmap, b, wT, w, split_k, shadow=None):
         S, V = Wmap.shape
         Vp = wT.shape[1]
-        wm = torch.empty((S, Vp), dtype=BF16, device=Wmap.device)
-        cast_pad(Wmap.detach().contiguous().float(), dst=wm)
+        if shadow is not None:                      # hip.optim.Bf16Shadow kept current by HipAdam (columns > V stay 0)
+            wm = shadow.tensor
+            if not shadow.fresh():
+                cast_pad(Wmap.detach().contiguous().float(), dst=wm)
+                shadow.version = Wmap._version
+        else:
+            wm = torch.empty((S, Vp), dtype=BF16, device=Wmap.device)
+            cast_pad(Wmap.detach().contiguous().float(), dst=wm)
         wm[:, V] = b.detach().to(BF16)
         src = gemm_nt(wm, wT, split_k=split_k)
         ctx.save_for_backward(w)
@@ -351,7 +357,7 @@ class MappingFn(torch.autograd.Function):
         dsrc = dsrc.contiguous()
         dW = gemm_nt(dsrc, w, out_dtype=F32) if ctx.needs_input_grad[0] else None   # [S, V] = dsrc[S,d] @ Wemb[V,d]^T
         db = colsum(transpose_bf16(dsrc)) if ctx.needs_input_grad[1] else None       # row sums of dsrc
-        return dW, db, None, None, None
+        return dW, db, None, None, None, None
 
 
 class MappingTrainableFn(torch.autograd.Function):

@@ -257,6 +257,23 @@ class MedTsLLM(nn.Module):
                 pred = torch.sigmoid(pred)
         return pred
 
+    def _mapping_shadow(self):
+        """Persistent bf16 copy [S, Vp] of mapping_layer.weight (the autocast weight cast). Re-cast only when the fp32
+        master changed behind its back; hip.optim.HipAdam writes it while updating the master (bf16_shadows())."""
+        W = self.mapping_layer.weight
+        sh = getattr(self, "_map_shadow", None)
+        if sh is None or sh.param is not W or sh.tensor.device != W.device:
+            from ..hip.optim import Bf16Shadow
+            sh = Bf16Shadow(W, torch.zeros((W.shape[0], pad64(self.vocab_size + 1)), dtype=torch.bfloat16, device=W.device))
+            self._map_shadow = sh
+        return sh
+
+    def bf16_shadows(self):
+        """Shadows an optimiser may keep current (HipAdam.register_shadow)."""
+        if self.word_embeddings.requires_grad or not self.mapping_layer.weight.is_cuda:
+            return []
+        return [self._mapping_shadow()]
+
     def encode_ts(self, x_enc):
         """R:models/medtsllm.py:263-297 -> (x_tok bf16 [B', P', d_llm], mean [B,C], stdev [B,C])."""
         if x_enc.ndim == 2:
@@ -272,7 +289,8 @@ class MedTsLLM(nn.Module):
         if self.word_embeddings.requires_grad:
             source = MappingTrainableFn.apply(self.mapping_layer.weight, self.mapping_layer.bias, self.word_embeddings, self._map_split_k)
         else:
-            source = MappingFn.apply(self.mapping_layer.weight, self.mapping_layer.bias, self._wT, self._w, self._map_split_k)
+            source = MappingFn.apply(self.mapping_layer.weight, self.mapping_layer.bias, self._wT, self._w, self._map_split_k,
+                                     self._mapping_shadow())
         q = LinearFn.apply(tokens, rl.query_projection.weight, rl.query_projection.bias)
         k = LinearFn.apply(source, rl.key_projection.weight, rl.key_projection.bias)
         v = LinearFn.apply(source, rl.value_projection.weight, rl.value_projection.bias)

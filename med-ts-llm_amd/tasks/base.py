@@ -86,11 +86,18 @@ class BaseTask(ABC):
         params = [p for p in self.model.parameters() if p.requires_grad]
         lr = self.config.training.learning_rate
         opt = self.config.training.optimizer
-        fused = {"fused": True} if self.device.type == "cuda" else {}   # same update rule, one kernel instead of ~8 per group
+        if self.device.type == "cuda" and opt in ("adam", "adamw"):
+            # same update rule as torch.optim.Adam/AdamW, one streaming launch for all tensors, and the bf16 autocast
+            # copy of the big mapping weight is written by the same kernel (hip/optim.py)
+            from ..hip.optim import HipAdam
+            o = HipAdam(params, lr=lr, weight_decay=0.01 if opt == "adamw" else 0.0, decoupled_weight_decay=opt == "adamw")
+            for sh in getattr(self.model, "bf16_shadows", lambda: [])():
+                o.register_shadow(sh)
+            return o
         if opt == "adam":
-            return optim.Adam(params, lr=lr, **fused)
+            return optim.Adam(params, lr=lr)
         if opt == "adamw":
-            return optim.AdamW(params, lr=lr, weight_decay=0.01, **fused)
+            return optim.AdamW(params, lr=lr, weight_decay=0.01)
         if opt == "sgd":
             return optim.SGD(params, lr=lr, momentum=0.9, nesterov=True)
         raise ValueError(f"Invalid optimizer selection: {opt}")

@@ -389,3 +389,33 @@ def test_assemble_and_denorm(ops):
     mean, sd = torch.randn(B, 3, generator=g(6)), torch.rand(B, 3, generator=g(7)) + 0.1
     assert rel_err(ops.revin_denorm(dev(y), dev(mean), dev(sd)), y * sd[:, None] + mean[:, None]) < 1e-6
     assert rel_err(ops.revin_denorm(dev(y), None, dev(sd)), y * sd[:, None]) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wd,decoupled", [(0.0, False), (0.01, False), (0.01, True)])
+def test_hip_adam_matches_torch(wd, decoupled):
+    """mtl_adam_step == torch.optim.Adam / AdamW (R:tasks/base.py:97,99) over 5 steps, incl. odd sizes, an unaligned
+    view and the bf16 shadow of the updated weight."""
+    from med_ts_llm_amd.hip.optim import HipAdam, Bf16Shadow
+    g = torch.Generator().manual_seed(3)
+    shapes = [(37, 1001), (5,), (64, 64), (3, 7, 5), (1,), (130, 259)]
+    ref_p = [torch.randn(s, generator=g).cuda().requires_grad_() for s in shapes]
+    our_p = [p.detach().clone().requires_grad_() for p in ref_p]
+    ref = (torch.optim.AdamW if decoupled else torch.optim.Adam)(ref_p, lr=1e-2, weight_decay=wd)
+    ours = HipAdam(our_p, lr=1e-2, weight_decay=wd, decoupled_weight_decay=decoupled)
+    shadow = Bf16Shadow(our_p[0], torch.zeros((37, 1024), dtype=torch.bfloat16, device="cuda"))
+    ours.register_shadow(shadow)
+    for step in range(5):
+        for a, b in zip(ref_p, our_p):
+            gr = torch.randn(a.shape, generator=g).cuda() * (10.0 ** (step - 2))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        v0 = our_p[0]._version
+        ref.step(), ours.step()
+        assert our_p[0]._version > v0 and shadow.fresh()
+        for a, b in zip(ref_p, our_p):
+            torch.testing.assert_close(b, a, rtol=2e-6, atol=2e-7)
+    torch.testing.assert_close(shadow.tensor[:, :1001], our_p[0].detach().to(torch.bfloat16), rtol=0, atol=0)
+    assert float(shadow.tensor[:, 1001:].abs().max()) == 0.0
+    sd = ours.state_dict()["state"][0]
+    assert set(sd) == {"step", "exp_avg", "exp_avg_sq"} and sd["step"] == 5
+    torch.testing.assert_close(sd["exp_avg"], ref.state_dict()["state"][0]["exp_avg"], rtol=1e-5, atol=1e-5)
