@@ -607,6 +607,8 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
     } while (0)
         if (bm == 256 && bn == 128 && nw == 16 && stages == 3) MTL_PERSIST(256, 128, 3, 16);
         else if (bm == 256 && bn == 128 && nw == 16 && stages == 2) MTL_PERSIST(256, 128, 2, 16);
+        else if (bm == 256 && bn == 128 && nw == 8 && stages == 2) MTL_PERSIST(256, 128, 2, 8);
+        else if (bm == 256 && bn == 128 && nw == 8 && stages == 3) MTL_PERSIST(256, 128, 3, 8);
         else if (bm == 128 && bn == 128 && nw == 8 && stages == 2) MTL_PERSIST(128, 128, 2, 8);
         else if (bm == 128 && bn == 128 && nw == 8 && stages == 3) MTL_PERSIST(128, 128, 3, 8);
         else if (bm == 128 && bn == 128 && nw == 4 && stages == 2) MTL_PERSIST(128, 128, 2, 4);

@@ -230,18 +230,19 @@ class MedTsLLM(nn.Module):
         if len(prompts[0]) == 0:
             return None
         tok = self._get_tokenizer()
-        id_lists = []
         for parts in prompts:
-            ids = []
             for p in parts:
                 if not isinstance(p, str):
                     raise NotImplementedError("'examples' prompting (tensor parts inside the prompt) is a 'next' row (DESIGN.md)")
-                if p not in self._id_cache:
-                    if len(self._id_cache) > 4096:
-                        self._id_cache.clear()
-                    self._id_cache[p] = tok(p, padding=False, truncation=False).input_ids   # each part separately
-                ids.append(self._id_cache[p])
-            id_lists.append(ids)
+        # each part is tokenised separately (R:models/medtsllm.py:300-301); the per-sample statistics strings are new on
+        # every step, so all uncached parts of the batch go through ONE batched tokenizer call
+        if len(self._id_cache) > 8192:
+            self._id_cache.clear()
+        new = sorted({p for parts in prompts for p in parts if p not in self._id_cache})
+        if new:
+            for p, ids in zip(new, tok(new, padding=False, truncation=False).input_ids):
+                self._id_cache[p] = ids
+        id_lists = [[self._id_cache[p] for p in parts] for parts in prompts]
         rows = P.left_pad_ids(id_lists, tok.pad_token_id)
         if all(r == rows[0] for r in rows):
             rows = rows[:1]                       # one shared prompt: the kernel broadcasts it

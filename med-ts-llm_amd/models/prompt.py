@@ -64,11 +64,24 @@ def input_stats_prompts(x_enc, input_stats_dim, input_stats_select="all", n_lags
         insert, s = f"feature {input_stats_dim}", ""
         xs = xs[:, :, input_stats_dim]
     with torch.no_grad():
-        mins = torch.min(xs, dim=1).values.tolist()
-        maxs = torch.max(xs, dim=1).values.tolist()
-        meds = torch.median(xs.float(), dim=1).values.tolist()
-        trends = (xs.diff(dim=1).sum(dim=1) > 0).tolist()
-        lags = calc_lags(xs.float(), n_lags).tolist()
+        # one packed D2H copy (= one stream sync) instead of the reference's five .tolist() calls; float64 holds every
+        # value exactly (fp32/bf16 statistics, 0/1 trends, integer lags), so the formatted strings are unchanged
+        per_feature = xs.ndim == 3
+        cols = [torch.min(xs, dim=1).values, torch.max(xs, dim=1).values, torch.median(xs.float(), dim=1).values,
+                (xs.diff(dim=1).sum(dim=1) > 0), calc_lags(xs.float(), n_lags)]
+        packed = torch.cat([c.reshape(xs.size(0), -1).double() for c in cols], dim=1).tolist()
+    C = xs.size(2) if per_feature else 1
+
+    def unpack(row, i, as_bool=False):
+        v = row[i * C:(i + 1) * C]
+        v = [bool(t) for t in v] if as_bool else v
+        return v if per_feature else v[0]
+
+    mins = [unpack(r, 0) for r in packed]
+    maxs = [unpack(r, 1) for r in packed]
+    meds = [unpack(r, 2) for r in packed]
+    trends = [unpack(r, 3, True) for r in packed]
+    lags = [[int(t) for t in r[4 * C:]] for r in packed]
     return [
         f"Input statistics ({insert}): "
         f"min value{s} = {_fmt_float(mins[b])}, "

@@ -243,3 +243,45 @@ def test_trainer_end_to_end_on_gpu(tmp_path, kind, task):
     trainer.model.load_state_dict(sd, strict=False)
     preds = trainer.predict(trainer.test_dataloader)
     assert preds.shape[0] == len(trainer.test_dataset) and torch.isfinite(preds).all()
+
+
+@pytest.mark.parametrize("task", ["forecasting", "anomaly_detection"])
+def test_stitched_eval_on_gpu(tmp_path, task):
+    """§8f-1 on the device: train one epoch on a sliding-window series dataset, then val()/test() through the HIP model
+    with device-side window stitching (tasks/evalpath.py); scores are finite and the stitched arrays cover every point."""
+    import numpy as np
+    from med_ts_llm_amd.tasks import get_trainer
+    from med_ts_llm_amd.tasks.windows import register_series
+    from med_ts_llm_amd.utils import dict_to_object
+
+    def source(config, split):
+        g = np.random.default_rng({"train": 1, "val": 2, "test": 3}[split])
+        n = 400
+        t = np.arange(n, dtype=np.float32)
+        data = np.stack([np.sin(t / 5), np.cos(t / 9), np.sin(t / 13) * 0.5], axis=-1).astype(np.float32) + 0.05 * g.standard_normal((n, 3)).astype(np.float32)
+        lab = np.zeros(n, dtype=np.int64)
+        lab[50:60] = 1
+        lab[200:230] = 1
+        data[lab == 1] += 2.0
+        return {"data": data, "labels": lab if config.task == "anomaly_detection" else None}
+
+    register_series("series_gpu", source)
+    _write_hf_dir(tmp_path, "gpt2")
+    cfg = _trainer_config(task, str(tmp_path), epochs=1)
+    cfg["data"]["dataset"] = "series_gpu"
+    cfg["training"]["eval_metric"] = "mse" if task == "forecasting" else "recon_mse"
+    cfg["tasks"]["anomaly_detection"] = {"score_metric": "mse", "threshold": "auto", "normalize_by_feature": True, "normalize_moving_window": 0}
+    trainer = get_trainer("DEBUG-eval", dict_to_object(cfg))
+    assert trainer.device.type == "cuda"
+    trainer.train()
+    scores = trainer.test()
+    if task == "forecasting":
+        preds, targets = trainer.predict(trainer.test_dataloader)
+        n = len(trainer.test_dataset)
+        assert preds.shape == targets.shape == (16 + (n - 1) * 16, 3) and torch.isfinite(preds).all()
+        assert np.isfinite(scores["test/mse"]) and np.isfinite(scores["test/mae"])
+        x = trainer.test_dataset.data
+        assert torch.equal(targets, x[64:64 + targets.shape[0]])        # stitched targets are the series itself
+    else:
+        assert {"test/f1", "test/auroc", "test/recon_mse", "test/anomaly_threshold"} <= set(scores)
+        assert all(np.isfinite(v) for v in scores.values())
