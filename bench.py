@@ -198,6 +198,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--full-backward", action="store_true", help="also compute the (unused) prompt-row input gradients")
+    ap.add_argument("--replicate-mapping", action="store_true", help="DP: keep the mapping layer replicated (all-reduce its gradient)")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the HIP multi-tensor Adam")
     args = ap.parse_args()
 
@@ -212,7 +213,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())   # (ranks may share a GPU only in the gloo DP test)
     torch.cuda.set_device(device)
 
     hf_cfg, B, L, C_, pred, n_tok, task = WORKLOADS[args.workload]
@@ -225,6 +226,7 @@ def main():
     model.fixed_prompt_ids = prompt_ids
     model.prune_dead_prompt_grads = not args.full_backward
     model.train()
+    sharded = world > 1 and not args.replicate_mapping and model.shard_mapping_layer(rank, world)
     params = [p for p in model.parameters() if p.requires_grad]
     if args.torch_adam:
         opt = torch.optim.Adam(params, lr=1e-4, fused=True)
@@ -311,7 +313,7 @@ def main():
             "config": {"workload": f"{args.workload}: [B={B}/GPU, L={L}, C={C_}] windows, P={P}, prompt {n_tok} tok -> T={T}, "
                                    f"frozen {args.workload.split('_B32')[0] if big else 'GPT-2-small'} (random init) backbone, concat covariates, {task} pred_len={pred}, "
                                    f"step = fwd+loss+bwd+{'allreduce+' if world > 1 else ''}Adam", "global_batch": B * world,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}" + (" (mapping layer row-sharded)" if sharded else "")},
             "final_loss": final_loss,
             "backward": "full (incl. unused prompt-row input gradients)" if args.full_backward else
                         "exact dead-gradient elimination: prompt rows never depend on a trainable parameter, their input gradient is not computed",

@@ -22,10 +22,46 @@ def init_from_env(device_type="cuda"):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if device_type == "cuda":
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     if not dist.is_initialized():
-        dist.init_process_group(backend="nccl" if device_type == "cuda" else "gloo", rank=rank, world_size=world)
+        # MTL_DIST_BACKEND=gloo lets several ranks share ONE GPU (RCCL refuses that): how the DP path is tested on a 1-GPU box
+        backend = os.environ.get("MTL_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
+
+
+def shard_range(n, rank, world):
+    """contiguous equal row range [r0, r1) of `n` rows owned by `rank` (n % world == 0)"""
+    assert n % world == 0, (n, world)
+    per = n // world
+    return rank * per, (rank + 1) * per
+
+
+def gather_rows(t, world, group=None):
+    """all ranks: concatenate every rank's [n/world, ...] row shard into the full [n, ...] tensor (a collective)"""
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t.contiguous(), group=group)
+    return torch.cat(parts, dim=0)
+
+
+class AllGatherRows(torch.autograd.Function):
+    """full[n, d] = concat over ranks of local[n/world, d]; backward hands every rank the GLOBAL-MEAN gradient of ITS rows:
+    d_local = (sum over ranks of d_full)[own rows] / world — each rank's loss is a mean over its LOCAL batch, so this
+    is the gradient of the mean over the global batch (same convention as FlatGradAllReduce). The exchange is one
+    small all-reduce of d_full in fp32 (num_tokens x d_llm: 3 MB for GPT-2), which is what lets the mapping layer's
+    [num_tokens, vocab] weight gradient (51.5 M elements, 70 % of the trainable payload) stay OFF the wire."""
+
+    @staticmethod
+    def forward(ctx, local, rank, world, group):
+        ctx.meta = (rank, world, group, local.shape[0])
+        return gather_rows(local, world, group)
+
+    @staticmethod
+    def backward(ctx, d_full):
+        rank, world, group, n_loc = ctx.meta
+        g = d_full.float().contiguous()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+        return (g[rank * n_loc:(rank + 1) * n_loc] / world).to(d_full.dtype), None, None, None
 
 
 class FlatGradAllReduce:
@@ -35,7 +71,9 @@ class FlatGradAllReduce:
     single-process gradient of the mean over the GLOBAL batch (equal shard sizes)."""
 
     def __init__(self, params, group=None):
-        self.params = [p for p in params if p.requires_grad]
+        # row-sharded parameters (p._dp_sharded, see AllGatherRows) already hold globally averaged gradients of rows no
+        # other rank owns: they are neither communicated nor averaged again
+        self.params = [p for p in params if p.requires_grad and not getattr(p, "_dp_sharded", False)]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         n = sum(p.numel() for p in self.params)

@@ -40,12 +40,15 @@ class PrintLogger:
 
     def save_state(self, name):
         """Checkpoint format of R:loggers/base_logger.py:29-40 (model.state_dict() is already filtered)."""
-        if self.debug or self.trainer.rank != 0:
+        if self.debug:
+            return
+        model_state = self.trainer.model.state_dict()    # a collective when the mapping layer is row-sharded: all ranks
+        if self.trainer.rank != 0:
             return
         d = self.logdir / "checkpoints"
         d.mkdir(parents=True, exist_ok=True)
         torch.save({"run_id": self.trainer.run_id, "epoch": self.trainer.epoch, "step": self.trainer.step,
-                    "datetime": datetime.now().isoformat(), "model": self.trainer.model.state_dict()}, d / f"{name}.pt")
+                    "datetime": datetime.now().isoformat(), "model": model_state}, d / f"{name}.pt")
 
     def log_end(self):
         pass
@@ -61,12 +64,14 @@ class BaseTask(ABC):
         self.dtype = self.get_dtype()
         self.rank, self.world_size, self.local_rank = parallel.init_from_env(self.device.type)
         if self.device.type == "cuda" and self.world_size > 1:
-            self.device = torch.device("cuda", self.local_rank)
+            self.device = torch.device("cuda", self.local_rank % torch.cuda.device_count())
         set_seed(self.config.setup.seed)
         self.build_datasets()
         self.build_dataloaders()
         self.model = self.build_model().to(self.device, self.dtype)
         self.finetuning = False
+        if self.world_size > 1 and self.config.setup.get("shard_mapping", True) and hasattr(self.model, "shard_mapping_layer"):
+            self.model.shard_mapping_layer(self.rank, self.world_size)      # DP: rows of the mapping layer live on one rank each
         self.optimizer = self.build_optimizer()
         self.scheduler = self.build_scheduler()
         self.loss_fn = self.build_loss().to(device=self.device)

@@ -74,3 +74,52 @@ def test_single_process_is_a_noop():
     g0 = lin.weight.grad.clone()
     parallel.FlatGradAllReduce(lin.parameters())()
     assert torch.equal(lin.weight.grad, g0)
+
+
+# ---- row-sharded mapping layer (parallel.AllGatherRows): CPU semantics
+def _shard_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from med_ts_llm_amd import parallel
+    parallel.init_from_env("cpu")
+    g = torch.Generator().manual_seed(3)
+    S, V, d, B = 8, 11, 5, 6
+    W, b, E = torch.randn(S, V, generator=g), torch.randn(S, generator=g), torch.randn(V, d, generator=g)
+    X, Y = torch.randn(B, d, generator=g), torch.randn(B, S, generator=g)
+    r0, r1 = parallel.shard_range(S, rank, world)
+    Wl, bl = W[r0:r1].clone().requires_grad_(), b[r0:r1].clone().requires_grad_()
+    Wl._dp_sharded = bl._dp_sharded = True
+    other = torch.nn.Linear(S, 1)
+    torch.manual_seed(0)
+    with torch.no_grad():
+        other.weight.copy_(torch.linspace(-1, 1, S)[None]), other.bias.zero_()
+    src = parallel.AllGatherRows.apply(Wl @ E + bl[:, None], rank, world, None)          # [S, d] prototypes
+    xs, ys = X[rank * 3:(rank + 1) * 3], Y[rank * 3:(rank + 1) * 3]
+    loss = ((other((xs @ src.t())) - ys[:, :1]) ** 2).mean()                             # mean over the LOCAL batch
+    loss.backward()
+    sync = parallel.FlatGradAllReduce([Wl, bl, *other.parameters()])
+    assert sync.flat.numel() == sum(p_.numel() for p_ in other.parameters())            # sharded rows are not communicated
+    sync()
+    Wf, bf = W.clone().requires_grad_(), b.clone().requires_grad_()
+    ref_other = torch.nn.Linear(S, 1)
+    ref_other.load_state_dict(other.state_dict())
+    ((ref_other(X @ (Wf @ E + bf[:, None]).t()) - Y[:, :1]) ** 2).mean().backward()       # mean over the GLOBAL batch
+    ok = (torch.allclose(Wl.grad, Wf.grad[r0:r1], rtol=1e-5, atol=1e-6) and torch.allclose(bl.grad, bf.grad[r0:r1], rtol=1e-5, atol=1e-6)
+          and torch.allclose(other.weight.grad, ref_other.weight.grad, rtol=1e-5, atol=1e-6))
+    full = parallel.gather_rows(Wl.detach(), world)
+    ok = ok and torch.equal(full, W)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_row_sharded_layer_gets_global_mean_gradient():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    for p_ in procs:
+        p_.join(120)
+        assert p_.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(2))
+    assert res == {0: True, 1: True}
