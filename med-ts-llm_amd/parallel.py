@@ -65,12 +65,19 @@ class AllGatherRows(torch.autograd.Function):
 
 
 class FlatGradAllReduce:
-    """Packs the gradients of `params` into one flat fp32 buffer, all-reduces it once, averages and unpacks.
+    """Averages the trainable gradients over the ranks through a few large flat fp32 buffers.
+
+    Buckets are filled in REVERSE parameter order (the order backward produces gradients: the output head first, the
+    patch/reprogramming front end last) and each bucket's all-reduce is launched asynchronously from a
+    post-accumulate-grad hook the moment its last gradient lands, so the head's payload travels while the frozen
+    backbone's backward is still computing; `sync()` after backward launches whatever is left, waits, divides by the
+    world size and points every p.grad at its slice of the flat buffer (no copy back). xGMI is point-to-point
+    (7 links x ~153 GB/s per GPU): few large collectives let RCCL drive all links; `bucket_elems` bounds a bucket.
 
     The per-rank loss is a mean over the LOCAL batch, so averaging the summed gradients over ranks reproduces the
     single-process gradient of the mean over the GLOBAL batch (equal shard sizes)."""
 
-    def __init__(self, params, group=None):
+    def __init__(self, params, group=None, bucket_elems=32 * 1024 * 1024, overlap=True):
         # row-sharded parameters (p._dp_sharded, see AllGatherRows) already hold globally averaged gradients of rows no
         # other rank owns: they are neither communicated nor averaged again
         self.params = [p for p in params if p.requires_grad and not getattr(p, "_dp_sharded", False)]
@@ -79,27 +86,61 @@ class FlatGradAllReduce:
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else "cpu"
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.views, off = [], 0
-        for p in self.params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+        self.buckets, self._where = [], {}
+        off, cur = 0, None
+        for p in reversed(self.params):
+            if cur is None or (cur["n"] > 0 and cur["n"] + p.numel() > bucket_elems):
+                cur = {"start": off, "n": 0, "items": [], "pending": 0, "handle": None}
+                self.buckets.append(cur)
+            view = self.flat[off:off + p.numel()].view_as(p)
+            cur["items"].append((p, view))
+            cur["n"] += p.numel()
+            self._where[id(p)] = (cur, view)
             off += p.numel()
+        self.views = [self._where[id(p)][1] for p in self.params]
+        self._hooks = []
+        if overlap and self.world > 1 and hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self._arm()
+
+    def _arm(self):
+        for b in self.buckets:
+            b["pending"], b["handle"], b["packed"] = len(b["items"]), None, set()
+
+    def _launch(self, b):
+        b["handle"] = dist.all_reduce(self.flat[b["start"]:b["start"] + b["n"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    @torch.no_grad()
+    def _on_grad(self, p):
+        b, view = self._where[id(p)]
+        if b["handle"] is not None or id(p) in b["packed"]:
+            return                       # a second backward before sync(): handled by the pack in __call__
+        view.copy_(p.grad)
+        b["packed"].add(id(p))
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
 
     @torch.no_grad()
     def __call__(self):
         if self.world <= 1:
             return
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                v.zero_()
-            else:
-                v.copy_(p.grad)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        for b in self.buckets:           # whatever the hooks did not launch (no hooks, unused parameters, ...)
+            if b["handle"] is None:
+                for p, view in b["items"]:
+                    if id(p) not in b["packed"]:
+                        if p.grad is None:
+                            view.zero_()
+                        else:
+                            view.copy_(p.grad)
+                self._launch(b)
+        for b in self.buckets:
+            b["handle"].wait()
         self.flat.div_(self.world)
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
+        for p, view in zip(self.params, self.views):
+            p.grad = view                # the optimiser reads the averaged gradient straight from the flat buffer
+        self._arm()
 
 
 def shard_batch(batch, rank, world):

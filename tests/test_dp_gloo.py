@@ -123,3 +123,46 @@ def test_row_sharded_layer_gets_global_mean_gradient():
         assert p_.exitcode == 0
     res = dict(q.get(timeout=5) for _ in range(2))
     assert res == {0: True, 1: True}
+
+
+# ---- overlapped path: buckets launched from post-accumulate-grad hooks during backward, two consecutive steps
+def _overlap_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from med_ts_llm_amd import parallel
+    parallel.init_from_env("cpu")
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 4), torch.nn.Tanh(), torch.nn.Linear(4, 3))
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 4), torch.nn.Tanh(), torch.nn.Linear(4, 3))
+    ref.load_state_dict(model.state_dict())
+    sync = parallel.FlatGradAllReduce(model.parameters(), bucket_elems=16)      # several buckets, hooks armed before backward
+    assert len(sync.buckets) >= 3 and sync.buckets[0]["items"][0][0] is list(model.parameters())[-1]   # head first
+    opt, ropt = torch.optim.SGD(model.parameters(), lr=0.1), torch.optim.SGD(ref.parameters(), lr=0.1)
+    ok = True
+    for step in range(2):
+        g = torch.Generator().manual_seed(10 + step)
+        batch = {"x_enc": torch.randn(8, 6, generator=g), "y": torch.randn(8, 3, generator=g)}
+        shard = parallel.shard_batch(batch, rank, world)
+        torch.nn.functional.mse_loss(model(shard["x_enc"]), shard["y"]).backward()
+        launched = sum(b["handle"] is not None for b in sync.buckets)
+        ok = ok and launched == len(sync.buckets)                                # every bucket went out DURING backward
+        sync()
+        torch.nn.functional.mse_loss(ref(batch["x_enc"]), batch["y"]).backward()
+        ok = ok and all(torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6) for a, b in zip(model.parameters(), ref.parameters()))
+        opt.step(), ropt.step()
+        opt.zero_grad(), ropt.zero_grad()
+    ok = ok and all(torch.allclose(a, b, rtol=1e-5, atol=1e-6) for a, b in zip(model.parameters(), ref.parameters()))
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_overlapped_bucketed_allreduce_two_steps():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    for p_ in procs:
+        p_.join(120)
+        assert p_.exitcode == 0
+    assert dict(q.get(timeout=5) for _ in range(2)) == {0: True, 1: True}

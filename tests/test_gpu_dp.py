@@ -51,11 +51,13 @@ def _step(model, inputs, sync):
     opt = HipAdam(params, lr=1e-3)
     for sh in model.bf16_shadows():
         opt.register_shadow(sh)
+    sync = sync(params) if sync is not None else None      # hooks armed before backward: buckets go out while it runs
     with torch.autocast("cuda", dtype=torch.bfloat16):
         loss = torch.nn.functional.mse_loss(model(inputs), inputs["y"])
     loss.backward()
     if sync is not None:
-        sync(params)
+        assert all(b["handle"] is not None for b in sync.buckets)
+        sync()
     grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
     opt.step()
     with torch.autocast("cuda", dtype=torch.bfloat16):                       # second forward uses the Adam-written bf16 shadow
@@ -72,7 +74,7 @@ def _worker(rank, world, port, q):
     model = _build(shard=(rank, world))
     assert model.mapping_layer.weight.shape[0] == S // world
     inputs = parallel.shard_batch(_batch(), rank, world)
-    loss, loss2, grads = _step(model, inputs, lambda params: parallel.FlatGradAllReduce(params)())
+    loss, loss2, grads = _step(model, inputs, lambda params: parallel.FlatGradAllReduce(params, bucket_elems=20000))
     for k in ("mapping_layer.weight", "mapping_layer.bias"):               # gather the row shards for the comparison
         grads[k] = parallel.gather_rows(grads[k], world)
     sd = model.state_dict()                                                  # collective: gathers the sharded rows
