@@ -273,13 +273,16 @@ def main():
     final_loss = float(loss.item())
 
     roofline = None
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
+        # profiled replay (outside the timed region). EVERY rank replays the steps — they contain collectives — but only
+        # rank 0 brackets its GEMM launches with events.
         lib = _native.lib()
-        lib.mtl_prof_enable(1)
+        if rank == 0:
+            lib.mtl_prof_enable(1)
         for i in range(min(args.steps, 5)):
             step(i)
         torch.cuda.synchronize()
-        rows = read_prof(lib)
+        rows = read_prof(lib) if rank == 0 else []
         lib.mtl_prof_enable(0)
         if rows:
             gap_ms = lib.mtl_prof_calibrate(C.c_void_p(torch.cuda.current_stream().cuda_stream))   # empty event bracket
