@@ -239,6 +239,8 @@ def main():
     loss_fn = torch.nn.MSELoss() if task != "semantic_segmentation" else torch.nn.CrossEntropyLoss()
     batches = [make_batch(B, L, C_, pred, 1000 + rank * 97 + i, device, task) for i in range(4)]
 
+    opt_events = None    # set during the profiled replay: optimiser time is reported separately
+
     def step(i):
         inputs = batches[i % len(batches)]
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=True):
@@ -247,7 +249,14 @@ def main():
         loss.backward()
         if sync is not None:
             sync()
-        opt.step()
+        if opt_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            opt.step()
+            e1.record()
+            opt_events.append((e0, e1))
+        else:
+            opt.step()
         opt.zero_grad()
         return loss
 
@@ -272,16 +281,19 @@ def main():
         elapsed = float(t.item())
     final_loss = float(loss.item())
 
-    roofline = None
+    roofline, optimizer_ms = None, None
     if not args.no_roofline:
         # profiled replay (outside the timed region). EVERY rank replays the steps — they contain collectives — but only
         # rank 0 brackets its GEMM launches with events.
         lib = _native.lib()
         if rank == 0:
             lib.mtl_prof_enable(1)
+        opt_events = []
         for i in range(min(args.steps, 5)):
             step(i)
         torch.cuda.synchronize()
+        optimizer_ms = sum(a.elapsed_time(b) for a, b in opt_events) / max(len(opt_events), 1)
+        opt_events = None
         rows = read_prof(lib) if rank == 0 else []
         lib.mtl_prof_enable(0)
         if rows:
@@ -322,7 +334,7 @@ def main():
                         "exact dead-gradient elimination: prompt rows never depend on a trainable parameter, their input gradient is not computed",
             "algorithmic_tflop_per_step_per_gpu": round(fl / 1e12, 3), "executed_tflop_per_step_per_gpu": round(fl_exec / 1e12, 3),
             "step_mfma_frac": round(fl_exec / (elapsed / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "optimizer_ms_per_step": optimizer_ms, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if world > 1:
