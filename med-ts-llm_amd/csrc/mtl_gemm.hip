@@ -607,14 +607,11 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
     } while (0)
         if (bm == 256 && bn == 128 && nw == 16 && stages == 3) MTL_PERSIST(256, 128, 3, 16);
         else if (bm == 256 && bn == 128 && nw == 16 && stages == 2) MTL_PERSIST(256, 128, 2, 16);
-        else if (bm == 256 && bn == 128 && nw == 8 && stages == 2) MTL_PERSIST(256, 128, 2, 8);
-        else if (bm == 256 && bn == 128 && nw == 8 && stages == 3) MTL_PERSIST(256, 128, 3, 8);
         else if (bm == 128 && bn == 128 && nw == 8 && stages == 2) MTL_PERSIST(128, 128, 2, 8);
         else if (bm == 128 && bn == 128 && nw == 8 && stages == 3) MTL_PERSIST(128, 128, 3, 8);
         else if (bm == 128 && bn == 128 && nw == 4 && stages == 2) MTL_PERSIST(128, 128, 2, 4);
         else if (bm == 128 && bn == 64 && nw == 4 && stages == 2) MTL_PERSIST(128, 64, 2, 4);
         else if (bm == 128 && bn == 64 && nw == 4 && stages == 3) MTL_PERSIST(128, 64, 3, 4);
-        else if (bm == 128 && bn == 64 && nw == 4 && stages == 4) MTL_PERSIST(128, 64, 4, 4);
         else return MTL_ERR_UNSUPPORTED;
 #undef MTL_PERSIST
     } else if (S == 1) {

@@ -8,7 +8,7 @@ import os
 import torch  # noqa: F401  (must be imported first so our kernels share torch's HIP runtime instance)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmedtsllm_hip.so")
+LIB_PATH = os.environ.get("MTL_LIB_PATH") or os.path.join(_HERE, "libmedtsllm_hip.so")   # override: diagnostic builds only
 
 MTL_F32, MTL_BF16 = 0, 1
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM = 0, 1, 2, 3, 4
