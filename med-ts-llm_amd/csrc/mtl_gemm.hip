@@ -590,14 +590,24 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         int bm = tuning().bm, bn = tuning().bn, stages = tuning().stages, nw = tuning().waves;
         const int t128 = tiles_m * tiles_n;            // grid size in 128x128 tiles
         if (bm == 0) bm = (t128 >= 8 * ncu) ? 256 : 128;   // Llama-class grids: 256x128 / 16 waves / 3 stages reaches 1.04-1.06 PF/s
-        if (bn == 0) bn = (bm == 256 || t128 >= 2 * ncu) ? 128 : 64;
-        if (nw == 0) nw = bm == 256 ? 16 : (bn == 128 ? 8 : 4);
+        if (bn == 0) {
+            bn = (bm == 256 || t128 >= 2 * ncu) ? 128 : 64;
+            // widths that divide 768-multiples (GPT-2 family: 768 / 2304 / 3072): fewer operand bytes per FLOP through the
+            // global->LDS path (the binding resource, profiles/r01_gemm_diag.txt) and whole numbers of tiles per CU.
+            // Measured (tools/bench_gemm.py): 128x192 wins for plain / GELU epilogues on >= 2 tiles per CU (qkv 41 -> 35 us,
+            // fc 66 -> 59 us), 128x96 wins or ties wherever 128x64 was chosen (mproj 52 -> 47 us); DGELU keeps 128x128.
+            const int64_t t192 = (int64_t)tiles_m * (p.N / 192);
+            if (bm == 128 && bn == 128 && p.N % 192 == 0 && t192 >= 2 * ncu && (EPI == MTL_EPI_STORE || EPI == MTL_EPI_GELU)) bn = 192;
+            else if (bm == 128 && bn == 64 && p.N % 96 == 0) bn = 96;
+        }
+        if (nw == 0) nw = bm == 256 ? 16 : (bn >= 128 ? 8 : 4);
         if (stages == 0) stages = bm == 256 ? 3 : 2;
         const int tm = (int)((p.M + bm - 1) / bm), tn = (int)((p.N + bn - 1) / bn), nt = tm * tn;
         const size_t lds = (size_t)stages * (bm + bn) * BK * 2;
         const int per_cu = (int)(160 * 1024 / lds) < 1 ? 1 : (int)(160 * 1024 / lds);
         const int grid = nt < per_cu * ncu ? nt : per_cu * ncu;
-        if (recording) rec.key |= (1 << 8) | ((bn == 128 ? 1 : 0) << 9) | ((nw == 8 ? 1 : (nw == 16 ? 2 : 0)) << 10) | (stages << 12) | ((bm == 256 ? 1 : 0) << 15);
+        if (recording) rec.key |= (1 << 8) | ((bn == 128 ? 1 : 0) << 9) | ((nw == 8 ? 1 : (nw == 16 ? 2 : 0)) << 10) | (stages << 12) | ((bm == 256 ? 1 : 0) << 15) |
+                                      ((bn == 96 ? 2 : (bn == 192 ? 3 : (bn == 128 ? 1 : 0))) << 16);
 #define MTL_PERSIST(BMV, BNV, STV, NWV)                                                                                \
     do {                                                                                                               \
         auto kfn = gemm_nt_persist_kernel<EPI, CDT, BMV, BNV, STV, NWV>;                                               \
@@ -611,6 +621,8 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         else if (bm == 128 && bn == 128 && nw == 8 && stages == 3) MTL_PERSIST(128, 128, 3, 8);
         else if (bm == 128 && bn == 128 && nw == 4 && stages == 2) MTL_PERSIST(128, 128, 2, 4);
         else if (bm == 128 && bn == 64 && nw == 4 && stages == 2) MTL_PERSIST(128, 64, 2, 4);
+        else if (bm == 128 && bn == 96 && nw == 4 && stages == 2) MTL_PERSIST(128, 96, 2, 4);
+        else if (bm == 128 && bn == 192 && nw == 8 && stages == 2) MTL_PERSIST(128, 192, 2, 8);
         else if (bm == 128 && bn == 64 && nw == 4 && stages == 3) MTL_PERSIST(128, 64, 3, 4);
         else return MTL_ERR_UNSUPPORTED;
 #undef MTL_PERSIST
@@ -629,7 +641,7 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
 }  // namespace
 
 extern "C" int mtl_gemm_tune(int mode, int bm, int bn, int stages, int waves) {
-    if ((mode != 0 && mode != 1) || (bm != 0 && bm != 128 && bm != 256) || (bn != 0 && bn != 64 && bn != 128) ||
+    if ((mode != 0 && mode != 1) || (bm != 0 && bm != 128 && bm != 256) || (bn != 0 && bn != 64 && bn != 128 && bn != 96 && bn != 192) ||
         (stages != 0 && stages != 2 && stages != 3 && stages != 4) || (waves != 0 && waves != 4 && waves != 8 && waves != 16))
         return MTL_ERR_ARG;
     tuning().mode = mode;
