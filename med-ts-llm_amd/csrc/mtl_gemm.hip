@@ -596,6 +596,9 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
             // global->LDS path (the binding resource, profiles/r01_gemm_diag.txt) and whole numbers of tiles per CU.
             // Measured (tools/bench_gemm.py): 128x192 wins for plain / GELU epilogues on >= 2 tiles per CU (qkv 41 -> 35 us,
             // fc 66 -> 59 us), 128x96 wins or ties wherever 128x64 was chosen (mproj 52 -> 47 us); DGELU keeps 128x128.
+            // Llama-class grids, plain epilogue: 256x192 / 8 waves (each wave 64x96) moves 22 % fewer operand bytes per FLOP
+            // than 256x128 (qkv 775 -> 727 us = 1.13 PF/s, gate|up 1404 -> 1336 us); residual epilogues keep 256x128
+            if (bm == 256 && EPI == MTL_EPI_STORE && (p.N % 192 == 0 || p.N >= 8192)) { bn = 192; if (nw == 0) nw = 8; if (stages == 0) stages = 2; }
             const int64_t t192 = (int64_t)tiles_m * (p.N / 192);
             if (bm == 128 && bn == 128 && p.N % 192 == 0 && t192 >= 2 * ncu && (EPI == MTL_EPI_STORE || EPI == MTL_EPI_GELU)) bn = 192;
             else if (bm == 128 && bn == 64 && p.N % 96 == 0) bn = 96;
@@ -623,6 +626,7 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         else if (bm == 128 && bn == 64 && nw == 4 && stages == 2) MTL_PERSIST(128, 64, 2, 4);
         else if (bm == 128 && bn == 96 && nw == 4 && stages == 2) MTL_PERSIST(128, 96, 2, 4);
         else if (bm == 128 && bn == 192 && nw == 8 && stages == 2) MTL_PERSIST(128, 192, 2, 8);
+        else if (bm == 256 && bn == 192 && nw == 8 && stages == 2) MTL_PERSIST(256, 192, 2, 8);
         else if (bm == 128 && bn == 64 && nw == 4 && stages == 3) MTL_PERSIST(128, 64, 3, 4);
         else return MTL_ERR_UNSUPPORTED;
 #undef MTL_PERSIST
