@@ -367,7 +367,9 @@ __device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int
 //   128x128 / 8 waves (2 workgroups/CU)  same LDS bytes per stage feed twice the MFMA work per resident slot
 //   256x128 / 16 waves, 3 stages (1 workgroup/CU): two 48-KiB stages in flight cover the loaded L2 latency with
 //   4.2 MFLOP of MFMA work each and halve the L1->LDS bytes per FLOP again
-template <int EPI, int CDT, int BM_, int BN_, int STAGES, int NW>
+// SPLIT: a work item is (k-slab s, tile): the slab's K range of that tile, raw fp32 partial sums to workspace slab s
+// (splitk_reduce_kernel applies the epilogue). Slab-major item order: neighbours share A/B panels. `vec_ok_i` carries S.
+template <int EPI, int CDT, int BM_, int BN_, int STAGES, int NW, bool SPLIT = false>
 __global__ __launch_bounds__(NW * 64) void gemm_nt_persist_kernel(const mtl_gemm_args p, const int vec_ok_i, const int tiles_m,
                                                              const int tiles_n) {
     constexpr int BK_ = 64;
@@ -389,9 +391,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_persist_kernel(const mtl_gemm
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;
     const int l15 = lane & 15, g = lane >> 4;
-    (void)vec_ok_i;                            // the persistent kernel is only launched when the vector epilogue applies
+    const int n_split = SPLIT ? vec_ok_i : 1;  // (the persistent kernel is only launched when the vector epilogue applies)
+    const int tiles_mn = tiles_m * tiles_n;
 
-    const int ntiles = tiles_m * tiles_n;
+    const int ntiles = tiles_mn * n_split;
     const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
     const int xblocks = (nblk - xcd + 7) >> 3;                 // blocks living on this XCD
     const int q = ntiles >> 3, r8 = ntiles & 7;
@@ -399,22 +402,24 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_persist_kernel(const mtl_gemm
     const int cnt = q + (xcd < r8 ? 1 : 0);
     if (slot >= cnt) return;
     const int my_count = (cnt - slot + xblocks - 1) / xblocks;
-    const int nkt = (int)(p.K / BK_);
+    const int nkt = (int)(p.K / BK_) / n_split;
     const int total = my_count * nkt;
 
     const bf16_t* asrc[NA];
     const bf16_t* bsrc[NB];
-    auto set_sources = [&](int tile) {
+    auto set_sources = [&](int item) {
         int tm, tn;
-        tile_coords(tile, tiles_m, tiles_n, tm, tn);
+        const int slab = SPLIT ? item / tiles_mn : 0;
+        tile_coords(SPLIT ? item - slab * tiles_mn : item, tiles_m, tiles_n, tm, tn);
         const int64_t m0 = (int64_t)tm * BM_, n0 = (int64_t)tn * BN_;
+        const int64_t k0 = (int64_t)slab * nkt * BK_;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int sl = i * NT + tid;
             const int rr = sl / CPR, pc = sl % CPR;
             const int c = pc ^ swz64(rr);
             int64_t am = m0 + rr; if (am > p.M - 1) am = p.M - 1;
-            asrc[i] = reinterpret_cast<const bf16_t*>(p.A) + remap_row(am, p.a_group_rows, p.a_group_stride, p.a_row_offset) * p.lda + c * 8;
+            asrc[i] = reinterpret_cast<const bf16_t*>(p.A) + remap_row(am, p.a_group_rows, p.a_group_stride, p.a_row_offset) * p.lda + c * 8 + k0;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_persist_kernel(const mtl_gemm
             const int rr = sl / CPR, pc = sl % CPR;
             const int c = pc ^ swz64(rr);
             int64_t bn = n0 + rr; if (bn > p.N - 1) bn = p.N - 1;
-            bsrc[i] = reinterpret_cast<const bf16_t*>(p.B) + bn * p.ldb + c * 8;
+            bsrc[i] = reinterpret_cast<const bf16_t*>(p.B) + bn * p.ldb + c * 8 + k0;
         }
     };
     auto stage = [&](int buf, int kt) {
@@ -443,6 +448,24 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_persist_kernel(const mtl_gemm
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // epilogue of a finished item: the fused one, or (SPLIT) a raw fp32 store into the item's workspace slab
+    auto finish = [&](int item) {
+        int tm, tn;
+        const int slab = SPLIT ? item / tiles_mn : 0;
+        tile_coords(SPLIT ? item - slab * tiles_mn : item, tiles_m, tiles_n, tm, tn);
+        const int64_t m0 = (int64_t)tm * BM_, n0 = (int64_t)tn * BN_;
+        const bool full = m0 + BM_ <= p.M && n0 + BN_ <= p.N;
+        if constexpr (SPLIT) {
+            mtl_gemm_args q = p;
+            q.C = reinterpret_cast<float*>(p.workspace) + (int64_t)slab * p.M * p.N;
+            q.ldc = p.N; q.bias = nullptr; q.alpha = 1.f; q.c_group_rows = 0;
+            if (full) epilogue_wave<MTL_EPI_STORE, MTL_F32, NI, true>(q, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * 4, acc);
+            else epilogue_wave<MTL_EPI_STORE, MTL_F32, NI, false>(q, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * 4, acc);
+        } else {
+            if (full) epilogue_wave<EPI, CDT, NI, true>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * 4, acc);
+            else epilogue_wave<EPI, CDT, NI, false>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * 4, acc);
+        }
+    };
     const int sw = swz64(l15);                 // wave / mi / ni row offsets are multiples of 16: swz unchanged
     const int a_off = (wr * 64 + l15) * ROWB;
     const int b_off = (wc * WCOLS + l15) * ROWB;
@@ -471,14 +494,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_persist_kernel(const mtl_gemm
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (done_tile >= 0) {           // epilogue of the previous tile: its stores are queued BEFORE the next DMA stage
-            int tm, tn;
-            tile_coords(done_tile, tiles_m, tiles_n, tm, tn);
-            const int64_t m0 = (int64_t)tm * BM_, n0 = (int64_t)tn * BN_;
-            if (m0 + BM_ <= p.M && n0 + BN_ <= p.N) {
-                epilogue_wave<EPI, CDT, NI, true>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * 4, acc);
-            } else {
-                epilogue_wave<EPI, CDT, NI, false>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * 4, acc);
-            }
+            finish(done_tile);
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -514,16 +530,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_persist_kernel(const mtl_gemm
             ++c_i;
         }
     }
-    if (done_tile >= 0) {
-        int tm, tn;
-        tile_coords(done_tile, tiles_m, tiles_n, tm, tn);
-        const int64_t m0 = (int64_t)tm * BM_, n0 = (int64_t)tn * BN_;
-        if (m0 + BM_ <= p.M && n0 + BN_ <= p.N) {
-            epilogue_wave<EPI, CDT, NI, true>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * 4, acc);
-        } else {
-            epilogue_wave<EPI, CDT, NI, false>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * 4, acc);
-        }
-    }
+    if (done_tile >= 0) finish(done_tile);
 }
 
 template <int EPI, int CDT>
@@ -589,7 +596,8 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         // tile choice, measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_ab*.txt)
         int bm = tuning().bm, bn = tuning().bn, stages = tuning().stages, nw = tuning().waves;
         const int t128 = tiles_m * tiles_n;            // grid size in 128x128 tiles
-        if (bm == 0) bm = (t128 >= 8 * ncu) ? 256 : 128;   // Llama-class grids: 256x128 / 16 waves / 3 stages reaches 1.04-1.06 PF/s
+        // Llama-class grids: 256x128 / 16 waves / 3 stages reaches 1.04-1.12 PF/s (also the M = B*n_grad backward GEMMs with long K)
+        if (bm == 0) bm = (t128 >= 8 * ncu || (t128 >= 4 * ncu && p.K >= 4096)) ? 256 : 128;
         if (bn == 0) {
             bn = (bm == 256 || t128 >= 2 * ncu) ? 128 : 64;
             // widths that divide 768-multiples (GPT-2 family: 768 / 2304 / 3072): fewer operand bytes per FLOP through the
@@ -634,6 +642,21 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         hipLaunchKernelGGL((gemm_nt_kernel<EPI, CDT, false>), dim3(tiles_m * tiles_n, 1), dim3(256), 0, st, p, vec_ok);
     } else {
         const int ws_vec = (p.N % 4 == 0) && aligned(p.workspace, 16);
+        const int nkt_total = (int)(p.K / BK);
+        if (tuning().mode == 1 && ws_vec && nkt_total % S == 0) {
+            // persistent split-K: S x tiles work items of K/S each through the 128x128 / 8-wave pipeline (mapping GEMM:
+            // K = padded vocabulary; the one-tile-per-workgroup kernel below reached 395 TF/s on it)
+            constexpr int BMV = 128, BNV = 128, STV = 2, NWV = 8;
+            const int tm = (int)((p.M + BMV - 1) / BMV), tn = (int)((p.N + BNV - 1) / BNV), items = tm * tn * S;
+            const size_t lds = (size_t)STV * (BMV + BNV) * BK * 2;
+            const int ncu = num_cus(), per_cu = (int)(160 * 1024 / lds);
+            const int grid = items < per_cu * ncu ? items : per_cu * ncu;
+            auto kfn = gemm_nt_persist_kernel<MTL_EPI_STORE, MTL_F32, BMV, BNV, STV, NWV, true>;
+            static std::once_flag once;
+            std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+            if (recording) rec.key |= (1 << 8) | (1 << 9) | (1 << 10) | (STV << 12) | (1 << 16);
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(NWV * 64), lds, st, p, S, tm, tn);
+        } else
         hipLaunchKernelGGL((gemm_nt_kernel<EPI, CDT, true>), dim3(tiles_m * tiles_n, S), dim3(256), 0, st, p, ws_vec);
         const int64_t items = p.M * ((p.N + 3) / 4);
         hipLaunchKernelGGL((splitk_reduce_kernel<EPI, CDT>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, p, S, vec_ok);

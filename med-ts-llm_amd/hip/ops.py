@@ -19,6 +19,22 @@ def pad64(n):
     return (int(n) + 63) // 64 * 64
 
 
+def pad_vocab(n):
+    """K padding of the mapping GEMM operands: a multiple of 64 * 16, so that every power-of-two split-K up to 16 divides
+    the k-steps evenly (persistent split-K path of mtl_gemm_nt); +1.9 % zero columns for GPT-2's 50 257 + 1."""
+    return (int(n) + 1023) // 1024 * 1024
+
+
+def mapping_split_k(rows, d, kp):
+    """power-of-two split of the mapping GEMM's K = kp so that ~2 work items per CU exist"""
+    tiles = ((rows + 127) // 128) * ((d + 127) // 128)
+    want = max(1, min(16, (512 + tiles - 1) // tiles, kp // 64))
+    s = 1
+    while s * 2 <= want and (kp // 64) % (s * 2) == 0:
+        s *= 2
+    return s
+
+
 def _dt(t):
     return N.MTL_BF16 if t.dtype == BF16 else N.MTL_F32
 

@@ -16,7 +16,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..hip import ops
-from ..hip.ops import (PatchTokenizeFn, LinearFn, MappingFn, MappingTrainableFn, CrossAttnFn, AssembleFn, BackboneFn, RevinDenormFn, pad64)
+from ..hip.ops import (PatchTokenizeFn, LinearFn, MappingFn, MappingTrainableFn, CrossAttnFn, AssembleFn, BackboneFn, RevinDenormFn, pad64, pad_vocab,
+                       mapping_split_k)
 from . import prompt as P
 from .backbone import FrozenBackbone, load_hf_dir, normalise_config
 
@@ -185,7 +186,7 @@ class MedTsLLM(nn.Module):
             self.backbone = FrozenBackbone(self._hf_cfg, self._hf_state, device, n_layers=self.llm_layers)
             bb = self.backbone
             V, d = self.vocab_size, self.d_llm
-            Vp = pad64(V + 1)
+            Vp = pad_vocab(V + 1) if not self.word_embeddings.requires_grad else pad64(V + 1)
             if not self.word_embeddings.requires_grad:       # frozen table: bf16 operands prepared once
                 wT = torch.zeros((d, Vp), dtype=BF16, device=device)
                 wT[:, :V] = bb.embed_f32.t().to(BF16)
@@ -300,7 +301,7 @@ class MedTsLLM(nn.Module):
         sh = getattr(self, "_map_shadow", None)
         if sh is None or sh.param is not W or sh.tensor.device != W.device:
             from ..hip.optim import Bf16Shadow
-            sh = Bf16Shadow(W, torch.zeros((W.shape[0], pad64(self.vocab_size + 1)), dtype=torch.bfloat16, device=W.device))
+            sh = Bf16Shadow(W, torch.zeros((W.shape[0], pad_vocab(self.vocab_size + 1)), dtype=torch.bfloat16, device=W.device))
             self._map_shadow = sh
         return sh
 
@@ -326,8 +327,7 @@ class MedTsLLM(nn.Module):
             source = MappingTrainableFn.apply(self.mapping_layer.weight, self.mapping_layer.bias, self.word_embeddings, self._map_split_k)
         else:
             W = self.mapping_layer.weight
-            tiles = ((W.shape[0] + 127) // 128) * ((self.d_llm + 127) // 128)
-            split_k = max(1, min(self._wT.shape[1] // 64, 16, (512 + tiles - 1) // tiles))
+            split_k = mapping_split_k(W.shape[0], self.d_llm, self._wT.shape[1])
             source = MappingFn.apply(W, self.mapping_layer.bias, self._wT, self._w, split_k, self._mapping_shadow())
             if self._map_shard is not None:      # rows of the other ranks (DP row sharding)
                 from ..parallel import AllGatherRows

@@ -393,7 +393,7 @@ def test_assemble_and_denorm(ops):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("wd,decoupled", [(0.0, False), (0.01, False), (0.01, True)])
-def test_hip_adam_matches_torch(wd, decoupled):
+def test_hip_adam_matches_torch(ops, wd, decoupled):
     """mtl_adam_step == torch.optim.Adam / AdamW (R:tasks/base.py:97,99) over 5 steps, incl. odd sizes, an unaligned
     view and the bf16 shadow of the updated weight."""
     from med_ts_llm_amd.hip.optim import HipAdam, Bf16Shadow
@@ -419,3 +419,20 @@ def test_hip_adam_matches_torch(wd, decoupled):
     sd = ours.state_dict()["state"][0]
     assert set(sd) == {"step", "exp_avg", "exp_avg_sq"} and sd["step"] == 5
     torch.testing.assert_close(sd["exp_avg"], ref.state_dict()["state"][0]["exp_avg"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,Nn,K,S", [(1024, 768, 64 * 32, 16), (200, 132, 64 * 8, 4), (128, 64, 64 * 6, 4)])
+def test_gemm_split_k_paths(ops, M, Nn, K, S):
+    """split-K through the persistent work-item kernel (k-steps divisible by S) and through the classic one (not
+    divisible): both equal the unsplit GEMM up to fp32 summation order, bf16 output identical after rounding almost everywhere"""
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g).to(BF16).cuda()
+    B = (torch.randn(Nn, K, generator=g) * 0.1).to(BF16).cuda()
+    bias = torch.randn(Nn, generator=g).cuda()
+    ref = (A.float() @ B.float().t() + bias)
+    one = ops.gemm_nt(A, B, bias=bias, out_dtype=F32)
+    split = ops.gemm_nt(A, B, bias=bias, out_dtype=F32, split_k=S)
+    assert rel_err(one, ref) < 2e-5 and rel_err(split, ref) < 2e-5
+    splitb = ops.gemm_nt(A, B, bias=bias, split_k=S)
+    assert splitb.dtype == BF16 and rel_err(splitb.float(), ref) < 4e-3
