@@ -136,7 +136,8 @@ __device__ __forceinline__ void epilogue4(const mtl_gemm_args& p, int64_t m, int
 // every store waits for the previous store to complete, and the still-"pending" bias registers force a vmcnt(0) in
 // front of the next k-step's first ds_read, draining the LDS-DMA pipeline.)
 template <int EPI, int CDT, int NI, bool FULL>
-__device__ __forceinline__ void epilogue_wave(const mtl_gemm_args& p, int64_t m_first, int64_t n_first, f32x4 (&acc)[NI][4]) {
+__device__ __forceinline__ void epilogue_wave(const mtl_gemm_args& p, int64_t m_first, int64_t n_first, f32x4 (&acc)[NI][4],
+                                              const bool dword_stores = false) {
     // lane owns rows m_first + mi*16 (mi = 0..3) and columns n_first + ni*16 .. +3.  Edge tiles (!FULL) LOAD from
     // clamped (always valid) addresses and predicate only the stores: no load result is ever consumed inside a branch.
     int64_t crow[4];
@@ -203,7 +204,23 @@ __device__ __forceinline__ void epilogue_wave(const mtl_gemm_args& p, int64_t m_
                 const u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
                 if (ok) *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + crow[mi] * p.ldc + n) = pk;
             } else {
-                if (ok) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + crow[mi] * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+                float* cp = reinterpret_cast<float*>(p.C) + crow[mi] * p.ldc + n;
+                if (EPI == MTL_EPI_STORE && dword_stores) {
+                    // rows that are only 4-B aligned (N % 4 != 0, e.g. the [num_tokens, 50257] mapping weight gradient):
+                    // four dword stores, still straight-line on interior tiles
+                    if (FULL) {
+                        // one dwordx4 store at a dword-aligned address: legal in the unaligned access mode ROCm runs
+                        // compute queues in (SH_MEM_CONFIG.ALIGNMENT_MODE); 4x fewer store instructions than dwords
+                        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                        *reinterpret_cast<f4u*>(cp) = (f4u){o[0], o[1], o[2], o[3]};
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (ok && n + e < p.N) cp[e] = o[e];
+                    }
+                } else {
+                    if (ok) *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
+                }
             }
         }
 }
@@ -462,8 +479,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_persist_kernel(const mtl_gemm
             if (full) epilogue_wave<MTL_EPI_STORE, MTL_F32, NI, true>(q, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * 4, acc);
             else epilogue_wave<MTL_EPI_STORE, MTL_F32, NI, false>(q, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * 4, acc);
         } else {
-            if (full) epilogue_wave<EPI, CDT, NI, true>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * 4, acc);
-            else epilogue_wave<EPI, CDT, NI, false>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * 4, acc);
+            const bool dw = vec_ok_i == 0;     // fp32 plain store without bias into 4-B aligned rows (host guarantees the rest)
+            if (full) epilogue_wave<EPI, CDT, NI, true>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * 4, acc, dw);
+            else epilogue_wave<EPI, CDT, NI, false>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * 4, acc, dw);
         }
     };
     const int sw = swz64(l15);                 // wave / mi / ni row offsets are multiples of 16: swz unchanged
@@ -591,7 +609,9 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
             }
         }
     } closer{pf, rec, recording, st};
-    if (S == 1 && tuning().mode == 1 && vec_ok && p.N >= 4) {   // the persistent kernel has the vector epilogue only
+    // the persistent kernel has the wave-level epilogue only: 16-B aligned rows, or (plain fp32 store, no bias) dword stores
+    const bool dword_ok = EPI == MTL_EPI_STORE && CDT == MTL_F32 && !p.bias && aligned(p.C, 4) && p.c_group_rows == 0;
+    if (S == 1 && tuning().mode == 1 && (vec_ok || dword_ok) && p.N >= 4) {
         const int ncu = num_cus();
         // tile choice, measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_ab*.txt)
         int bm = tuning().bm, bn = tuning().bn, stages = tuning().stages, nw = tuning().waves;

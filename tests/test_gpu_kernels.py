@@ -436,3 +436,18 @@ def test_gemm_split_k_paths(ops, M, Nn, K, S):
     assert rel_err(one, ref) < 2e-5 and rel_err(split, ref) < 2e-5
     splitb = ops.gemm_nt(A, B, bias=bias, split_k=S)
     assert splitb.dtype == BF16 and rel_err(splitb.float(), ref) < 4e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,Nn,K", [(1024, 50257, 128), (300, 1001, 64), (128, 7, 64)])
+def test_gemm_fp32_out_unaligned_rows(ops, M, Nn, K):
+    """N % 4 != 0 with fp32 output (the mapping weight gradient [num_tokens, 50257]): rows are only 4-B aligned, the
+    persistent kernel stores dwords; exact on small-integer operands, padding beyond N untouched"""
+    g = torch.Generator().manual_seed(Nn)
+    A = torch.randint(-3, 4, (M, K), generator=g).to(BF16).cuda()
+    B = torch.randint(-3, 4, (Nn, K), generator=g).to(BF16).cuda()
+    buf = torch.full((M * Nn + 8,), 7.0, dtype=F32, device="cuda")
+    out = buf[:M * Nn].view(M, Nn)
+    ops.gemm_nt(A, B, out=out)
+    assert torch.equal(out, A.float() @ B.float().t())
+    assert torch.all(buf[M * Nn:] == 7.0)
