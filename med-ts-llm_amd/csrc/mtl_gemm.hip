@@ -666,16 +666,24 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         if (tuning().mode == 1 && ws_vec && nkt_total % S == 0) {
             // persistent split-K: S x tiles work items of K/S each through the 128x128 / 8-wave pipeline (mapping GEMM:
             // K = padded vocabulary; the one-tile-per-workgroup kernel below reached 395 TF/s on it)
-            constexpr int BMV = 128, BNV = 128, STV = 2, NWV = 8;
-            const int tm = (int)((p.M + BMV - 1) / BMV), tn = (int)((p.N + BNV - 1) / BNV), items = tm * tn * S;
-            const size_t lds = (size_t)STV * (BMV + BNV) * BK * 2;
-            const int ncu = num_cus(), per_cu = (int)(160 * 1024 / lds);
-            const int grid = items < per_cu * ncu ? items : per_cu * ncu;
-            auto kfn = gemm_nt_persist_kernel<MTL_EPI_STORE, MTL_F32, BMV, BNV, STV, NWV, true>;
-            static std::once_flag once;
-            std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-            if (recording) rec.key |= (1 << 8) | (1 << 9) | (1 << 10) | (STV << 12) | (1 << 16);
-            hipLaunchKernelGGL(kfn, dim3(grid), dim3(NWV * 64), lds, st, p, S, tm, tn);
+            auto go = [&](auto bmv, auto bnv) {
+                constexpr int BMV = decltype(bmv)::value, BNV = decltype(bnv)::value, STV = 2, NWV = 8;
+                const int tm = (int)((p.M + BMV - 1) / BMV), tn = (int)((p.N + BNV - 1) / BNV), items = tm * tn * S;
+                const size_t lds = (size_t)STV * (BMV + BNV) * BK * 2;
+                const int ncu = num_cus(), per_cu = (int)(160 * 1024 / lds);
+                const int grid = items < per_cu * ncu ? items : per_cu * ncu;
+                auto kfn = gemm_nt_persist_kernel<MTL_EPI_STORE, MTL_F32, BMV, BNV, STV, NWV, true>;
+                static std::once_flag once;
+                std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+                if (recording) rec.key |= (1 << 8) | (1 << 10) | (STV << 12) | ((BNV == 192 ? 3 : 1) << 16) | ((BMV == 256 ? 1 : 0) << 15);
+                hipLaunchKernelGGL(kfn, dim3(grid), dim3(NWV * 64), lds, st, p, S, tm, tn);
+            };
+            using I128 = std::integral_constant<int, 128>; using I192 = std::integral_constant<int, 192>; using I256 = std::integral_constant<int, 256>;
+            // operands of a split GEMM stream from HBM (K is huge): the fewest operand bytes per FLOP wins (256x192 when it still
+            // leaves >= 1 item per CU: mapping GEMM 154 -> ~110 us)
+            if (p.N % 192 == 0 && p.M % 256 == 0 && (p.M / 256) * (p.N / 192) * S >= num_cus()) go(I256{}, I192{});
+            else if (p.N % 192 == 0) go(I128{}, I192{});
+            else go(I128{}, I128{});
         } else
         hipLaunchKernelGGL((gemm_nt_kernel<EPI, CDT, true>), dim3(tiles_m * tiles_n, S), dim3(256), 0, st, p, ws_vec);
         const int64_t items = p.M * ((p.N + 3) / 4);

@@ -27,8 +27,8 @@ def pad_vocab(n):
 
 def mapping_split_k(rows, d, kp):
     """power-of-two split of the mapping GEMM's K = kp so that ~2 work items per CU exist"""
-    tiles = ((rows + 127) // 128) * ((d + 127) // 128)
-    want = max(1, min(16, (512 + tiles - 1) // tiles, kp // 64))
+    tiles = ((rows + 255) // 256) * ((d + 191) // 192)            # the split path prefers 256x192 work items
+    want = max(1, min(16, (512 + tiles - 1) // tiles, kp // 64 // 16))
     s = 1
     while s * 2 <= want and (kp // 64) % (s * 2) == 0:
         s *= 2
