@@ -12,7 +12,7 @@ shapes = [("qkv   ", 8192, 2304, 768, N.EPI_STORE), ("aproj ", 8192, 768, 768, N
           ("dx_qkv", 8192, 768, 2304, N.EPI_STORE), ("llama_qkv", 8192, 12288, 4096, N.EPI_STORE), ("llama_down", 8192, 4096, 11008, N.EPI_RESID), ("llama_gateup", 8192, 22016, 4096, N.EPI_STORE), ("llama_dx", 4096, 4096, 12288, N.EPI_STORE)]
 if len(sys.argv) > 1:
     shapes = [s for s in shapes if s[0].strip() in sys.argv[1:]]
-variants = [(1, 128, 128, 2, 8), (1, 128, 192, 2, 8), (1, 256, 128, 3, 16), (1, 256, 192, 2, 8)]
+variants = [(1, 0, 0, 0, 0)]
 g = torch.Generator().manual_seed(0)
 for name, M, Nn, K, epi in shapes:
     A = torch.randn(M, K, generator=g).to(BF16).cuda()
@@ -26,15 +26,31 @@ for name, M, Nn, K, epi in shapes:
     elif epi == N.EPI_DGELU:
         kw = dict(aux_in=torch.randn(M, Nn, generator=g).to(BF16).cuda())
     outs, times = {}, {v: [] for v in variants}
+    CM = os.environ.get("GEMM_COLD", "")
+    COLD = bool(CM)      # GEMM_COLD=1 (all) or any of the letters A, B, C: which operands rotate      # rotate operands/outputs through pools larger than L2 + MALL (as inside a training step)
+    if COLD:
+        poolA = [A.clone() for _ in range(8)]
+        poolB = [B.clone() for _ in range(24)]
+        flush = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
     for rnd in range(5):
         for v in variants:
             lib.mtl_gemm_tune(*v)
             out = ops.gemm_nt(A, B, bias=bias, epilogue=epi, **kw)
+            poolC = [torch.empty_like(out) for _ in range(8)] if COLD else None
             torch.cuda.synchronize()
+            if COLD:
+                flush.fill_(rnd)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(20):
-                ops.gemm_nt(A, B, bias=bias, epilogue=epi, out=out, **{k: v_ for k, v_ in kw.items() if k != "out_dtype"})
+            PF = os.environ.get("GEMM_PREFETCH") == "1"
+            sink = torch.zeros((), dtype=torch.float32, device="cuda")
+            for it in range(20):
+                if COLD and PF:      # touch the weights the next GEMM will use (stand-in for a side-stream prefetch into the memory-side cache)
+                    torch.sum(poolB[it % 24], dim=(0, 1), dtype=torch.float32, out=sink)
+                if COLD:
+                    ops.gemm_nt(poolA[it % 8] if CM in "1" or "A" in CM else A, poolB[it % 24] if CM in "1" or "B" in CM else B, bias=bias, epilogue=epi, out=poolC[it % 8] if CM in "1" or "C" in CM else out, **{k: v_ for k, v_ in kw.items() if k != "out_dtype"})
+                else:
+                    ops.gemm_nt(A, B, bias=bias, epilogue=epi, out=out, **{k: v_ for k, v_ in kw.items() if k != "out_dtype"})
             e1.record()
             torch.cuda.synchronize()
             times[v].append(e0.elapsed_time(e1) / 20 * 1e3)
