@@ -186,7 +186,11 @@ def pmc_traffic(kernel):
     if not os.path.exists(path):
         return None
     with open(path) as f:
-        return json.load(f).get(kernel)
+        table = json.load(f)
+    for name in (kernel, kernel[:-1] + ", false>", kernel[:-1] + ", true>"):     # rocprof prints the SPLIT template flag too
+        if name in table:
+            return table[name]
+    return None
 
 
 def main():
