@@ -259,30 +259,47 @@ class MedTsLLM(nn.Module):
         return P.build_prompt_parts(inputs, cfg, self.dataset_description, self.task_description, bos)
 
     def _prompt_ids(self, inputs, device):
-        """-> int32 [B or 1, n_tok] left-padded ids (None when prompting is off). Constant parts are tokenised once."""
+        """-> (ids, splice): ids int32 [B or 1, n_tok] left-padded token ids (None when prompting is off); constant
+        parts are tokenised once. splice = None, or for "examples" prompting (R:models/medtsllm.py:313-319,403,
+        R:datasets/ecg.py:139-166) a dict(emb [B, P_ex, d_llm], pos [B]) describing where each sample's example
+        embeddings replace the placeholder (pad) tokens that reserve their rows in `ids`."""
         if self.fixed_prompt_ids is not None:
-            return self.fixed_prompt_ids.to(device=device, dtype=torch.int32)
+            return self.fixed_prompt_ids.to(device=device, dtype=torch.int32), None
         prompts = self.build_prompt(inputs)
         if len(prompts[0]) == 0:
-            return None
+            return None, None
         tok = self._get_tokenizer()
-        for parts in prompts:
-            for p in parts:
-                if not isinstance(p, str):
-                    raise NotImplementedError("'examples' prompting (tensor parts inside the prompt) is a 'next' row (DESIGN.md)")
         # each part is tokenised separately (R:models/medtsllm.py:300-301); the per-sample statistics strings are new on
         # every step, so all uncached parts of the batch go through ONE batched tokenizer call
         if len(self._id_cache) > 8192:
             self._id_cache.clear()
-        new = sorted({p for parts in prompts for p in parts if p not in self._id_cache})
+        new = sorted({p for parts in prompts for p in parts if isinstance(p, str) and p not in self._id_cache})
         if new:
             for p, ids in zip(new, tok(new, padding=False, truncation=False).input_ids):
                 self._id_cache[p] = ids
-        id_lists = [[self._id_cache[p] for p in parts] for parts in prompts]
-        rows = P.left_pad_ids(id_lists, tok.pad_token_id)
-        if all(r == rows[0] for r in rows):
-            rows = rows[:1]                       # one shared prompt: the kernel broadcasts it
-        return torch.tensor(rows, dtype=torch.int32, device=device)
+        tensors = [[p for p in parts if not isinstance(p, str)] for parts in prompts]
+        splice = None
+        if any(tensors):
+            # tensor parts go through encode_ts like the main input (R: encode_part); one per sample, equal shapes
+            if any(len(t) != 1 for t in tensors) or self.covariate_mode in ("independent", "merge-end"):
+                raise NotImplementedError("'examples' prompting: exactly one tensor part per sample, and a covariate mode "
+                                          "whose encode_ts keeps the batch size (the reference's own concat fails otherwise)")
+            ex = torch.cat([t[0].to(device) for t in tensors], dim=0)
+            emb = self.encode_ts(ex)[0]                                   # [B, P_ex, d_llm] bf16, differentiable
+            pad = [tok.pad_token_id] * emb.shape[1]
+            id_lists = [[self._id_cache[p] if isinstance(p, str) else pad for p in parts] for parts in prompts]
+            rows = P.left_pad_ids(id_lists, tok.pad_token_id)
+            pos = []
+            for parts, ids, row in zip(prompts, id_lists, rows):
+                k = next(i for i, p in enumerate(parts) if not isinstance(p, str))
+                pos.append(len(row) - sum(len(x) for x in ids) + sum(len(x) for x in ids[:k]))
+            splice = {"emb": emb, "pos": torch.tensor(pos, dtype=torch.long, device=device), "first": min(pos)}
+        else:
+            id_lists = [[self._id_cache[p] for p in parts] for parts in prompts]
+            rows = P.left_pad_ids(id_lists, tok.pad_token_id)
+            if all(r == rows[0] for r in rows):
+                rows = rows[:1]                       # one shared prompt: the kernel broadcasts it
+        return torch.tensor(rows, dtype=torch.int32, device=device), splice
 
     # ------------------------------------------------------------------ forward
     def forward(self, inputs):
@@ -359,14 +376,23 @@ class MedTsLLM(nn.Module):
         if self.device is None:
             self.device = x_enc.device
         bb = self._ensure_backbone(x_enc.device)
-        ids = self._prompt_ids(inputs, x_enc.device)
-        x_tok, mean, stdev = self.encode_ts(x_enc)
+        ids, splice = self._prompt_ids(inputs, x_enc.device)      # (example tensors are encoded first: RevIN state is then
+        x_tok, mean, stdev = self.encode_ts(x_enc)                 #  overwritten by the main input, as in the reference)
         cm = self.covariate_mode
         if ids is not None and cm in ("independent", "merge-end") and ids.shape[0] != 1:
             ids = ids.repeat_interleave(C, dim=0)        # R:models/medtsllm.py:343-344
         h0 = AssembleFn.apply(x_tok, ids, bb.embed_f32, bb.wpe)
         # only the x_tok rows of h0 have a trainable ancestor: prompt-row gradients are dead
         n_grad = x_tok.shape[1] if self.prune_dead_prompt_grads else None
+        if splice is not None:
+            # the placeholder rows hold pad_embedding (+ wpe): adding (example - pad_embedding) puts the example there
+            emb, pos = splice["emb"], splice["pos"]
+            rows = pos[:, None] + torch.arange(emb.shape[1], device=pos.device)[None, :]
+            bidx = torch.arange(emb.shape[0], device=pos.device)[:, None].expand_as(rows)
+            delta = emb.float() - bb.embed_f32[self._get_tokenizer().pad_token_id]
+            h0 = h0.index_put((bidx, rows), delta, accumulate=True)
+            if n_grad is not None:                       # gradients are alive from the first example row on
+                n_grad = h0.shape[1] - splice["first"]
         dec = BackboneFn.apply(h0, bb, self.n_patches, n_grad)   # [B', n_patches, d_llm] (final norm on the consumed rows only)
         mode = self.embedding_downsample_mode
         if mode == "truncate":

@@ -128,13 +128,19 @@ def encode_ts(x_enc, p, word_emb, m):
 
 
 # ----------------------------------------------------------------------------- a6: prompt embedding assembly
-def prompt_embeddings(token_ids, embed_w, pad_token_id):
-    """R:models/medtsllm.py:299-311,331-337.
+def prompt_embeddings(token_ids, embed_w, pad_token_id, encode_tensor=None):
+    """R:models/medtsllm.py:299-319,331-337.
 
-    token_ids: per sample, a list of per-part id lists (each part tokenised separately). Parts are
-    concatenated, then LEFT-padded to the batch max with the pad(=eos) embedding; no attention mask.
+    token_ids: per sample, a list of parts, each tokenised separately: a list of ids, or ("examples" prompting,
+    R:models/medtsllm.py:313-319) a tensor [1, L_ex, C] that goes through encode_ts (`encode_tensor`) and contributes
+    its patch embeddings. Parts are concatenated, then LEFT-padded to the batch max with the pad(=eos) embedding; no
+    attention mask.
     """
-    seqs = [embed_w[torch.tensor([i for part in parts for i in part], dtype=torch.long)] for parts in token_ids]
+    def embed(part):
+        if torch.is_tensor(part):
+            return encode_tensor(part)[0]
+        return embed_w[torch.tensor(list(part), dtype=torch.long)]
+    seqs = [torch.cat([embed(part) for part in parts], dim=0) for parts in token_ids]
     max_len = max(s.shape[0] for s in seqs)
     pad = embed_w[pad_token_id]
     out = []
@@ -272,7 +278,8 @@ def medtsllm_forward(x_enc, p, w, bcfg, m, token_ids=None, pad_token_id=0, train
     cov = m["covariate_mode"]
     d_llm = x_tok.shape[-1]
     if token_ids is not None and len(token_ids[0]) > 0:
-        prompt = prompt_embeddings(token_ids, backbone_embed_weight(w, bcfg), pad_token_id).to(x_tok.dtype)
+        enc_ex = lambda t: encode_ts(t.to(x_enc.dtype), p, word_emb, m)[0]       # [1, P_ex', d_llm] (R: encode_part -> encode_ts)
+        prompt = prompt_embeddings(token_ids, backbone_embed_weight(w, bcfg), pad_token_id, enc_ex).to(x_tok.dtype)
     else:
         prompt = torch.zeros(B, 0, d_llm, dtype=x_enc.dtype)
     if cov in ("independent", "merge-end"):

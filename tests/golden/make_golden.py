@@ -163,6 +163,8 @@ PROMPT_CONST = {"dataset": True, "task": True, "clip": False, "input_stats": Fal
                 "input_stats_dim": 0, "input_stats_select": "all"}
 PROMPT_CLIP = {"dataset": True, "task": True, "clip": True, "input_stats": True, "examples": False,
                "input_stats_dim": "all", "input_stats_select": "all"}
+PROMPT_EXAMPLES = {"dataset": True, "task": True, "clip": False, "input_stats": True, "examples": True,
+                   "input_stats_dim": 0, "input_stats_select": "all"}
 PROMPT_NONE = {"dataset": False, "task": False, "clip": False, "input_stats": False, "examples": False,
                "input_stats_dim": 0, "input_stats_select": "all"}
 
@@ -177,6 +179,9 @@ CASES = [
     ("llama_wavg_fc",       "llama",     "forecasting",           2, 64,  3, 16,  "weighted-average", "linear", PROMPT_CONST, 0),
     ("llama_mergeend_fc",   "llama",     "forecasting",           2, 64,  3, 16,  "merge-end",   "linear",   PROMPT_CONST, 0),
     ("llamagqa_concat_fc",  "llama_gqa", "forecasting",           3, 72,  2, 24,  "concat",      "linear",   PROMPT_FULL,  0),
+    # "examples" prompting: a (text, tensor[1, L_ex, C]) pair per sample is spliced into the prompt, the tensor goes through encode_ts
+    ("gpt2_concat_fc_examples", "gpt2",  "forecasting",           2, 64,  3, 16,  "concat",      "linear",   PROMPT_EXAMPLES, 0),
+    ("llama_add_semseg_examples", "llama", "semantic_segmentation", 2, 64, 3, 64, "add",         "linear",   PROMPT_EXAMPLES, 4),
 ]
 
 
@@ -201,6 +206,10 @@ def run_case(name, kind, task, B, L, C, pred, cov, down, prompting, n_classes, l
     inputs = {"x_enc": x}
     if prompting.get("clip"):
         inputs["descriptions"] = [f"Patient {i}, lead II." for i in range(B)]
+    examples = None
+    if prompting.get("examples"):      # what datasets/ecg.py:collate_fn hands over: [(text, tensor[1, L_ex, C])] per sample
+        examples = torch.randn(B, 40, C, generator=g) * 0.7 + 0.2
+        inputs["examples"] = [("Example segment:", examples[i:i + 1]) for i in range(B)]
 
     rec = {}
     hooks = []
@@ -267,9 +276,12 @@ def run_case(name, kind, task, B, L, C, pred, cov, down, prompting, n_classes, l
 
     # ---- prompt strings / token ids (a6)
     prompts = model.build_prompt(inputs)
-    tok_ids = [[model.tokenizer(p, return_tensors="pt", padding=False, truncation=False).input_ids[0].tolist()
+    tok_ids = [[model.tokenizer(p, return_tensors="pt", padding=False, truncation=False).input_ids[0].tolist() if isinstance(p, str) else None
                 for p in parts] for parts in prompts]
+    prompts = [[p if isinstance(p, str) else "<TENSOR>" for p in parts] for parts in prompts]
     out["x_enc"] = t2n(x)
+    if examples is not None:
+        out["examples"] = t2n(examples)
 
     meta = {
         "name": name, "backbone": kind, "task": task, "B": B, "L": L, "C": C, "pred_len": pred,

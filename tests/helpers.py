@@ -10,7 +10,16 @@ GOLDEN = Path(__file__).resolve().parent / "golden"
 CASES = [
     "gpt2_concat_fc", "gpt2_indep_recon", "gpt2_interleave_ad", "gpt2_uni_seg",
     "llama_concat_semseg", "llama_add_fc", "llama_wavg_fc", "llama_mergeend_fc", "llamagqa_concat_fc",
+    "gpt2_concat_fc_examples", "llama_add_semseg_examples",     # "examples" prompting: a tensor part inside the prompt
 ]
+
+
+def prompt_parts_with_examples(meta, data):
+    """golden per-part token ids, with the "<TENSOR>" parts replaced by the sample's example tensor [1, L_ex, C]"""
+    out = []
+    for b, parts in enumerate(meta["prompt_token_ids"]):
+        out.append([torch.from_numpy(data["examples"][b:b + 1]) if ids is None else ids for ids in parts])
+    return out
 
 
 def _flat(a):

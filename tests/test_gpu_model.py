@@ -60,6 +60,9 @@ CASES = [
     ("gpt2", "segmentation", 2, 64, 1, 64, "univariate", "linear", True),
     # vocabulary > 100 000: the sub-sampled word-embedding table is a trainable parameter (Llama-3 quirk, R:models/medtsllm.py:220-222)
     ("llama_gqa_bigvocab", "reconstruction", 2, 64, 2, 64, "concat", "linear", False),
+    # "examples" prompting: a tensor part inside the prompt goes through encode_ts (R:models/medtsllm.py:313-319)
+    ("gpt2", "forecasting", 2, 64, 3, 16, "concat", "linear", "examples"),
+    ("llama", "semantic_segmentation", 2, 64, 3, 64, "add", "linear", "examples"),
 ]
 
 
@@ -72,7 +75,9 @@ def test_full_model_fwd_bwd(kind, task, B, L, C, pred, cov, down, prompt_on):
 
     cfg = hf_cfg("llama_gqa", vocab=100_100) if kind == "llama_gqa_bigvocab" else hf_cfg(kind)
     sd = random_state_dict(cfg, seed=7, std=0.06)
-    prompting = {"dataset": prompt_on, "task": prompt_on, "clip": False, "input_stats": prompt_on, "examples": False,
+    ex_on = prompt_on == "examples"
+    prompt_on = bool(prompt_on)
+    prompting = {"dataset": prompt_on, "task": prompt_on, "clip": False, "input_stats": prompt_on, "examples": ex_on,
                  "input_stats_dim": 0, "input_stats_select": "all"}
     n_classes = 4 if task == "semantic_segmentation" else 0
     config = dict_to_object(model_config(task, L, pred, cov, down, prompting))
@@ -89,6 +94,9 @@ def test_full_model_fwd_bwd(kind, task, B, L, C, pred, cov, down, prompt_on):
     g = torch.Generator().manual_seed(13)
     x = torch.randn(B, L, C, generator=g) * torch.tensor([1.0, 2.5, 0.3][:C]) + torch.tensor([0.5, -1.0, 3.0][:C])
     inputs = {"x_enc": x.cuda()}
+    if ex_on:
+        ex = torch.randn(B, 40, C, generator=g) * 0.7 + 0.2
+        inputs["examples"] = [("Example segment:", ex[i:i + 1].cuda()) for i in range(B)]
     pred_hip = model(inputs)
 
     # ---- oracle on the same weights / prompt ids
@@ -102,7 +110,7 @@ def test_full_model_fwd_bwd(kind, task, B, L, C, pred, cov, down, prompt_on):
         # input statistics (median / rFFT lags) are data dependent: take the strings the GPU model itself builds so that
         # both sides see byte-identical prompts (CPU vs GPU FFT round-off can reorder near-tied top-k lags)
         parts = model.build_prompt(inputs)
-        tok_ids = [[model.tokenizer(s, padding=False, truncation=False).input_ids for s in ps] for ps in parts]
+        tok_ids = [[model.tokenizer(s, padding=False, truncation=False).input_ids if isinstance(s, str) else s.cpu() for s in ps] for ps in parts]
     meta = {"task": task, "pred_len": pred, "patch_len": 16, "stride": 8, "n_heads": 2, "d_ff": 64, "covariate_mode": cov,
             "embedding_downsample_mode": down, "n_classes": n_classes, "C": C}
     m = oracle_mcfg(meta)

@@ -45,10 +45,18 @@ def test_prompt_strings_and_token_ids_exact(name):
     inputs = {"x_enc": torch.from_numpy(data["x_enc"])}
     if meta["descriptions"]:
         inputs["descriptions"] = meta["descriptions"]
+    if "examples" in data:
+        inputs["examples"] = [("Example segment:", torch.from_numpy(data["examples"][b:b + 1])) for b in range(meta["B"])]
     parts = model.build_prompt(inputs)
+    if "examples" in data:      # the tensor part sits where the reference puts it
+        for b, ps in enumerate(parts):
+            assert sum(torch.is_tensor(p) for p in ps) == 1 and torch.equal(next(p for p in ps if torch.is_tensor(p)), inputs["examples"][b][1])
+    parts = [[p if isinstance(p, str) else "<TENSOR>" for p in ps] for ps in parts]
     assert parts == meta["prompts"]
-    ids = [[model.tokenizer(p, padding=False, truncation=False).input_ids for p in ps] for ps in parts]
+    ids = [[model.tokenizer(p, padding=False, truncation=False).input_ids if p != "<TENSOR>" else None for p in ps] for ps in parts]
     assert ids == meta["prompt_token_ids"]
+    if "examples" in data:
+        return
     assert model.task_description == meta["task_description"]
     if parts[0]:
         from med_ts_llm_amd.models.prompt import left_pad_ids

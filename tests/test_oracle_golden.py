@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import medtsllm_oracle as O
-from helpers import CASES, load_case, oracle_mcfg, golden_loss, rel_err, abs_err, GOLDEN
+from helpers import CASES, load_case, oracle_mcfg, golden_loss, rel_err, abs_err, GOLDEN, prompt_parts_with_examples
 
 TOL = 1e-5
 
@@ -29,7 +29,7 @@ def test_forward_backward_vs_reference(name):
     m = oracle_mcfg(meta)
     p = {k[len("param."):]: torch.from_numpy(v).clone().requires_grad_(True) for k, v in data.items() if k.startswith("param.")}
     x = torch.from_numpy(data["x_enc"])
-    tok = meta["prompt_token_ids"]
+    tok = prompt_parts_with_examples(meta, data) if "examples" in data else meta["prompt_token_ids"]
 
     mean, stdev = O.revin_stats(x)
     assert rel_err(mean, data["revin_mean"]) < 1e-6
