@@ -129,10 +129,12 @@ class BaseTask(ABC):
 
         def mk(ds, train):
             sampler = None
-            if self.world_size > 1:
+            # evaluation is not sharded: window stitching (tasks/evalpath.py) needs every window in order, so each rank
+            # scores the full split (identical results on all ranks, no collective in the eval path)
+            if self.world_size > 1 and train:
                 sampler = DistributedSampler(ds, num_replicas=self.world_size, rank=self.rank, shuffle=train and shuffle,
                                              seed=self.config.setup.seed, drop_last=train)
-            return DataLoader(ds, batch_size=bs // self.world_size if self.world_size > 1 else bs, collate_fn=collate,
+            return DataLoader(ds, batch_size=bs // self.world_size if (self.world_size > 1 and train) else bs, collate_fn=collate,
                               shuffle=(train and shuffle and sampler is None), sampler=sampler, num_workers=nw,
                               pin_memory=(self.device.type == "cuda"), drop_last=(train and self.world_size > 1))
 
