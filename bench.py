@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GPT2_SMALL = {"model_type": "gpt2", "vocab_size": 50257, "n_positions": 1024, "n_embd": 768, "n_layer": 12, "n_head": 12,
-              "layer_norm_epsilon": 1e-5}
+              "layer_norm_epsilon": 1e-5, "embd_pdrop": 0.1, "attn_pdrop": 0.1, "resid_pdrop": 0.1}    # the released gpt2 config
 LLAMA2_7B = {"model_type": "llama", "vocab_size": 32000, "hidden_size": 4096, "intermediate_size": 11008, "num_hidden_layers": 32,
              "num_attention_heads": 32, "num_key_value_heads": 32, "rms_norm_eps": 1e-5, "rope_theta": 10000.0}
 LLAMA3_8B = {"model_type": "llama", "vocab_size": 128256, "hidden_size": 4096, "intermediate_size": 14336, "num_hidden_layers": 32,
@@ -203,6 +203,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--full-backward", action="store_true", help="also compute the (unused) prompt-row input gradients")
     ap.add_argument("--replicate-mapping", action="store_true", help="DP: keep the mapping layer replicated (all-reduce its gradient)")
+    ap.add_argument("--no-llm-dropout", action="store_true", help="GPT-2: switch the frozen LLM's train-mode dropouts (0.1) off")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the HIP multi-tensor Adam")
     args = ap.parse_args()
 
@@ -229,6 +230,7 @@ def main():
     prompt_ids = torch.randint(0, hf_cfg["vocab_size"], (1, n_tok), generator=torch.Generator().manual_seed(1), dtype=torch.int32)
     model.fixed_prompt_ids = prompt_ids
     model.prune_dead_prompt_grads = not args.full_backward
+    model.llm_dropout = not args.no_llm_dropout
     model.train()
     sharded = world > 1 and not args.replicate_mapping and model.shard_mapping_layer(rank, world)
     params = [p for p in model.parameters() if p.requires_grad]

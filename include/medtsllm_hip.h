@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MTL_ABI_VERSION 1
+#define MTL_ABI_VERSION 2
 
 enum { MTL_OK = 0, MTL_ERR_ARG = -1, MTL_ERR_ALIGN = -2, MTL_ERR_UNSUPPORTED = -3, MTL_ERR_LAUNCH = -4,
        MTL_ERR_WORKSPACE = -5 };
@@ -88,6 +88,10 @@ typedef struct {
     float alpha;
     int split_k;                     /* >1: fp32 partial slabs in `workspace`, reduced by a second kernel    */
     void* workspace; size_t workspace_bytes;
+    /* MTL_EPI_RESID only: C = aux_in + dropout(v) (GPT-2 resid_pdrop, HF:models/gpt2/modeling_gpt2.py:243,330,397):
+     * keep mask = mtl counter hash of (drop_seed, physical C row, column) >= drop_p * 2^32, kept values / (1 - drop_p).
+     * drop_p == 0 -> off. The backward regenerates the mask from the same triple (mtl_norm_bwd). */
+    float drop_p; uint32_t drop_seed;
 } mtl_gemm_args;
 size_t mtl_gemm_workspace_bytes(int64_t M, int64_t N, int split_k);
 int mtl_gemm_nt(const mtl_gemm_args* args, void* stream);
@@ -192,7 +196,13 @@ int mtl_norm_fwd(const float* x, const float* gamma, const float* beta, void* y,
  * full-size forward), logical otherwise (statistics saved by a gathered forward). */
 int mtl_norm_bwd(const void* dy, int64_t ld_dy, const float* x, const float* gamma, const float* stats,
                  const float* dres_in, float* dres_out, void* dres_out_bf16, int64_t M, int64_t d, int rms,
-                 int64_t group_rows, int64_t group_stride, int64_t row_offset, int stats_physical, void* stream);
+                 int64_t group_rows, int64_t group_stride, int64_t row_offset, int stats_physical,
+                 float bf16_drop_p, uint32_t bf16_drop_seed, void* stream);
+/* (bf16_drop_p > 0: the bf16 copy is dropout'(dres_out) with the keep mask of (seed, physical row, column) — the gradient
+ *  that flows into the residual branch whose forward output was dropped with that mask; dres_out itself stays unmasked.)
+ * Plain dropout of an f32 [M, d] matrix with the same counter hash (GPT-2 embd_pdrop on inputs_embeds + wpe,
+ * HF:models/gpt2/modeling_gpt2.py:579; its own backward: apply it to the gradient). x may alias y. */
+int mtl_dropout_f32(const float* x, float* y, int64_t M, int64_t d, float p, uint32_t seed, void* stream);
 
 /* ------------------------------------------------------------------ Llama elementwise
  * RoPE, half-split rotate_half form (HF:models/llama/modeling_llama.py:130-160), in place on the q and k
@@ -226,7 +236,9 @@ int mtl_assemble_llm_input(const int32_t* ids, int64_t ids_B, const float* embed
  * (the kernels above chained on `stream`, no host work in between). Replaces
  * self.llm(inputs_embeds=enc).last_hidden_state (R:models/medtsllm.py:350) = HF GPT2Model.forward
  * (HF:models/gpt2/modeling_gpt2.py:514-628) / LlamaModel.forward (HF:models/llama/modeling_llama.py:367-417),
- * eager attention semantics (R:models/medtsllm.py:159-160 always selects "eager"), all dropouts off.
+ * eager attention semantics (R:models/medtsllm.py:159-160 always selects "eager"). GPT-2's train-mode dropouts
+ * (attn_pdrop on the attention probabilities, resid_pdrop on both residual branches) are applied when a
+ * mtl_backbone_dropout is passed; embd_pdrop is the caller's (mtl_dropout_f32 on h0).
  * Weights: bf16 [out, in] row-major plus the transposed copy [in, out] (frozen, prepared once);
  * per-layer pointer arrays live in HOST memory. */
 enum { MTL_ARCH_GPT2 = 0, MTL_ARCH_LLAMA = 1 };
@@ -243,20 +255,22 @@ typedef struct {
     const float* lnf_w; const float* lnf_b;
     const float* rope_cos; const float* rope_sin;                                         /* llama: f32 [T, hd]       */
 } mtl_backbone_weights;
+typedef struct { float attn_p, resid_p; uint32_t seed; } mtl_backbone_dropout;   /* per-layer seeds are derived from `seed` */
 /* bytes of the `saved` buffer (activations kept for the backward) and of the scratch `work` buffer */
 size_t mtl_backbone_saved_bytes(const mtl_backbone_weights* w, int64_t B, int64_t T);
 size_t mtl_backbone_work_bytes(const mtl_backbone_weights* w, int64_t B, int64_t T);
 /* h0 f32 [B, T, d] (input embeddings, wpe already added for GPT-2). out bf16 [B, n_last, d]: final norm applied
  * to the last n_last tokens of every sample (only those are consumed downstream, R:models/medtsllm.py:353). */
 int mtl_backbone_fwd(const mtl_backbone_weights* w, const float* h0, void* out, void* saved, void* work,
-                     int64_t B, int64_t T, int64_t n_last, void* stream);
+                     int64_t B, int64_t T, int64_t n_last, const mtl_backbone_dropout* drop /* NULL: off */, void* stream);
 /* dout bf16 [B, n_last, d] -> dh0 f32 [B, T, d]. `saved` from the matching forward.
  * n_grad (n_last <= n_grad <= T): only the LAST n_grad tokens of every sample receive a gradient; rows before that are
  * left zero. The leading tokens are the text prompt: causal attention never lets them see a patch token, so they are
  * independent of every trainable parameter and their gradient is never consumed (SURVEY.md §7 "legal shortcut ii").
  * All backward GEMMs / norms / attention then run on B*n_grad rows. n_grad = T computes the full dh0. */
 int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, const void* dout, float* dh0, void* saved,
-                     void* work, int64_t B, int64_t T, int64_t n_last, int64_t n_grad, void* stream);
+                     void* work, int64_t B, int64_t T, int64_t n_last, int64_t n_grad,
+                     const mtl_backbone_dropout* drop /* the forward's */, void* stream);
 
 #ifdef __cplusplus
 }

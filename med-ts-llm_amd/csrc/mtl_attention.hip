@@ -94,16 +94,6 @@ __device__ __forceinline__ void load_tile(bf16_t* tile, const bf16_t* src, int64
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 
-// attention dropout: counter-based keep mask, a pure function of (seed, batch*head, query, key) so the backward kernels
-// regenerate exactly the forward's mask (tests/test_gpu_kernels.py replicates the hash on the host).
-__device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint32_t bh, uint32_t q, uint32_t key) {
-    uint32_t h = seed ^ (bh * 0x9E3779B1u);
-    h = (h ^ (q * 0x85EBCA77u)) * 0xC2B2AE3Du;
-    h = (h ^ (h >> 15) ^ (key * 0x27D4EB2Fu)) * 0x165667B1u;
-    h ^= h >> 13; h *= 0x85EBCA6Bu; h ^= h >> 16;
-    return h;
-}
-
 // =============================================================================================== forward
 template <int D, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a) {
@@ -131,7 +121,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a
     // running max is kept in the exp2 domain: m2 = max(score) * scale * log2(e); p = exp2(s * c - m2): one FMA + v_exp_f32
     const float c = a.scale * LOG2E;
     float m_run = NEG_BIG, l_run = 0.f;
-    const uint32_t drop_thr = DROP ? (uint32_t)fminf(a.dropout_p * 4294967296.0f, 4294967040.0f) : 0u;
+    const uint32_t drop_thr = DROP ? drop_threshold(a.dropout_p) : 0u;
     const float drop_scale = DROP ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
     const uint32_t bh = (uint32_t)(b * a.Hq + h);
 
@@ -206,7 +196,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const uint32_t key = (uint32_t)(kb + t * 16 + g * 4 + r);
-                        p[t][r] = drop_hash(a.dropout_seed, bh, (uint32_t)qrow, key) >= drop_thr ? p[t][r] * drop_scale : 0.f;
+                        p[t][r] = drop_hash(a.dropout_seed, bh, (uint32_t)(qrow + coff), key) >= drop_thr ? p[t][r] * drop_scale : 0.f;   // absolute query index
                     }
             }
             const bf16x8 pf = pack8(p[0], p[1]);
@@ -270,7 +260,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
     if (g == 0 && q_valid) a.delta[stat_idx] = dl;
     const float c = f.scale * LOG2E;
     const float lse2 = f.lse[stat_idx] * LOG2E;   // exp(s*scale - lse) == exp2(s*c - lse2)
-    const uint32_t drop_thr = DROP ? (uint32_t)fminf(f.dropout_p * 4294967296.0f, 4294967040.0f) : 0u;
+    const uint32_t drop_thr = DROP ? drop_threshold(f.dropout_p) : 0u;
     const float drop_scale = DROP ? 1.0f / (1.0f - f.dropout_p) : 1.0f;
     const uint32_t bh = (uint32_t)(b * f.Hq + h);
 
@@ -313,7 +303,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
                     const bool masked = key >= f.Tk || (CAUSAL && key > qrow + coff);
                     const float p = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse2);
                     float dpv = dp[r];
-                    if (DROP) dpv = drop_hash(f.dropout_seed, bh, (uint32_t)qrow, (uint32_t)key) >= drop_thr ? dpv * drop_scale : 0.f;
+                    if (DROP) dpv = drop_hash(f.dropout_seed, bh, (uint32_t)(qrow + coff), (uint32_t)key) >= drop_thr ? dpv * drop_scale : 0.f;
                     ds[t][r] = p * (dpv - dl);
                 }
             }
@@ -361,7 +351,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const mtl_attn_bwd_ar
     if (krow > f.Tk - 1) krow = f.Tk - 1;
 
     const float c = f.scale * LOG2E;
-    const uint32_t drop_thr = DROP ? (uint32_t)fminf(f.dropout_p * 4294967296.0f, 4294967040.0f) : 0u;
+    const uint32_t drop_thr = DROP ? drop_threshold(f.dropout_p) : 0u;
     const float drop_scale = DROP ? 1.0f / (1.0f - f.dropout_p) : 1.0f;
     f32x4 dk[NDT], dv[NDT];
 #pragma unroll
@@ -420,7 +410,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const mtl_attn_bwd_ar
                             const bool masked = q >= f.Tq || (CAUSAL && krow > q + coff);
                             const float pv = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse_s[ql]);
                             float keep = 1.0f;
-                            if (DROP) keep = drop_hash(f.dropout_seed, (uint32_t)(b * f.Hq + h), (uint32_t)q, (uint32_t)krow) >= drop_thr ? drop_scale : 0.f;
+                            if (DROP) keep = drop_hash(f.dropout_seed, (uint32_t)(b * f.Hq + h), (uint32_t)(q + coff), (uint32_t)krow) >= drop_thr ? drop_scale : 0.f;
                             p[t][r] = pv * keep;                               // feeds dV = (dropped P)^T dO
                             ds[t][r] = pv * (dp[r] * keep - delta_s[ql]);      // feeds dK
                         }
@@ -860,9 +850,10 @@ extern "C" int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream) {
     }
     const dim3 grid((unsigned)((a->Tq + 63) / 64), (unsigned)a->Hq, (unsigned)a->B), block(256);
     const bool drop = a->dropout_p > 0.f;
-    if (drop && (a->dropout_p >= 1.f || a->causal)) return MTL_ERR_UNSUPPORTED;   // dropout: reprogramming (non-causal) attention only
+    if (drop && a->dropout_p >= 1.f) return MTL_ERR_UNSUPPORTED;
 #define MTL_FWD(DD)                                                                                        \
-    if (a->causal) hipLaunchKernelGGL((attn_fwd_kernel<DD, true, false>), grid, block, 0, st, *a);         \
+    if (a->causal && drop) hipLaunchKernelGGL((attn_fwd_kernel<DD, true, true>), grid, block, 0, st, *a);  \
+    else if (a->causal) hipLaunchKernelGGL((attn_fwd_kernel<DD, true, false>), grid, block, 0, st, *a);    \
     else if (drop) hipLaunchKernelGGL((attn_fwd_kernel<DD, false, true>), grid, block, 0, st, *a);         \
     else hipLaunchKernelGGL((attn_fwd_kernel<DD, false, false>), grid, block, 0, st, *a)
     if (a->D == 32) { MTL_FWD(32); } else if (a->D == 64) { MTL_FWD(64); } else { MTL_FWD(128); }
@@ -913,9 +904,12 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
     if (a->kv_row0 < 0 || a->kv_row0 >= f.Tk) return MTL_ERR_ARG;
     const dim3 gk((unsigned)((f.Tk - a->kv_row0 + 63) / 64), (unsigned)f.Hkv, (unsigned)(f.k_bs == 0 ? splits : f.B));
     const bool drop = f.dropout_p > 0.f;
-    if (drop && (f.dropout_p >= 1.f || f.causal)) return MTL_ERR_UNSUPPORTED;
+    if (drop && f.dropout_p >= 1.f) return MTL_ERR_UNSUPPORTED;
 #define MTL_BWD(DD)                                                                                        \
-    if (f.causal) {                                                                                        \
+    if (f.causal && drop) {                                                                                \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, true, true>), gq, block, 0, st, *a);                    \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<DD, true, true>), gk, block, 0, st, *a);                   \
+    } else if (f.causal) {                                                                                 \
         hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, true, false>), gq, block, 0, st, *a);                   \
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<DD, true, false>), gk, block, 0, st, *a);                  \
     } else if (drop) {                                                                                     \

@@ -76,8 +76,9 @@ const RowMap kIdentity = {0, 0, 0};
 
 int gemm(const void* A, int64_t lda, const void* Bm, int64_t ldb, void* C, int64_t ldc, int cdt, int64_t M, int64_t N, int64_t K,
          const float* bias, int epi, const void* aux_in, int64_t ld_aux_in, void* aux_out, int64_t ld_aux_out, void* stream,
-         RowMap am = kIdentity, RowMap cm = kIdentity) {
+         RowMap am = kIdentity, RowMap cm = kIdentity, float drop_p = 0.f, uint32_t drop_seed = 0u) {
     mtl_gemm_args g = {};
+    g.drop_p = drop_p; g.drop_seed = drop_seed;
     g.a_group_rows = am.rows; g.a_group_stride = am.stride; g.a_row_offset = am.offset;
     g.c_group_rows = cm.rows; g.c_group_stride = cm.stride; g.c_row_offset = cm.offset;
     g.A = A; g.lda = lda; g.B = Bm; g.ldb = ldb; g.C = C; g.ldc = ldc; g.c_dtype = cdt;
@@ -131,8 +132,12 @@ extern "C" size_t mtl_backbone_work_bytes(const mtl_backbone_weights* w, int64_t
 }
 
 extern "C" int mtl_backbone_fwd(const mtl_backbone_weights* w, const float* h0, void* out, void* saved, void* work, int64_t B,
-                                int64_t T, int64_t n_last, void* stream) {
+                                int64_t T, int64_t n_last, const mtl_backbone_dropout* drop, void* stream) {
     MTL_TRY(check_weights(w));
+    // GPT-2 train-mode dropouts (HF:models/gpt2/modeling_gpt2.py:65,243,397): attention probabilities + both residual branches
+    const float attn_p = drop ? drop->attn_p : 0.f, resid_p = drop ? drop->resid_p : 0.f;
+    const uint32_t dseed = drop ? drop->seed : 0u;
+    if (attn_p < 0.f || attn_p >= 1.f || resid_p < 0.f || resid_p >= 1.f) return MTL_ERR_ARG;
     if (!h0 || !out || !saved || !work || B <= 0 || T <= 0 || n_last <= 0 || n_last > T) return MTL_ERR_ARG;
     const Dims D = dims_of(w, B, T);
     const SavedLayout S = saved_layout(D, T);
@@ -160,8 +165,10 @@ extern "C" int mtl_backbone_fwd(const mtl_backbone_weights* w, const float* h0, 
         if (D.llama) MTL_TRY(mtl_rope_inplace(qkv, D.Nqkv, w->rope_cos, w->rope_sin, D.M, D.T, D.Hq + D.Hkv, D.hd, 0, stream));
         mtl_attn_fwd_args fa = {};
         attn_args(D, qkv, attn, lse, &fa);
+        fa.dropout_p = attn_p; fa.dropout_seed = drop_site_seed(dseed, i, 0);
         MTL_TRY(mtl_attention_fwd(&fa, stream));
-        MTL_TRY(gemm(attn, D.No, w->w_o[i], D.No, H(2 * i + 1), D.d, MTL_F32, D.M, D.d, D.No, bo, MTL_EPI_RESID, H(2 * i), D.d, nullptr, 0, stream));
+        MTL_TRY(gemm(attn, D.No, w->w_o[i], D.No, H(2 * i + 1), D.d, MTL_F32, D.M, D.d, D.No, bo, MTL_EPI_RESID, H(2 * i), D.d, nullptr, 0, stream,
+                     kIdentity, kIdentity, resid_p, drop_site_seed(dseed, i, 1)));
         // --- MLP block
         MTL_TRY(mtl_norm_fwd(H(2 * i + 1), w->ln2_w[i], w->ln2_b ? w->ln2_b[i] : nullptr, wk + W.xln, D.d, st2, D.M, D.d, w->eps, rms, 0, 0, 0, stream));
         if (D.llama) {
@@ -170,15 +177,19 @@ extern "C" int mtl_backbone_fwd(const mtl_backbone_weights* w, const float* h0, 
         } else {
             MTL_TRY(gemm(wk + W.xln, D.d, w->w_fc[i], D.d, wk + W.act, D.ffn, MTL_BF16, D.M, D.ffn, D.d, bf, MTL_EPI_GELU, nullptr, 0, fc, D.ffn, stream));
         }
-        MTL_TRY(gemm(wk + W.act, D.ffn, w->w_proj[i], D.ffn, H(2 * i + 2), D.d, MTL_F32, D.M, D.d, D.ffn, bp, MTL_EPI_RESID, H(2 * i + 1), D.d, nullptr, 0, stream));
+        MTL_TRY(gemm(wk + W.act, D.ffn, w->w_proj[i], D.ffn, H(2 * i + 2), D.d, MTL_F32, D.M, D.d, D.ffn, bp, MTL_EPI_RESID, H(2 * i + 1), D.d, nullptr, 0, stream,
+                     kIdentity, kIdentity, resid_p, drop_site_seed(dseed, i, 2)));
     }
     float* stf = reinterpret_cast<float*>(sv + S.stats_f);
     return mtl_norm_fwd(H(2 * D.L), w->lnf_w, w->lnf_b, out, D.d, stf, D.B * n_last, D.d, w->eps, rms, n_last, D.T, D.T - n_last, stream);
 }
 
 extern "C" int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, const void* dout, float* dh0, void* saved, void* work,
-                                int64_t B, int64_t T, int64_t n_last, int64_t n_grad, void* stream) {
+                                int64_t B, int64_t T, int64_t n_last, int64_t n_grad, const mtl_backbone_dropout* drop, void* stream) {
     MTL_TRY(check_weights(w));
+    const float attn_p = drop ? drop->attn_p : 0.f, resid_p = drop ? drop->resid_p : 0.f;
+    const uint32_t dseed = drop ? drop->seed : 0u;
+    if (attn_p < 0.f || attn_p >= 1.f || resid_p < 0.f || resid_p >= 1.f) return MTL_ERR_ARG;
     if (!h0 || !dout || !dh0 || !saved || !work || B <= 0 || T <= 0 || n_last <= 0 || n_last > T) return MTL_ERR_ARG;
     if (n_grad < n_last || n_grad > T) return MTL_ERR_ARG;
     const Dims D = dims_of(w, B, T);
@@ -201,7 +212,10 @@ extern "C" int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, 
         if (hipMemsetAsync(wk + W.dres_b, 0, (size_t)D.M * D.d * 2, st) != hipSuccess) return MTL_ERR_LAUNCH;
     }
     const float* stf = reinterpret_cast<const float*>(sv + S.stats_f);
-    MTL_TRY(mtl_norm_bwd(dout, D.d, H(2 * D.L), w->lnf_w, stf, nullptr, dh0, wk + W.dres_b, D.B * n_last, D.d, rms, n_last, D.T, D.T - n_last, 0, stream));
+    // the bf16 copy of the residual gradient is the A operand of the next branch's first GEMM: it carries that branch's
+    // resid_pdrop mask (the fp32 stream dh0 is the identity path and stays unmasked)
+    MTL_TRY(mtl_norm_bwd(dout, D.d, H(2 * D.L), w->lnf_w, stf, nullptr, dh0, wk + W.dres_b, D.B * n_last, D.d, rms, n_last, D.T, D.T - n_last, 0,
+                         resid_p, drop_site_seed(dseed, D.L - 1, 2), stream));
     for (int i = D.L - 1; i >= 0; --i) {
         const float* st1 = reinterpret_cast<const float*>(sv + S.stats + S.stats_stride * (size_t)(2 * i));
         const float* st2 = reinterpret_cast<const float*>(sv + S.stats + S.stats_stride * (size_t)(2 * i + 1));
@@ -219,11 +233,13 @@ extern "C" int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, 
         }
         MTL_TRY(gemm(wk + W.dact, D.Nfc, w->w_fc_t[i], D.Nfc, wk + W.dx, D.d, MTL_BF16, Mg, D.d, D.Nfc, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream,
                      D.llama ? kIdentity : rm));
-        MTL_TRY(mtl_norm_bwd(wk + W.dx, D.d, H(2 * i + 1), w->ln2_w[i], st2, dh0, dh0, wk + W.dres_b, Mg, D.d, rms, rm.rows, rm.stride, rm.offset, 1, stream));
+        MTL_TRY(mtl_norm_bwd(wk + W.dx, D.d, H(2 * i + 1), w->ln2_w[i], st2, dh0, dh0, wk + W.dres_b, Mg, D.d, rms, rm.rows, rm.stride, rm.offset, 1,
+                             resid_p, drop_site_seed(dseed, i, 1), stream));
         // --- attention block backward: h_mid = h_in + o_proj(attn(qkv(norm1(h_in))))
         MTL_TRY(gemm(wk + W.dres_b, D.d, w->w_o_t[i], D.d, wk + W.dO, D.No, MTL_BF16, Mg, D.No, D.d, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream, rm, rm));
         mtl_attn_bwd_args ba = {};
         attn_args(D, qkv, attn, lse, &ba.f);
+        ba.f.dropout_p = attn_p; ba.f.dropout_seed = drop_site_seed(dseed, i, 0);
         bf16_t* dq = reinterpret_cast<bf16_t*>(wk + W.dqkv);
         // queries = the last n_grad rows (they see every key); dK/dV only for keys >= r0, fed by those queries only
         ba.f.q = reinterpret_cast<const bf16_t*>(ba.f.q) + r0 * ba.f.q_ts;
@@ -239,7 +255,8 @@ extern "C" int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, 
         MTL_TRY(mtl_attention_bwd(&ba, stream));
         if (D.llama) MTL_TRY(mtl_rope_inplace_rows(wk + W.dqkv, D.Nqkv, w->rope_cos, w->rope_sin, Mg, D.T, D.Hq + D.Hkv, D.hd, 1, rm.rows, rm.stride, rm.offset, stream));
         MTL_TRY(gemm(wk + W.dqkv, D.Nqkv, w->w_qkv_t[i], D.Nqkv, wk + W.dx, D.d, MTL_BF16, Mg, D.d, D.Nqkv, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream, rm));
-        MTL_TRY(mtl_norm_bwd(wk + W.dx, D.d, H(2 * i), w->ln1_w[i], st1, dh0, dh0, wk + W.dres_b, Mg, D.d, rms, rm.rows, rm.stride, rm.offset, 1, stream));
+        MTL_TRY(mtl_norm_bwd(wk + W.dx, D.d, H(2 * i), w->ln1_w[i], st1, dh0, dh0, wk + W.dres_b, Mg, D.d, rms, rm.rows, rm.stride, rm.offset, 1,
+                             i > 0 ? resid_p : 0.f, drop_site_seed(dseed, i - 1, 2), stream));
     }
     return MTL_OK;
 }

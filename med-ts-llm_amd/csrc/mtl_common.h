@@ -58,6 +58,21 @@ __device__ __forceinline__ float dgelu_new_f(float x) {
     return s + x * s * (1.0f - s) * (2.0f * k0 * (1.0f + 3.0f * k1 * x2));
 }
 
+// dropout: counter-based keep mask, a pure function of (seed, a, b, c) so that a backward kernel regenerates exactly the
+// forward's mask; tests replicate the hash on the host. Attention: (seed, batch*head, query, key); matrices: (seed, 0, row, col).
+__device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint32_t bh, uint32_t q, uint32_t key) {
+    uint32_t h = seed ^ (bh * 0x9E3779B1u);
+    h = (h ^ (q * 0x85EBCA77u)) * 0xC2B2AE3Du;
+    h = (h ^ (h >> 15) ^ (key * 0x27D4EB2Fu)) * 0x165667B1u;
+    h ^= h >> 13; h *= 0x85EBCA6Bu; h ^= h >> 16;
+    return h;
+}
+__host__ __device__ __forceinline__ uint32_t drop_threshold(float p) { return (uint32_t)fminf(p * 4294967296.0f, 4294967040.0f); }
+// seed of layer i's k-th dropout site (k = 0 attention probabilities, 1 attention-branch residual, 2 MLP-branch residual)
+__host__ __device__ __forceinline__ uint32_t drop_site_seed(uint32_t seed, int layer, int k) {
+    return seed ^ (0x9E3779B9u * (uint32_t)(3 * layer + k + 1));
+}
+
 #define MTL_CHECK_LAUNCH()                                   \
     do {                                                     \
         hipError_t e__ = hipGetLastError();                  \

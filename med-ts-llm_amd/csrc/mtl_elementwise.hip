@@ -317,6 +317,33 @@ extern "C" int mtl_revin_denorm(const float* y, const float* mean, const float* 
     return MTL_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void dropout_f32_kernel(const float* x, float* y, int64_t M, int d, uint32_t thr, float scale, uint32_t seed) {
+    const int64_t nq = (int64_t)M * (d / 4);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / (d / 4);
+        const int c = (int)(i - row * (d / 4)) * 4;
+        float4 v = *reinterpret_cast<const float4*>(x + row * d + c);
+        v.x = drop_hash(seed, 0u, (uint32_t)row, (uint32_t)c) >= thr ? v.x * scale : 0.f;
+        v.y = drop_hash(seed, 0u, (uint32_t)row, (uint32_t)(c + 1)) >= thr ? v.y * scale : 0.f;
+        v.z = drop_hash(seed, 0u, (uint32_t)row, (uint32_t)(c + 2)) >= thr ? v.z * scale : 0.f;
+        v.w = drop_hash(seed, 0u, (uint32_t)row, (uint32_t)(c + 3)) >= thr ? v.w * scale : 0.f;
+        *reinterpret_cast<float4*>(y + row * d + c) = v;
+    }
+}
+}  // namespace
+
+extern "C" int mtl_dropout_f32(const float* x, float* y, int64_t M, int64_t d, float p, uint32_t seed, void* stream) {
+    if (!x || !y || M <= 0 || d <= 0 || p < 0.f || p >= 1.f) return MTL_ERR_ARG;
+    if (d % 4 != 0) return MTL_ERR_ALIGN;
+    const int64_t nq = M * (d / 4);
+    const unsigned blocks = (unsigned)((nq + 255) / 256 < 8192 ? (nq + 255) / 256 : 8192);
+    hipLaunchKernelGGL(dropout_f32_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y, M, (int)d,
+                       drop_threshold(p), 1.0f / (1.0f - p), seed);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
 extern "C" int mtl_abi_version(void) { return MTL_ABI_VERSION; }
 
 extern "C" const char* mtl_strerror(int code) {

@@ -75,13 +75,20 @@ __device__ __forceinline__ void epilogue4(const mtl_gemm_args& p, int64_t m, int
     } else if constexpr (EPI == MTL_EPI_RESID) {
         // v is rounded to bf16 first (a bf16 Linear output) and then added to the fp32 residual stream
         const float* r = reinterpret_cast<const float*>(p.aux_in) + crow * p.ld_aux_in + n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = bf16_to_f32(f32_to_bf16(o[e]));
+        if (p.drop_p > 0.f) {   // resid_pdrop: same (seed, physical row, column) hash as epilogue_wave
+            const uint32_t thr = drop_threshold(p.drop_p);
+            const float sc = 1.0f / (1.0f - p.drop_p);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = drop_hash(p.drop_seed, 0u, (uint32_t)crow, (uint32_t)(n + e)) >= thr ? o[e] * sc : 0.f;
+        }
         if (vec_ok) {
             const float4 r4 = *reinterpret_cast<const float4*>(r);
-            o[0] = r4.x + bf16_to_f32(f32_to_bf16(o[0])); o[1] = r4.y + bf16_to_f32(f32_to_bf16(o[1]));
-            o[2] = r4.z + bf16_to_f32(f32_to_bf16(o[2])); o[3] = r4.w + bf16_to_f32(f32_to_bf16(o[3]));
+            o[0] += r4.x; o[1] += r4.y; o[2] += r4.z; o[3] += r4.w;
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (e < nvalid) o[e] = r[e] + bf16_to_f32(f32_to_bf16(o[e]));
+            for (int e = 0; e < 4; ++e) if (e < nvalid) o[e] += r[e];
         }
     } else if constexpr (EPI == MTL_EPI_DGELU) {
         const bf16_t* h = reinterpret_cast<const bf16_t*>(p.aux_in) + crow * p.ld_aux_in + n;
@@ -192,8 +199,15 @@ __device__ __forceinline__ void epilogue_wave(const mtl_gemm_args& p, int64_t m_
                 o[2] = gelu_new_f(__uint_as_float(pk[1] << 16)); o[3] = gelu_new_f(__uint_as_float(pk[1] & 0xffff0000u));
             } else if constexpr (EPI == MTL_EPI_RESID) {
                 const u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};   // bf16 Linear output, then fp32 add
-                o[0] = res[ni][mi].x + __uint_as_float(pk[0] << 16); o[1] = res[ni][mi].y + __uint_as_float(pk[0] & 0xffff0000u);
-                o[2] = res[ni][mi].z + __uint_as_float(pk[1] << 16); o[3] = res[ni][mi].w + __uint_as_float(pk[1] & 0xffff0000u);
+                float v[4] = {__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u), __uint_as_float(pk[1] << 16),
+                              __uint_as_float(pk[1] & 0xffff0000u)};
+                if (p.drop_p > 0.f) {                                                      // resid_pdrop (uniform branch)
+                    const uint32_t thr = drop_threshold(p.drop_p);
+                    const float sc = 1.0f / (1.0f - p.drop_p);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = drop_hash(p.drop_seed, 0u, (uint32_t)crow[mi], (uint32_t)(n + e)) >= thr ? v[e] * sc : 0.f;
+                }
+                o[0] = res[ni][mi].x + v[0]; o[1] = res[ni][mi].y + v[1]; o[2] = res[ni][mi].z + v[2]; o[3] = res[ni][mi].w + v[3];
             } else if constexpr (EPI == MTL_EPI_DGELU) {
                 o[0] *= dgelu_new_f(__uint_as_float(hk[ni][mi][0] << 16)); o[1] *= dgelu_new_f(__uint_as_float(hk[ni][mi][0] & 0xffff0000u));
                 o[2] *= dgelu_new_f(__uint_as_float(hk[ni][mi][1] << 16)); o[3] *= dgelu_new_f(__uint_as_float(hk[ni][mi][1] & 0xffff0000u));

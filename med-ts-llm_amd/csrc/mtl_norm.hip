@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict_
                                                        const float* __restrict__ gamma, const float* __restrict__ stats,
                                                        const float* dres_in, float* dres_out, bf16_t* dres_out_bf16,
                                                        int64_t M, int d, int64_t group_rows, int64_t group_stride,
-                                                       int64_t row_offset, int stats_physical) {
+                                                       int64_t row_offset, int stats_physical, float drop_p, uint32_t drop_seed) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -124,6 +124,14 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict_
             }
             *reinterpret_cast<float4*>(dres_out + prow * (int64_t)d + c) = o;
             if (dres_out_bf16) {
+                if (drop_p > 0.f) {   // gradient entering a residual branch whose forward output was dropped with this mask
+                    const uint32_t thr = drop_threshold(drop_p);
+                    const float sc = 1.0f / (1.0f - drop_p);
+                    o.x = drop_hash(drop_seed, 0u, (uint32_t)prow, (uint32_t)c) >= thr ? o.x * sc : 0.f;
+                    o.y = drop_hash(drop_seed, 0u, (uint32_t)prow, (uint32_t)(c + 1)) >= thr ? o.y * sc : 0.f;
+                    o.z = drop_hash(drop_seed, 0u, (uint32_t)prow, (uint32_t)(c + 2)) >= thr ? o.z * sc : 0.f;
+                    o.w = drop_hash(drop_seed, 0u, (uint32_t)prow, (uint32_t)(c + 3)) >= thr ? o.w * sc : 0.f;
+                }
                 u32x2 pk = {pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w)};
                 *reinterpret_cast<u32x2*>(dres_out_bf16 + prow * (int64_t)d + c) = pk;
             }
@@ -169,8 +177,9 @@ extern "C" int mtl_norm_fwd(const float* x, const float* gamma, const float* bet
 
 extern "C" int mtl_norm_bwd(const void* dy, int64_t ld_dy, const float* x, const float* gamma, const float* stats,
                             const float* dres_in, float* dres_out, void* dres_out_bf16, int64_t M, int64_t d, int rms,
-                            int64_t group_rows, int64_t group_stride, int64_t row_offset, int stats_physical, void* stream) {
-    if (!dy || !x || !gamma || !stats || !dres_out || M <= 0 || d <= 0) return MTL_ERR_ARG;
+                            int64_t group_rows, int64_t group_stride, int64_t row_offset, int stats_physical,
+                            float bf16_drop_p, uint32_t bf16_drop_seed, void* stream) {
+    if (!dy || !x || !gamma || !stats || !dres_out || M <= 0 || d <= 0 || bf16_drop_p < 0.f || bf16_drop_p >= 1.f) return MTL_ERR_ARG;
     if (d % 4 != 0 || ld_dy % 4 != 0) return MTL_ERR_ALIGN;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((M + 3) / 4)), block(256);
@@ -178,10 +187,10 @@ extern "C" int mtl_norm_bwd(const void* dy, int64_t ld_dy, const float* x, const
         constexpr int NV = decltype(nv)::value;
         if (rms)
             hipLaunchKernelGGL((norm_bwd_kernel<NV, true>), grid, block, 0, st, (const bf16_t*)dy, ld_dy, x, gamma, stats, dres_in,
-                               dres_out, (bf16_t*)dres_out_bf16, M, (int)d, group_rows, group_stride, row_offset, stats_physical);
+                               dres_out, (bf16_t*)dres_out_bf16, M, (int)d, group_rows, group_stride, row_offset, stats_physical, bf16_drop_p, bf16_drop_seed);
         else
             hipLaunchKernelGGL((norm_bwd_kernel<NV, false>), grid, block, 0, st, (const bf16_t*)dy, ld_dy, x, gamma, stats, dres_in,
-                               dres_out, (bf16_t*)dres_out_bf16, M, (int)d, group_rows, group_stride, row_offset, stats_physical);
+                               dres_out, (bf16_t*)dres_out_bf16, M, (int)d, group_rows, group_stride, row_offset, stats_physical, bf16_drop_p, bf16_drop_seed);
         MTL_CHECK_LAUNCH();
         return MTL_OK;
     };

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("MTL_LIB_PATH") or os.path.join(_HERE, "libmedtsllm_hi
 MTL_F32, MTL_BF16 = 0, 1
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM = 0, 1, 2, 3, 4
 ARCH_GPT2, ARCH_LLAMA = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 i64, vp, f32, i32 = C.c_int64, C.c_void_p, C.c_float, C.c_int
 
@@ -28,7 +28,12 @@ class GemmArgs(C.Structure):
                 ("a_group_rows", i64), ("a_group_stride", i64), ("a_row_offset", i64),
                 ("c_group_rows", i64), ("c_group_stride", i64), ("c_row_offset", i64),
                 ("bias", vp), ("epilogue", i32), ("aux_in", vp), ("ld_aux_in", i64), ("aux_out", vp), ("ld_aux_out", i64),
-                ("alpha", f32), ("split_k", i32), ("workspace", vp), ("workspace_bytes", C.c_size_t)]
+                ("alpha", f32), ("split_k", i32), ("workspace", vp), ("workspace_bytes", C.c_size_t),
+                ("drop_p", f32), ("drop_seed", C.c_uint32)]
+
+
+class BackboneDropout(C.Structure):
+    _fields_ = [("attn_p", f32), ("resid_p", f32), ("seed", C.c_uint32)]
 
 
 class AdamTensor(C.Structure):
@@ -95,7 +100,8 @@ SIGNATURES = {
     "mtl_attention_tune": (i32, [i32]),
     "mtl_attention_bwd": (i32, [C.POINTER(AttnBwdArgs), vp]),
     "mtl_norm_fwd": (i32, [vp, vp, vp, vp, i64, vp, i64, i64, f32, i32, i64, i64, i64, vp]),
-    "mtl_norm_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, i64, i64, i32, i64, i64, i64, i32, vp]),
+    "mtl_norm_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, i64, i64, i32, i64, i64, i64, i32, f32, C.c_uint32, vp]),
+    "mtl_dropout_f32": (i32, [vp, vp, i64, i64, f32, C.c_uint32, vp]),
     "mtl_rope_inplace": (i32, [vp, i64, vp, vp, i64, i64, i64, i64, i32, vp]),
     "mtl_rope_inplace_rows": (i32, [vp, i64, vp, vp, i64, i64, i64, i64, i32, i64, i64, i64, vp]),
     "mtl_swiglu_bwd_rows": (i32, [vp, vp, vp, i64, i64, i64, i64, i64, vp]),
@@ -104,8 +110,8 @@ SIGNATURES = {
     "mtl_assemble_llm_input": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, vp]),
     "mtl_backbone_saved_bytes": (C.c_size_t, [C.POINTER(BackboneWeights), i64, i64]),
     "mtl_backbone_work_bytes": (C.c_size_t, [C.POINTER(BackboneWeights), i64, i64]),
-    "mtl_backbone_fwd": (i32, [C.POINTER(BackboneWeights), vp, vp, vp, vp, i64, i64, i64, vp]),
-    "mtl_backbone_bwd": (i32, [C.POINTER(BackboneWeights), vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]),
+    "mtl_backbone_fwd": (i32, [C.POINTER(BackboneWeights), vp, vp, vp, vp, i64, i64, i64, C.POINTER(BackboneDropout), vp]),
+    "mtl_backbone_bwd": (i32, [C.POINTER(BackboneWeights), vp, vp, vp, vp, vp, i64, i64, i64, i64, C.POINTER(BackboneDropout), vp]),
 }
 
 _lib = None

@@ -46,7 +46,7 @@ def _req(cond, msg):
 
 # =============================================================================================== raw wrappers
 def gemm_nt(A, B, out=None, out_dtype=BF16, bias=None, epilogue=N.EPI_STORE, aux_in=None, aux_out=None, alpha=1.0,
-            split_k=1, M=None, a_rows=None, c_rows=None):
+            split_k=1, M=None, a_rows=None, c_rows=None, drop=(0.0, 0)):
     """C[M,N] = epi(alpha * A[M,K] @ B[N,K]^T + bias). A, B bf16 with unit inner stride, K % 64 == 0."""
     _req(A.dtype == BF16 and B.dtype == BF16 and A.dim() == 2 and B.dim() == 2, "gemm_nt: bf16 2-D operands")
     _req(A.stride(1) == 1 and B.stride(1) == 1 and A.shape[1] == B.shape[1], "gemm_nt: K mismatch / inner stride")
@@ -69,6 +69,7 @@ def gemm_nt(A, B, out=None, out_dtype=BF16, bias=None, epilogue=N.EPI_STORE, aux
     if aux_out is not None:
         g.aux_out, g.ld_aux_out = aux_out.data_ptr(), aux_out.stride(0)
     g.alpha, g.split_k = alpha, split_k
+    g.drop_p, g.drop_seed = float(drop[0]), int(drop[1]) & 0xFFFFFFFF      # MTL_EPI_RESID only (resid_pdrop)
     ws = None
     if split_k > 1:
         nbytes = lib().mtl_gemm_workspace_bytes(M, Nn, split_k)
@@ -233,7 +234,7 @@ def norm_fwd(x, gamma, beta, eps, rms=False, rows=None, M=None):
     return y, stats
 
 
-def norm_bwd(dy, x, gamma, stats, dres_in=None, rms=False, rows=None, want_bf16=False, dres_out=None):
+def norm_bwd(dy, x, gamma, stats, dres_in=None, rms=False, rows=None, want_bf16=False, dres_out=None, bf16_drop=(0.0, 0)):
     d = x.shape[-1]
     M = dy.shape[0]
     if dres_out is None:
@@ -242,7 +243,7 @@ def norm_bwd(dy, x, gamma, stats, dres_in=None, rms=False, rows=None, want_bf16=
               else torch.empty(x.shape, dtype=BF16, device=x.device)) if want_bf16 else None
     gr, gs, ro = rows if rows is not None else (0, 0, 0)
     check(lib().mtl_norm_bwd(ptr(dy), dy.stride(0), ptr(x), ptr(gamma), ptr(stats), ptr(dres_in), ptr(dres_out), ptr(dres_b),
-                             M, d, 1 if rms else 0, gr, gs, ro, 0, stream()), "mtl_norm_bwd")
+                             M, d, 1 if rms else 0, gr, gs, ro, 0, float(bf16_drop[0]), int(bf16_drop[1]) & 0xFFFFFFFF, stream()), "mtl_norm_bwd")
     return (dres_out, dres_b) if want_bf16 else dres_out
 
 
@@ -448,26 +449,48 @@ class AssembleFn(torch.autograd.Function):
         return to_bf16(dh0[:, ctx.n_tok:, :]), None, None, None
 
 
+def dropout_f32(x, p, seed, out=None):
+    """x f32 [..., d] -> dropout(x) with the library's counter-hash mask of (seed, flattened row, column)"""
+    x = x.contiguous()
+    out = torch.empty_like(x) if out is None else out
+    check(lib().mtl_dropout_f32(ptr(x), ptr(out), x.numel() // x.shape[-1], x.shape[-1], float(p), int(seed) & 0xFFFFFFFF, stream()), "mtl_dropout_f32")
+    return out
+
+
+class EmbdDropoutFn(torch.autograd.Function):
+    """GPT-2 embd_pdrop on inputs_embeds + wpe (HF:models/gpt2/modeling_gpt2.py:579); backward = the same mask on the gradient"""
+
+    @staticmethod
+    def forward(ctx, h0, p, seed):
+        ctx.meta = (p, seed)
+        return dropout_f32(h0, p, seed)
+
+    @staticmethod
+    def backward(ctx, dh):
+        p, seed = ctx.meta
+        return dropout_f32(dh, p, seed), None, None
+
+
 class BackboneFn(torch.autograd.Function):
     """Frozen decoder stack (R:models/medtsllm.py:350) fwd + activation-gradient-only bwd, one C call each."""
 
     @staticmethod
-    def forward(ctx, h0, backbone, n_last, n_grad=None):
+    def forward(ctx, h0, backbone, n_last, n_grad=None, drop=None):
         """n_grad: number of trailing tokens per sample whose input gradient is consumed (the patch tokens). The text
         prompt rows before them never depend on a trainable parameter (causal attention), so their gradient is dead and
         the backward runs on B*n_grad rows only; dh0 is zero there. None -> full backward."""
         h0 = h0.contiguous()
-        out, saved = backbone.run_forward(h0, n_last, keep=ctx.needs_input_grad[0])
-        ctx.backbone, ctx.n_last, ctx.saved, ctx.n_grad = backbone, n_last, saved, n_grad
+        out, saved = backbone.run_forward(h0, n_last, keep=ctx.needs_input_grad[0], drop=drop)
+        ctx.backbone, ctx.n_last, ctx.saved, ctx.n_grad, ctx.drop = backbone, n_last, saved, n_grad, drop
         ctx.save_for_backward(h0)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         (h0,) = ctx.saved_tensors
-        dh0 = ctx.backbone.run_backward(h0, dout.contiguous(), ctx.saved, ctx.n_last, ctx.n_grad)
+        dh0 = ctx.backbone.run_backward(h0, dout.contiguous(), ctx.saved, ctx.n_last, ctx.n_grad, drop=ctx.drop)
         ctx.saved = None
-        return dh0, None, None, None
+        return dh0, None, None, None, None
 
 
 class RevinDenormFn(torch.autograd.Function):

@@ -51,7 +51,10 @@ def normalise_config(cfg):
         d, H = cfg["n_embd"], cfg["n_head"]
         return dict(arch="gpt2", n_layers=cfg["n_layer"], d=d, n_heads=H, n_kv_heads=H, head_dim=d // H,
                     ffn=cfg.get("n_inner") or 4 * d, eps=cfg.get("layer_norm_epsilon", 1e-5), vocab=cfg["vocab_size"],
-                    n_positions=cfg.get("n_positions", 1024))
+                    n_positions=cfg.get("n_positions", 1024),
+                    # GPT2Config defaults (HF:models/gpt2/configuration_gpt2.py): active whenever the model is in train mode
+                    embd_pdrop=float(cfg.get("embd_pdrop", 0.1)), attn_pdrop=float(cfg.get("attn_pdrop", 0.1)),
+                    resid_pdrop=float(cfg.get("resid_pdrop", 0.1)))
     if mt == "llama":
         d, H = cfg["hidden_size"], cfg["num_attention_heads"]
         theta = cfg.get("rope_theta")
@@ -150,8 +153,16 @@ class FrozenBackbone:
         self._structs[T] = w
         return w
 
-    def run_forward(self, h0, n_last, keep=True):
-        """h0 f32 [B,T,d] (wpe already added for GPT-2) -> (out bf16 [B,n_last,d], saved buffer)."""
+    @staticmethod
+    def _drop_struct(drop):
+        """drop = (attn_p, resid_p, seed) or None -> ctypes pointer (NULL when off)"""
+        if not drop or (drop[0] <= 0 and drop[1] <= 0):
+            return None
+        return C.byref(N.BackboneDropout(float(drop[0]), float(drop[1]), int(drop[2]) & 0xFFFFFFFF))
+
+    def run_forward(self, h0, n_last, keep=True, drop=None):
+        """h0 f32 [B,T,d] (wpe already added for GPT-2) -> (out bf16 [B,n_last,d], saved buffer).
+        drop = (attn_p, resid_p, seed): GPT-2's train-mode dropouts inside the stack (the backward needs the same tuple)."""
         B, T, d = h0.shape
         if self.arch == "gpt2" and T > self.cfg["n_positions"]:
             raise ValueError(f"sequence length {T} exceeds GPT-2's {self.cfg['n_positions']} learned positions")
@@ -160,11 +171,13 @@ class FrozenBackbone:
         saved = torch.empty(lib.mtl_backbone_saved_bytes(C.byref(w), B, T), dtype=torch.uint8, device=h0.device)
         work = torch.empty(lib.mtl_backbone_work_bytes(C.byref(w), B, T), dtype=torch.uint8, device=h0.device)
         out = torch.empty((B, n_last, d), dtype=BF16, device=h0.device)
-        N.check(lib.mtl_backbone_fwd(C.byref(w), N.ptr(h0), N.ptr(out), N.ptr(saved), N.ptr(work), B, T, n_last, N.stream()),
-                "mtl_backbone_fwd")
+        if drop and self.arch != "gpt2" and (drop[0] > 0 or drop[1] > 0):
+            raise ValueError("dropout inside the frozen stack exists for GPT-2 only (Llama has none)")
+        N.check(lib.mtl_backbone_fwd(C.byref(w), N.ptr(h0), N.ptr(out), N.ptr(saved), N.ptr(work), B, T, n_last, self._drop_struct(drop),
+                                     N.stream()), "mtl_backbone_fwd")
         return out, (saved if keep else None)
 
-    def run_backward(self, h0, dout, saved, n_last, n_grad=None):
+    def run_backward(self, h0, dout, saved, n_last, n_grad=None, drop=None):
         """n_grad: trailing tokens per sample that need a gradient (default all T); see mtl_backbone_bwd."""
         B, T, d = h0.shape
         n_grad = T if n_grad is None else max(int(n_grad), n_last)
@@ -175,7 +188,7 @@ class FrozenBackbone:
         work = torch.empty(lib.mtl_backbone_work_bytes(C.byref(w), B, T), dtype=torch.uint8, device=h0.device)
         dh0 = torch.empty_like(h0)
         N.check(lib.mtl_backbone_bwd(C.byref(w), N.ptr(h0), N.ptr(dout), N.ptr(dh0), N.ptr(saved), N.ptr(work), B, T, n_last,
-                                     n_grad, N.stream()), "mtl_backbone_bwd")
+                                     n_grad, self._drop_struct(drop), N.stream()), "mtl_backbone_bwd")
         return dh0
 
     def state_tensors(self):

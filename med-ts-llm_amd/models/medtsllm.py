@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..hip import ops
-from ..hip.ops import (PatchTokenizeFn, LinearFn, MappingFn, MappingTrainableFn, CrossAttnFn, AssembleFn, BackboneFn, RevinDenormFn, pad64, pad_vocab,
+from ..hip.ops import (PatchTokenizeFn, LinearFn, MappingFn, MappingTrainableFn, CrossAttnFn, AssembleFn, BackboneFn, EmbdDropoutFn, RevinDenormFn, pad64, pad_vocab,
                        mapping_split_k)
 from . import prompt as P
 from .backbone import FrozenBackbone, load_hf_dir, normalise_config
@@ -116,6 +116,7 @@ class MedTsLLM(nn.Module):
 
         self.mapping_layer = nn.Linear(self.vocab_size, self.num_tokens)
         self._map_shard = None
+        self.llm_dropout = True      # GPT-2 train-mode dropouts (set False to freeze them off, e.g. for benchmarking parity)
         self.patch_embedding = _PatchEmbedding(self.d_patch, self.patch_len, self.stride, self.dropout)
         self.reprogramming_layer = _ReprogrammingLayer(self.d_model, self.n_attention_heads, self.d_ff, self.d_llm)
         self.output_projection = _FlattenHead(self.d_ff * self.n_patches, self.n_outputs)
@@ -393,7 +394,17 @@ class MedTsLLM(nn.Module):
             h0 = h0.index_put((bidx, rows), delta, accumulate=True)
             if n_grad is not None:                       # gradients are alive from the first example row on
                 n_grad = h0.shape[1] - splice["first"]
-        dec = BackboneFn.apply(h0, bb, self.n_patches, n_grad)   # [B', n_patches, d_llm] (final norm on the consumed rows only)
+        # GPT-2's own dropouts are live whenever the module is in train mode (the reference calls model.train() on the whole
+        # model, frozen LLM included): embd_pdrop on inputs_embeds + wpe, attn_pdrop / resid_pdrop inside the stack
+        drop = None
+        if self.training and bb.arch == "gpt2" and self.llm_dropout:
+            c = bb.cfg
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())          # host RNG: no device sync
+            if c["embd_pdrop"] > 0:
+                h0 = EmbdDropoutFn.apply(h0, c["embd_pdrop"], seed ^ 0x5bd1e995)
+            if c["attn_pdrop"] > 0 or c["resid_pdrop"] > 0:
+                drop = (c["attn_pdrop"], c["resid_pdrop"], seed)
+        dec = BackboneFn.apply(h0, bb, self.n_patches, n_grad, drop)   # [B', n_patches, d_llm] (final norm on the consumed rows only)
         mode = self.embedding_downsample_mode
         if mode == "truncate":
             dec = dec[:, :, :self.d_ff]

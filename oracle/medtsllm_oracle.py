@@ -157,25 +157,34 @@ def gelu_new(x):
     return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
 
 
-def causal_attention(q, k, v, scale):
+def causal_attention(q, k, v, scale, drop_mult=None):
     """Eager causal attention, softmax in fp32 — HF:models/gpt2/modeling_gpt2.py:54-72,
-    HF:models/llama/modeling_llama.py:191-213. q,k,v [B, H, T, hd]."""
+    HF:models/llama/modeling_llama.py:191-213. q,k,v [B, H, T, hd]. drop_mult: explicit attention-dropout multipliers
+    [B, H, T, T] (keep / (1 - p), or 0), applied to the probabilities like nn.Dropout (HF gpt2 :65)."""
     T = q.shape[-2]
     s = (q @ k.transpose(-1, -2)) * scale
     mask = torch.ones(T, T, dtype=torch.bool).tril()
     s = s.masked_fill(~mask, torch.finfo(s.dtype).min)
     a = torch.softmax(s.float(), dim=-1).to(q.dtype)
+    if drop_mult is not None:
+        a = a * drop_mult
     return a @ v
 
 
-def gpt2_forward(h, w, cfg):
-    """HF:models/gpt2/modeling_gpt2.py:514-628 (GPT2Model.forward with inputs_embeds, eager attention,
-    all dropouts off). w: HF state-dict names ("wpe.weight", "h.0.ln_1.weight", ...)."""
+def gpt2_forward(h, w, cfg, masks=None):
+    """HF:models/gpt2/modeling_gpt2.py:514-628 (GPT2Model.forward with inputs_embeds, eager attention).
+    w: HF state-dict names ("wpe.weight", "h.0.ln_1.weight", ...). masks = None: all dropouts off (eval, or pdrop 0).
+    masks = {"embd": [B,T,d], "attn": [L x [B,H,T,T]], "resid1": [L x [B,T,d]], "resid2": [L x [B,T,d]]} of explicit
+    dropout multipliers (keep / (1-p) or 0) reproduces train mode deterministically: embd_pdrop after the position
+    add (:579), attn_pdrop on the probabilities (:65), resid_pdrop after each c_proj (:243 / :330 and :397)."""
     B, T, d = h.shape
     H = cfg["n_head"]
     hd = d // H
     eps = cfg.get("layer_norm_epsilon", 1e-5)
     h = h + w["wpe.weight"][:T].unsqueeze(0)
+    mk = masks or {}
+    if "embd" in mk:
+        h = h * mk["embd"]
     for i in range(cfg["n_layer"]):
         pre = f"h.{i}."
         x = F.layer_norm(h, (d,), w[pre + "ln_1.weight"], w[pre + "ln_1.bias"], eps)
@@ -184,11 +193,13 @@ def gpt2_forward(h, w, cfg):
         q = q.view(B, T, H, hd).transpose(1, 2)
         k = k.view(B, T, H, hd).transpose(1, 2)
         v = v.view(B, T, H, hd).transpose(1, 2)
-        a = causal_attention(q, k, v, hd ** -0.5).transpose(1, 2).reshape(B, T, d)
-        h = h + (a @ w[pre + "attn.c_proj.weight"] + w[pre + "attn.c_proj.bias"])
+        a = causal_attention(q, k, v, hd ** -0.5, mk["attn"][i] if "attn" in mk else None).transpose(1, 2).reshape(B, T, d)
+        br = a @ w[pre + "attn.c_proj.weight"] + w[pre + "attn.c_proj.bias"]
+        h = h + (br * mk["resid1"][i] if "resid1" in mk else br)
         x = F.layer_norm(h, (d,), w[pre + "ln_2.weight"], w[pre + "ln_2.bias"], eps)
         m = gelu_new(x @ w[pre + "mlp.c_fc.weight"] + w[pre + "mlp.c_fc.bias"])
-        h = h + (m @ w[pre + "mlp.c_proj.weight"] + w[pre + "mlp.c_proj.bias"])
+        br = m @ w[pre + "mlp.c_proj.weight"] + w[pre + "mlp.c_proj.bias"]
+        h = h + (br * mk["resid2"][i] if "resid2" in mk else br)
     return F.layer_norm(h, (d,), w["ln_f.weight"], w["ln_f.bias"], eps)
 
 
@@ -241,9 +252,9 @@ def llama_forward(h, w, cfg):
     return rms_norm(h, w["norm.weight"], eps)
 
 
-def backbone_forward(h, w, cfg):
+def backbone_forward(h, w, cfg, masks=None):
     if cfg["model_type"] == "gpt2":
-        return gpt2_forward(h, w, cfg)
+        return gpt2_forward(h, w, cfg, masks)
     if cfg["model_type"] == "llama":
         return llama_forward(h, w, cfg)
     raise ValueError(cfg["model_type"])

@@ -72,7 +72,7 @@ def golden_loss(pred, target, task):
 def hf_cfg(kind, vocab=512):
     if kind == "gpt2":
         return {"model_type": "gpt2", "vocab_size": vocab, "n_positions": 256, "n_embd": 128, "n_layer": 2, "n_head": 2,
-                "layer_norm_epsilon": 1e-5}
+                "layer_norm_epsilon": 1e-5, "embd_pdrop": 0.0, "attn_pdrop": 0.0, "resid_pdrop": 0.0}
     if kind == "llama":
         return {"model_type": "llama", "vocab_size": vocab, "hidden_size": 256, "intermediate_size": 384, "num_hidden_layers": 2,
                 "num_attention_heads": 4, "num_key_value_heads": 4, "head_dim": 64, "rms_norm_eps": 1e-5, "rope_theta": 10000.0}
@@ -107,3 +107,42 @@ def fixture_tokenizer(kind="gpt2"):
                                   eos_token="<|endoftext|>")
     tok.pad_token = tok.eos_token
     return tok
+
+
+# ----------------------------------------------------------------------------- host replicas of the library's dropout hash
+def drop_hash(seed, bh, q, key):
+    """drop_hash() of csrc/mtl_common.h in uint32 arithmetic on numpy arrays / ints"""
+    import numpy as np
+    M = np.uint64(0xFFFFFFFF)
+    seed, bh, q, key = (np.asarray(v, dtype=np.uint64) for v in (seed, bh, q, key))
+    h = (seed ^ ((bh * np.uint64(0x9E3779B1)) & M)) & M
+    h = ((h ^ ((q * np.uint64(0x85EBCA77)) & M)) * np.uint64(0xC2B2AE3D)) & M
+    h = ((h ^ (h >> np.uint64(15)) ^ ((key * np.uint64(0x27D4EB2F)) & M)) * np.uint64(0x165667B1)) & M
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0x85EBCA6B)) & M
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def drop_threshold(p):
+    import numpy as np
+    return min(int(np.float32(p) * np.float32(4294967296.0)), 4294967040)
+
+
+def drop_site_seed(seed, layer, k):
+    return (seed ^ ((0x9E3779B9 * (3 * layer + k + 1)) & 0xFFFFFFFF)) & 0xFFFFFFFF
+
+
+def drop_mult_matrix(seed, p, rows, cols):
+    """[rows, cols] multipliers keep / (1 - p) of the (seed, 0, row, col) mask (GEMM resid / norm-bwd / embd dropout)"""
+    import numpy as np
+    r, c = np.meshgrid(np.arange(rows, dtype=np.uint64), np.arange(cols, dtype=np.uint64), indexing="ij")
+    keep = drop_hash(seed, 0, r, c) >= drop_threshold(p)
+    return torch.from_numpy(keep.astype(np.float32)) / (1.0 - float(np.float32(p)))
+
+
+def drop_mult_attention(seed, p, B, H, Tq, Tk):
+    import numpy as np
+    bh, q, k = np.meshgrid(np.arange(B * H, dtype=np.uint64), np.arange(Tq, dtype=np.uint64), np.arange(Tk, dtype=np.uint64), indexing="ij")
+    keep = drop_hash(seed, bh, q, k) >= drop_threshold(p)
+    return torch.from_numpy(keep.astype(np.float32).reshape(B, H, Tq, Tk)) / (1.0 - float(np.float32(p)))

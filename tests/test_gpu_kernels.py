@@ -451,3 +451,57 @@ def test_gemm_fp32_out_unaligned_rows(ops, M, Nn, K):
     ops.gemm_nt(A, B, out=out)
     assert torch.equal(out, A.float() @ B.float().t())
     assert torch.all(buf[M * Nn:] == 7.0)
+
+
+# ----------------------------------------------------------------------------- GPT-2 train-mode dropout building blocks
+@pytest.mark.gpu
+def test_dropout_sites_match_host_hash(ops):
+    """resid_pdrop in the RESID GEMM epilogue (both kernels), its backward twin in norm_bwd's bf16 copy, and the plain
+    f32 dropout (embd_pdrop): all three use the (seed, 0, row, col) counter hash replicated in tests/helpers.py."""
+    from helpers import drop_mult_matrix
+    p, seed = 0.1, 0xBEEF1234
+    for M, Nn, K in [(256, 192, 128), (100, 36, 64)]:          # wave-level epilogue / classic kernel (unaligned N)
+        A = torch.randn(M, K, generator=g(1)).to(BF16).cuda()
+        B = (torch.randn(Nn, K, generator=g(2)) * 0.1).to(BF16).cuda()
+        bias = torch.randn(Nn, generator=g(3)).cuda()
+        res = torch.randn(M, Nn, generator=g(4)).cuda()
+        out = ops.gemm_nt(A, B, bias=bias, epilogue=ops.N.EPI_RESID, aux_in=res, out_dtype=F32, drop=(p, seed))
+        lin = rb(A.float().cpu() @ B.float().cpu().t() + bias.cpu())
+        mult = drop_mult_matrix(seed, p, M, Nn)
+        assert abs(float((mult > 0).float().mean()) - (1 - p)) < 0.03
+        assert rel_err(out, res.cpu() + lin * mult) < 1e-5
+    # norm backward: fp32 stream unmasked, bf16 copy masked
+    M, d = 64, 256
+    x = torch.randn(M, d, generator=g(5)).cuda()
+    gamma, beta = torch.randn(d, generator=g(6)).cuda(), torch.randn(d, generator=g(7)).cuda()
+    y, stats = ops.norm_fwd(x, gamma, beta, 1e-5)
+    dy = torch.randn(M, d, generator=g(8)).to(BF16).cuda()
+    plain, plain_b = ops.norm_bwd(dy, x, gamma, stats, want_bf16=True)
+    masked, masked_b = ops.norm_bwd(dy, x, gamma, stats, want_bf16=True, bf16_drop=(p, seed))
+    assert torch.equal(plain, masked)
+    assert rel_err(masked_b.float(), rb(plain.cpu() * drop_mult_matrix(seed, p, M, d))) < 1e-6
+    # plain dropout and its backward
+    h = torch.randn(3, 50, d, generator=g(9)).cuda()
+    assert torch.equal(ops.dropout_f32(h, p, seed).cpu(), h.cpu() * drop_mult_matrix(seed, p, 150, d).view(3, 50, d))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pdrop", [0.1, 0.5])
+def test_attention_causal_dropout(ops, pdrop):
+    """attn_pdrop on the causal backbone attention (HF gpt2 :65): forward and all three gradients vs the host-mask reference,
+    including the pruned backward (queries = last n_grad rows: the mask must be indexed by ABSOLUTE query position)"""
+    from helpers import drop_mult_attention
+    B, T, H, D, seed = 2, 100, 2, 64, 777
+    q, k, v = (torch.randn(B, T, H * D, generator=g(i)).to(BF16) for i in (1, 2, 3))
+    do = torch.randn(B, T, H * D, generator=g(4)).to(BF16)
+    scale = 1.0 / math.sqrt(D)
+    mult = drop_mult_attention(seed, pdrop, B, H, T, T)
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    s = torch.einsum("bqhd,bkhd->bhqk", qf.view(B, T, H, D), kf.view(B, T, H, D)) * scale
+    s = s.masked_fill(~torch.ones(T, T, dtype=torch.bool).tril(), float("-inf"))
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1) * mult, vf.view(B, T, H, D)).reshape(B, T, H * D)
+    ref.backward(do.float())
+    o, lse = ops.attention_fwd(dev(q), dev(k), dev(v), H, H, D, scale, True, dropout=(pdrop, seed))
+    assert rel_err(o.float(), ref) < TOL_BF16
+    dq, dk, dv = ops.attention_bwd(dev(q), dev(k), dev(v), o, lse, dev(do), H, H, D, scale, True, dropout=(pdrop, seed))
+    assert rel_err(dq.float(), qf.grad) < 1e-2 and rel_err(dk.float(), kf.grad) < 1e-2 and rel_err(dv.float(), vf.grad) < 1e-2

@@ -293,3 +293,70 @@ def test_stitched_eval_on_gpu(tmp_path, task):
     else:
         assert {"test/f1", "test/auroc", "test/recon_mse", "test/anomaly_threshold"} <= set(scores)
         assert all(np.isfinite(v) for v in scores.values())
+
+
+def _gpt2_masks(seed, attn_p, resid_p, B, T, H, d, L):
+    from helpers import drop_mult_matrix, drop_mult_attention, drop_site_seed
+    return {"attn": [drop_mult_attention(drop_site_seed(seed, i, 0), attn_p, B, H, T, T) for i in range(L)],
+            "resid1": [drop_mult_matrix(drop_site_seed(seed, i, 1), resid_p, B * T, d).view(B, T, d) for i in range(L)],
+            "resid2": [drop_mult_matrix(drop_site_seed(seed, i, 2), resid_p, B * T, d).view(B, T, d) for i in range(L)]}
+
+
+@pytest.mark.parametrize("n_grad_extra", [0, 23, None])
+def test_gpt2_stack_train_mode_dropouts(n_grad_extra):
+    """a7, GPT-2 in train mode: attn_pdrop + resid_pdrop inside the stack (HF gpt2 :65,243,397). The kernels' counter-hash
+    masks are rebuilt on the host and handed to the oracle as explicit multipliers, so forward and the input gradient
+    (full and pruned) are compared exactly like the deterministic case."""
+    from med_ts_llm_amd.models.backbone import FrozenBackbone, random_state_dict
+    from oracle import medtsllm_oracle as O
+    cfg = hf_cfg("gpt2")
+    sd = random_state_dict(cfg, seed=3, std=0.06)
+    bb = FrozenBackbone(cfg, sd, "cuda")
+    B, T, n_last, d, H, L = 2, 100, 37, cfg["n_embd"], cfg["n_head"], cfg["n_layer"]
+    attn_p, resid_p, seed = 0.1, 0.2, 987654321
+    g = torch.Generator().manual_seed(5)
+    h0 = torch.randn(B, T, d, generator=g)
+    dout = torch.randn(B, n_last, d, generator=g).to(BF16)
+    h0r = h0.clone().requires_grad_(True)
+    ref = O.backbone_forward(h0r, sd, cfg, _gpt2_masks(seed, attn_p, resid_p, B, T, H, d, L))[:, -n_last:, :]
+    (ref * dout.float()).sum().backward()
+    h_in = (h0 + sd["wpe.weight"][:T]).cuda()
+    drop = (attn_p, resid_p, seed)
+    out, saved = bb.run_forward(h_in, n_last, drop=drop)
+    assert rel_err(out.float(), ref) < L3
+    plain, _ = bb.run_forward(h_in, n_last)
+    assert rel_err(plain.float(), ref) > 10 * L3                      # the masks really are applied
+    n_grad = None if n_grad_extra is None else n_last + n_grad_extra
+    dh0 = bb.run_backward(h_in, dout.cuda(), saved, n_last, n_grad, drop=drop).cpu()
+    lo = 0 if n_grad is None else T - n_grad
+    assert rel_err(dh0[:, lo:], h0r.grad[:, lo:]) < 2 * L3
+
+
+def test_full_model_gpt2_llm_dropout_train_vs_eval():
+    """the model applies GPT-2's own dropouts (embd / attn / resid, from the backbone config) in train mode only; they are
+    seeded per call, scale-preserving, switched off by eval() and by llm_dropout = False; gradients stay finite and alive"""
+    from med_ts_llm_amd.models import model_lookup
+    from med_ts_llm_amd.models.backbone import random_state_dict
+    from med_ts_llm_amd.utils import dict_to_object
+    cfg = dict(hf_cfg("gpt2"), embd_pdrop=0.1, attn_pdrop=0.1, resid_pdrop=0.1)
+    sd = random_state_dict(cfg, seed=7, std=0.06)
+    off = {"dataset": False, "task": False, "clip": False, "input_stats": False, "examples": False, "input_stats_dim": 0, "input_stats_select": "all"}
+    torch.manual_seed(11)
+    model = model_lookup["medtsllm"](dict_to_object(model_config("forecasting", 64, 16, "concat", "linear", off)), FakeDataset(3),
+                                     backbone_state=(cfg, sd)).to("cuda")
+    x = {"x_enc": torch.randn(4, 64, 3, generator=torch.Generator().manual_seed(2)).cuda()}
+    model.eval()
+    e1, e2 = model(x), model(x)
+    assert torch.equal(e1, e2)
+    model.train()
+    torch.manual_seed(1); t1 = model(x)
+    torch.manual_seed(2); t2 = model(x)
+    torch.manual_seed(1); t3 = model(x)
+    assert torch.equal(t1, t3) and not torch.equal(t1, t2)              # a function of the host RNG state only
+    assert 1e-3 < rel_err(t1, e1) < 1.0                                   # perturbed (random tiny model: strongly), same scale
+    t1.float().pow(2).mean().backward()
+    for n, p_ in model.named_parameters():
+        if p_.requires_grad:
+            assert p_.grad is not None and torch.isfinite(p_.grad).all(), n
+    model.llm_dropout = False
+    assert torch.equal(model(x), e1)
