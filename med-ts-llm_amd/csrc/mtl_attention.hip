@@ -483,7 +483,7 @@ __device__ __forceinline__ void load_rows(bf16_t* tile, const bf16_t* src, int64
     }
 }
 
-template <int D, int NW>
+template <int D, int NW, bool DROP = false>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fwd_args a) {
     constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -495,6 +495,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fw
     load_rows<D, NW * 64>(ktile, reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + hk * a.k_hs, a.k_ts, a.Tk);
     load_rows<D, NW * 64>(vtile, reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + hk * a.v_hs, a.v_ts, a.Tk);
     __syncthreads();
+    const uint32_t bh = (uint32_t)(b * a.Hq + h);
+    const uint32_t drop_thr = DROP ? drop_threshold(a.dropout_p) : 0u;
+    const float drop_scale = DROP ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
     const float c = a.scale * LOG2E;
     const int64_t coff = a.causal_off;
     const int nt = (int)((a.Tq + 15) / 16), npairs = (nt + 1) / 2;
@@ -562,6 +565,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fw
                 m_run = m_new;
             }
             l_run += psum;
+            if (DROP) {   // attn_pdrop: the normaliser keeps the undropped sum, the P.V operand carries the mask
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        p[t][r] = drop_hash(a.dropout_seed, bh, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4 + r)) >= drop_thr ? p[t][r] * drop_scale : 0.f;
+            }
             const bf16x8 pf = pack8(p[0], p[1]);
             const int ra = (int)(kb + g * 4), rb = (int)(kb + 16 + g * 4);   // rows >= Tk are zero-filled and carry p == 0
 #pragma unroll
@@ -584,7 +594,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fw
     }
 }
 
-template <int D, int NW>
+template <int D, int NW, bool DROP = false>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn_bwd_args a) {
     constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -599,6 +609,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn
     load_rows<D, NW * 64>(ktile, reinterpret_cast<const bf16_t*>(f.k) + b * f.k_bs + hk * f.k_hs, f.k_ts, f.Tk);
     load_rows<D, NW * 64>(vtile, reinterpret_cast<const bf16_t*>(f.v) + b * f.v_bs + hk * f.v_hs, f.v_ts, f.Tk);
     __syncthreads();
+    const uint32_t bh = (uint32_t)(b * f.Hq + h);
+    const uint32_t drop_thr = DROP ? drop_threshold(f.dropout_p) : 0u;
+    const float drop_scale = DROP ? 1.0f / (1.0f - f.dropout_p) : 1.0f;
     const float c = f.scale * LOG2E;
     const int64_t coff = f.causal_off;
     const int nt = (int)((f.Tq + 15) / 16), npairs = (nt + 1) / 2;
@@ -652,7 +665,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn
                     const int64_t key = kb + t * 16 + g * 4 + r;
                     const bool masked = key >= f.Tk || key > qrow + coff;
                     const float pv = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse2);
-                    ds[t][r] = pv * (dp[r] - dl);
+                    float dpv = dp[r];
+                    if (DROP) dpv = drop_hash(f.dropout_seed, bh, (uint32_t)(qrow + coff), (uint32_t)key) >= drop_thr ? dpv * drop_scale : 0.f;
+                    ds[t][r] = pv * (dpv - dl);
                 }
             }
             const bf16x8 dsf = pack8(ds[0], ds[1]);
@@ -676,7 +691,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn
 
 // dK/dV with every query row (Q, dO, lse, delta) of the head resident in LDS; waves take pairs of 16-key tiles.
 // dynamic LDS: Q tile [Tq][D+8] | dO tile [Tq][D+8] | lse2[Tq] | delta[Tq]
-template <int D, int NW>
+template <int D, int NW, bool DROP = false>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(const mtl_attn_bwd_args a) {
     constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -687,6 +702,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(const mtl_att
     float* delta_s = lse_s + ceil32(f.Tq);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
     const int64_t b = blockIdx.z, hk = blockIdx.y;
+    const uint32_t drop_thr = DROP ? drop_threshold(f.dropout_p) : 0u;
+    const float drop_scale = DROP ? 1.0f / (1.0f - f.dropout_p) : 1.0f;
     const int group = (int)(f.Hq / f.Hkv);
     const float c = f.scale * LOG2E;
     const int64_t coff = f.causal_off;
@@ -750,8 +767,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(const mtl_att
                         const int64_t q = qb + t * 16 + g * 4 + r;
                         const bool masked = q >= f.Tq || krow > q + coff;
                         const float pv = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse_s[q]);
-                        p[t][r] = pv;
-                        ds[t][r] = pv * (dp[r] - delta_s[q]);
+                        float keep = 1.0f;
+                        if (DROP) keep = drop_hash(f.dropout_seed, (uint32_t)(b * f.Hq + hk * group + hg), (uint32_t)(q + coff), (uint32_t)krow) >= drop_thr ? drop_scale : 0.f;
+                        p[t][r] = pv * keep;                               // feeds dV = (dropped P)^T dO
+                        ds[t][r] = pv * (dp[r] * keep - delta_s[q]);       // feeds dK
                     }
                 }
                 const bf16x8 pf = pack8(p[0], p[1]);
@@ -809,7 +828,7 @@ int check_fwd(const mtl_attn_fwd_args& f) {
 
 namespace {
 
-// resident-K/V path: causal, per-sample K/V, no dropout, >= 4 rows, and both tiles fit the 160 KiB LDS
+// resident-K/V path: causal, per-sample K/V, >= 4 rows, and both tiles fit the 160 KiB LDS
 constexpr size_t kLdsBudget = 156 * 1024;
 int g_attn_mode = 1;   // 1 = use the resident kernels when they fit, 0 = always the chunked kernels (A/B knob)
 
@@ -824,7 +843,7 @@ namespace {
 
 size_t pad32(int64_t v) { return (size_t)((v + 31) & ~(int64_t)31); }
 bool resident_ok(const mtl_attn_fwd_args& f, int64_t rows) {
-    return g_attn_mode == 1 && f.causal && f.k_bs != 0 && f.dropout_p <= 0.f && (f.D == 64 || f.D == 128) &&
+    return g_attn_mode == 1 && f.causal && f.k_bs != 0 && f.dropout_p < 1.f && (f.D == 64 || f.D == 128) &&
            2 * pad32(rows) * (f.D + 8) * 2 + 2 * pad32(rows) * 4 <= kLdsBudget;
 }
 
@@ -838,7 +857,13 @@ extern "C" int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream) {
     if (resident_ok(*a, a->Tk)) {
         const size_t lds = 2 * pad32(a->Tk) * (a->D + 8) * 2;
         const int npairs = (int)(((a->Tq + 15) / 16 + 1) / 2);
-        if (a->D == 64) {
+        if (a->D == 64 && a->dropout_p > 0.f) {
+            static std::once_flag once; std::call_once(once, [&] { set_lds(attn_fwd_res_kernel<64, 8, true>, kLdsBudget); });
+            hipLaunchKernelGGL((attn_fwd_res_kernel<64, 8, true>), dim3((unsigned)((npairs + 7) / 8), (unsigned)a->Hq, (unsigned)a->B), dim3(512), lds, st, *a);
+        } else if (a->D == 128 && a->dropout_p > 0.f) {
+            static std::once_flag once; std::call_once(once, [&] { set_lds(attn_fwd_res_kernel<128, 8, true>, kLdsBudget); });
+            hipLaunchKernelGGL((attn_fwd_res_kernel<128, 8, true>), dim3((unsigned)((npairs + 7) / 8), (unsigned)a->Hq, (unsigned)a->B), dim3(512), lds, st, *a);
+        } else if (a->D == 64) {
             static std::once_flag once; std::call_once(once, [&] { set_lds(attn_fwd_res_kernel<64, 8>, kLdsBudget); });
             hipLaunchKernelGGL((attn_fwd_res_kernel<64, 8>), dim3((unsigned)((npairs + 7) / 8), (unsigned)a->Hq, (unsigned)a->B), dim3(512), lds, st, *a);
         } else {
@@ -878,7 +903,17 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
         const size_t lds_q = 2 * pad32(f.Tk) * (f.D + 8) * 2;
         const size_t lds_k = 2 * pad32(f.Tq) * (f.D + 8) * 2 + 2 * pad32(f.Tq) * 4;
         const int npq = (int)(((f.Tq + 15) / 16 + 1) / 2), npk = (int)(((f.Tk - a->kv_row0 + 15) / 16 + 1) / 2);
-        if (f.D == 64) {
+        if (f.dropout_p > 0.f && f.D == 64) {
+            static std::once_flag once;
+            std::call_once(once, [&] { set_lds(attn_bwd_dq_res_kernel<64, 8, true>, kLdsBudget); set_lds(attn_bwd_dkv_res_kernel<64, 4, true>, kLdsBudget); });
+            hipLaunchKernelGGL((attn_bwd_dq_res_kernel<64, 8, true>), dim3((unsigned)((npq + 7) / 8), (unsigned)f.Hq, (unsigned)f.B), dim3(512), lds_q, st, *a);
+            hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<64, 4, true>), dim3((unsigned)((npk + 3) / 4), (unsigned)f.Hkv, (unsigned)f.B), dim3(256), lds_k, st, *a);
+        } else if (f.dropout_p > 0.f) {
+            static std::once_flag once;
+            std::call_once(once, [&] { set_lds(attn_bwd_dq_res_kernel<128, 8, true>, kLdsBudget); set_lds(attn_bwd_dkv_res_kernel<128, 4, true>, kLdsBudget); });
+            hipLaunchKernelGGL((attn_bwd_dq_res_kernel<128, 8, true>), dim3((unsigned)((npq + 7) / 8), (unsigned)f.Hq, (unsigned)f.B), dim3(512), lds_q, st, *a);
+            hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<128, 4, true>), dim3((unsigned)((npk + 3) / 4), (unsigned)f.Hkv, (unsigned)f.B), dim3(256), lds_k, st, *a);
+        } else if (f.D == 64) {
             static std::once_flag once;
             std::call_once(once, [&] { set_lds(attn_bwd_dq_res_kernel<64, 8>, kLdsBudget); set_lds(attn_bwd_dkv_res_kernel<64, 4>, kLdsBudget); });
             hipLaunchKernelGGL((attn_bwd_dq_res_kernel<64, 8>), dim3((unsigned)((npq + 7) / 8), (unsigned)f.Hq, (unsigned)f.B), dim3(512), lds_q, st, *a);

@@ -486,8 +486,9 @@ def test_dropout_sites_match_host_hash(ops):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("resident", [1, 0])
 @pytest.mark.parametrize("pdrop", [0.1, 0.5])
-def test_attention_causal_dropout(ops, pdrop):
+def test_attention_causal_dropout(ops, pdrop, resident):
     """attn_pdrop on the causal backbone attention (HF gpt2 :65): forward and all three gradients vs the host-mask reference,
     including the pruned backward (queries = last n_grad rows: the mask must be indexed by ABSOLUTE query position)"""
     from helpers import drop_mult_attention
@@ -501,7 +502,11 @@ def test_attention_causal_dropout(ops, pdrop):
     s = s.masked_fill(~torch.ones(T, T, dtype=torch.bool).tril(), float("-inf"))
     ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1) * mult, vf.view(B, T, H, D)).reshape(B, T, H * D)
     ref.backward(do.float())
-    o, lse = ops.attention_fwd(dev(q), dev(k), dev(v), H, H, D, scale, True, dropout=(pdrop, seed))
+    ops.lib().mtl_attention_tune(resident)        # K/V-resident kernels, or the chunked ones
+    try:
+        o, lse = ops.attention_fwd(dev(q), dev(k), dev(v), H, H, D, scale, True, dropout=(pdrop, seed))
+        dq, dk, dv = ops.attention_bwd(dev(q), dev(k), dev(v), o, lse, dev(do), H, H, D, scale, True, dropout=(pdrop, seed))
+    finally:
+        ops.lib().mtl_attention_tune(1)
     assert rel_err(o.float(), ref) < TOL_BF16
-    dq, dk, dv = ops.attention_bwd(dev(q), dev(k), dev(v), o, lse, dev(do), H, H, D, scale, True, dropout=(pdrop, seed))
     assert rel_err(dq.float(), qf.grad) < 1e-2 and rel_err(dk.float(), kf.grad) < 1e-2 and rel_err(dv.float(), vf.grad) < 1e-2
