@@ -233,6 +233,7 @@ def main():
     model.llm_dropout = not args.no_llm_dropout
     model.train()
     sharded = world > 1 and not args.replicate_mapping and model.shard_mapping_layer(rank, world)
+    torch.manual_seed(1234 + 7919 * rank)      # rank-specific dropout streams (weights above were built from one seed)
     params = [p for p in model.parameters() if p.requires_grad]
     if args.torch_adam:
         opt = torch.optim.Adam(params, lr=1e-4, fused=True)

@@ -70,6 +70,8 @@ class BaseTask(ABC):
         self.build_dataloaders()
         self.model = self.build_model().to(self.device, self.dtype)
         self.finetuning = False
+        if self.world_size > 1:     # identical initial weights on every rank (seeded above), rank-specific dropout streams from here on
+            torch.manual_seed(self.config.setup.seed + 7919 * (self.rank + 1))
         if self.world_size > 1 and self.config.setup.get("shard_mapping", True) and hasattr(self.model, "shard_mapping_layer"):
             self.model.shard_mapping_layer(self.rank, self.world_size)      # DP: rows of the mapping layer live on one rank each
         self.optimizer = self.build_optimizer()
