@@ -667,6 +667,7 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         else if (bm == 128 && bn == 128 && nw == 4 && stages == 2) MTL_PERSIST(128, 128, 2, 4);
         else if (bm == 128 && bn == 64 && nw == 4 && stages == 2) MTL_PERSIST(128, 64, 2, 4);
         else if (bm == 128 && bn == 96 && nw == 4 && stages == 2) MTL_PERSIST(128, 96, 2, 4);
+        else if (bm == 128 && bn == 96 && nw == 4 && stages == 3) MTL_PERSIST(128, 96, 3, 4);
         else if (bm == 128 && bn == 192 && nw == 8 && stages == 2) MTL_PERSIST(128, 192, 2, 8);
         else if (bm == 256 && bn == 192 && nw == 8 && stages == 2) MTL_PERSIST(256, 192, 2, 8);
         else if (bm == 128 && bn == 64 && nw == 4 && stages == 3) MTL_PERSIST(128, 64, 3, 4);
