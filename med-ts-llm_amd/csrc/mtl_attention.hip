@@ -483,6 +483,36 @@ __device__ __forceinline__ void load_rows(bf16_t* tile, const bf16_t* src, int64
     }
 }
 
+// two matrices (K and V, or Q and dO) in ONE round trip: every load of both is issued before the first LDS store
+template <int D, int NT, int BATCH>
+__device__ __forceinline__ void load_rows_pair(bf16_t* tile_a, const bf16_t* src_a, int64_t ts_a, bf16_t* tile_b, const bf16_t* src_b,
+                                               int64_t ts_b, int64_t rows) {
+    constexpr int LDT = D + 8, CPR = D / 8;
+    const int64_t total = ceil32(rows) * CPR;
+    for (int64_t base = 0; base < total; base += (int64_t)BATCH * NT) {
+        u32x4 va[BATCH], vb[BATCH];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            const int64_t s = base + threadIdx.x + (int64_t)i * NT;
+            const int64_t r = s / CPR;
+            va[i] = (u32x4){0u, 0u, 0u, 0u};
+            vb[i] = va[i];
+            if (s < total && r < rows) {
+                va[i] = *reinterpret_cast<const u32x4*>(src_a + r * ts_a + (s % CPR) * 8);
+                vb[i] = *reinterpret_cast<const u32x4*>(src_b + r * ts_b + (s % CPR) * 8);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            const int64_t s = base + threadIdx.x + (int64_t)i * NT;
+            if (s < total) {
+                *reinterpret_cast<u32x4*>(tile_a + (s / CPR) * LDT + (s % CPR) * 8) = va[i];
+                *reinterpret_cast<u32x4*>(tile_b + (s / CPR) * LDT + (s % CPR) * 8) = vb[i];
+            }
+        }
+    }
+}
+
 template <int D, int NW, bool DROP = false>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fwd_args a) {
     constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
@@ -492,8 +522,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fw
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
     const int64_t b = blockIdx.z, h = blockIdx.y, hk = h / (a.Hq / a.Hkv);
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * a.q_hs;
-    load_rows<D, NW * 64>(ktile, reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + hk * a.k_hs, a.k_ts, a.Tk);
-    load_rows<D, NW * 64>(vtile, reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + hk * a.v_hs, a.v_ts, a.Tk);
+    load_rows_pair<D, NW * 64, 4>(ktile, reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + hk * a.k_hs, a.k_ts,
+                                  vtile, reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + hk * a.v_hs, a.v_ts, a.Tk);
     __syncthreads();
     const uint32_t bh = (uint32_t)(b * a.Hq + h);
     const uint32_t drop_thr = DROP ? drop_threshold(a.dropout_p) : 0u;
@@ -606,8 +636,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(f.q) + b * f.q_bs + h * f.q_hs;
     const bf16_t* O = reinterpret_cast<const bf16_t*>(f.o) + b * f.o_bs + h * f.o_hs;
     const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dout) + b * a.do_bs + h * a.do_hs;
-    load_rows<D, NW * 64>(ktile, reinterpret_cast<const bf16_t*>(f.k) + b * f.k_bs + hk * f.k_hs, f.k_ts, f.Tk);
-    load_rows<D, NW * 64>(vtile, reinterpret_cast<const bf16_t*>(f.v) + b * f.v_bs + hk * f.v_hs, f.v_ts, f.Tk);
+    load_rows_pair<D, NW * 64, 4>(ktile, reinterpret_cast<const bf16_t*>(f.k) + b * f.k_bs + hk * f.k_hs, f.k_ts,
+                                  vtile, reinterpret_cast<const bf16_t*>(f.v) + b * f.v_bs + hk * f.v_hs, f.v_ts, f.Tk);
     __syncthreads();
     const uint32_t bh = (uint32_t)(b * f.Hq + h);
     const uint32_t drop_thr = DROP ? drop_threshold(f.dropout_p) : 0u;
@@ -739,8 +769,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(const mtl_att
                 const int64_t h = hk * group + hg;
                 const int64_t stat0 = (b * f.Hq + h) * (f.stat_stride ? f.stat_stride : f.Tq);
                 __syncthreads();
-                load_rows<D, NW * 64, 4>(qtile, reinterpret_cast<const bf16_t*>(f.q) + b * f.q_bs + h * f.q_hs, f.q_ts, f.Tq);
-                load_rows<D, NW * 64, 4>(dotile, reinterpret_cast<const bf16_t*>(a.dout) + b * a.do_bs + h * a.do_hs, a.do_ts, f.Tq);
+                load_rows_pair<D, NW * 64, 4>(qtile, reinterpret_cast<const bf16_t*>(f.q) + b * f.q_bs + h * f.q_hs, f.q_ts,
+                                              dotile, reinterpret_cast<const bf16_t*>(a.dout) + b * a.do_bs + h * a.do_hs, a.do_ts, f.Tq);
                 for (int64_t i = threadIdx.x; i < ceil32(f.Tq); i += NW * 64) {
                     lse_s[i] = i < f.Tq ? f.lse[stat0 + i] * LOG2E : 0.f;
                     delta_s[i] = i < f.Tq ? a.delta[stat0 + i] : 0.f;
