@@ -168,7 +168,37 @@ class SegmentationTask(BaseTask):
         return self.loss_fn(self.model(inputs), inputs["labels"].to(self.dtype))
 
 
-class SemanticSegmentationTask(BaseTask):
+class SemanticSegmentationTask(_StitchedEval, BaseTask):
+    def predict(self, dataloader):
+        """R:tasks/semantic_segmentation.py:78-121 -> (class probabilities [n_scored_points, n_classes], int targets)"""
+        ds = dataloader.dataset
+        if not self._stitched(dataloader):
+            return BaseTask.predict(self, dataloader)
+        pred_len, step, n_classes = self.config.pred_len, ds.step_size, ds.n_classes
+        n_points = ds.n_points if ds.clip_dataset else pred_len + ((len(ds) - 1) * step)
+        w = self._windows(dataloader, ("labels",))
+        tr = (lambda t: t)
+        if n_classes == 2:      # the model returns P(class 1): column 0 is its complement
+            p1 = E.stitch_dataset(ds, n_points, 1, w["pred"].reshape(w["pred"].shape[0], -1, 1), tr, float("nan"))[:, 0]
+            preds = torch.stack([1 - p1, p1], dim=1)
+        else:
+            preds = E.stitch_dataset(ds, n_points, n_classes, w["pred"], tr, float("nan"))
+        starts = [(ds.inverse_index(i)[0] if ds.univariate else ds.inverse_index(i))[0] for i in range(w["labels"].shape[0])]
+        targets = E.stitch_last_wins(w["labels"].reshape(w["labels"].shape[0], -1).to(torch.int), starts, n_points, -1)
+        preds, targets = E.crop_to_scored_points(ds, [preds, targets], n_points, step, pred_len)
+        assert not preds.isnan().any() and not (targets < 0).any()
+        return preds.cpu(), targets.cpu()
+
+    def score(self, pred_scores, target):
+        """R:tasks/semantic_segmentation.py:138-148"""
+        from sklearn.metrics import accuracy_score, f1_score, jaccard_score, precision_score, recall_score
+        avg = "binary" if pred_scores.size(1) == 2 else "macro"
+        pred, target = pred_scores.argmax(dim=1).int().numpy(), target.numpy()
+        return {"accuracy": accuracy_score(target, pred), "f1": f1_score(target, pred, average=avg, zero_division=0),
+                "precision": precision_score(target, pred, average=avg, zero_division=0),
+                "recall": recall_score(target, pred, average=avg, zero_division=0),
+                "iou": jaccard_score(target, pred, average=avg, zero_division=0)}
+
     def build_loss(self):
         is_binary = self.train_dataset.n_classes == 2
         name = self.config.training.loss

@@ -36,6 +36,18 @@ def labels_for(split, n):
     return lab
 
 
+def semseg_labels(split, n, n_classes):
+    g = np.random.default_rng({"train": 41, "val": 42, "test": 43}[split] + n_classes)
+    lab = np.zeros(n, dtype=np.int64)
+    i = 0
+    while i < n:
+        ln = int(g.integers(5, 30))
+        lab[i:i + ln] = int(g.integers(0, n_classes))
+        i += ln
+    lab[:n_classes] = np.arange(n_classes)      # every class present in every split
+    return lab
+
+
 class FakeForecast(torch.nn.Module):
     def __init__(self, pred_len):
         super().__init__()
@@ -45,6 +57,21 @@ class FakeForecast(torch.nn.Module):
         x = inputs["x_enc"]
         ramp = torch.arange(self.pred_len, dtype=x.dtype)[None, :, None] * 0.01
         return x[:, -1:, :] + 0.25 * x[:, :self.pred_len, :].flip(1) + ramp
+
+
+class FakeSemSeg(torch.nn.Module):
+    """eval-mode outputs of a semantic-segmentation model: class probabilities [B, L, n_cls], or P(class 1) [B, L] when binary"""
+
+    def __init__(self, n_classes):
+        super().__init__()
+        self.n_classes = n_classes
+
+    def forward(self, inputs):
+        x = inputs["x_enc"]
+        if self.n_classes == 2:
+            return torch.sigmoid(1.3 * x[:, :, 0] + 0.1 * x[:, :1, 1])
+        w = torch.linspace(-1.0, 1.0, self.n_classes, dtype=x.dtype)
+        return torch.softmax(x[:, :, :1] * w + 0.3 * x[:, :1, 1:2] * w.flip(0), dim=-1)
 
 
 class FakeRecon(torch.nn.Module):
@@ -62,6 +89,8 @@ def build(ref_tasks, dict_to_object, llm_dir, task, L, pred, step, n, C, extra_t
         "setup": {"seed": 0, "device": "cpu", "dtype": "fp32", "num_workers": 0, "logger": "print"},
         "datasets": {"synthetic_eval": {"n": n, "C": C}},
     })
+    if task == "semantic_segmentation":
+        cfgd["training"]["loss"] = "ce"
     cfgd["tasks"].update(extra_tasks or {})
     return ref_tasks.get_trainer("DEBUG-eval-golden", dict_to_object(cfgd))
 
@@ -76,27 +105,31 @@ def main():
         import datasets as ref_datasets
         import tasks as ref_tasks
         from utils import dict_to_object
-        from datasets.base import BaseDataset, ForecastDataset, ReconstructionDataset, AnomalyDetectionDataset
+        from datasets.base import BaseDataset, ForecastDataset, ReconstructionDataset, AnomalyDetectionDataset, SemanticSegmentationDataset
         from tasks.anomaly_detection import adjust_anomalies as ref_adjust, running_mean as ref_running_mean
 
         N, C = 230, 3
 
         class SynthBase(BaseDataset):
             """synthetic multichannel physiological waveforms sampled at 125 Hz."""
-            supported_tasks = ["forecasting", "reconstruction", "anomaly_detection"]
+            supported_tasks = ["forecasting", "reconstruction", "anomaly_detection", "semantic_segmentation"]
+            semseg_classes = 4
 
             def get_data(self, split=None):
                 split = split or self.split
                 out = {"data": series(split, N, C)}
                 if self.task == "anomaly_detection":
                     out["labels"] = labels_for(split, N)
+                if self.task == "semantic_segmentation":
+                    out["labels"] = semseg_labels(split, N, type(self).semseg_classes)
                 return out
 
         def mk(base):
             return type("Synth" + base.__name__, (SynthBase, base), {"__doc__": SynthBase.__doc__})
 
         ref_datasets.dataset_lookup["synthetic_eval"] = {"forecasting": mk(ForecastDataset), "reconstruction": mk(ReconstructionDataset),
-                                                         "anomaly_detection": mk(AnomalyDetectionDataset)}
+                                                         "anomaly_detection": mk(AnomalyDetectionDataset),
+                                                         "semantic_segmentation": mk(SemanticSegmentationDataset)}
         out = {"N": np.int64(N), "C": np.int64(C)}
         for split in ("train", "val", "test"):
             out[f"raw.{split}"] = series(split, N, C)
@@ -137,6 +170,20 @@ def main():
                 sc = tr.score_anomalies(r.anomaly_preds, r.anomaly_labels)
                 for k, v in sc.items():
                     out[f"ad.{tag}.{split}.score.{k}"] = np.float64(v)
+
+        # ---- semantic segmentation: 4 classes and binary; overlap (step 8) and step 40 > pred 32
+        for ncls in (4, 2):
+            SynthBase.semseg_classes = ncls
+            for split in ("train", "val", "test"):
+                out[f"ss{ncls}.labels.{split}"] = semseg_labels(split, N, ncls)
+            for tag, step in (("s8", 8), ("s40", 40)):
+                tr = build(ref_tasks, dict_to_object, d, "semantic_segmentation", 32, 32, step, N, C)
+                tr.model = FakeSemSeg(ncls)
+                for split, dl in (("val", tr.val_dataloader), ("test", tr.test_dataloader)):
+                    p, t = tr.predict(dl)
+                    out[f"ss{ncls}.{tag}.{split}.preds"], out[f"ss{ncls}.{tag}.{split}.targets"] = p.numpy(), t.numpy()
+                    for k, v in tr.score(p, t).items():
+                        out[f"ss{ncls}.{tag}.{split}.score.{k}"] = np.float64(v)
 
         # ---- point-adjust and running mean on their own (incl. a segment starting at index 0)
         rng = np.random.default_rng(5)

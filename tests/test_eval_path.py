@@ -44,22 +44,43 @@ class FakeRecon(torch.nn.Module):
         return 0.9 * x + 0.05 * x.roll(1, dims=1) + 0.01 * x[:, :1, :]
 
 
+SEMSEG_CLASSES = [4]
+
+
 def _source(config, split):
     out = {"data": G[f"raw.{split}"]}
     if config.task == "anomaly_detection":
         out["labels"] = G[f"labels.{split}"]
+    if config.task == "semantic_segmentation":
+        out["labels"] = G[f"ss{SEMSEG_CLASSES[0]}.labels.{split}"]
     return out
+
+
+class FakeSemSeg(torch.nn.Module):
+    supported_tasks = ["semantic_segmentation"]
+
+    def __init__(self, n_classes):
+        super().__init__()
+        self.n_classes = n_classes
+        self.dummy = torch.nn.Parameter(torch.zeros(1))
+
+    def forward(self, inputs):
+        x = inputs["x_enc"]
+        if self.n_classes == 2:
+            return torch.sigmoid(1.3 * x[:, :, 0] + 0.1 * x[:, :1, 1])
+        w = torch.linspace(-1.0, 1.0, self.n_classes, dtype=x.dtype, device=x.device)
+        return torch.softmax(x[:, :, :1] * w + 0.3 * x[:, :1, 1:2] * w.flip(0), dim=-1)
 
 
 register_series("series_eval", _source)
 
 
-def _trainer(task, L, pred, step, fake, extra_tasks=None):
+def _trainer(task, L, pred, step, fake, extra_tasks=None, loss="mse"):
     from med_ts_llm_amd.tasks.base import BaseTask
     cfg = {"DEBUG": True, "task": task, "model": "medtsllm", "history_len": L, "pred_len": pred,
            "data": {"dataset": "series_eval", "mode": "multivariate", "cols": "all", "normalize": True, "step": step},
            "training": {"epochs": 1, "batch_size": 3, "optimizer": "adam", "learning_rate": 1e-3, "dropout": 0.0,
-                        "loss": "mse", "eval_metric": "mse", "eval_metric_direction": "min"},
+                        "loss": loss, "eval_metric": "mse", "eval_metric_direction": "min"},
            "setup": {"seed": 0, "device": "cpu", "dtype": "fp32", "num_workers": 0},
            "tasks": {"segmentation": {"mode": "boundary-prediction"}, **(extra_tasks or {})}}
     orig = BaseTask.build_model
@@ -105,6 +126,20 @@ def test_anomaly_predict_matches_reference(tag, tcfg):
         assert r.anomaly_threshold == pytest.approx(float(G[k + "threshold"]), rel=1e-6)
         assert np.array_equal(r.anomaly_preds.numpy(), G[k + "anomaly_preds"])
         for name, v in tr.score_anomalies(r.anomaly_preds, r.anomaly_labels).items():
+            assert v == pytest.approx(float(G[k + "score." + name]), rel=1e-9)
+
+
+@pytest.mark.parametrize("ncls", [4, 2])
+@pytest.mark.parametrize("tag,step", [("s8", 8), ("s40", 40)])
+def test_semantic_segmentation_predict_matches_reference(ncls, tag, step):
+    SEMSEG_CLASSES[0] = ncls
+    tr = _trainer("semantic_segmentation", 32, 32, step, FakeSemSeg(ncls), loss="ce")
+    assert tr.val_dataset.n_classes == ncls
+    for split, dl in (("val", tr.val_dataloader), ("test", tr.test_dataloader)):
+        p, t = tr.predict(dl)
+        k = f"ss{ncls}.{tag}.{split}."
+        assert np.array_equal(p.numpy(), G[k + "preds"]) and np.array_equal(t.numpy(), G[k + "targets"])
+        for name, v in tr.score(p, t).items():
             assert v == pytest.approx(float(G[k + "score." + name]), rel=1e-9)
 
 
