@@ -153,7 +153,7 @@ def test_full_model_fwd_bwd(kind, task, B, L, C, pred, cov, down, prompt_on):
         print(f"   grad {n:55s} hip {e_hip:.3e}  reference-mixed {e_ref:.3e}")
         # sums with heavy cancellation (|sum| ~ 1e-3 of the L1 mass: biases fed by sign-alternating gradients, the
         # 1 x C feature-weighting, and the analytically-zero key bias) amplify ANY bf16-level perturbation of the
-        # incoming gradient by ~sqrt(N); measured on MI355X (tools/debug4.py) the deviation is the random projection of a
+        # incoming gradient by ~sqrt(N); measured on MI355X (tools/parity_cancellation_evidence.py) the deviation is the random projection of a
         # 1e-2 norm-wise error, not a bias. They get a loose absolute bar; every large weight keeps the tight one.
         loose = n.endswith("key_projection.bias") or n.startswith("feature_weighting") or n == "mapping_layer.bias" \
             or n.endswith("query_projection.bias")

@@ -1,3 +1,6 @@
+"""Evidence for the loose parity bar on cancellation-prone gradients (key/query bias, 1xC feature weighting, mapping bias): on the GPU box,
+compares plain torch CUDA fp32/bf16 linears against CPU fp32 on the same shapes and shows that the deviation is the random projection of a
+bf16-rounded incoming gradient, not an error of the HIP kernels (referenced from DESIGN.md section 3 and tests/test_gpu_model.py)."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
