@@ -360,3 +360,28 @@ def test_full_model_gpt2_llm_dropout_train_vs_eval():
             assert p_.grad is not None and torch.isfinite(p_.grad).all(), n
     model.llm_dropout = False
     assert torch.equal(model(x), e1)
+
+
+def test_backbone_stack_at_gpt2_max_positions():
+    """maximum size: T = n_positions = 1024 (GPT-2's learned-position limit; interleave-mode sequences get there) — the
+    K/V-resident attention no longer fits the LDS, so the chunked causal kernels carry the stack; one more token is rejected"""
+    from med_ts_llm_amd.models.backbone import FrozenBackbone, random_state_dict
+    from oracle import medtsllm_oracle as O
+    cfg = dict(hf_cfg("gpt2"), n_positions=1024)
+    sd = random_state_dict(cfg, seed=3, std=0.06)
+    bb = FrozenBackbone(cfg, sd, "cuda")
+    B, T, n_last, d = 1, 1024, 200, cfg["n_embd"]
+    g = torch.Generator().manual_seed(5)
+    h0 = torch.randn(B, T, d, generator=g)
+    dout = torch.randn(B, n_last, d, generator=g).to(BF16)
+    h0r = h0.clone().requires_grad_(True)
+    ref = O.backbone_forward(h0r, sd, cfg)[:, -n_last:, :]
+    (ref * dout.float()).sum().backward()
+    h_in = (h0 + sd["wpe.weight"][:T]).cuda()
+    out, saved = bb.run_forward(h_in, n_last)
+    assert rel_err(out.float(), ref) < L3
+    dh0 = bb.run_backward(h_in, dout.cuda(), saved, n_last, n_last + 56).cpu()
+    lo = T - (n_last + 56)
+    assert rel_err(dh0[:, lo:], h0r.grad[:, lo:]) < 2 * L3 and torch.all(dh0[:, :lo] == 0)
+    with pytest.raises(ValueError):
+        bb.run_forward(torch.zeros(1, 1025, d, device="cuda"), 1)
