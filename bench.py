@@ -44,6 +44,8 @@ WORKLOADS = {
     "llama2_7b_semseg_B32_L1024_C12": (LLAMA2_7B, 32, 1024, 12, 1024, 128, "semantic_segmentation"),
     # BASELINE.json configs[4] shape: reconstruction, frozen Llama-3-8B (GQA 32/8, vocab 128256 -> 100 000 TRAINABLE sub-sampled rows)
     "llama3_8b_recon_B32_L1024_C12": (LLAMA3_8B, 32, 1024, 12, 1024, 128, "reconstruction"),
+    # BASELINE.json configs[3] shape: PSM anomaly detection = reconstruction of 25-channel L=2048 windows (P=256, T=384; head 32768 -> 51200)
+    "llama2_7b_psm_B32_L2048_C25": (LLAMA2_7B, 32, 2048, 25, 2048, 128, "anomaly_detection"),
 }
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md
 
