@@ -510,3 +510,28 @@ def test_attention_causal_dropout(ops, pdrop, resident):
         ops.lib().mtl_attention_tune(1)
     assert rel_err(o.float(), ref) < TOL_BF16
     assert rel_err(dq.float(), qf.grad) < 1e-2 and rel_err(dk.float(), kf.grad) < 1e-2 and rel_err(dv.float(), vf.grad) < 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(128, 64, 2, 4), (128, 96, 2, 4), (128, 96, 3, 4), (128, 128, 2, 8), (128, 128, 3, 8), (128, 128, 2, 4),
+                                 (128, 192, 2, 8), (256, 128, 3, 16), (256, 128, 2, 16), (256, 192, 2, 8)])
+def test_gemm_every_tile_configuration(ops, cfg):
+    """each persistent-kernel tile configuration, forced through mtl_gemm_tune, on ragged shapes (edge tiles in M and N)
+    with the plain, residual and accumulate epilogues; the launch heuristic only ever picks among these"""
+    lib = ops.lib()
+    for (M, Nn, K) in [(300, 260, 128), (37, 100, 64), (515, 388, 320)]:
+        A = torch.randn(M, K, generator=g(M)).to(BF16).cuda()
+        B = (torch.randn(Nn, K, generator=g(Nn)) * 0.2).to(BF16).cuda()
+        bias = torch.randn(Nn, generator=g(K)).cuda()
+        res = torch.randn(M, Nn, generator=g(7)).cuda()
+        lin = A.double().cpu() @ B.double().cpu().t()
+        lib.mtl_gemm_tune(1, *cfg)
+        try:
+            plain = ops.gemm_nt(A, B, bias=bias)
+            resid = ops.gemm_nt(A, B, bias=bias, epilogue=ops.N.EPI_RESID, aux_in=res, out_dtype=F32)
+            accum = ops.gemm_nt(A, B, epilogue=ops.N.EPI_ACCUM, out=res.clone())
+        finally:
+            lib.mtl_gemm_tune(1, 0, 0, 0, 0)
+        assert rel_err(plain.float(), lin + bias.double().cpu()) < TOL_BF16
+        assert rel_err(resid, res.double().cpu() + rb((lin + bias.double().cpu()).float()).double()) < 1e-4   # a few bf16 rounding ties
+        assert rel_err(accum, res.double().cpu() + lin) < 1e-5
