@@ -177,7 +177,7 @@ def read_prof(lib):
         k = keys[i]
         epi, cdt, split = (k & 0xff) // 4, ((k & 0xff) // 2) % 2, k & 1
         if k & (1 << 8):
-            name = (f"gemm_nt_persist_kernel<{epi}, {cdt}, {256 if k & (1 << 15) else 128}, {(64, 128, 96, 192)[(k >> 16) & 3]}, "
+            name = (f"gemm_nt_persist_kernel<{epi}, {cdt}, {256 if k & (1 << 15) else 128}, {256 if k & (1 << 18) else (64, 128, 96, 192)[(k >> 16) & 3]}, "
                     f"{(k >> 12) & 7}, {(4, 8, 16)[(k >> 10) & 3]}>")
         else:
             name = f"gemm_nt_kernel<{epi}, {cdt}, {'true' if split else 'false'}>"

@@ -98,7 +98,7 @@ int mtl_gemm_nt(const mtl_gemm_args* args, void* stream);
 /* Measurement aid (bench.py roofline leg; off by default, no effect on results): while enabled every GEMM launch is
  * bracketed by HIP events on its launch stream. mtl_prof_read aggregates per kernel instance
  * key: bits 0-7 = epilogue*4 + c_dtype*2 + (split_k > 1); bit 8 = persistent kernel, bit 9 = 128-wide tile (else 64),
- * bits 10-11 = waves (0: 4, 1: 8, 2: 16), bits 12-14 = LDS stages, bit 15 = 256-row tile (else 128), bits 16-17 = tile width (0: 64, 1: 128, 2: 96, 3: 192): launches, total ms, total algorithmic FLOPs (2*M*N*K).
+ * bits 10-11 = waves (0: 4, 1: 8, 2: 16), bits 12-14 = LDS stages, bit 15 = 256-row tile (else 128), bits 16-17 = tile width (0: 64, 1: 128, 2: 96, 3: 192), bit 18 = 256-wide tile: launches, total ms, total algorithmic FLOPs (2*M*N*K).
  * mtl_prof_calibrate returns the duration (ms) of an empty event bracket on `stream` (fixed per-launch overhead). */
 int mtl_prof_enable(int on);
 double mtl_prof_calibrate(void* stream);

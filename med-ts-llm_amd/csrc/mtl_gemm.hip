@@ -143,8 +143,8 @@ __device__ __forceinline__ void epilogue4(const mtl_gemm_args& p, int64_t m, int
 // every store waits for the previous store to complete, and the still-"pending" bias registers force a vmcnt(0) in
 // front of the next k-step's first ds_read, draining the LDS-DMA pipeline.)
 template <int EPI, int CDT, int NI, bool FULL>
-__device__ __forceinline__ void epilogue_wave(const mtl_gemm_args& p, int64_t m_first, int64_t n_first, f32x4 (&acc)[NI][4],
-                                              const bool dword_stores = false) {
+__device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m_first, int64_t n_first, f32x4 (*acc)[4],
+                                               const bool dword_stores) {
     // lane owns rows m_first + mi*16 (mi = 0..3) and columns n_first + ni*16 .. +3.  Edge tiles (!FULL) LOAD from
     // clamped (always valid) addresses and predicate only the stores: no load result is ever consumed inside a branch.
     int64_t crow[4];
@@ -237,6 +237,17 @@ __device__ __forceinline__ void epilogue_wave(const mtl_gemm_args& p, int64_t m_
                 }
             }
         }
+}
+
+// column tiles are processed NCH at a time so that the prefetched auxiliary operands (residual: 4 float4 per column tile)
+// stay within the register budget of the wide wave tiles (64x96, 64x128 per wave); <= 4 column tiles go in one piece
+template <int EPI, int CDT, int NI, bool FULL>
+__device__ __forceinline__ void epilogue_wave(const mtl_gemm_args& p, int64_t m_first, int64_t n_first, f32x4 (&acc)[NI][4],
+                                              const bool dword_stores = false) {
+    constexpr int NCH = NI > 4 ? 2 : NI;
+    static_assert(NI % NCH == 0, "column tiles per wave must split evenly");
+#pragma unroll
+    for (int c0 = 0; c0 < NI; c0 += NCH) epilogue_chunk<EPI, CDT, NCH, FULL>(p, m_first, n_first + c0 * 16, &acc[c0], dword_stores);
 }
 
 // SPLIT: raw fp32 partial sums go to workspace slab [split][M][N]; epilogue runs in splitk_reduce_kernel.
@@ -641,6 +652,12 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
             // Llama-class grids, plain epilogue: 256x192 / 8 waves (each wave 64x96) moves 22 % fewer operand bytes per FLOP
             // than 256x128 (qkv 775 -> 727 us = 1.13 PF/s, gate|up 1404 -> 1336 us); residual epilogues keep 256x128
             if (bm == 256 && EPI == MTL_EPI_STORE && (p.N % 192 == 0 || p.N >= 8192)) { bn = 192; if (nw == 0) nw = 8; if (stages == 0) stages = 2; }
+            // ... and 256x256 / 8 waves (each wave 64x128, 32 B/clk/CU of operand traffic at MFMA peak) beats both wherever the
+            // last column tile wastes < 6 %: qkv 768 -> 683 us (1.21 PF/s), down 695 -> 638, o-proj 296 -> 254, dX 371 -> 329 us
+            // (1.25 PF/s = 50 % of peak). Plain and residual epilogues only (the others do not fit the register budget).
+            if (bm == 256 && (EPI == MTL_EPI_STORE || EPI == MTL_EPI_RESID) && ((p.N + 255) / 256) * 256 * 100 <= p.N * 106) {
+                bn = 256; if (nw == 0 || nw == 8) nw = 8; if (stages == 0 || stages == 2) stages = 2;
+            }
             const int64_t t192 = (int64_t)tiles_m * (p.N / 192);
             if (bm == 128 && bn == 128 && p.N % 192 == 0 && t192 >= 2 * ncu && (EPI == MTL_EPI_STORE || EPI == MTL_EPI_GELU)) bn = 192;
             else if (bm == 128 && bn == 64 && p.N % 96 == 0) bn = 96;
@@ -652,7 +669,7 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         const int per_cu = (int)(160 * 1024 / lds) < 1 ? 1 : (int)(160 * 1024 / lds);
         const int grid = nt < per_cu * ncu ? nt : per_cu * ncu;
         if (recording) rec.key |= (1 << 8) | ((bn == 128 ? 1 : 0) << 9) | ((nw == 8 ? 1 : (nw == 16 ? 2 : 0)) << 10) | (stages << 12) | ((bm == 256 ? 1 : 0) << 15) |
-                                      ((bn == 96 ? 2 : (bn == 192 ? 3 : (bn == 128 ? 1 : 0))) << 16);
+                                      ((bn == 96 ? 2 : (bn == 192 ? 3 : (bn == 128 ? 1 : 0))) << 16) | ((bn == 256 ? 1 : 0) << 18);
 #define MTL_PERSIST(BMV, BNV, STV, NWV)                                                                                \
     do {                                                                                                               \
         auto kfn = gemm_nt_persist_kernel<EPI, CDT, BMV, BNV, STV, NWV>;                                               \
@@ -670,6 +687,7 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         else if (bm == 128 && bn == 96 && nw == 4 && stages == 3) MTL_PERSIST(128, 96, 3, 4);
         else if (bm == 128 && bn == 192 && nw == 8 && stages == 2) MTL_PERSIST(128, 192, 2, 8);
         else if (bm == 256 && bn == 192 && nw == 8 && stages == 2) MTL_PERSIST(256, 192, 2, 8);
+        else if (bm == 256 && bn == 256 && nw == 8 && stages == 2) MTL_PERSIST(256, 256, 2, 8);
         else if (bm == 128 && bn == 64 && nw == 4 && stages == 3) MTL_PERSIST(128, 64, 3, 4);
         else return MTL_ERR_UNSUPPORTED;
 #undef MTL_PERSIST
@@ -711,7 +729,7 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
 }  // namespace
 
 extern "C" int mtl_gemm_tune(int mode, int bm, int bn, int stages, int waves) {
-    if ((mode != 0 && mode != 1) || (bm != 0 && bm != 128 && bm != 256) || (bn != 0 && bn != 64 && bn != 128 && bn != 96 && bn != 192) ||
+    if ((mode != 0 && mode != 1) || (bm != 0 && bm != 128 && bm != 256) || (bn != 0 && bn != 64 && bn != 128 && bn != 96 && bn != 192 && bn != 256) ||
         (stages != 0 && stages != 2 && stages != 3 && stages != 4) || (waves != 0 && waves != 4 && waves != 8 && waves != 16))
         return MTL_ERR_ARG;
     tuning().mode = mode;
