@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MTL_ABI_VERSION 2
+#define MTL_ABI_VERSION 3
 
 enum { MTL_OK = 0, MTL_ERR_ARG = -1, MTL_ERR_ALIGN = -2, MTL_ERR_UNSUPPORTED = -3, MTL_ERR_LAUNCH = -4,
        MTL_ERR_WORKSPACE = -5 };
@@ -70,7 +70,9 @@ enum { MTL_EPI_STORE = 0,   /* C = v                                  (C bf16 or
        MTL_EPI_GELU = 1,    /* aux_out(bf16) = v ; C(bf16) = gelu_new(v)   (HF:activations.py:65-66)         */
        MTL_EPI_RESID = 2,   /* C(f32) = aux_in(f32) + v               (residual stream update)              */
        MTL_EPI_DGELU = 3,   /* C(bf16) = v * gelu_new'(aux_in(bf16))  (backward through the activation)     */
-       MTL_EPI_ACCUM = 4 }; /* C(f32) += v                            (gradient accumulation)               */
+       MTL_EPI_ACCUM = 4,   /* C(f32) += v                            (gradient accumulation)               */
+       MTL_EPI_SWIGLU = 5 };/* C(bf16) = v with columns INTERLEAVED (2j = gate_j, 2j+1 = up_j: B rows in that order);
+                             * aux_out(bf16)[m, j] = silu(gate_j) * up_j   (HF:models/llama/modeling_llama.py:174-176) */
 typedef struct {
     const void* A; int64_t lda;      /* bf16 [M, K]                                                          */
     const void* B; int64_t ldb;      /* bf16 [N, K]                                                          */
@@ -220,7 +222,9 @@ int mtl_rope_inplace_rows(void* qkv, int64_t ld, const float* cos_t, const float
                           int64_t n_rot_heads, int64_t D, int inverse, int64_t group_rows, int64_t group_stride,
                           int64_t row_offset, void* stream);
 int mtl_swiglu_bwd_rows(const void* gu, const void* dh, void* dgu, int64_t M, int64_t F, int64_t group_rows,
-                        int64_t group_stride, int64_t row_offset, void* stream);
+                        int64_t group_stride, int64_t row_offset, int interleaved, void* stream);
+/* (interleaved != 0: gu and dgu hold (gate_j, up_j) in columns (2j, 2j+1), the layout MTL_EPI_SWIGLU writes, instead of
+ *  [gate | up] halves.) */
 
 /* ------------------------------------------------------------------ LLM input assembly (a6 tail, K10/K11)
  * h0[b, t, :] = (t < n_tok ? embed[ids[b, t]] : x_tok[b, t - n_tok, :]) + (wpe ? wpe[t] : 0)   -> f32 [B, T, d]
@@ -248,7 +252,7 @@ typedef struct {
     float eps;
     const void* const* w_qkv;   const void* const* w_qkv_t;  const float* const* b_qkv;   /* [(Hq+2Hkv)*hd, d]        */
     const void* const* w_o;     const void* const* w_o_t;    const float* const* b_o;     /* [d, Hq*hd]               */
-    const void* const* w_fc;    const void* const* w_fc_t;   const float* const* b_fc;    /* gpt2 [ffn,d]; llama [2ffn,d] = gate|up */
+    const void* const* w_fc;    const void* const* w_fc_t;   const float* const* b_fc;    /* gpt2 [ffn,d]; llama [2ffn,d], rows interleaved: 2j = gate_j, 2j+1 = up_j */
     const void* const* w_proj;  const void* const* w_proj_t; const float* const* b_proj;  /* [d, ffn]                 */
     const float* const* ln1_w;  const float* const* ln1_b;
     const float* const* ln2_w;  const float* const* ln2_b;

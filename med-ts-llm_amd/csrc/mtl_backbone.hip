@@ -172,8 +172,8 @@ extern "C" int mtl_backbone_fwd(const mtl_backbone_weights* w, const float* h0, 
         // --- MLP block
         MTL_TRY(mtl_norm_fwd(H(2 * i + 1), w->ln2_w[i], w->ln2_b ? w->ln2_b[i] : nullptr, wk + W.xln, D.d, st2, D.M, D.d, w->eps, rms, 0, 0, 0, stream));
         if (D.llama) {
-            MTL_TRY(gemm(wk + W.xln, D.d, w->w_fc[i], D.d, fc, D.Nfc, MTL_BF16, D.M, D.Nfc, D.d, bf, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream));
-            MTL_TRY(mtl_swiglu_fwd(fc, wk + W.act, D.M, D.ffn, stream));
+            // gate|up GEMM with the SwiGLU fused into its epilogue (weights row-interleaved: columns 2j / 2j+1 = gate_j / up_j)
+            MTL_TRY(gemm(wk + W.xln, D.d, w->w_fc[i], D.d, fc, D.Nfc, MTL_BF16, D.M, D.Nfc, D.d, bf, MTL_EPI_SWIGLU, nullptr, 0, wk + W.act, D.ffn, stream));
         } else {
             MTL_TRY(gemm(wk + W.xln, D.d, w->w_fc[i], D.d, wk + W.act, D.ffn, MTL_BF16, D.M, D.ffn, D.d, bf, MTL_EPI_GELU, nullptr, 0, fc, D.ffn, stream));
         }
@@ -226,7 +226,7 @@ extern "C" int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, 
         // --- MLP block backward: h_out = h_mid + proj(act(fc(norm2(h_mid))))
         if (D.llama) {
             MTL_TRY(gemm(wk + W.dres_b, D.d, w->w_proj_t[i], D.d, wk + W.dhact, D.ffn, MTL_BF16, Mg, D.ffn, D.d, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream, rm));
-            MTL_TRY(mtl_swiglu_bwd_rows(fc, wk + W.dhact, wk + W.dact, Mg, D.ffn, rm.rows, rm.stride, rm.offset, stream));
+            MTL_TRY(mtl_swiglu_bwd_rows(fc, wk + W.dhact, wk + W.dact, Mg, D.ffn, rm.rows, rm.stride, rm.offset, 1, stream));
         } else {
             // C (and the saved pre-activation read by the dgelu epilogue) keep physical rows; the next GEMM gathers them
             MTL_TRY(gemm(wk + W.dres_b, D.d, w->w_proj_t[i], D.d, wk + W.dact, D.ffn, MTL_BF16, Mg, D.ffn, D.d, nullptr, MTL_EPI_DGELU, fc, D.ffn, nullptr, 0, stream, rm, rm));

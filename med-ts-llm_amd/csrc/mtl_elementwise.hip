@@ -140,17 +140,25 @@ __global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restr
 }
 
 // gu rows may be gathered (saved activations keep their physical layout); dh / dgu are compact
+template <bool INTERLEAVED>
 __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dh, bf16_t* __restrict__ dgu, int64_t M,
                                   int64_t F, int64_t gr, int64_t gs, int64_t ro) {
     const int64_t total = M * (F >> 1);
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = idx / (F >> 1), f = (idx % (F >> 1)) * 2;
         const int64_t pm = remap_row(m, gr, gs, ro);
-        const uint32_t g = *reinterpret_cast<const uint32_t*>(gu + pm * 2 * F + f);
-        const uint32_t u = *reinterpret_cast<const uint32_t*>(gu + pm * 2 * F + F + f);
+        float gv[2], uv[2];
+        if (INTERLEAVED) {          // columns (2f, 2f+1, 2f+2, 2f+3) = (g_f, u_f, g_f+1, u_f+1): one 8-byte access
+            const u32x2 q = *reinterpret_cast<const u32x2*>(gu + pm * 2 * F + 2 * f);
+            gv[0] = __uint_as_float(q[0] << 16); uv[0] = __uint_as_float(q[0] & 0xffff0000u);
+            gv[1] = __uint_as_float(q[1] << 16); uv[1] = __uint_as_float(q[1] & 0xffff0000u);
+        } else {
+            const uint32_t g = *reinterpret_cast<const uint32_t*>(gu + pm * 2 * F + f);
+            const uint32_t u = *reinterpret_cast<const uint32_t*>(gu + pm * 2 * F + F + f);
+            gv[0] = __uint_as_float(g << 16); gv[1] = __uint_as_float(g & 0xffff0000u);
+            uv[0] = __uint_as_float(u << 16); uv[1] = __uint_as_float(u & 0xffff0000u);
+        }
         const uint32_t d = *reinterpret_cast<const uint32_t*>(dh + m * F + f);
-        float gv[2] = {__uint_as_float(g << 16), __uint_as_float(g & 0xffff0000u)};
-        float uv[2] = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
         float dv[2] = {__uint_as_float(d << 16), __uint_as_float(d & 0xffff0000u)};
         float dg[2], du[2];
 #pragma unroll
@@ -159,8 +167,13 @@ __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* _
             du[e] = dv[e] * gv[e] * sg;
             dg[e] = dv[e] * uv[e] * sg * (1.0f + gv[e] * (1.0f - sg));
         }
-        *reinterpret_cast<uint32_t*>(dgu + m * 2 * F + f) = pack_bf16x2(dg[0], dg[1]);
-        *reinterpret_cast<uint32_t*>(dgu + m * 2 * F + F + f) = pack_bf16x2(du[0], du[1]);
+        if (INTERLEAVED) {
+            const u32x2 q = {pack_bf16x2(dg[0], du[0]), pack_bf16x2(dg[1], du[1])};
+            *reinterpret_cast<u32x2*>(dgu + m * 2 * F + 2 * f) = q;
+        } else {
+            *reinterpret_cast<uint32_t*>(dgu + m * 2 * F + f) = pack_bf16x2(dg[0], dg[1]);
+            *reinterpret_cast<uint32_t*>(dgu + m * 2 * F + F + f) = pack_bf16x2(du[0], du[1]);
+        }
     }
 }
 
@@ -285,17 +298,21 @@ extern "C" int mtl_swiglu_fwd(const void* gu, void* h, int64_t M, int64_t F, voi
 }
 
 extern "C" int mtl_swiglu_bwd_rows(const void* gu, const void* dh, void* dgu, int64_t M, int64_t F, int64_t group_rows,
-                                   int64_t group_stride, int64_t row_offset, void* stream) {
+                                   int64_t group_stride, int64_t row_offset, int interleaved, void* stream) {
     if (!gu || !dh || !dgu || M <= 0 || F <= 0) return MTL_ERR_ARG;
     if (F % 2 != 0) return MTL_ERR_ALIGN;
-    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(M * F / 2, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gu,
+    if (interleaved)
+        hipLaunchKernelGGL(swiglu_bwd_kernel<true>, dim3(grid_for(M * F / 2, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gu,
+                           (const bf16_t*)dh, (bf16_t*)dgu, M, F, group_rows, group_stride, row_offset);
+    else
+    hipLaunchKernelGGL(swiglu_bwd_kernel<false>, dim3(grid_for(M * F / 2, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gu,
                        (const bf16_t*)dh, (bf16_t*)dgu, M, F, group_rows, group_stride, row_offset);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
 
 extern "C" int mtl_swiglu_bwd(const void* gu, const void* dh, void* dgu, int64_t M, int64_t F, void* stream) {
-    return mtl_swiglu_bwd_rows(gu, dh, dgu, M, F, 0, 0, 0, stream);
+    return mtl_swiglu_bwd_rows(gu, dh, dgu, M, F, 0, 0, 0, 0, stream);
 }
 
 extern "C" int mtl_assemble_llm_input(const int32_t* ids, int64_t ids_B, const float* embed, const void* x_tok, const float* wpe,

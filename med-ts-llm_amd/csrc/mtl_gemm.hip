@@ -217,6 +217,15 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
             if constexpr (CDT == MTL_BF16) {
                 const u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
                 if (ok) *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + crow[mi] * p.ldc + n) = pk;
+                if constexpr (EPI == MTL_EPI_SWIGLU) {
+                    // columns (n .. n+3) = (gate_j, up_j, gate_j+1, up_j+1), j = n/2; the activation sees the bf16-rounded Linear
+                    // outputs and silu's own output is a bf16 tensor before the product (HF:modeling_llama.py:176)
+                    const float g0 = __uint_as_float(pk[0] << 16), u0 = __uint_as_float(pk[0] & 0xffff0000u);
+                    const float g1 = __uint_as_float(pk[1] << 16), u1 = __uint_as_float(pk[1] & 0xffff0000u);
+                    const float s0 = bf16_to_f32(f32_to_bf16(g0 * __builtin_amdgcn_rcpf(1.0f + __expf(-g0))));
+                    const float s1 = bf16_to_f32(f32_to_bf16(g1 * __builtin_amdgcn_rcpf(1.0f + __expf(-g1))));
+                    if (ok) *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(p.aux_out) + crow[mi] * p.ld_aux_out + (n >> 1)) = pack_bf16x2(s0 * u0, s1 * u1);
+                }
             } else {
                 float* cp = reinterpret_cast<float*>(p.C) + crow[mi] * p.ldc + n;
                 if (EPI == MTL_EPI_STORE && dword_stores) {
@@ -651,11 +660,11 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
             // fc 66 -> 59 us), 128x96 wins or ties wherever 128x64 was chosen (mproj 52 -> 47 us); DGELU keeps 128x128.
             // Llama-class grids, plain epilogue: 256x192 / 8 waves (each wave 64x96) moves 22 % fewer operand bytes per FLOP
             // than 256x128 (qkv 775 -> 727 us = 1.13 PF/s, gate|up 1404 -> 1336 us); residual epilogues keep 256x128
-            if (bm == 256 && EPI == MTL_EPI_STORE && (p.N % 192 == 0 || p.N >= 8192)) { bn = 192; if (nw == 0) nw = 8; if (stages == 0) stages = 2; }
+            if (bm == 256 && (EPI == MTL_EPI_STORE || EPI == MTL_EPI_SWIGLU) && (p.N % 192 == 0 || p.N >= 8192)) { bn = 192; if (nw == 0) nw = 8; if (stages == 0) stages = 2; }
             // ... and 256x256 / 8 waves (each wave 64x128, 32 B/clk/CU of operand traffic at MFMA peak) beats both wherever the
             // last column tile wastes < 6 %: qkv 768 -> 683 us (1.21 PF/s), down 695 -> 638, o-proj 296 -> 254, dX 371 -> 329 us
             // (1.25 PF/s = 50 % of peak). Plain and residual epilogues only (the others do not fit the register budget).
-            if (bm == 256 && (EPI == MTL_EPI_STORE || EPI == MTL_EPI_RESID) && ((p.N + 255) / 256) * 256 * 100 <= p.N * 106) {
+            if (bm == 256 && (EPI == MTL_EPI_STORE || EPI == MTL_EPI_RESID || EPI == MTL_EPI_SWIGLU) && ((p.N + 255) / 256) * 256 * 100 <= p.N * 106) {
                 bn = 256; if (nw == 0 || nw == 8) nw = 8; if (stages == 0 || stages == 2) stages = 2;
             }
             const int64_t t192 = (int64_t)tiles_m * (p.N / 192);
@@ -692,6 +701,7 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         else return MTL_ERR_UNSUPPORTED;
 #undef MTL_PERSIST
     } else if (S == 1) {
+        if (EPI == MTL_EPI_SWIGLU) return MTL_ERR_UNSUPPORTED;      // the fused activation lives in the wave-level epilogue only
         hipLaunchKernelGGL((gemm_nt_kernel<EPI, CDT, false>), dim3(tiles_m * tiles_n, 1), dim3(256), 0, st, p, vec_ok);
     } else {
         const int ws_vec = (p.N % 4 == 0) && aligned(p.workspace, 16);
@@ -825,6 +835,10 @@ extern "C" int mtl_gemm_nt(const mtl_gemm_args* a, void* stream) {
         case MTL_EPI_ACCUM:
             if (p.c_dtype != MTL_F32 || S > 1) return MTL_ERR_ARG;
             return launch<MTL_EPI_ACCUM, MTL_F32>(p, vec_ok, st);
+        case MTL_EPI_SWIGLU:
+            if (p.c_dtype != MTL_BF16 || !p.aux_out || S > 1) return MTL_ERR_ARG;
+            if (!vec_ok || p.ld_aux_out % 2 != 0 || !aligned(p.aux_out, 4)) return MTL_ERR_ALIGN;   // wave-level epilogue only
+            return launch<MTL_EPI_SWIGLU, MTL_BF16>(p, vec_ok, st);
         default:
             return MTL_ERR_UNSUPPORTED;
     }

@@ -11,9 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MTL_LIB_PATH") or os.path.join(_HERE, "libmedtsllm_hip.so")   # override: diagnostic builds only
 
 MTL_F32, MTL_BF16 = 0, 1
-EPI_STORE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM = 0, 1, 2, 3, 4
+EPI_STORE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM, EPI_SWIGLU = 0, 1, 2, 3, 4, 5
 ARCH_GPT2, ARCH_LLAMA = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 i64, vp, f32, i32 = C.c_int64, C.c_void_p, C.c_float, C.c_int
 
@@ -104,7 +104,7 @@ SIGNATURES = {
     "mtl_dropout_f32": (i32, [vp, vp, i64, i64, f32, C.c_uint32, vp]),
     "mtl_rope_inplace": (i32, [vp, i64, vp, vp, i64, i64, i64, i64, i32, vp]),
     "mtl_rope_inplace_rows": (i32, [vp, i64, vp, vp, i64, i64, i64, i64, i32, i64, i64, i64, vp]),
-    "mtl_swiglu_bwd_rows": (i32, [vp, vp, vp, i64, i64, i64, i64, i64, vp]),
+    "mtl_swiglu_bwd_rows": (i32, [vp, vp, vp, i64, i64, i64, i64, i64, i32, vp]),
     "mtl_swiglu_fwd": (i32, [vp, vp, i64, i64, vp]),
     "mtl_swiglu_bwd": (i32, [vp, vp, vp, i64, i64, vp]),
     "mtl_assemble_llm_input": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, vp]),

@@ -261,10 +261,11 @@ def swiglu_fwd(gu):
     return h
 
 
-def swiglu_bwd(gu, dh):
+def swiglu_bwd(gu, dh, interleaved=False):
+    """interleaved: gu / dgu columns (2j, 2j+1) = (gate_j, up_j), the layout the MTL_EPI_SWIGLU GEMM epilogue writes"""
     M, F2 = gu.shape
     dgu = torch.empty_like(gu)
-    check(lib().mtl_swiglu_bwd(ptr(gu), ptr(dh), ptr(dgu), M, F2 // 2, stream()), "mtl_swiglu_bwd")
+    check(lib().mtl_swiglu_bwd_rows(ptr(gu), ptr(dh), ptr(dgu), M, F2 // 2, 0, 0, 0, 1 if interleaved else 0, stream()), "mtl_swiglu_bwd_rows")
     return dgu
 
 

@@ -102,7 +102,8 @@ class FrozenBackbone:
             else:
                 p = f"layers.{i}."
                 wq = torch.cat([sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.v_proj.weight"]], 0)
-                wg = torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 0)
+                # gate / up rows INTERLEAVED (2j = gate_j, 2j+1 = up_j): MTL_EPI_SWIGLU needs the pair in one lane's 4 columns
+                wg = torch.stack([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], dim=1).reshape(-1, d)
                 for name, w_oi in (("qkv", wq), ("o", sd[p + "self_attn.o_proj.weight"]), ("fc", wg), ("proj", sd[p + "mlp.down_proj.weight"])):
                     k["w_" + name].append(bf(w_oi))
                     k["w_" + name + "_t"].append(bf(w_oi.t()))

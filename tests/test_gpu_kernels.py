@@ -535,3 +535,24 @@ def test_gemm_every_tile_configuration(ops, cfg):
         assert rel_err(plain.float(), lin + bias.double().cpu()) < TOL_BF16
         assert rel_err(resid, res.double().cpu() + rb((lin + bias.double().cpu()).float()).double()) < 1e-4   # a few bf16 rounding ties
         assert rel_err(accum, res.double().cpu() + lin) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,F,K", [(300, 96, 128), (8192, 1024, 256)])
+def test_gemm_swiglu_epilogue_and_interleaved_backward(ops, M, F, K):
+    """gate|up GEMM with the SwiGLU fused into the epilogue (row-interleaved weights: column 2j = gate_j, 2j+1 = up_j) ==
+    plain GEMM + mtl_swiglu_fwd on the [gate | up] layout; the interleaved backward == the plain one, re-interleaved"""
+    x = torch.randn(M, K, generator=g(1)).to(BF16).cuda()
+    wg = (torch.randn(F, K, generator=g(2)) * 0.2).to(BF16).cuda()
+    wu = (torch.randn(F, K, generator=g(3)) * 0.2).to(BF16).cuda()
+    gu_ref = ops.gemm_nt(x, torch.cat([wg, wu], 0))                       # [M, 2F] = [gate | up]
+    h_ref = ops.swiglu_fwd(gu_ref)
+    w_il = torch.stack([wg, wu], dim=1).reshape(2 * F, K).contiguous()
+    act = torch.empty(M, F, dtype=BF16, device="cuda")
+    gu_il = ops.gemm_nt(x, w_il, epilogue=ops.N.EPI_SWIGLU, aux_out=act)
+    assert torch.equal(gu_il.view(M, F, 2)[:, :, 0], gu_ref[:, :F]) and torch.equal(gu_il.view(M, F, 2)[:, :, 1], gu_ref[:, F:])
+    assert rel_err(act.float(), h_ref.float()) < 1e-3                     # same roundings; __expf vs expf in the sigmoid
+    dh = torch.randn(M, F, generator=g(4)).to(BF16).cuda()
+    d_ref = ops.swiglu_bwd(gu_ref, dh)
+    d_il = ops.swiglu_bwd(gu_il, dh, interleaved=True)
+    assert torch.equal(d_il.view(M, F, 2)[:, :, 0], d_ref[:, :F]) and torch.equal(d_il.view(M, F, 2)[:, :, 1], d_ref[:, F:])
