@@ -71,8 +71,10 @@ enum { MTL_EPI_STORE = 0,   /* C = v                                  (C bf16 or
        MTL_EPI_RESID = 2,   /* C(f32) = aux_in(f32) + v               (residual stream update)              */
        MTL_EPI_DGELU = 3,   /* C(bf16) = v * gelu_new'(aux_in(bf16))  (backward through the activation)     */
        MTL_EPI_ACCUM = 4,   /* C(f32) += v                            (gradient accumulation)               */
-       MTL_EPI_SWIGLU = 5 };/* C(bf16) = v with columns INTERLEAVED (2j = gate_j, 2j+1 = up_j: B rows in that order);
+       MTL_EPI_SWIGLU = 5,  /* C(bf16) = v with columns INTERLEAVED (2j = gate_j, 2j+1 = up_j: B rows in that order);
                              * aux_out(bf16)[m, j] = silu(gate_j) * up_j   (HF:models/llama/modeling_llama.py:174-176) */
+       MTL_EPI_DSWIGLU = 6 };/* its backward: v = d(act)[m, n]; aux_in(bf16)[m, 2n..2n+1] = saved (gate_n, up_n);
+                             * C(bf16) has 2N columns: C[m, 2n] = d gate_n, C[m, 2n+1] = d up_n (ldc >= 2N, ldc % 8 == 0) */
 typedef struct {
     const void* A; int64_t lda;      /* bf16 [M, K]                                                          */
     const void* B; int64_t ldb;      /* bf16 [N, K]                                                          */

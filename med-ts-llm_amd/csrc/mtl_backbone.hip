@@ -53,7 +53,7 @@ SavedLayout saved_layout(const Dims& D, int64_t n_last) {
 
 // ---- `work` layout (scratch shared by fwd and bwd)
 struct WorkLayout {
-    size_t xln, act, dres_b, dact, dx, dqkv, dO, delta, dhact, total;
+    size_t xln, act, dres_b, dact, dx, dqkv, dO, delta, total;
 };
 WorkLayout work_layout(const Dims& D) {
     WorkLayout w;
@@ -66,7 +66,6 @@ WorkLayout work_layout(const Dims& D) {
     w.dqkv = off; off += align_up((size_t)D.M * D.Nqkv * 2);
     w.dO = off; off += align_up((size_t)D.M * D.No * 2);
     w.delta = off; off += align_up((size_t)D.B * D.Hq * D.T * 4);
-    w.dhact = off; off += D.llama ? align_up((size_t)D.M * D.ffn * 2) : 0;
     w.total = off;
     return w;
 }
@@ -225,14 +224,16 @@ extern "C" int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, 
         char* fc = sv + S.fc + S.fc_stride * (size_t)i;
         // --- MLP block backward: h_out = h_mid + proj(act(fc(norm2(h_mid))))
         if (D.llama) {
-            MTL_TRY(gemm(wk + W.dres_b, D.d, w->w_proj_t[i], D.d, wk + W.dhact, D.ffn, MTL_BF16, Mg, D.ffn, D.d, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream, rm));
-            MTL_TRY(mtl_swiglu_bwd_rows(fc, wk + W.dhact, wk + W.dact, Mg, D.ffn, rm.rows, rm.stride, rm.offset, 1, stream));
+            // d(act) GEMM with the SwiGLU backward fused into its epilogue: reads the saved (gate, up) pairs, writes d(gate|up)
+            // interleaved, at physical rows like the GPT-2 path (the next GEMM gathers them)
+            MTL_TRY(gemm(wk + W.dres_b, D.d, w->w_proj_t[i], D.d, wk + W.dact, D.Nfc, MTL_BF16, Mg, D.ffn, D.d, nullptr, MTL_EPI_DSWIGLU, fc, D.Nfc, nullptr, 0,
+                         stream, rm, rm));
         } else {
             // C (and the saved pre-activation read by the dgelu epilogue) keep physical rows; the next GEMM gathers them
             MTL_TRY(gemm(wk + W.dres_b, D.d, w->w_proj_t[i], D.d, wk + W.dact, D.ffn, MTL_BF16, Mg, D.ffn, D.d, nullptr, MTL_EPI_DGELU, fc, D.ffn, nullptr, 0, stream, rm, rm));
         }
         MTL_TRY(gemm(wk + W.dact, D.Nfc, w->w_fc_t[i], D.Nfc, wk + W.dx, D.d, MTL_BF16, Mg, D.d, D.Nfc, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream,
-                     D.llama ? kIdentity : rm));
+                     rm));
         MTL_TRY(mtl_norm_bwd(wk + W.dx, D.d, H(2 * i + 1), w->ln2_w[i], st2, dh0, dh0, wk + W.dres_b, Mg, D.d, rms, rm.rows, rm.stride, rm.offset, 1,
                              resid_p, drop_site_seed(dseed, i, 1), stream));
         // --- attention block backward: h_mid = h_in + o_proj(attn(qkv(norm1(h_in))))

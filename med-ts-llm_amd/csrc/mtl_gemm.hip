@@ -171,7 +171,8 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
     }
     float4 res[EPI == MTL_EPI_RESID || EPI == MTL_EPI_ACCUM ? NI : 1][4];
     u32x2 hk[EPI == MTL_EPI_DGELU ? NI : 1][4];
-    if constexpr (EPI == MTL_EPI_RESID || EPI == MTL_EPI_ACCUM || EPI == MTL_EPI_DGELU) {
+    u32x4 gq[EPI == MTL_EPI_DSWIGLU ? NI : 1][4];        // saved (gate, up) pairs of the lane's 4 activation columns
+    if constexpr (EPI == MTL_EPI_RESID || EPI == MTL_EPI_ACCUM || EPI == MTL_EPI_DGELU || EPI == MTL_EPI_DSWIGLU) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -179,6 +180,7 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
                 if constexpr (EPI == MTL_EPI_RESID) res[ni][mi] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.aux_in) + crow[mi] * p.ld_aux_in + ncol[ni]);
                 if constexpr (EPI == MTL_EPI_ACCUM) res[ni][mi] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.C) + crow[mi] * p.ldc + ncol[ni]);
                 if constexpr (EPI == MTL_EPI_DGELU) hk[ni][mi] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.aux_in) + crow[mi] * p.ld_aux_in + ncol[ni]);
+                if constexpr (EPI == MTL_EPI_DSWIGLU) gq[ni][mi] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.aux_in) + crow[mi] * p.ld_aux_in + 2 * ncol[ni]);
             }
     }
     // edge tiles: hipcc sinks the bias/residual math into the predicated store blocks, which leaves the load results
@@ -214,7 +216,20 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
             } else if constexpr (EPI == MTL_EPI_ACCUM) {
                 o[0] += res[ni][mi].x; o[1] += res[ni][mi].y; o[2] += res[ni][mi].z; o[3] += res[ni][mi].w;
             }
-            if constexpr (CDT == MTL_BF16) {
+            if constexpr (EPI == MTL_EPI_DSWIGLU) {
+                // d(act) is a bf16 tensor in the unfused chain: round first. d gate = dh*up*sig*(1 + g*(1 - sig)), d up = dh*g*sig
+                const u32x2 dk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                const float dh[4] = {__uint_as_float(dk[0] << 16), __uint_as_float(dk[0] & 0xffff0000u), __uint_as_float(dk[1] << 16),
+                                     __uint_as_float(dk[1] & 0xffff0000u)};
+                u32x4 outq;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gv = __uint_as_float(gq[ni][mi][e] << 16), uv = __uint_as_float(gq[ni][mi][e] & 0xffff0000u);
+                    const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-gv));
+                    outq[e] = pack_bf16x2(dh[e] * uv * sg * (1.0f + gv * (1.0f - sg)), dh[e] * gv * sg);
+                }
+                if (ok) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + crow[mi] * p.ldc + 2 * n) = outq;
+            } else if constexpr (CDT == MTL_BF16) {
                 const u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
                 if (ok) *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + crow[mi] * p.ldc + n) = pk;
                 if constexpr (EPI == MTL_EPI_SWIGLU) {
@@ -664,7 +679,8 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
             // ... and 256x256 / 8 waves (each wave 64x128, 32 B/clk/CU of operand traffic at MFMA peak) beats both wherever the
             // last column tile wastes < 6 %: qkv 768 -> 683 us (1.21 PF/s), down 695 -> 638, o-proj 296 -> 254, dX 371 -> 329 us
             // (1.25 PF/s = 50 % of peak). Plain and residual epilogues only (the others do not fit the register budget).
-            if (bm == 256 && (EPI == MTL_EPI_STORE || EPI == MTL_EPI_RESID || EPI == MTL_EPI_SWIGLU) && ((p.N + 255) / 256) * 256 * 100 <= p.N * 106) {
+            if (bm == 256 && (EPI == MTL_EPI_STORE || EPI == MTL_EPI_RESID || EPI == MTL_EPI_SWIGLU || EPI == MTL_EPI_DSWIGLU) &&
+                ((p.N + 255) / 256) * 256 * 100 <= p.N * 106) {
                 bn = 256; if (nw == 0 || nw == 8) nw = 8; if (stages == 0 || stages == 2) stages = 2;
             }
             const int64_t t192 = (int64_t)tiles_m * (p.N / 192);
@@ -701,7 +717,7 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         else return MTL_ERR_UNSUPPORTED;
 #undef MTL_PERSIST
     } else if (S == 1) {
-        if (EPI == MTL_EPI_SWIGLU) return MTL_ERR_UNSUPPORTED;      // the fused activation lives in the wave-level epilogue only
+        if (EPI == MTL_EPI_SWIGLU || EPI == MTL_EPI_DSWIGLU) return MTL_ERR_UNSUPPORTED;      // the fused activation lives in the wave-level epilogue only
         hipLaunchKernelGGL((gemm_nt_kernel<EPI, CDT, false>), dim3(tiles_m * tiles_n, 1), dim3(256), 0, st, p, vec_ok);
     } else {
         const int ws_vec = (p.N % 4 == 0) && aligned(p.workspace, 16);
@@ -835,6 +851,10 @@ extern "C" int mtl_gemm_nt(const mtl_gemm_args* a, void* stream) {
         case MTL_EPI_ACCUM:
             if (p.c_dtype != MTL_F32 || S > 1) return MTL_ERR_ARG;
             return launch<MTL_EPI_ACCUM, MTL_F32>(p, vec_ok, st);
+        case MTL_EPI_DSWIGLU:
+            if (p.c_dtype != MTL_BF16 || !p.aux_in || S > 1 || p.bias) return MTL_ERR_ARG;
+            if (!vec_ok || p.ldc % 8 != 0 || !aligned(p.C, 16) || p.ld_aux_in % 8 != 0 || !aligned(p.aux_in, 16)) return MTL_ERR_ALIGN;
+            return launch<MTL_EPI_DSWIGLU, MTL_BF16>(p, vec_ok, st);
         case MTL_EPI_SWIGLU:
             if (p.c_dtype != MTL_BF16 || !p.aux_out || S > 1) return MTL_ERR_ARG;
             if (!vec_ok || p.ld_aux_out % 2 != 0 || !aligned(p.aux_out, 4)) return MTL_ERR_ALIGN;   // wave-level epilogue only

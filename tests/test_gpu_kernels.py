@@ -556,3 +556,35 @@ def test_gemm_swiglu_epilogue_and_interleaved_backward(ops, M, F, K):
     d_ref = ops.swiglu_bwd(gu_ref, dh)
     d_il = ops.swiglu_bwd(gu_il, dh, interleaved=True)
     assert torch.equal(d_il.view(M, F, 2)[:, :, 0], d_ref[:, :F]) and torch.equal(d_il.view(M, F, 2)[:, :, 1], d_ref[:, F:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,F,K,tune", [(300, 96, 128, None), (2048, 1024, 256, None), (1024, 512, 128, (256, 256, 2, 8)),
+                                        (1000, 320, 64, (128, 192, 2, 8))])
+def test_gemm_dswiglu_epilogue(ops, M, F, K, tune):
+    """d(act) GEMM with the SwiGLU backward fused into the epilogue (MTL_EPI_DSWIGLU) == plain GEMM + mtl_swiglu_bwd_rows on the
+    interleaved layout, incl. gathered physical rows (same row map for the saved pairs and the output)"""
+    lib = ops.lib()
+    dy = torch.randn(M, K, generator=g(1)).to(BF16).cuda()
+    wp = (torch.randn(F, K, generator=g(2)) * 0.2).to(BF16).cuda()
+    gu = torch.randn(M, 2 * F, generator=g(3)).to(BF16).cuda()
+    dh = ops.gemm_nt(dy, wp)
+    ref = ops.swiglu_bwd(gu, dh, interleaved=True)
+    out = torch.zeros(M, 2 * F, dtype=BF16, device="cuda")
+    try:
+        if tune is not None:
+            lib.mtl_gemm_tune(1, *tune)
+        ops.gemm_nt(dy, wp, out=out, epilogue=ops.N.EPI_DSWIGLU, aux_in=gu)
+    finally:
+        lib.mtl_gemm_tune(1, 0, 0, 0, 0)
+    assert rel_err(out.float(), ref.float()) < 1e-3                        # same roundings; __expf vs expf in the sigmoid
+    # pruned backward: logical row m lives at physical row (m // 60) * 100 + 40 + m % 60 of the saved pairs and of the output
+    if M == 300:
+        rows = (60, 100, 40)
+        phys = torch.arange(M).div(60, rounding_mode="floor") * 100 + 40 + torch.arange(M) % 60
+        gu_p = torch.zeros(500, 2 * F, dtype=BF16, device="cuda"); gu_p[phys.cuda()] = gu
+        out_p = torch.zeros(500, 2 * F, dtype=BF16, device="cuda")
+        ops.gemm_nt(dy, wp, out=out_p, epilogue=ops.N.EPI_DSWIGLU, aux_in=gu_p, c_rows=rows)
+        assert torch.equal(out_p[phys.cuda()], out)
+        mask = torch.ones(500, dtype=torch.bool); mask[phys] = False
+        assert not out_p[mask.cuda()].any()
