@@ -435,11 +435,16 @@ __device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int
 //   4.2 MFLOP of MFMA work each and halve the L1->LDS bytes per FLOP again
 // SPLIT: a work item is (k-slab s, tile): the slab's K range of that tile, raw fp32 partial sums to workspace slab s
 // (splitk_reduce_kernel applies the epilogue). Slab-major item order: neighbours share A/B panels. `vec_ok_i` carries S.
-template <int EPI, int CDT, int BM_, int BN_, int STAGES, int NW, bool SPLIT = false>
-__global__ __launch_bounds__(NW * 64) void gemm_nt_persist_kernel(const mtl_gemm_args p, const int vec_ok_i, const int tiles_m,
-                                                             const int tiles_n) {
+// KS = 2 (grids of at most one tile per CU): the workgroup's waves form two groups that run the same pipeline over the two
+// halves of K, each with its own LDS ring (twice the LDS-DMA bytes in flight and two waves per SIMD, which a lone 4-wave
+// workgroup per CU lacks: M = B*n_grad backward GEMMs 46 -> ~30 us cold); group 1 hands its partial sums over through LDS.
+// Host guarantees one tile per workgroup and an even number of k-tiles.
+template <int EPI, int CDT, int BM_, int BN_, int STAGES, int NW_ALL, bool SPLIT = false, int KS = 1>
+__global__ __launch_bounds__(NW_ALL * 64) void gemm_nt_persist_kernel(const mtl_gemm_args p, const int vec_ok_i, const int tiles_m,
+                                                                 const int tiles_n) {
     constexpr int BK_ = 64;
-    constexpr int NT = NW * 64;                // threads
+    constexpr int NW = NW_ALL / KS;            // waves per k-group (all tile geometry below is per group)
+    constexpr int NT = NW * 64;                // threads per k-group
     constexpr int WM = BM_ / 64;               // waves along M
     constexpr int WN = NW / WM;                // waves along N
     constexpr int WCOLS = BN_ / WN;            // columns per wave
@@ -451,10 +456,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_persist_kernel(const mtl_gemm
     constexpr int NL = NA + NB;                // LDS-DMA instructions per wave per stage
     constexpr int A_BYTES = BM_ * ROWB, B_BYTES = BN_ * ROWB;
     constexpr int STAGE = A_BYTES + B_BYTES;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    const int lane = threadIdx.x & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kgrp = KS > 1 ? wave_all / NW : 0;
+    const int wave = KS > 1 ? wave_all % NW : wave_all;
+    const int tid = wave * 64 + lane;          // thread index inside the k-group
+    char* const smem = smem_all + (KS > 1 ? kgrp * STAGES * STAGE : 0);
     const int wr = wave / WN, wc = wave % WN;
     const int l15 = lane & 15, g = lane >> 4;
     const int n_split = SPLIT ? vec_ok_i : 1;  // (the persistent kernel is only launched when the vector epilogue applies)
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_persist_kernel(const mtl_gemm
     const int cnt = q + (xcd < r8 ? 1 : 0);
     if (slot >= cnt) return;
     const int my_count = (cnt - slot + xblocks - 1) / xblocks;
-    const int nkt = (int)(p.K / BK_) / n_split;
+    const int nkt = (int)(p.K / BK_) / n_split / KS;
     const int total = my_count * nkt;
 
     const bf16_t* asrc[NA];
@@ -478,7 +486,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_persist_kernel(const mtl_gemm
         const int slab = SPLIT ? item / tiles_mn : 0;
         tile_coords(SPLIT ? item - slab * tiles_mn : item, tiles_m, tiles_n, tm, tn);
         const int64_t m0 = (int64_t)tm * BM_, n0 = (int64_t)tn * BN_;
-        const int64_t k0 = (int64_t)slab * nkt * BK_;
+        const int64_t k0 = (int64_t)(slab * KS + kgrp) * nkt * BK_;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int sl = i * NT + tid;
@@ -597,6 +605,26 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_persist_kernel(const mtl_gemm
             ++c_i;
         }
     }
+    if constexpr (KS > 1) {
+        // hand-over of group 1's partial sums: lane-linear 16-B slots (conflict-free), in the rings nobody reads any more
+        static_assert(KS == 1 || (size_t)NW * NI * 4 * 64 * 16 <= (size_t)KS * STAGES * STAGE, "reduction scratch must fit the rings");
+        f32x4* red = reinterpret_cast<f32x4*>(smem_all) + wave * (NI * 4 * 64) + lane;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // every wave is past its last ds_read
+        asm volatile("" ::: "memory");
+        if (kgrp == 1) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) red[(ni * 4 + mi) * 64] = acc[ni][mi];
+        }
+        __syncthreads();
+        if (kgrp == 1) return;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) acc[ni][mi] += red[(ni * 4 + mi) * 64];
+    }
     if (done_tile >= 0) finish(done_tile);
 }
 
@@ -683,14 +711,28 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
                 ((p.N + 255) / 256) * 256 * 100 <= p.N * 106) {
                 bn = 256; if (nw == 0 || nw == 8) nw = 8; if (stages == 0 || stages == 2) stages = 2;
             }
+            // GELU / dGELU GEMMs on 768-multiples: inside a training step the operands arrive L2-cold (the microbench with
+            // GEMM_COLD=1 is the proxy that predicts in-step times; warm it prefers 128x192). 256x192 / 8 waves: fc 90 -> 71 us
+            // cold, b_dact 39 -> 36 us; in-step -3.3 % per GPT-2-small step
+            if (bm == 128 && p.N % 192 == 0 && (int64_t)((p.M + 255) / 256) * (p.N / 192) >= ncu && (EPI == MTL_EPI_GELU || EPI == MTL_EPI_DGELU)) {
+                bm = 256; bn = 192; if (nw == 0) nw = 8; if (stages == 0) stages = 2;
+            }
             const int64_t t192 = (int64_t)tiles_m * (p.N / 192);
             if (bm == 128 && bn == 128 && p.N % 192 == 0 && t192 >= 2 * ncu && (EPI == MTL_EPI_STORE || EPI == MTL_EPI_GELU)) bn = 192;
             else if (bm == 128 && bn == 64 && p.N % 96 == 0) bn = 96;
         }
+        const bool auto_cfg = nw == 0 && stages == 0;
         if (nw == 0) nw = bm == 256 ? 16 : (bn >= 128 ? 8 : 4);
         if (stages == 0) stages = bm == 256 ? 3 : 2;
         const int tm = (int)((p.M + bm - 1) / bm), tn = (int)((p.N + bn - 1) / bn), nt = tm * tn;
-        const size_t lds = (size_t)stages * (bm + bn) * BK * 2;
+        // at most one 128x96 tile per CU: two k-groups of 4 waves (KS = 2; tune: waves = 8 on a 128x96 tile)
+        const int nkt_all = (int)(p.K / BK);
+        int ks = 1;
+        // (in-step A/B, GPT-2-small metric step: two k-groups 7.20 ms, one group with a 3-deep ring 7.38, 128x128 / 8 waves / 3 stages 7.22+,
+        //  one group with 2 stages 7.60)
+        if (bm == 128 && bn == 96 && nt <= ncu && nkt_all % 2 == 0 && nkt_all >= 4 && stages == 2 && (auto_cfg || nw == 8)) { ks = 2; nw = 8; }
+        else if (bm == 128 && bn == 96 && nw == 8) return MTL_ERR_UNSUPPORTED;
+        const size_t lds = (size_t)ks * stages * (bm + bn) * BK * 2;
         const int per_cu = (int)(160 * 1024 / lds) < 1 ? 1 : (int)(160 * 1024 / lds);
         const int grid = nt < per_cu * ncu ? nt : per_cu * ncu;
         if (recording) rec.key |= (1 << 8) | ((bn == 128 ? 1 : 0) << 9) | ((nw == 8 ? 1 : (nw == 16 ? 2 : 0)) << 10) | (stages << 12) | ((bm == 256 ? 1 : 0) << 15) |
@@ -702,7 +744,13 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(NWV * 64), lds, st, p, vec_ok, tm, tn);                               \
     } while (0)
-        if (bm == 256 && bn == 128 && nw == 16 && stages == 3) MTL_PERSIST(256, 128, 3, 16);
+        if (ks == 2) {
+            auto kfn = gemm_nt_persist_kernel<EPI, CDT, 128, 96, 2, 8, false, 2>;
+            static std::once_flag once;
+            std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+            if (recording) rec.key |= 1 << 19;
+            hipLaunchKernelGGL(kfn, dim3(nt), dim3(512), lds, st, p, vec_ok, tm, tn);
+        } else if (bm == 256 && bn == 128 && nw == 16 && stages == 3) MTL_PERSIST(256, 128, 3, 16);
         else if (bm == 256 && bn == 128 && nw == 16 && stages == 2) MTL_PERSIST(256, 128, 2, 16);
         else if (bm == 128 && bn == 128 && nw == 8 && stages == 2) MTL_PERSIST(128, 128, 2, 8);
         else if (bm == 128 && bn == 128 && nw == 8 && stages == 3) MTL_PERSIST(128, 128, 3, 8);
@@ -714,6 +762,9 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         else if (bm == 256 && bn == 192 && nw == 8 && stages == 2) MTL_PERSIST(256, 192, 2, 8);
         else if (bm == 256 && bn == 256 && nw == 8 && stages == 2) MTL_PERSIST(256, 256, 2, 8);
         else if (bm == 128 && bn == 64 && nw == 4 && stages == 3) MTL_PERSIST(128, 64, 3, 4);
+        else if (bm == 128 && bn == 96 && nw == 4 && stages == 4) MTL_PERSIST(128, 96, 4, 4);
+        else if (bm == 128 && bn == 96 && nw == 4 && stages == 5) MTL_PERSIST(128, 96, 5, 4);
+        else if (bm == 128 && bn == 128 && nw == 8 && stages == 4) MTL_PERSIST(128, 128, 4, 8);
         else return MTL_ERR_UNSUPPORTED;
 #undef MTL_PERSIST
     } else if (S == 1) {
@@ -756,7 +807,7 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
 
 extern "C" int mtl_gemm_tune(int mode, int bm, int bn, int stages, int waves) {
     if ((mode != 0 && mode != 1) || (bm != 0 && bm != 128 && bm != 256) || (bn != 0 && bn != 64 && bn != 128 && bn != 96 && bn != 192 && bn != 256) ||
-        (stages != 0 && stages != 2 && stages != 3 && stages != 4) || (waves != 0 && waves != 4 && waves != 8 && waves != 16))
+        (stages != 0 && (stages < 2 || stages > 5)) || (waves != 0 && waves != 4 && waves != 8 && waves != 16))
         return MTL_ERR_ARG;
     tuning().mode = mode;
     tuning().bm = bm;

@@ -95,6 +95,12 @@ def test_full_size_pruned_backward_equals_full_backward(model):
         _, gf = _grads(model, x, y)
     finally:
         model.prune_dead_prompt_grads = True
+    # identical rows, different GEMM shapes (M = B*n_grad vs B*T) and hence different tile configurations / fp32 summation orders
+    # (the M = B*n_grad GEMMs run as two k-groups). One-ulp flips of bf16 activations propagate through 12 layers: the floor
+    # between two equally valid tile configurations of the SAME full backward (tools/grad_noise.py,
+    # profiles/r01_grad_noise_floor.txt) is 1e-3 .. 9e-3 per tensor, 1.9e-2 on the key bias, whose exact gradient is zero
+    # (softmax is invariant to a shift of every score of a row). A pruning bug (wrong rows) shows up as O(1).
     for n in gp:
         scale = float(gf[n].norm()) + 1e-12
-        assert float((gp[n] - gf[n]).norm()) / scale < 2e-3, n     # identical rows, different GEMM shapes (M = B*n_grad vs B*T)
+        tol = 5e-2 if n.endswith("key_projection.bias") else 2.5e-2
+        assert float((gp[n] - gf[n]).norm()) / scale < tol, n

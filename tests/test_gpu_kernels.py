@@ -538,6 +538,32 @@ def test_gemm_every_tile_configuration(ops, cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,Nn,K", [(300, 260, 256), (515, 388, 384), (4096, 768, 768), (128, 96, 3072)])
+def test_gemm_two_k_groups(ops, M, Nn, K):
+    """128x96 tile with two 4-wave k-groups (the configuration picked for grids of at most one tile per CU): same results as the
+    single-group kernel up to fp32 summation order, for the plain / residual / accumulate / dgelu epilogues"""
+    lib = ops.lib()
+    A = torch.randn(M, K, generator=g(M)).to(BF16).cuda()
+    B = (torch.randn(Nn, K, generator=g(Nn)) * 0.2).to(BF16).cuda()
+    bias = torch.randn(Nn, generator=g(K)).cuda()
+    res = torch.randn(M, Nn, generator=g(7)).cuda()
+    pre = torch.randn(M, Nn, generator=g(8)).to(BF16).cuda()
+    outs = {}
+    for cfg in [(128, 96, 2, 4), (128, 96, 2, 8)]:
+        lib.mtl_gemm_tune(1, *cfg)
+        try:
+            outs[cfg] = (ops.gemm_nt(A, B, bias=bias), ops.gemm_nt(A, B, bias=bias, epilogue=ops.N.EPI_RESID, aux_in=res, out_dtype=F32),
+                         ops.gemm_nt(A, B, epilogue=ops.N.EPI_ACCUM, out=res.clone()), ops.gemm_nt(A, B, epilogue=ops.N.EPI_DGELU, aux_in=pre))
+        finally:
+            lib.mtl_gemm_tune(1, 0, 0, 0, 0)
+    lin = A.double().cpu() @ B.double().cpu().t()
+    assert rel_err(outs[(128, 96, 2, 8)][0].float(), lin + bias.double().cpu()) < TOL_BF16
+    for a, b in zip(outs[(128, 96, 2, 4)], outs[(128, 96, 2, 8)]):
+        assert rel_err(b.float(), a.float().double().cpu()) < 2e-3          # bf16 outputs: a few one-ulp flips from the summation order
+    assert rel_err(outs[(128, 96, 2, 8)][2], res.double().cpu() + lin) < 1e-5
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,F,K", [(300, 96, 128), (8192, 1024, 256)])
 def test_gemm_swiglu_epilogue_and_interleaved_backward(ops, M, F, K):
     """gate|up GEMM with the SwiGLU fused into the epilogue (row-interleaved weights: column 2j = gate_j, 2j+1 = up_j) ==

@@ -9,10 +9,12 @@ lib = N.lib()
 BF16 = torch.bfloat16
 shapes = [("qkv   ", 8192, 2304, 768, N.EPI_STORE), ("aproj ", 8192, 768, 768, N.EPI_RESID), ("fc    ", 8192, 3072, 768, N.EPI_GELU),
           ("mproj ", 8192, 768, 3072, N.EPI_RESID), ("b_dact", 4096, 3072, 768, N.EPI_DGELU), ("b_dxfc", 4096, 768, 3072, N.EPI_STORE), ("b_dO", 4096, 768, 768, N.EPI_STORE), ("dact  ", 8192, 3072, 768, N.EPI_DGELU), ("dx_fc ", 8192, 768, 3072, N.EPI_STORE),
-          ("dx_qkv", 8192, 768, 2304, N.EPI_STORE), ("llama_qkv", 8192, 12288, 4096, N.EPI_STORE), ("llama_down", 8192, 4096, 11008, N.EPI_RESID), ("llama_gateup", 8192, 22016, 4096, N.EPI_STORE), ("llama_dx", 4096, 4096, 12288, N.EPI_STORE), ("llama_oproj", 8192, 4096, 4096, N.EPI_RESID), ("llama_dgu", 4096, 11008, 4096, N.EPI_STORE)]
+          ("dx_qkv", 8192, 768, 2304, N.EPI_STORE), ("b_dxqkv", 4096, 768, 2304, N.EPI_STORE), ("llama_qkv", 8192, 12288, 4096, N.EPI_STORE), ("llama_down", 8192, 4096, 11008, N.EPI_RESID), ("llama_gateup", 8192, 22016, 4096, N.EPI_STORE), ("llama_dx", 4096, 4096, 12288, N.EPI_STORE), ("llama_oproj", 8192, 4096, 4096, N.EPI_RESID), ("llama_dgu", 4096, 11008, 4096, N.EPI_STORE)]
 if len(sys.argv) > 1:
     shapes = [s for s in shapes if s[0].strip() in sys.argv[1:]]
 variants = [(1, 256, 128, 3, 16), (1, 256, 192, 2, 8), (1, 256, 256, 2, 8)]
+if os.environ.get("GEMM_VARIANTS"):      # e.g. GEMM_VARIANTS="128,96,2,4;128,96,4,4"
+    variants = [(1,) + tuple(int(x) for x in v.split(",")) for v in os.environ["GEMM_VARIANTS"].split(";")]
 g = torch.Generator().manual_seed(0)
 for name, M, Nn, K, epi in shapes:
     A = torch.randn(M, K, generator=g).to(BF16).cuda()
@@ -35,7 +37,11 @@ for name, M, Nn, K, epi in shapes:
     for rnd in range(5):
         for v in variants:
             lib.mtl_gemm_tune(*v)
-            out = ops.gemm_nt(A, B, bias=bias, epilogue=epi, **kw)
+            try:
+                out = ops.gemm_nt(A, B, bias=bias, epilogue=epi, **kw)
+            except RuntimeError:
+                times[v].append(float("inf")); outs[v] = None
+                continue
             poolC = [torch.empty_like(out) for _ in range(8)] if COLD else None
             torch.cuda.synchronize()
             if COLD:
@@ -60,6 +66,9 @@ for name, M, Nn, K, epi in shapes:
     line = f"{name} M={M} N={Nn} K={K} epi={epi}: "
     for v in variants:
         t = sorted(times[v])[len(times[v]) // 2]
+        if outs[v] is None:
+            line += f" mode{v}: unsupported |"
+            continue
         same = torch.equal(outs[v], ref)
         line += f" mode{v}: {t:7.1f}us {fl / t / 1e6:7.1f}TF {'==' if same else '!='} |"
     print(line)
