@@ -92,3 +92,77 @@ def anomaly_scores(preds, targets, normalize_by_feature, moving_window):
     if moving_window > 0:
         scores = scores / running_mean(scores, moving_window)
     return scores
+
+
+# ---------------------------------------------------------------- segmentation (boundary detection) post-processing
+def _segments(points, n):
+    """consecutive (start, end) pairs of 0 | points | n-1 (R:tasks/segmentation.py:142-146)"""
+    edges = torch.cat([torch.tensor([0]), points.to(torch.int64).reshape(-1), torch.tensor([n - 1])])
+    return torch.stack([edges[:-1], edges[1:]], dim=1)
+
+
+def _boundary_result(preds, pred_points, targets):
+    n = preds.shape[0]
+    pred_labels = torch.zeros_like(targets)
+    pred_labels[pred_points.to(torch.int64)] = 1
+    label_points = targets.nonzero().squeeze()
+    return {"preds_raw": preds, "pred_points": pred_points, "pred_labels": pred_labels, "pred_segments": _segments(pred_points, n),
+            "labels": targets, "label_points": label_points, "label_segments": _segments(label_points, n)}
+
+
+def boundaries_from_scores(preds, targets, distance_thresh):
+    """R:tasks/segmentation.py:115-154 — boundary-prediction mode: peaks of the stitched per-point scores at least
+    `distance_thresh` apart (scipy.signal.find_peaks, as the reference); "auto" = the 10 % quantile of the true
+    segment lengths."""
+    import scipy.signal
+    if distance_thresh == "auto":
+        seg_lens = targets.nonzero().squeeze().unfold(0, 2, 1).diff(dim=1).squeeze()
+        distance_thresh = seg_lens.float().quantile(0.1).item()
+    elif distance_thresh == "optimize":
+        raise NotImplementedError("distance_thresh='optimize' needs bayes_opt (R:tasks/segmentation.py:297-323), which this "
+                                  "image does not have; use 'auto' or a number")
+    pts = scipy.signal.find_peaks(preds.numpy(), distance=distance_thresh)[0]
+    return _boundary_result(preds, torch.tensor(pts, dtype=torch.int), targets)
+
+
+def boundaries_from_ramps(preds, targets):
+    """R:tasks/segmentation.py:156-192 — steps-to-boundary mode: a boundary shows as a maximum right after a minimum of
+    the predicted ramp. Prominent maxima and minima are paired: each point of the larger family snaps to its nearest
+    point of the other family when that one is closer than half the mean true segment length."""
+    import scipy.signal
+    targets = (targets == 0).int()
+    half = targets.size(0) / targets.sum().item() / 2
+    x = preds.numpy()
+    hi, lo = scipy.signal.find_peaks(x, prominence=0.5)[0], scipy.signal.find_peaks(-x, prominence=0.5)[0]
+    a, b = (hi, lo) if len(hi) >= len(lo) else (lo, hi)
+    a, b = torch.tensor(a), torch.tensor(b)
+    if a.numel() and b.numel():
+        d = (b[None, :] - a[:, None]).abs()
+        near = d.argmin(dim=1)                                   # first minimum on ties, as a sequential argmin
+        a = torch.where(d.gather(1, near[:, None]).squeeze(1) > half, a, b[near])
+    return _boundary_result(preds, a, targets)
+
+
+def all_pairs_iou(seg1, seg2):
+    """[n1, 2] x [n2, 2] (start, end) segments -> IoU matrix [n1, n2] (R:tasks/segmentation.py:261-273)"""
+    s1, e1, s2, e2 = seg1[:, :1], seg1[:, 1:2], seg2[:, 0][None, :], seg2[:, 1][None, :]
+    inter = (torch.minimum(e1, e2) - torch.maximum(s1, s2)).clamp(min=0)
+    return inter / ((e1 - s1) + (e2 - s2) - inter)
+
+
+def segmentation_scores(r):
+    """R:tasks/segmentation.py:194-234"""
+    pp, tp = r["pred_points"], r["label_points"]
+    if len(pp) == 0:
+        return {"point_mae": float("inf"), "point_rmse": float("inf"), "segment_miou": 0, "pred_label_ratio": 0.0}
+    dist = (pp.reshape(-1, 1) - tp).abs()                       # [n_pred, n_true]
+    iou = all_pairs_iou(r["pred_segments"], r["label_segments"])
+    nearest = dist.min(dim=0).values.float()
+    m = {"point_mae": nearest.mean().item(), "point_rmse": nearest.pow(2).mean().sqrt().item(),
+         "segment_miou": iou.max(dim=0).values.float().mean().item(),
+         "pred_label_ratio": r["pred_labels"].sum().item() / r["labels"].sum().item()}
+    for t in (50, 100, 200):
+        m[f"point_acc@{t}"] = (dist < t).any(dim=0).float().mean().item()
+    for t in (0.5, 0.75, 0.9):
+        m[f"segment_acc@{int(t * 100)}iou"] = (iou > t).any(dim=0).float().mean().item()
+    return m

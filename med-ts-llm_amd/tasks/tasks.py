@@ -159,13 +159,57 @@ class AnomalyDetectionTask(ReconstructionTask):
         return scores
 
 
-class SegmentationTask(BaseTask):
+class SegmentationTask(_StitchedEval, BaseTask):
+    """boundary detection (R:tasks/segmentation.py): per-point boundary scores (BCE) or a steps-to-boundary ramp (MSE / MAE)"""
+
     def build_loss(self):
-        mode = self.config.tasks.segmentation.mode
-        return torch.nn.BCEWithLogitsLoss() if mode == "boundary-prediction" else _regression_loss(self.config.training.loss)
+        mode, loss = self.config.tasks.segmentation.mode, self.config.training.loss
+        if loss == "bce":                                            # R:tasks/segmentation.py:58-71
+            assert mode == "boundary-prediction"
+            return torch.nn.BCEWithLogitsLoss()
+        if loss in ("mse", "mae"):
+            assert mode == "steps-to-boundary"
+            return torch.nn.MSELoss() if loss == "mse" else torch.nn.L1Loss()
+        raise ValueError(f"Invalid loss function selection: {loss}")
 
     def compute_loss(self, inputs):
         return self.loss_fn(self.model(inputs), inputs["labels"].to(self.dtype))
+
+    def predict(self, dataloader):
+        """R:tasks/segmentation.py:73-113 -> dict of stitched scores, detected boundary points / labels / segments and the
+        true ones (host tensors, as the reference returns)."""
+        ds = dataloader.dataset
+        if not self._stitched(dataloader):
+            return BaseTask.predict(self, dataloader)
+        if ds.univariate:
+            raise NotImplementedError("segmentation over univariate datasets")
+        mode = self.config.tasks.segmentation.mode
+        pred_len, step = self.config.pred_len, ds.step_size
+        n_points = ds.n_points if ds.clip_dataset else pred_len + ((len(ds) - 1) * step)
+        w = self._windows(dataloader, ("labels",))
+        W = w["pred"].shape[0]
+        starts = [ds.inverse_index(i)[0] for i in range(W)]
+        preds = E.stitch_last_wins(w["pred"].reshape(W, -1), starts, n_points, float("nan"))
+        tdt = torch.int if mode == "boundary-prediction" else torch.float
+        targets = E.stitch_last_wins(w["labels"].reshape(W, -1).to(tdt), starts, n_points, -1)
+        preds, targets = E.crop_to_scored_points(ds, [preds, targets], n_points, step, pred_len)
+        assert not preds.isnan().any() and not (targets < 0).any()
+        preds, targets = preds.cpu(), targets.cpu()
+        if mode == "boundary-prediction":
+            return E.boundaries_from_scores(preds, targets, self.config.tasks.segmentation.distance_thresh)
+        if mode == "steps-to-boundary":
+            return E.boundaries_from_ramps(preds, targets)
+        raise ValueError(f"Segmentation mode {mode} not supported")
+
+    def score(self, results):
+        return E.segmentation_scores(results)
+
+    def _val_test(self, dataloader, prefix):
+        if not self._stitched(dataloader):
+            return self._eval_loss(dataloader, prefix)
+        scores = {f"{prefix}/{k}": v for k, v in self.score(self.predict(dataloader)).items()}
+        self.log_scores(scores)
+        return scores
 
 
 class SemanticSegmentationTask(_StitchedEval, BaseTask):

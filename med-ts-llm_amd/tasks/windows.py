@@ -104,7 +104,36 @@ class SemSegSeries(ReconstructionSeries):
         return len(self.labels.unique())
 
 
+def steps_to_boundary_labels(boundary):
+    """R:datasets/base.py:265-277 — binary boundary marks -> regression target: at point i the distance to the next
+    boundary c (first boundary >= i; the series end closes the last segment) divided by that segment's length
+    (c minus the previous boundary; the first segment starts at 0). A boundary point itself gets 0."""
+    b = np.asarray(boundary)
+    n = len(b)
+    cps = np.append(np.nonzero(b)[0], n)
+    i = np.arange(n)
+    j = np.searchsorted(cps, i, side="left")
+    nxt = cps[j]
+    prev = np.where(j > 0, cps[np.maximum(j - 1, 0)], 0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return ((nxt - i) / (nxt - prev)).astype(np.float32)
+
+
+class SegmentationSeries(ReconstructionSeries):
+    """R:datasets/base.py:236-281: windows of (x_enc, labels); labels are boundary marks (boundary-prediction) or the
+    normalised steps-to-boundary ramp."""
+
+    def __init__(self, config, split, source=None):
+        super().__init__(config, split, source)
+        assert self.task == "segmentation" and self.labels is not None
+        mode = config.tasks.segmentation.mode
+        if mode == "steps-to-boundary":
+            self.labels = torch.tensor(steps_to_boundary_labels(self.labels.numpy()))
+        elif mode != "boundary-prediction":
+            raise ValueError(f"Segmentation mode {mode} not supported")
+
+
 def make_series_dataset(config, split, source=None):
     cls = {"forecasting": ForecastSeries, "pretraining": ForecastSeries, "reconstruction": ReconstructionSeries,
-           "anomaly_detection": ReconstructionSeries, "semantic_segmentation": SemSegSeries, "segmentation": SemSegSeries}[config.task]
+           "anomaly_detection": ReconstructionSeries, "semantic_segmentation": SemSegSeries, "segmentation": SegmentationSeries}[config.task]
     return cls(config, split, source)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Golden vectors for the evaluation path, produced by the REAL reference task classes
-(tasks/forecasting.py, tasks/reconstruction.py, tasks/anomaly_detection.py) in THIS container only.
+(tasks/forecasting.py, tasks/reconstruction.py, tasks/anomaly_detection.py, tasks/semantic_segmentation.py, tasks/segmentation.py) in THIS container only.
 
 The reference trainer is built on CPU around a tiny local GPT-2 exactly as make_golden.py does; its model is then
 swapped for a deterministic window -> output function, so that the vectors pin the stitching / scoring logic
@@ -48,6 +48,33 @@ def semseg_labels(split, n, n_classes):
     return lab
 
 
+def boundary_labels(split, n):
+    """binary boundary marks every 17-33 points (segmentation task)"""
+    g = np.random.default_rng({"train": 51, "val": 52, "test": 53}[split])
+    lab = np.zeros(n, dtype=np.int64)
+    i = int(g.integers(6, 20))
+    while i < n - 3:
+        lab[i] = 1
+        i += int(g.integers(17, 34))
+    return lab
+
+
+class FakeBoundary(torch.nn.Module):
+    """eval-mode output of a boundary-prediction model: per-point scores in (0, 1), [B, L]"""
+
+    def forward(self, inputs):
+        x = inputs["x_enc"]
+        return torch.sigmoid(1.5 * x[:, :, 0] - 0.5 * x[:, :, 1] + 0.2 * x[:, :1, 2])
+
+
+class FakeRamp(torch.nn.Module):
+    """eval-mode output of a steps-to-boundary model: a ramp-like regression, [B, L]"""
+
+    def forward(self, inputs):
+        x = inputs["x_enc"]
+        return 0.5 + 0.6 * x[:, :, 0] + 0.15 * x[:, :, 2]
+
+
 class FakeForecast(torch.nn.Module):
     def __init__(self, pred_len):
         super().__init__()
@@ -91,6 +118,8 @@ def build(ref_tasks, dict_to_object, llm_dir, task, L, pred, step, n, C, extra_t
     })
     if task == "semantic_segmentation":
         cfgd["training"]["loss"] = "ce"
+    if task == "segmentation":
+        cfgd["training"]["loss"] = "bce" if (extra_tasks or {}).get("segmentation", {}).get("mode") == "boundary-prediction" else "mse"
     cfgd["tasks"].update(extra_tasks or {})
     return ref_tasks.get_trainer("DEBUG-eval-golden", dict_to_object(cfgd))
 
@@ -105,14 +134,15 @@ def main():
         import datasets as ref_datasets
         import tasks as ref_tasks
         from utils import dict_to_object
-        from datasets.base import BaseDataset, ForecastDataset, ReconstructionDataset, AnomalyDetectionDataset, SemanticSegmentationDataset
+        from datasets.base import (BaseDataset, ForecastDataset, ReconstructionDataset, AnomalyDetectionDataset, SemanticSegmentationDataset,
+                                   SegmentationDataset)
         from tasks.anomaly_detection import adjust_anomalies as ref_adjust, running_mean as ref_running_mean
 
         N, C = 230, 3
 
         class SynthBase(BaseDataset):
             """synthetic multichannel physiological waveforms sampled at 125 Hz."""
-            supported_tasks = ["forecasting", "reconstruction", "anomaly_detection", "semantic_segmentation"]
+            supported_tasks = ["forecasting", "reconstruction", "anomaly_detection", "semantic_segmentation", "segmentation"]
             semseg_classes = 4
 
             def get_data(self, split=None):
@@ -122,6 +152,8 @@ def main():
                     out["labels"] = labels_for(split, N)
                 if self.task == "semantic_segmentation":
                     out["labels"] = semseg_labels(split, N, type(self).semseg_classes)
+                if self.task == "segmentation":
+                    out["labels"] = boundary_labels(split, N)
                 return out
 
         def mk(base):
@@ -129,7 +161,8 @@ def main():
 
         ref_datasets.dataset_lookup["synthetic_eval"] = {"forecasting": mk(ForecastDataset), "reconstruction": mk(ReconstructionDataset),
                                                          "anomaly_detection": mk(AnomalyDetectionDataset),
-                                                         "semantic_segmentation": mk(SemanticSegmentationDataset)}
+                                                         "semantic_segmentation": mk(SemanticSegmentationDataset),
+                                                         "segmentation": mk(SegmentationDataset)}
         out = {"N": np.int64(N), "C": np.int64(C)}
         for split in ("train", "val", "test"):
             out[f"raw.{split}"] = series(split, N, C)
@@ -184,6 +217,26 @@ def main():
                     out[f"ss{ncls}.{tag}.{split}.preds"], out[f"ss{ncls}.{tag}.{split}.targets"] = p.numpy(), t.numpy()
                     for k, v in tr.score(p, t).items():
                         out[f"ss{ncls}.{tag}.{split}.score.{k}"] = np.float64(v)
+
+        # ---- segmentation (boundary detection): both label modes, distance threshold "auto" and fixed, overlap and step > pred
+        for split in ("train", "val", "test"):
+            out[f"sg.labels.{split}"] = boundary_labels(split, N)
+        seg_variants = {"bp_auto": ({"mode": "boundary-prediction", "distance_thresh": "auto"}, FakeBoundary()),
+                        "bp_d12": ({"mode": "boundary-prediction", "distance_thresh": 12}, FakeBoundary()),
+                        "stb": ({"mode": "steps-to-boundary", "distance_thresh": "auto"}, FakeRamp())}
+        for tag, (tcfg, fake) in seg_variants.items():
+            for stag, step in (("s8", 8), ("s40", 40)):
+                tr = build(ref_tasks, dict_to_object, d, "segmentation", 32, 32, step, N, C, extra_tasks={"segmentation": tcfg})
+                tr.model = fake
+                if tag == "stb" and stag == "s8":
+                    out["sg.stb.converted_labels.val"] = tr.val_dataset.labels.numpy()
+                for split, dl in (("val", tr.val_dataloader), ("test", tr.test_dataloader)):
+                    r = tr.predict(dl)
+                    k = f"sg.{tag}.{stag}.{split}."
+                    for name in ("preds_raw", "pred_points", "pred_labels", "pred_segments", "labels", "label_points", "label_segments"):
+                        out[k + name] = r[name].numpy()
+                    for name, v in tr.score(r).items():
+                        out[k + "score." + name] = np.float64(v)
 
         # ---- point-adjust and running mean on their own (incl. a segment starting at index 0)
         rng = np.random.default_rng(5)

@@ -53,7 +53,27 @@ def _source(config, split):
         out["labels"] = G[f"labels.{split}"]
     if config.task == "semantic_segmentation":
         out["labels"] = G[f"ss{SEMSEG_CLASSES[0]}.labels.{split}"]
+    if config.task == "segmentation":
+        out["labels"] = G[f"sg.labels.{split}"]
     return out
+
+
+class FakeBoundary(torch.nn.Module):
+    supported_tasks = ["segmentation"]
+
+    def __init__(self):
+        super().__init__()
+        self.dummy = torch.nn.Parameter(torch.zeros(1))
+
+    def forward(self, inputs):
+        x = inputs["x_enc"]
+        return torch.sigmoid(1.5 * x[:, :, 0] - 0.5 * x[:, :, 1] + 0.2 * x[:, :1, 2])
+
+
+class FakeRamp(FakeBoundary):
+    def forward(self, inputs):
+        x = inputs["x_enc"]
+        return 0.5 + 0.6 * x[:, :, 0] + 0.15 * x[:, :, 2]
 
 
 class FakeSemSeg(torch.nn.Module):
@@ -143,6 +163,38 @@ def test_semantic_segmentation_predict_matches_reference(ncls, tag, step):
             assert v == pytest.approx(float(G[k + "score." + name]), rel=1e-9)
 
 
+@pytest.mark.parametrize("tag,tcfg,fake,loss", [("bp_auto", {"mode": "boundary-prediction", "distance_thresh": "auto"}, FakeBoundary, "bce"),
+                                                ("bp_d12", {"mode": "boundary-prediction", "distance_thresh": 12}, FakeBoundary, "bce"),
+                                                ("stb", {"mode": "steps-to-boundary", "distance_thresh": "auto"}, FakeRamp, "mse")])
+@pytest.mark.parametrize("stag,step", [("s8", 8), ("s40", 40)])
+def test_segmentation_predict_matches_reference(tag, tcfg, fake, loss, stag, step):
+    """boundary detection (R:tasks/segmentation.py): stitched scores, detected points / labels / segments exact; metrics to round-off"""
+    tr = _trainer("segmentation", 32, 32, step, fake(), {"segmentation": tcfg}, loss=loss)
+    if tag == "stb" and stag == "s8":
+        assert np.array_equal(tr.val_dataset.labels.numpy(), G["sg.stb.converted_labels.val"], equal_nan=True)
+    for split, dl in (("val", tr.val_dataloader), ("test", tr.test_dataloader)):
+        r = tr.predict(dl)
+        k = f"sg.{tag}.{stag}.{split}."
+        for name in ("preds_raw", "pred_points", "pred_labels", "pred_segments", "labels", "label_points", "label_segments"):
+            assert np.array_equal(r[name].numpy(), G[k + name]), (k, name)
+        sc = tr.score(r)
+        assert set(sc) == {n[len(k) + 6:] for n in G.files if n.startswith(k + "score.")}
+        for name, v in sc.items():
+            assert v == pytest.approx(float(G[k + "score." + name]), rel=1e-6)
+    assert tr.test()[f"test/segment_miou"] == pytest.approx(float(G[f"sg.{tag}.{stag}.test.score.segment_miou"]), rel=1e-6)
+
+
+def test_segmentation_loss_mode_contract():
+    """R:tasks/segmentation.py:58-71: bce <-> boundary-prediction, mse / mae <-> steps-to-boundary"""
+    with pytest.raises(AssertionError):
+        _trainer("segmentation", 32, 32, 8, FakeBoundary(), {"segmentation": {"mode": "steps-to-boundary", "distance_thresh": "auto"}}, loss="bce")
+    with pytest.raises(ValueError):
+        _trainer("segmentation", 32, 32, 8, FakeBoundary(), {"segmentation": {"mode": "boundary-prediction", "distance_thresh": "auto"}}, loss="ce")
+    tr = _trainer("segmentation", 32, 32, 8, FakeBoundary(), {"segmentation": {"mode": "boundary-prediction", "distance_thresh": "optimize"}}, loss="bce")
+    with pytest.raises(NotImplementedError):
+        tr.predict(tr.val_dataloader)
+
+
 def test_point_adjust_and_running_mean_match_reference():
     for i in range(8):
         out = E.adjust_anomalies(torch.tensor(G[f"adj.{i}.pred"], dtype=torch.int), torch.tensor(G[f"adj.{i}.gt"], dtype=torch.int))
@@ -184,3 +236,10 @@ def test_forecast_and_anomaly_stitching_on_device():
     r = tr.predict(tr.test_dataloader, split="test")
     assert np.array_equal(r.recon_preds.numpy(), G["ad.f10_win5.test.recon_preds"])
     assert np.array_equal(r.anomaly_preds.numpy(), G["ad.f10_win5.test.anomaly_preds"])
+    tr = _trainer("segmentation", 32, 32, 8, FakeRamp(), {"segmentation": {"mode": "steps-to-boundary", "distance_thresh": "auto"}}, loss="mse")
+    tr.device = torch.device("cuda")
+    tr.model = tr.model.cuda()
+    r = tr.predict(tr.val_dataloader)
+    np.testing.assert_allclose(r["preds_raw"].numpy(), G["sg.stb.s8.val.preds_raw"], rtol=1e-6, atol=1e-7)   # fake model's fma order
+    assert np.array_equal(r["pred_points"].numpy(), G["sg.stb.s8.val.pred_points"])
+    assert np.array_equal(r["label_segments"].numpy(), G["sg.stb.s8.val.label_segments"])
