@@ -178,7 +178,7 @@ def read_prof(lib):
         epi, cdt, split = (k & 0xff) // 4, ((k & 0xff) // 2) % 2, k & 1
         if k & (1 << 8):
             name = (f"gemm_nt_persist_kernel<{epi}, {cdt}, {256 if k & (1 << 15) else 128}, {256 if k & (1 << 18) else (64, 128, 96, 192)[(k >> 16) & 3]}, "
-                    f"{(k >> 12) & 7}, {(4, 8, 16)[(k >> 10) & 3]}>")
+                    f"{(k >> 12) & 7}, {(4, 8, 16)[(k >> 10) & 3]}, {'true' if split else 'false'}, {2 if k & (1 << 19) else 1}>")
         else:
             name = f"gemm_nt_kernel<{epi}, {cdt}, {'true' if split else 'false'}>"
         rows.append({"kernel": name, "launches": int(launches[i]), "total_ms": ms[i], "flops": fl[i]})
@@ -192,10 +192,7 @@ def pmc_traffic(kernel):
         return None
     with open(path) as f:
         table = json.load(f)
-    for name in (kernel, kernel[:-1] + ", false>", kernel[:-1] + ", true>"):     # rocprof prints the SPLIT template flag too
-        if name in table:
-            return table[name]
-    return None
+    return table.get(kernel)
 
 
 def main():

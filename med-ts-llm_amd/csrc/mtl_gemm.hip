@@ -13,6 +13,7 @@
 //   * split-K (fp32 slabs + reduce kernel) for the batch-independent mapping GEMM (M=1024, N=d_llm, K=V).
 #include "mtl_common.h"
 
+#include <cmath>
 #include <mutex>
 #include <vector>
 
@@ -416,8 +417,7 @@ __device__ __forceinline__ int swz64(int row) { return (row >> 1) & 7; }
 // grouped (GM rows at a time) tile order: consecutive linear ids form compact GM x n patches, so the workgroups that
 // run concurrently on one XCD stream the SAME few A/B panels through its 4 MiB L2 (measured: the flat row-major
 // order re-fetched B once per tile row -> 38x the algorithmic HBM bytes on the Llama shapes).
-__device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int& tm, int& tn) {
-    constexpr int GM = 8;
+__device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int GM, int& tm, int& tn) {
     const int gsize = GM * tiles_n;
     const int grp = t / gsize, rem = t - grp * gsize;
     const int first_m = grp * GM;
@@ -441,7 +441,7 @@ __device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int
 // Host guarantees one tile per workgroup and an even number of k-tiles.
 template <int EPI, int CDT, int BM_, int BN_, int STAGES, int NW_ALL, bool SPLIT = false, int KS = 1>
 __global__ __launch_bounds__(NW_ALL * 64) void gemm_nt_persist_kernel(const mtl_gemm_args p, const int vec_ok_i, const int tiles_m,
-                                                                 const int tiles_n) {
+                                                                 const int tiles_n, const int gm) {
     constexpr int BK_ = 64;
     constexpr int NW = NW_ALL / KS;            // waves per k-group (all tile geometry below is per group)
     constexpr int NT = NW * 64;                // threads per k-group
@@ -452,9 +452,11 @@ __global__ __launch_bounds__(NW_ALL * 64) void gemm_nt_persist_kernel(const mtl_
     constexpr int CPR = BK_ / 8;               // 16-B chunks per tile row
     constexpr int ROWB = BK_ * 2;              // bytes per tile row
     constexpr int NA = BM_ * CPR / NT;         // 16-B staging slots per thread, A tile
-    constexpr int NB = BN_ * CPR / NT;         // ... B tile
+    constexpr int NB = (BN_ * CPR + NT - 1) / NT;   // ... B tile (256x96 / 8 waves: the B image is padded to 128 rows; the
+    constexpr int BN_PAD = NB * NT / CPR;      //     extra rows re-load clamped rows and are never read)
     constexpr int NL = NA + NB;                // LDS-DMA instructions per wave per stage
-    constexpr int A_BYTES = BM_ * ROWB, B_BYTES = BN_ * ROWB;
+    constexpr int A_BYTES = BM_ * ROWB, B_BYTES = BN_PAD * ROWB;
+    static_assert(BM_ * CPR % NT == 0, "A tile must be whole LDS-DMA instructions");
     constexpr int STAGE = A_BYTES + B_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     const int lane = threadIdx.x & 63;
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(NW_ALL * 64) void gemm_nt_persist_kernel(const mtl_
     auto set_sources = [&](int item) {
         int tm, tn;
         const int slab = SPLIT ? item / tiles_mn : 0;
-        tile_coords(SPLIT ? item - slab * tiles_mn : item, tiles_m, tiles_n, tm, tn);
+        tile_coords(SPLIT ? item - slab * tiles_mn : item, tiles_m, tiles_n, gm, tm, tn);
         const int64_t m0 = (int64_t)tm * BM_, n0 = (int64_t)tn * BN_;
         const int64_t k0 = (int64_t)(slab * KS + kgrp) * nkt * BK_;
 #pragma unroll
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(NW_ALL * 64) void gemm_nt_persist_kernel(const mtl_
     auto finish = [&](int item) {
         int tm, tn;
         const int slab = SPLIT ? item / tiles_mn : 0;
-        tile_coords(SPLIT ? item - slab * tiles_mn : item, tiles_m, tiles_n, tm, tn);
+        tile_coords(SPLIT ? item - slab * tiles_mn : item, tiles_m, tiles_n, gm, tm, tn);
         const int64_t m0 = (int64_t)tm * BM_, n0 = (int64_t)tn * BN_;
         const bool full = m0 + BM_ <= p.M && n0 + BN_ <= p.N;
         if constexpr (SPLIT) {
@@ -645,6 +647,22 @@ __global__ void splitk_reduce_kernel(const mtl_gemm_args p, const int S, const i
     epilogue4<EPI, CDT>(p, m, n, v, vec_ok_i != 0);
 }
 
+// rows of a tile group (tile_coords): each XCD walks a contiguous chunk of ~tiles/8 ids = g rows x (chunk/g) columns of tiles.
+// When the chunk is at most ~2 rounds of the XCD's resident workgroups, its panels stay in that L2 for the whole launch and the
+// unique operand rows ~ g*BM + (chunk/g)*BN are least at g = sqrt(chunk*BN/BM) (a chunk never spans more than tiles_n columns).
+// PMC: the 256x96 residual GEMM read 100 MB per launch with g = 8 against 80 MB algorithmic; in-step -2.5 % per GPT-2-small step.
+// Longer chunks (Llama grids) keep g = 8: larger and smaller groups both measured 0.5-0.9 % slower per Llama-2-7B step.
+int group_rows(int tiles_m, int tiles_n, int bm, int bn, int per_cu) {
+    const double chunk = (double)tiles_m * tiles_n / 8.0;
+    if (chunk > 2.0 * 32.0 * per_cu) return 8;
+    double g = std::sqrt(chunk * bn / bm);
+    if (g < chunk / tiles_n) g = chunk / tiles_n;
+    int gi = (int)(g + 0.5);
+    if (gi < 1) gi = 1;
+    if (gi > tiles_m) gi = tiles_m;
+    return gi;
+}
+
 bool aligned(const void* ptr, size_t a) { return (reinterpret_cast<uintptr_t>(ptr) % a) == 0; }
 
 // experiment knobs (mtl_gemm_tune): mode 0 = one tile per workgroup, 1 = persistent flat-K; bn = 0 auto / 64 / 128
@@ -717,6 +735,12 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
             if (bm == 128 && p.N % 192 == 0 && (int64_t)((p.M + 255) / 256) * (p.N / 192) >= ncu && (EPI == MTL_EPI_GELU || EPI == MTL_EPI_DGELU)) {
                 bm = 256; bn = 192; if (nw == 0) nw = 8; if (stages == 0) stages = 2;
             }
+            // residual GEMMs on 96-multiples with at least one 256x96 tile per CU: one 8-wave workgroup per CU with a 3-deep ring
+            // (96 KB of operands in flight instead of 2 x 28 KB; 21 % fewer operand bytes per FLOP than 128x96): cold aproj 25.2 ->
+            // 24.5 us, mproj 59.3 -> 57.8 us, in-step -1.7 % per GPT-2-small step
+            if (bm == 128 && EPI == MTL_EPI_RESID && p.N % 96 == 0 && (int64_t)((p.M + 255) / 256) * (p.N / 96) >= ncu) {
+                bm = 256; bn = 96; if (nw == 0) nw = 8; if (stages == 0) stages = 3;
+            }
             const int64_t t192 = (int64_t)tiles_m * (p.N / 192);
             if (bm == 128 && bn == 128 && p.N % 192 == 0 && t192 >= 2 * ncu && (EPI == MTL_EPI_STORE || EPI == MTL_EPI_GELU)) bn = 192;
             else if (bm == 128 && bn == 64 && p.N % 96 == 0) bn = 96;
@@ -732,7 +756,8 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         //  one group with 2 stages 7.60)
         if (bm == 128 && bn == 96 && nt <= ncu && nkt_all % 2 == 0 && nkt_all >= 4 && stages == 2 && (auto_cfg || nw == 8)) { ks = 2; nw = 8; }
         else if (bm == 128 && bn == 96 && nw == 8) return MTL_ERR_UNSUPPORTED;
-        const size_t lds = (size_t)ks * stages * (bm + bn) * BK * 2;
+        const int bn_lds = (bm == 256 && bn == 96) ? 128 : bn;      // B image padded to whole LDS-DMA instructions (8 waves)
+        const size_t lds = (size_t)ks * stages * (bm + bn_lds) * BK * 2;
         const int per_cu = (int)(160 * 1024 / lds) < 1 ? 1 : (int)(160 * 1024 / lds);
         const int grid = nt < per_cu * ncu ? nt : per_cu * ncu;
         if (recording) rec.key |= (1 << 8) | ((bn == 128 ? 1 : 0) << 9) | ((nw == 8 ? 1 : (nw == 16 ? 2 : 0)) << 10) | (stages << 12) | ((bm == 256 ? 1 : 0) << 15) |
@@ -742,14 +767,14 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         auto kfn = gemm_nt_persist_kernel<EPI, CDT, BMV, BNV, STV, NWV>;                                               \
         static std::once_flag once;                                                                                    \
         std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(NWV * 64), lds, st, p, vec_ok, tm, tn);                               \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(NWV * 64), lds, st, p, vec_ok, tm, tn, group_rows(tm, tn, bm, bn, per_cu)); \
     } while (0)
         if (ks == 2) {
             auto kfn = gemm_nt_persist_kernel<EPI, CDT, 128, 96, 2, 8, false, 2>;
             static std::once_flag once;
             std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
             if (recording) rec.key |= 1 << 19;
-            hipLaunchKernelGGL(kfn, dim3(nt), dim3(512), lds, st, p, vec_ok, tm, tn);
+            hipLaunchKernelGGL(kfn, dim3(nt), dim3(512), lds, st, p, vec_ok, tm, tn, group_rows(tm, tn, bm, bn, 1));
         } else if (bm == 256 && bn == 128 && nw == 16 && stages == 3) MTL_PERSIST(256, 128, 3, 16);
         else if (bm == 256 && bn == 128 && nw == 16 && stages == 2) MTL_PERSIST(256, 128, 2, 16);
         else if (bm == 128 && bn == 128 && nw == 8 && stages == 2) MTL_PERSIST(128, 128, 2, 8);
@@ -762,9 +787,8 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         else if (bm == 256 && bn == 192 && nw == 8 && stages == 2) MTL_PERSIST(256, 192, 2, 8);
         else if (bm == 256 && bn == 256 && nw == 8 && stages == 2) MTL_PERSIST(256, 256, 2, 8);
         else if (bm == 128 && bn == 64 && nw == 4 && stages == 3) MTL_PERSIST(128, 64, 3, 4);
-        else if (bm == 128 && bn == 96 && nw == 4 && stages == 4) MTL_PERSIST(128, 96, 4, 4);
-        else if (bm == 128 && bn == 96 && nw == 4 && stages == 5) MTL_PERSIST(128, 96, 5, 4);
-        else if (bm == 128 && bn == 128 && nw == 8 && stages == 4) MTL_PERSIST(128, 128, 4, 8);
+        else if (bm == 256 && bn == 96 && nw == 8 && stages == 3) MTL_PERSIST(256, 96, 3, 8);
+        else if (bm == 256 && bn == 96 && nw == 8 && stages == 2) MTL_PERSIST(256, 96, 2, 8);
         else return MTL_ERR_UNSUPPORTED;
 #undef MTL_PERSIST
     } else if (S == 1) {
@@ -786,7 +810,7 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
                 static std::once_flag once;
                 std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
                 if (recording) rec.key |= (1 << 8) | (1 << 10) | (STV << 12) | ((BNV == 192 ? 3 : 1) << 16) | ((BMV == 256 ? 1 : 0) << 15);
-                hipLaunchKernelGGL(kfn, dim3(grid), dim3(NWV * 64), lds, st, p, S, tm, tn);
+                hipLaunchKernelGGL(kfn, dim3(grid), dim3(NWV * 64), lds, st, p, S, tm, tn, group_rows(tm, tn, BMV, BNV, per_cu));
             };
             using I128 = std::integral_constant<int, 128>; using I192 = std::integral_constant<int, 192>; using I256 = std::integral_constant<int, 256>;
             // operands of a split GEMM stream from HBM (K is huge): the fewest operand bytes per FLOP wins (256x192 when it still

@@ -514,7 +514,7 @@ def test_attention_causal_dropout(ops, pdrop, resident):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [(128, 64, 2, 4), (128, 96, 2, 4), (128, 96, 3, 4), (128, 128, 2, 8), (128, 128, 3, 8), (128, 128, 2, 4),
-                                 (128, 192, 2, 8), (256, 128, 3, 16), (256, 128, 2, 16), (256, 192, 2, 8)])
+                                 (128, 192, 2, 8), (256, 128, 3, 16), (256, 128, 2, 16), (256, 192, 2, 8), (256, 96, 3, 8), (256, 96, 2, 8)])
 def test_gemm_every_tile_configuration(ops, cfg):
     """each persistent-kernel tile configuration, forced through mtl_gemm_tune, on ragged shapes (edge tiles in M and N)
     with the plain, residual and accumulate epilogues; the launch heuristic only ever picks among these"""
