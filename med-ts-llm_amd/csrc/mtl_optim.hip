@@ -46,8 +46,9 @@ __global__ __launch_bounds__(THREADS) void adam_multi_kernel(const AdamTable tab
         float pp[4], gg[4], mm[4], vv[4];
         const int nv = (t.n - e0) >= 4 ? 4 : (int)(t.n - e0);
         if (vec && nv == 4) {
-            const float4 p4 = *reinterpret_cast<const float4*>(t.p + e0), g4 = *reinterpret_cast<const float4*>(t.g + e0);
-            const float4 m4 = *reinterpret_cast<const float4*>(t.m + e0), v4 = *reinterpret_cast<const float4*>(t.v + e0);
+            // streamed once per step: non-temporal so that 2 GB of optimiser state does not evict the model from L2 / MALL
+            const f32x4 p4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(t.p + e0)), g4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(t.g + e0));
+            const f32x4 m4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(t.m + e0)), v4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(t.v + e0));
             pp[0] = p4.x; pp[1] = p4.y; pp[2] = p4.z; pp[3] = p4.w;
             gg[0] = g4.x; gg[1] = g4.y; gg[2] = g4.z; gg[3] = g4.w;
             mm[0] = m4.x; mm[1] = m4.y; mm[2] = m4.z; mm[3] = m4.w;
@@ -63,9 +64,9 @@ __global__ __launch_bounds__(THREADS) void adam_multi_kernel(const AdamTable tab
 #pragma unroll
         for (int e = 0; e < 4; ++e) pp[e] = adam_one(pp[e], gg[e], mm[e], vv[e], h);
         if (vec && nv == 4) {
-            *reinterpret_cast<float4*>(t.p + e0) = make_float4(pp[0], pp[1], pp[2], pp[3]);
-            *reinterpret_cast<float4*>(t.m + e0) = make_float4(mm[0], mm[1], mm[2], mm[3]);
-            *reinterpret_cast<float4*>(t.v + e0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            __builtin_nontemporal_store((f32x4){pp[0], pp[1], pp[2], pp[3]}, reinterpret_cast<f32x4*>(t.p + e0));
+            __builtin_nontemporal_store((f32x4){mm[0], mm[1], mm[2], mm[3]}, reinterpret_cast<f32x4*>(t.m + e0));
+            __builtin_nontemporal_store((f32x4){vv[0], vv[1], vv[2], vv[3]}, reinterpret_cast<f32x4*>(t.v + e0));
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
