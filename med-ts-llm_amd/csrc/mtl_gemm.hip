@@ -441,7 +441,7 @@ __device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int
 // Host guarantees one tile per workgroup and an even number of k-tiles.
 template <int EPI, int CDT, int BM_, int BN_, int STAGES, int NW_ALL, bool SPLIT = false, int KS = 1>
 __global__ __launch_bounds__(NW_ALL * 64) void gemm_nt_persist_kernel(const mtl_gemm_args p, const int vec_ok_i, const int tiles_m,
-                                                                 const int tiles_n, const int gm) {
+                                                                 const int tiles_n, const int gm_all) {
     constexpr int BK_ = 64;
     constexpr int NW = NW_ALL / KS;            // waves per k-group (all tile geometry below is per group)
     constexpr int NT = NW * 64;                // threads per k-group
@@ -483,6 +483,10 @@ __global__ __launch_bounds__(NW_ALL * 64) void gemm_nt_persist_kernel(const mtl_
 
     const bf16_t* asrc[NA];
     const bf16_t* bsrc[NB];
+    const int gm = gm_all & 0xff;
+    // k-tile rotation per XCD (a tile's k-steps commute): the eight XCDs walk the SAME B panels; started at the same k they ask the
+    // memory side for the same lines at the same moment. Workgroups of one XCD keep a common k, so they still share through its L2.
+    const int s_off = (gm_all >> 8) ? (xcd * nkt) >> 3 : 0;
     auto set_sources = [&](int item) {
         int tm, tn;
         const int slab = SPLIT ? item / tiles_mn : 0;
@@ -509,7 +513,9 @@ __global__ __launch_bounds__(NW_ALL * 64) void gemm_nt_persist_kernel(const mtl_
     auto stage = [&](int buf, int kt) {
         char* la = smem + buf * STAGE;
         char* lb = la + A_BYTES;
-        const int64_t koff = (int64_t)kt * BK_;
+        int ktp = kt + s_off;
+        if (ktp >= nkt) ktp -= nkt;
+        const int64_t koff = (int64_t)ktp * BK_;
 #pragma unroll
         for (int i = 0; i < NA; ++i)
             __builtin_amdgcn_global_load_lds((gbl_void_t*)(asrc[i] + koff), (lds_void_t*)(la + (i * NT + wave * 64) * 16), 16, 0, 0);
@@ -647,20 +653,28 @@ __global__ void splitk_reduce_kernel(const mtl_gemm_args p, const int S, const i
     epilogue4<EPI, CDT>(p, m, n, v, vec_ok_i != 0);
 }
 
-// rows of a tile group (tile_coords): each XCD walks a contiguous chunk of ~tiles/8 ids = g rows x (chunk/g) columns of tiles.
-// When the chunk is at most ~2 rounds of the XCD's resident workgroups, its panels stay in that L2 for the whole launch and the
-// unique operand rows ~ g*BM + (chunk/g)*BN are least at g = sqrt(chunk*BN/BM) (a chunk never spans more than tiles_n columns).
-// PMC: the 256x96 residual GEMM read 100 MB per launch with g = 8 against 80 MB algorithmic; in-step -2.5 % per GPT-2-small step.
-// Longer chunks (Llama grids) keep g = 8: larger and smaller groups both measured 0.5-0.9 % slower per Llama-2-7B step.
-int group_rows(int tiles_m, int tiles_n, int bm, int bn, int per_cu) {
-    const double chunk = (double)tiles_m * tiles_n / 8.0;
-    if (chunk > 2.0 * 32.0 * per_cu) return 8;
+// Tile order of a launch, packed into the kernel's `gm_all` argument: bits 0-7 the rows g of a tile group (tile_coords), bit 8 the
+// per-XCD k rotation. Each XCD walks a contiguous chunk of ~tiles/8 ids = g rows x (chunk/g) columns of tiles.
+// * Short chunks (at most ~2 rounds of the XCD's resident workgroups; every GPT-2-small GEMM): g = sqrt(chunk*BN/BM) (at least
+//   chunk/tiles_n) balances the A and B rows a chunk touches — PMC, residual GEMM 256x96: 100 MB read per launch with g = 8 ->
+//   80.5 MB (= algorithmic). In-step sweep of one forced g for all launches: g in {4, 8, 16} 6.64 ms per step, every g that does
+//   NOT divide the chunk 6.46-6.52 ms — with aligned groups all eight XCDs start on the same B panels at the same moment.
+// * That contention is what the k rotation removes: XCD x starts every tile at k-tile x*nkt/8 and wraps (a tile's k-steps
+//   commute; the workgroups of one XCD keep a common k and still share operands through its L2), so the XCDs never ask the
+//   memory side for the same lines at once: 6.50 -> 6.29 ms per GPT-2-small step (-3.3 %). fp32 summation order thereby depends
+//   on the XCD a tile runs on: deterministic for a launch configuration, not bit-identical across configurations.
+// * Long chunks / long K (Llama grids): g = 8 and no rotation — other g and the rotation each measured 0.2-0.9 % slower per
+//   Llama-2-7B step (the XCDs drift apart on their own over 64-172 k-steps).
+int tile_order(int tiles_m, int tiles_n, int bm, int bn, int per_cu, int64_t K) {
+    const int nt = tiles_m * tiles_n;
+    if (nt > 8 * 2 * 32 * per_cu) return 8;
+    const int rotate = K / BK <= 48 ? 1 << 8 : 0;
+    const double chunk = nt / 8.0;
     double g = std::sqrt(chunk * bn / bm);
     if (g < chunk / tiles_n) g = chunk / tiles_n;
     int gi = (int)(g + 0.5);
-    if (gi < 1) gi = 1;
-    if (gi > tiles_m) gi = tiles_m;
-    return gi;
+    gi = gi < 1 ? 1 : (gi > tiles_m ? tiles_m : (gi > 255 ? 255 : gi));
+    return gi | rotate;
 }
 
 bool aligned(const void* ptr, size_t a) { return (reinterpret_cast<uintptr_t>(ptr) % a) == 0; }
@@ -767,14 +781,14 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         auto kfn = gemm_nt_persist_kernel<EPI, CDT, BMV, BNV, STV, NWV>;                                               \
         static std::once_flag once;                                                                                    \
         std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(NWV * 64), lds, st, p, vec_ok, tm, tn, group_rows(tm, tn, bm, bn, per_cu)); \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(NWV * 64), lds, st, p, vec_ok, tm, tn, tile_order(tm, tn, bm, bn, per_cu, p.K)); \
     } while (0)
         if (ks == 2) {
             auto kfn = gemm_nt_persist_kernel<EPI, CDT, 128, 96, 2, 8, false, 2>;
             static std::once_flag once;
             std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
             if (recording) rec.key |= 1 << 19;
-            hipLaunchKernelGGL(kfn, dim3(nt), dim3(512), lds, st, p, vec_ok, tm, tn, group_rows(tm, tn, bm, bn, 1));
+            hipLaunchKernelGGL(kfn, dim3(nt), dim3(512), lds, st, p, vec_ok, tm, tn, tile_order(tm, tn, bm, bn, 1, p.K));
         } else if (bm == 256 && bn == 128 && nw == 16 && stages == 3) MTL_PERSIST(256, 128, 3, 16);
         else if (bm == 256 && bn == 128 && nw == 16 && stages == 2) MTL_PERSIST(256, 128, 2, 16);
         else if (bm == 128 && bn == 128 && nw == 8 && stages == 2) MTL_PERSIST(128, 128, 2, 8);
@@ -810,7 +824,7 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
                 static std::once_flag once;
                 std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
                 if (recording) rec.key |= (1 << 8) | (1 << 10) | (STV << 12) | ((BNV == 192 ? 3 : 1) << 16) | ((BMV == 256 ? 1 : 0) << 15);
-                hipLaunchKernelGGL(kfn, dim3(grid), dim3(NWV * 64), lds, st, p, S, tm, tn, group_rows(tm, tn, BMV, BNV, per_cu));
+                hipLaunchKernelGGL(kfn, dim3(grid), dim3(NWV * 64), lds, st, p, S, tm, tn, tile_order(tm, tn, BMV, BNV, per_cu, p.K));
             };
             using I128 = std::integral_constant<int, 128>; using I192 = std::integral_constant<int, 192>; using I256 = std::integral_constant<int, 256>;
             // operands of a split GEMM stream from HBM (K is huge): the fewest operand bytes per FLOP wins (256x192 when it still

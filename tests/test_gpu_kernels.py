@@ -576,9 +576,14 @@ def test_gemm_swiglu_epilogue_and_interleaved_backward(ops, M, F, K):
     w_il = torch.stack([wg, wu], dim=1).reshape(2 * F, K).contiguous()
     act = torch.empty(M, F, dtype=BF16, device="cuda")
     gu_il = ops.gemm_nt(x, w_il, epilogue=ops.N.EPI_SWIGLU, aux_out=act)
-    assert torch.equal(gu_il.view(M, F, 2)[:, :, 0], gu_ref[:, :F]) and torch.equal(gu_il.view(M, F, 2)[:, :, 1], gu_ref[:, F:])
-    assert rel_err(act.float(), h_ref.float()) < 1e-3                     # same roundings; __expf vs expf in the sigmoid
+    # same products, but the fp32 summation order of a tile depends on the XCD it runs on (per-XCD k rotation) and the two launches
+    # map columns to tiles differently: equal up to a few one-ulp bf16 flips
+    assert rel_err(gu_il.view(M, F, 2)[:, :, 0].float(), gu_ref[:, :F].float()) < 1e-3
+    assert rel_err(gu_il.view(M, F, 2)[:, :, 1].float(), gu_ref[:, F:].float()) < 1e-3
+    assert rel_err(act.float(), ops.swiglu_fwd(torch.cat([gu_il.view(M, F, 2)[:, :, 0], gu_il.view(M, F, 2)[:, :, 1]], 1).contiguous()).float()) < 1e-3
+    assert rel_err(act.float(), h_ref.float()) < 2e-3                     # + __expf vs expf in the sigmoid
     dh = torch.randn(M, F, generator=g(4)).to(BF16).cuda()
+    gu_ref = torch.cat([gu_il.view(M, F, 2)[:, :, 0], gu_il.view(M, F, 2)[:, :, 1]], 1).contiguous()    # identical pre-activations for the layout check
     d_ref = ops.swiglu_bwd(gu_ref, dh)
     d_il = ops.swiglu_bwd(gu_il, dh, interleaved=True)
     assert torch.equal(d_il.view(M, F, 2)[:, :, 0], d_ref[:, :F]) and torch.equal(d_il.view(M, F, 2)[:, :, 1], d_ref[:, F:])
