@@ -659,16 +659,27 @@ __global__ void splitk_reduce_kernel(const mtl_gemm_args p, const int S, const i
 //   chunk/tiles_n) balances the A and B rows a chunk touches — PMC, residual GEMM 256x96: 100 MB read per launch with g = 8 ->
 //   80.5 MB (= algorithmic). In-step sweep of one forced g for all launches: g in {4, 8, 16} 6.64 ms per step, every g that does
 //   NOT divide the chunk 6.46-6.52 ms — with aligned groups all eight XCDs start on the same B panels at the same moment.
-// * That contention is what the k rotation removes: XCD x starts every tile at k-tile x*nkt/8 and wraps (a tile's k-steps
-//   commute; the workgroups of one XCD keep a common k and still share operands through its L2), so the XCDs never ask the
-//   memory side for the same lines at once: 6.50 -> 6.29 ms per GPT-2-small step (-3.3 %). fp32 summation order thereby depends
-//   on the XCD a tile runs on: deterministic for a launch configuration, not bit-identical across configurations.
-// * Long chunks / long K (Llama grids): g = 8 and no rotation — other g and the rotation each measured 0.2-0.9 % slower per
-//   Llama-2-7B step (the XCDs drift apart on their own over 64-172 k-steps).
-int tile_order(int tiles_m, int tiles_n, int bm, int bn, int per_cu, int64_t K) {
+// * Per-XCD k rotation (two-k-group launches: one tile per workgroup, all tiles in flight together): XCD x starts its tiles at
+//   k-tile x*nkt/8 and wraps (a tile's k-steps commute; the workgroups of one XCD keep a common k and still share operands
+//   through its L2), so the XCDs are never on the same lines at once. Per-kernel A/B inside one process (bench.py's event
+//   brackets, 3 alternations): two-k-group GEMMs 24.7 -> 22.2 us (-10 %), but the kernels whose workgroups walk several tiles
+//   lose 3-5 % (qkv 36.7 -> 38.7, residual 36.7 -> 38.3, GELU 62.0 -> 65.1 us), so only the former rotate. (A rotation keyed on
+//   the tile row instead, which breaks the sharing inside an XCD, is 2-4 % slower per step than none.) The fp32 summation
+//   order of such a tile depends on the XCD it runs on: deterministic for a launch configuration, not bit-identical across
+//   configurations.
+// * Long chunks / long K (Llama grids): g = 8 — other g measured 0.5-0.9 % slower per Llama-2-7B step.
+// MTL_GEMM_RULES_OFF=<bitmask> switches single launch rules off for in-step A/B runs of bench.py (1: 256x192 for the GELU GEMM,
+// 2: 256x96 for residual GEMMs, 4: two k-groups, 8: per-XCD k rotation, 16: balanced group height). Diagnostic only.
+int rules_off() {
+    static const int v = getenv("MTL_GEMM_RULES_OFF") ? atoi(getenv("MTL_GEMM_RULES_OFF")) : 0;
+    return v;
+}
+
+int tile_order(int tiles_m, int tiles_n, int bm, int bn, int per_cu, int64_t K, bool one_tile_per_wg = false) {
     const int nt = tiles_m * tiles_n;
     if (nt > 8 * 2 * 32 * per_cu) return 8;
-    const int rotate = K / BK <= 48 ? 1 << 8 : 0;
+    const int rotate = (one_tile_per_wg && K / BK <= 48 && !(rules_off() & 8)) ? 1 << 8 : 0;
+    if (rules_off() & 16) return 8 | rotate;
     const double chunk = nt / 8.0;
     double g = std::sqrt(chunk * bn / bm);
     if (g < chunk / tiles_n) g = chunk / tiles_n;
@@ -743,16 +754,16 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
                 ((p.N + 255) / 256) * 256 * 100 <= p.N * 106) {
                 bn = 256; if (nw == 0 || nw == 8) nw = 8; if (stages == 0 || stages == 2) stages = 2;
             }
-            // GELU / dGELU GEMMs on 768-multiples: inside a training step the operands arrive L2-cold (the microbench with
-            // GEMM_COLD=1 is the proxy that predicts in-step times; warm it prefers 128x192). 256x192 / 8 waves: fc 90 -> 71 us
-            // cold, b_dact 39 -> 36 us; in-step -3.3 % per GPT-2-small step
-            if (bm == 128 && p.N % 192 == 0 && (int64_t)((p.M + 255) / 256) * (p.N / 192) >= ncu && (EPI == MTL_EPI_GELU || EPI == MTL_EPI_DGELU)) {
+            // GELU GEMM on 768-multiples: 256x192 / 8 waves. Per-kernel A/B inside one bench.py process (event brackets, alternating
+            // runs): 71.4 us with 128x192 -> 63.5 us; the warm same-buffer microbench prefers 128x192, the L2-cold one
+            // (GEMM_COLD=1) ranks them as the step does. The dGELU GEMM keeps 128x128 (33.7 us vs 36.3 us with 256x192).
+            if (bm == 128 && p.N % 192 == 0 && (int64_t)((p.M + 255) / 256) * (p.N / 192) >= ncu && EPI == MTL_EPI_GELU && !(rules_off() & 1)) {
                 bm = 256; bn = 192; if (nw == 0) nw = 8; if (stages == 0) stages = 2;
             }
             // residual GEMMs on 96-multiples with at least one 256x96 tile per CU: one 8-wave workgroup per CU with a 3-deep ring
             // (96 KB of operands in flight instead of 2 x 28 KB; 21 % fewer operand bytes per FLOP than 128x96): cold aproj 25.2 ->
             // 24.5 us, mproj 59.3 -> 57.8 us, in-step -1.7 % per GPT-2-small step
-            if (bm == 128 && EPI == MTL_EPI_RESID && p.N % 96 == 0 && (int64_t)((p.M + 255) / 256) * (p.N / 96) >= ncu) {
+            if (bm == 128 && EPI == MTL_EPI_RESID && p.N % 96 == 0 && (int64_t)((p.M + 255) / 256) * (p.N / 96) >= ncu && !(rules_off() & 2)) {
                 bm = 256; bn = 96; if (nw == 0) nw = 8; if (stages == 0) stages = 3;
             }
             const int64_t t192 = (int64_t)tiles_m * (p.N / 192);
@@ -768,7 +779,7 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         int ks = 1;
         // (in-step A/B, GPT-2-small metric step: two k-groups 7.20 ms, one group with a 3-deep ring 7.38, 128x128 / 8 waves / 3 stages 7.22+,
         //  one group with 2 stages 7.60)
-        if (bm == 128 && bn == 96 && nt <= ncu && nkt_all % 2 == 0 && nkt_all >= 4 && stages == 2 && (auto_cfg || nw == 8)) { ks = 2; nw = 8; }
+        if (bm == 128 && bn == 96 && nt <= ncu && nkt_all % 2 == 0 && nkt_all >= 4 && stages == 2 && ((auto_cfg && !(rules_off() & 4)) || nw == 8)) { ks = 2; nw = 8; }
         else if (bm == 128 && bn == 96 && nw == 8) return MTL_ERR_UNSUPPORTED;
         const int bn_lds = (bm == 256 && bn == 96) ? 128 : bn;      // B image padded to whole LDS-DMA instructions (8 waves)
         const size_t lds = (size_t)ks * stages * (bm + bn_lds) * BK * 2;
@@ -788,7 +799,7 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
             static std::once_flag once;
             std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
             if (recording) rec.key |= 1 << 19;
-            hipLaunchKernelGGL(kfn, dim3(nt), dim3(512), lds, st, p, vec_ok, tm, tn, tile_order(tm, tn, bm, bn, 1, p.K));
+            hipLaunchKernelGGL(kfn, dim3(nt), dim3(512), lds, st, p, vec_ok, tm, tn, tile_order(tm, tn, bm, bn, 1, p.K, true));
         } else if (bm == 256 && bn == 128 && nw == 16 && stages == 3) MTL_PERSIST(256, 128, 3, 16);
         else if (bm == 256 && bn == 128 && nw == 16 && stages == 2) MTL_PERSIST(256, 128, 2, 16);
         else if (bm == 128 && bn == 128 && nw == 8 && stages == 2) MTL_PERSIST(128, 128, 2, 8);
