@@ -14,6 +14,7 @@
 #include "mtl_common.h"
 
 #include <cmath>
+#include <cstdio>
 #include <mutex>
 #include <vector>
 
@@ -668,6 +669,7 @@ __global__ void splitk_reduce_kernel(const mtl_gemm_args p, const int S, const i
 //   order of such a tile depends on the XCD it runs on: deterministic for a launch configuration, not bit-identical across
 //   configurations.
 // * Long chunks / long K (Llama grids): g = 8 — other g measured 0.5-0.9 % slower per Llama-2-7B step.
+// (MTL_GEMM_FORCE, in the launcher, forces one tile configuration for one epilogue and N the same way.)
 // MTL_GEMM_RULES_OFF=<bitmask> switches single launch rules off for in-step A/B runs of bench.py (1: 256x192 for the GELU GEMM,
 // 2: 256x96 for residual GEMMs, 4: two k-groups, 8: per-XCD k rotation, 16: balanced group height). Diagnostic only.
 int rules_off() {
@@ -769,6 +771,12 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
             const int64_t t192 = (int64_t)tiles_m * (p.N / 192);
             if (bm == 128 && bn == 128 && p.N % 192 == 0 && t192 >= 2 * ncu && (EPI == MTL_EPI_STORE || EPI == MTL_EPI_GELU)) bn = 192;
             else if (bm == 128 && bn == 64 && p.N % 96 == 0) bn = 96;
+        }
+        {   // diagnostic: MTL_GEMM_FORCE="epi,N,bm,bn,stages,waves" forces one tile configuration for the launches of that epilogue and N
+            static const char* spec = getenv("MTL_GEMM_FORCE");
+            static int f[6] = {-1, 0, 0, 0, 0, 0};
+            static const bool parsed = spec && sscanf(spec, "%d,%d,%d,%d,%d,%d", &f[0], &f[1], &f[2], &f[3], &f[4], &f[5]) == 6;
+            if (parsed && f[0] == EPI && f[1] == p.N && tuning().bm == 0) { bm = f[2]; bn = f[3]; stages = f[4]; nw = f[5]; }
         }
         const bool auto_cfg = nw == 0 && stages == 0;
         if (nw == 0) nw = bm == 256 ? 16 : (bn >= 128 ? 8 : 4);
