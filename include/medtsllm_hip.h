@@ -102,14 +102,20 @@ int mtl_gemm_nt(const mtl_gemm_args* args, void* stream);
 /* Measurement aid (bench.py roofline leg; off by default, no effect on results): while enabled every GEMM launch is
  * bracketed by HIP events on its launch stream. mtl_prof_read aggregates per kernel instance
  * key: bits 0-7 = epilogue*4 + c_dtype*2 + (split_k > 1); bit 8 = persistent kernel, bit 9 = 128-wide tile (else 64),
- * bits 10-11 = waves (0: 4, 1: 8, 2: 16), bits 12-14 = LDS stages, bit 15 = 256-row tile (else 128), bits 16-17 = tile width (0: 64, 1: 128, 2: 96, 3: 192), bit 18 = 256-wide tile: launches, total ms, total algorithmic FLOPs (2*M*N*K).
+ * bits 10-11 = waves (0: 4, 1: 8, 2: 16), bits 12-14 = LDS stages, bit 15 = 256-row tile (else 128), bits 16-17 = tile width (0: 64, 1: 128, 2: 96, 3: 192), bit 18 = 256-wide tile, bit 19 = two k-groups: launches, total ms, total algorithmic FLOPs (2*M*N*K).
  * mtl_prof_calibrate returns the duration (ms) of an empty event bracket on `stream` (fixed per-launch overhead). */
 int mtl_prof_enable(int on);
 double mtl_prof_calibrate(void* stream);
 /* Experiment knob for A/B runs: mode 0 = one output tile per workgroup, 1 = persistent flat-K (default);
- * bm / bn = tile rows (128, 256) / columns (64, 128), stages = LDS ring depth (2, 3), waves per workgroup (4, 8, 16);
- * 0 = automatic. Supported combinations: 128x64/4w/2, 128x128/{4,8}w/2, 128x128/8w/3, 256x128/16w/{2,3}; anything else
- * makes mtl_gemm_nt return MTL_ERR_UNSUPPORTED. Results are identical in every mode. */
+ * bm / bn = tile rows (128, 256) / columns (64, 96, 128, 192, 256), stages = LDS ring depth (2, 3), waves per workgroup (4, 8, 16);
+ * 0 = automatic. Instantiated combinations: 128x64/4w/{2,3}, 128x96/4w/{2,3}, 128x96/8w/2 (two k-groups; needs at most one tile
+ * per CU and an even number of 64-wide k-tiles >= 4), 128x128/{4,8}w/2, 128x128/8w/3, 128x192/8w/2, 256x96/8w/{2,3}, 256x128/16w/{2,3},
+ * 256x192/8w/2, 256x256/8w/2; anything else makes mtl_gemm_nt return MTL_ERR_UNSUPPORTED. Results agree in every mode up to the
+ * fp32 summation order (two k-groups and their per-XCD k rotation change it).
+ * Diagnostics read from the environment once per process (in-step A/B runs; never needed in production):
+ *   MTL_GEMM_RULES_OFF=<mask>  switch single automatic launch rules off (1 GELU 256x192, 2 residual 256x96, 4 two k-groups,
+ *                              8 per-XCD k rotation, 16 balanced tile-group height)
+ *   MTL_GEMM_FORCE="epi,N,bm,bn,stages,waves"  force one tile configuration for the launches of one epilogue and N */
 int mtl_gemm_tune(int mode, int bm, int bn, int stages, int waves);
 int mtl_prof_read(int* keys, int64_t* launches, double* total_ms, double* total_flops, int cap);
 
