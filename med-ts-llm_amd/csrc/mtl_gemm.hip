@@ -485,6 +485,7 @@ __global__ __launch_bounds__(NW_ALL * 64) void gemm_nt_persist_kernel(const mtl_
     const bf16_t* asrc[NA];
     const bf16_t* bsrc[NB];
     const int gm = gm_all & 0xff;
+    const int col_rot = (gm_all & (1 << 9)) ? (xcd * tiles_n) >> 3 : 0;   // per-XCD column rotation (host: chunks of whole tile rows only)
     // k-tile rotation per XCD (a tile's k-steps commute): the eight XCDs walk the SAME B panels; started at the same k they ask the
     // memory side for the same lines at the same moment. Workgroups of one XCD keep a common k, so they still share through its L2.
     const int s_off = (gm_all >> 8) ? (xcd * nkt) >> 3 : 0;
@@ -492,6 +493,7 @@ __global__ __launch_bounds__(NW_ALL * 64) void gemm_nt_persist_kernel(const mtl_
         int tm, tn;
         const int slab = SPLIT ? item / tiles_mn : 0;
         tile_coords(SPLIT ? item - slab * tiles_mn : item, tiles_m, tiles_n, gm, tm, tn);
+        if (col_rot) { tn += col_rot; if (tn >= tiles_n) tn -= tiles_n; }
         const int64_t m0 = (int64_t)tm * BM_, n0 = (int64_t)tn * BN_;
         const int64_t k0 = (int64_t)(slab * KS + kgrp) * nkt * BK_;
 #pragma unroll
@@ -536,6 +538,7 @@ __global__ __launch_bounds__(NW_ALL * 64) void gemm_nt_persist_kernel(const mtl_
         int tm, tn;
         const int slab = SPLIT ? item / tiles_mn : 0;
         tile_coords(SPLIT ? item - slab * tiles_mn : item, tiles_m, tiles_n, gm, tm, tn);
+        if (col_rot) { tn += col_rot; if (tn >= tiles_n) tn -= tiles_n; }
         const int64_t m0 = (int64_t)tm * BM_, n0 = (int64_t)tn * BN_;
         const bool full = m0 + BM_ <= p.M && n0 + BN_ <= p.N;
         if constexpr (SPLIT) {
@@ -655,7 +658,7 @@ __global__ void splitk_reduce_kernel(const mtl_gemm_args p, const int S, const i
 }
 
 // Tile order of a launch, packed into the kernel's `gm_all` argument: bits 0-7 the rows g of a tile group (tile_coords), bit 8 the
-// per-XCD k rotation. Each XCD walks a contiguous chunk of ~tiles/8 ids = g rows x (chunk/g) columns of tiles.
+// per-XCD k rotation, bit 9 the per-XCD column rotation. Each XCD walks a contiguous chunk of ~tiles/8 ids = g rows x (chunk/g) columns of tiles.
 // * Short chunks (at most ~2 rounds of the XCD's resident workgroups; every GPT-2-small GEMM): g = sqrt(chunk*BN/BM) (at least
 //   chunk/tiles_n) balances the A and B rows a chunk touches — PMC, residual GEMM 256x96: 100 MB read per launch with g = 8 ->
 //   80.5 MB (= algorithmic). In-step sweep of one forced g for all launches: g in {4, 8, 16} 6.64 ms per step, every g that does
@@ -671,7 +674,7 @@ __global__ void splitk_reduce_kernel(const mtl_gemm_args p, const int S, const i
 // * Long chunks / long K (Llama grids): g = 8 — other g measured 0.5-0.9 % slower per Llama-2-7B step.
 // (MTL_GEMM_FORCE, in the launcher, forces one tile configuration for one epilogue and N the same way.)
 // MTL_GEMM_RULES_OFF=<bitmask> switches single launch rules off for in-step A/B runs of bench.py (1: 256x192 for the GELU GEMM,
-// 2: 256x96 for residual GEMMs, 4: two k-groups, 8: per-XCD k rotation, 16: balanced group height). Diagnostic only.
+// 2: 256x96 for residual GEMMs, 4: two k-groups, 8: per-XCD k rotation, 16: balanced group height, 32: XCD-affine rows + column rotation). Diagnostic only.
 int rules_off() {
     static const int v = getenv("MTL_GEMM_RULES_OFF") ? atoi(getenv("MTL_GEMM_RULES_OFF")) : 0;
     return v;
@@ -682,6 +685,12 @@ int tile_order(int tiles_m, int tiles_n, int bm, int bn, int per_cu, int64_t K, 
     if (nt > 8 * 2 * 32 * per_cu) return 8;
     const int rotate = (one_tile_per_wg && K / BK <= 48 && !(rules_off() & 8)) ? 1 << 8 : 0;
     if (rules_off() & 16) return 8 | rotate;
+    // whole tile rows per XCD (tiles_m % 8 == 0): g = tiles_m/8 makes every XCD's chunk one group (its own eighth of the rows, all
+    // columns: fewest A bytes) and a per-XCD column rotation (bit 9) keeps the XCDs off the same B panels. Per-kernel A/B against
+    // the sqrt rule: qkv 35.6 -> 34.2, two-k-group 21.1 -> 20.5, dGELU 33.1 -> 32.2, residual 36.0 -> 34.8, GELU 61.0 -> 59.9 us.
+    // Doing it for only some of a layer's GEMMs made every kernel 3-6 % slower; giving the norm and attention kernels the same
+    // row -> XCD ownership changed nothing (tools/ab build, 3 alternations), so the effect is not producer -> consumer L2 reuse.
+    if (tiles_m % 8 == 0 && !(rules_off() & 32)) return (tiles_m / 8 > 255 ? 255 : tiles_m / 8) | rotate | (1 << 9);
     const double chunk = nt / 8.0;
     double g = std::sqrt(chunk * bn / bm);
     if (g < chunk / tiles_n) g = chunk / tiles_n;
