@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MTL_ABI_VERSION 3
+#define MTL_ABI_VERSION 4
 
 enum { MTL_OK = 0, MTL_ERR_ARG = -1, MTL_ERR_ALIGN = -2, MTL_ERR_UNSUPPORTED = -3, MTL_ERR_LAUNCH = -4,
        MTL_ERR_WORKSPACE = -5 };
@@ -96,6 +96,11 @@ typedef struct {
      * keep mask = mtl counter hash of (drop_seed, physical C row, column) >= drop_p * 2^32, kept values / (1 - drop_p).
      * drop_p == 0 -> off. The backward regenerates the mask from the same triple (mtl_norm_bwd). */
     float drop_p; uint32_t drop_seed;
+    /* MTL_EPI_GELU / MTL_EPI_SWIGLU only: the output that only a backward pass reads (GELU: aux_out, the saved pre-activation;
+     * SWIGLU: C, the saved gate|up pre-activations) is written for row m only when (m % bwd_group_rows) >= bwd_first_row.
+     * A pruned backward (mtl_backbone_bwd's n_grad) never reads the other rows; inference passes bwd_first_row = bwd_group_rows
+     * and writes none. bwd_group_rows == 0 -> every row. */
+    int64_t bwd_group_rows, bwd_first_row;
 } mtl_gemm_args;
 size_t mtl_gemm_workspace_bytes(int64_t M, int64_t N, int split_k);
 int mtl_gemm_nt(const mtl_gemm_args* args, void* stream);
@@ -273,10 +278,12 @@ size_t mtl_backbone_saved_bytes(const mtl_backbone_weights* w, int64_t B, int64_
 size_t mtl_backbone_work_bytes(const mtl_backbone_weights* w, int64_t B, int64_t T);
 /* h0 f32 [B, T, d] (input embeddings, wpe already added for GPT-2). out bf16 [B, n_last, d]: final norm applied
  * to the last n_last tokens of every sample (only those are consumed downstream, R:models/medtsllm.py:353). */
+/* n_save (0 <= n_save <= T): the MLP pre-activations that only the backward reads are stored for the last n_save tokens of every
+ * sample: pass the n_grad the matching mtl_backbone_bwd will use (T when unknown), 0 for inference. */
 int mtl_backbone_fwd(const mtl_backbone_weights* w, const float* h0, void* out, void* saved, void* work,
-                     int64_t B, int64_t T, int64_t n_last, const mtl_backbone_dropout* drop /* NULL: off */, void* stream);
+                     int64_t B, int64_t T, int64_t n_last, int64_t n_save, const mtl_backbone_dropout* drop /* NULL: off */, void* stream);
 /* dout bf16 [B, n_last, d] -> dh0 f32 [B, T, d]. `saved` from the matching forward.
- * n_grad (n_last <= n_grad <= T): only the LAST n_grad tokens of every sample receive a gradient; rows before that are
+ * n_grad (n_last <= n_grad <= the forward's n_save): only the LAST n_grad tokens of every sample receive a gradient; rows before that are
  * left zero. The leading tokens are the text prompt: causal attention never lets them see a patch token, so they are
  * independent of every trainable parameter and their gradient is never consumed (SURVEY.md §7 "legal shortcut ii").
  * All backward GEMMs / norms / attention then run on B*n_grad rows. n_grad = T computes the full dh0. */

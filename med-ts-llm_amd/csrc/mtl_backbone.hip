@@ -75,9 +75,11 @@ const RowMap kIdentity = {0, 0, 0};
 
 int gemm(const void* A, int64_t lda, const void* Bm, int64_t ldb, void* C, int64_t ldc, int cdt, int64_t M, int64_t N, int64_t K,
          const float* bias, int epi, const void* aux_in, int64_t ld_aux_in, void* aux_out, int64_t ld_aux_out, void* stream,
-         RowMap am = kIdentity, RowMap cm = kIdentity, float drop_p = 0.f, uint32_t drop_seed = 0u) {
+         RowMap am = kIdentity, RowMap cm = kIdentity, float drop_p = 0.f, uint32_t drop_seed = 0u, int64_t bwd_group = 0,
+         int64_t bwd_first = 0) {
     mtl_gemm_args g = {};
     g.drop_p = drop_p; g.drop_seed = drop_seed;
+    g.bwd_group_rows = bwd_group; g.bwd_first_row = bwd_first;
     g.a_group_rows = am.rows; g.a_group_stride = am.stride; g.a_row_offset = am.offset;
     g.c_group_rows = cm.rows; g.c_group_stride = cm.stride; g.c_row_offset = cm.offset;
     g.A = A; g.lda = lda; g.B = Bm; g.ldb = ldb; g.C = C; g.ldc = ldc; g.c_dtype = cdt;
@@ -131,8 +133,9 @@ extern "C" size_t mtl_backbone_work_bytes(const mtl_backbone_weights* w, int64_t
 }
 
 extern "C" int mtl_backbone_fwd(const mtl_backbone_weights* w, const float* h0, void* out, void* saved, void* work, int64_t B,
-                                int64_t T, int64_t n_last, const mtl_backbone_dropout* drop, void* stream) {
+                                int64_t T, int64_t n_last, int64_t n_save, const mtl_backbone_dropout* drop, void* stream) {
     MTL_TRY(check_weights(w));
+    if (n_save < 0 || n_save > T) return MTL_ERR_ARG;
     // GPT-2 train-mode dropouts (HF:models/gpt2/modeling_gpt2.py:65,243,397): attention probabilities + both residual branches
     const float attn_p = drop ? drop->attn_p : 0.f, resid_p = drop ? drop->resid_p : 0.f;
     const uint32_t dseed = drop ? drop->seed : 0u;
@@ -172,9 +175,12 @@ extern "C" int mtl_backbone_fwd(const mtl_backbone_weights* w, const float* h0, 
         MTL_TRY(mtl_norm_fwd(H(2 * i + 1), w->ln2_w[i], w->ln2_b ? w->ln2_b[i] : nullptr, wk + W.xln, D.d, st2, D.M, D.d, w->eps, rms, 0, 0, 0, stream));
         if (D.llama) {
             // gate|up GEMM with the SwiGLU fused into its epilogue (weights row-interleaved: columns 2j / 2j+1 = gate_j / up_j)
-            MTL_TRY(gemm(wk + W.xln, D.d, w->w_fc[i], D.d, fc, D.Nfc, MTL_BF16, D.M, D.Nfc, D.d, bf, MTL_EPI_SWIGLU, nullptr, 0, wk + W.act, D.ffn, stream));
+            // (the saved pre-activations are only read by the backward: stored for the last n_save tokens of every sample)
+            MTL_TRY(gemm(wk + W.xln, D.d, w->w_fc[i], D.d, fc, D.Nfc, MTL_BF16, D.M, D.Nfc, D.d, bf, MTL_EPI_SWIGLU, nullptr, 0, wk + W.act, D.ffn, stream,
+                         kIdentity, kIdentity, 0.f, 0u, n_save < D.T ? D.T : 0, D.T - n_save));
         } else {
-            MTL_TRY(gemm(wk + W.xln, D.d, w->w_fc[i], D.d, wk + W.act, D.ffn, MTL_BF16, D.M, D.ffn, D.d, bf, MTL_EPI_GELU, nullptr, 0, fc, D.ffn, stream));
+            MTL_TRY(gemm(wk + W.xln, D.d, w->w_fc[i], D.d, wk + W.act, D.ffn, MTL_BF16, D.M, D.ffn, D.d, bf, MTL_EPI_GELU, nullptr, 0, fc, D.ffn, stream,
+                         kIdentity, kIdentity, 0.f, 0u, n_save < D.T ? D.T : 0, D.T - n_save));
         }
         MTL_TRY(gemm(wk + W.act, D.ffn, w->w_proj[i], D.ffn, H(2 * i + 2), D.d, MTL_F32, D.M, D.d, D.ffn, bp, MTL_EPI_RESID, H(2 * i + 1), D.d, nullptr, 0, stream,
                      kIdentity, kIdentity, resid_p, drop_site_seed(dseed, i, 2)));

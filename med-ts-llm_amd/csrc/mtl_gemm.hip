@@ -64,7 +64,9 @@ __device__ __forceinline__ void epilogue4(const mtl_gemm_args& p, int64_t m, int
     }
     if constexpr (EPI == MTL_EPI_GELU) {
         bf16_t* aux = reinterpret_cast<bf16_t*>(p.aux_out) + crow * p.ld_aux_out + n;
-        if (vec_ok) {
+        const bool save = p.bwd_group_rows == 0 || (uint32_t)m % (uint32_t)p.bwd_group_rows >= (uint32_t)p.bwd_first_row;
+        if (!save) {
+        } else if (vec_ok) {
             u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
             *reinterpret_cast<u32x2*>(aux) = pk;
         } else {
@@ -157,6 +159,14 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
         mok[mi] = FULL || m < p.M;
         crow[mi] = remap_row(mok[mi] ? m : p.M - 1, p.c_group_rows, p.c_group_stride, p.c_row_offset);
     }
+    bool bwd_ok[4] = {true, true, true, true};   // rows whose backward-only output is stored (GELU: aux_out, SWIGLU: C)
+    if constexpr (EPI == MTL_EPI_GELU || EPI == MTL_EPI_SWIGLU) {
+        if (p.bwd_group_rows > 0) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                bwd_ok[mi] = (uint32_t)(m_first + mi * 16) % (uint32_t)p.bwd_group_rows >= (uint32_t)p.bwd_first_row;
+        }
+    }
     bool nok[NI];
     int64_t ncol[NI];
     float4 b4[NI];
@@ -198,7 +208,7 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
                           acc[ni][mi][3] * p.alpha + b4[ni].w};
             if constexpr (EPI == MTL_EPI_GELU) {
                 const u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-                if (ok) *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.aux_out) + crow[mi] * p.ld_aux_out + n) = pk;
+                if (ok && bwd_ok[mi]) *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.aux_out) + crow[mi] * p.ld_aux_out + n) = pk;
                 o[0] = gelu_new_f(__uint_as_float(pk[0] << 16)); o[1] = gelu_new_f(__uint_as_float(pk[0] & 0xffff0000u));
                 o[2] = gelu_new_f(__uint_as_float(pk[1] << 16)); o[3] = gelu_new_f(__uint_as_float(pk[1] & 0xffff0000u));
             } else if constexpr (EPI == MTL_EPI_RESID) {
@@ -233,7 +243,7 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
                 if (ok) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + crow[mi] * p.ldc + 2 * n) = outq;
             } else if constexpr (CDT == MTL_BF16) {
                 const u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-                if (ok) *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + crow[mi] * p.ldc + n) = pk;
+                if (ok && (EPI != MTL_EPI_SWIGLU || bwd_ok[mi])) *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + crow[mi] * p.ldc + n) = pk;
                 if constexpr (EPI == MTL_EPI_SWIGLU) {
                     // columns (n .. n+3) = (gate_j, up_j, gate_j+1, up_j+1), j = n/2; the activation sees the bf16-rounded Linear
                     // outputs and silu's own output is a bf16 tensor before the product (HF:modeling_llama.py:176)
@@ -941,6 +951,7 @@ extern "C" int mtl_gemm_nt(const mtl_gemm_args* a, void* stream) {
     if (p.K % BK != 0 || p.lda % 8 != 0 || p.ldb % 8 != 0) return MTL_ERR_ALIGN;
     if (!aligned(p.A, 16) || !aligned(p.B, 16)) return MTL_ERR_ALIGN;
     if (p.M >= (int64_t)1 << 31 || p.a_group_rows >= (int64_t)1 << 31 || p.c_group_rows >= (int64_t)1 << 31) return MTL_ERR_ARG;
+    if (p.bwd_group_rows < 0 || p.bwd_group_rows >= (int64_t)1 << 31 || p.bwd_first_row < 0 || p.bwd_first_row > p.bwd_group_rows) return MTL_ERR_ARG;
     if (p.c_dtype != MTL_F32 && p.c_dtype != MTL_BF16) return MTL_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int S = p.split_k > 1 ? p.split_k : 1;

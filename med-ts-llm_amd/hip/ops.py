@@ -46,7 +46,7 @@ def _req(cond, msg):
 
 # =============================================================================================== raw wrappers
 def gemm_nt(A, B, out=None, out_dtype=BF16, bias=None, epilogue=N.EPI_STORE, aux_in=None, aux_out=None, alpha=1.0,
-            split_k=1, M=None, a_rows=None, c_rows=None, drop=(0.0, 0)):
+            split_k=1, M=None, a_rows=None, c_rows=None, drop=(0.0, 0), bwd_rows=None):
     """C[M,N] = epi(alpha * A[M,K] @ B[N,K]^T + bias). A, B bf16 with unit inner stride, K % 64 == 0."""
     _req(A.dtype == BF16 and B.dtype == BF16 and A.dim() == 2 and B.dim() == 2, "gemm_nt: bf16 2-D operands")
     _req(A.stride(1) == 1 and B.stride(1) == 1 and A.shape[1] == B.shape[1], "gemm_nt: K mismatch / inner stride")
@@ -70,6 +70,8 @@ def gemm_nt(A, B, out=None, out_dtype=BF16, bias=None, epilogue=N.EPI_STORE, aux
         g.aux_out, g.ld_aux_out = aux_out.data_ptr(), aux_out.stride(0)
     g.alpha, g.split_k = alpha, split_k
     g.drop_p, g.drop_seed = float(drop[0]), int(drop[1]) & 0xFFFFFFFF      # MTL_EPI_RESID only (resid_pdrop)
+    if bwd_rows is not None:       # GELU / SWIGLU: (group_rows, first_row) of the rows whose backward-only output is stored
+        g.bwd_group_rows, g.bwd_first_row = bwd_rows
     ws = None
     if split_k > 1:
         nbytes = lib().mtl_gemm_workspace_bytes(M, Nn, split_k)
@@ -481,7 +483,9 @@ class BackboneFn(torch.autograd.Function):
         prompt rows before them never depend on a trainable parameter (causal attention), so their gradient is dead and
         the backward runs on B*n_grad rows only; dh0 is zero there. None -> full backward."""
         h0 = h0.contiguous()
-        out, saved = backbone.run_forward(h0, n_last, keep=ctx.needs_input_grad[0], drop=drop)
+        T = h0.shape[1]
+        n_save = (T if n_grad is None else max(int(n_grad), n_last)) if ctx.needs_input_grad[0] else 0
+        out, saved = backbone.run_forward(h0, n_last, keep=ctx.needs_input_grad[0], drop=drop, n_save=n_save)
         ctx.backbone, ctx.n_last, ctx.saved, ctx.n_grad, ctx.drop = backbone, n_last, saved, n_grad, drop
         ctx.save_for_backward(h0)
         return out

@@ -161,10 +161,13 @@ class FrozenBackbone:
             return None
         return C.byref(N.BackboneDropout(float(drop[0]), float(drop[1]), int(drop[2]) & 0xFFFFFFFF))
 
-    def run_forward(self, h0, n_last, keep=True, drop=None):
+    def run_forward(self, h0, n_last, keep=True, drop=None, n_save=None):
         """h0 f32 [B,T,d] (wpe already added for GPT-2) -> (out bf16 [B,n_last,d], saved buffer).
-        drop = (attn_p, resid_p, seed): GPT-2's train-mode dropouts inside the stack (the backward needs the same tuple)."""
+        drop = (attn_p, resid_p, seed): GPT-2's train-mode dropouts inside the stack (the backward needs the same tuple).
+        n_save: trailing tokens per sample whose backward-only state (MLP pre-activations) is stored — the n_grad the backward
+        will use; default all T when the buffer is kept, 0 otherwise."""
         B, T, d = h0.shape
+        n_save = (T if keep else 0) if n_save is None else min(max(int(n_save), 0), T)
         if self.arch == "gpt2" and T > self.cfg["n_positions"]:
             raise ValueError(f"sequence length {T} exceeds GPT-2's {self.cfg['n_positions']} learned positions")
         w = self._struct(T)
@@ -174,8 +177,9 @@ class FrozenBackbone:
         out = torch.empty((B, n_last, d), dtype=BF16, device=h0.device)
         if drop and self.arch != "gpt2" and (drop[0] > 0 or drop[1] > 0):
             raise ValueError("dropout inside the frozen stack exists for GPT-2 only (Llama has none)")
-        N.check(lib.mtl_backbone_fwd(C.byref(w), N.ptr(h0), N.ptr(out), N.ptr(saved), N.ptr(work), B, T, n_last, self._drop_struct(drop),
-                                     N.stream()), "mtl_backbone_fwd")
+        N.check(lib.mtl_backbone_fwd(C.byref(w), N.ptr(h0), N.ptr(out), N.ptr(saved), N.ptr(work), B, T, n_last, n_save,
+                                     self._drop_struct(drop), N.stream()), "mtl_backbone_fwd")
+        saved._n_save = n_save
         return out, (saved if keep else None)
 
     def run_backward(self, h0, dout, saved, n_last, n_grad=None, drop=None):
@@ -184,6 +188,8 @@ class FrozenBackbone:
         n_grad = T if n_grad is None else max(int(n_grad), n_last)
         if saved is None:
             raise RuntimeError("backbone backward without saved activations (forward ran under no_grad)")
+        if n_grad > getattr(saved, "_n_save", T):
+            raise RuntimeError(f"backbone backward over {n_grad} tokens per sample, but the forward stored its state for {saved._n_save}")
         w = self._struct(T)
         lib = N.lib()
         work = torch.empty(lib.mtl_backbone_work_bytes(C.byref(w), B, T), dtype=torch.uint8, device=h0.device)

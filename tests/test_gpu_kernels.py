@@ -590,6 +590,32 @@ def test_gemm_swiglu_epilogue_and_interleaved_backward(ops, M, F, K):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("epi", ["gelu", "swiglu"])
+def test_gemm_backward_only_output_is_row_pruned(ops, epi):
+    """bwd_rows=(group, first): the output only a backward reads (GELU: saved pre-activation, SWIGLU: saved gate|up) is written for
+    rows with m % group >= first and left untouched elsewhere; the forward output is complete either way"""
+    M, Nn, K, grp, first = 600, 192, 128, 50, 30
+    A = torch.randn(M, K, generator=g(1)).to(BF16).cuda()
+    B = (torch.randn(Nn, K, generator=g(2)) * 0.2).to(BF16).cuda()
+    rows = torch.arange(M)
+    keep = (rows % grp >= first).cuda()
+    if epi == "gelu":
+        full_pre, pruned_pre = torch.empty(M, Nn, dtype=BF16, device="cuda"), torch.full((M, Nn), 7.0, dtype=BF16, device="cuda")
+        act_full = ops.gemm_nt(A, B, epilogue=ops.N.EPI_GELU, aux_out=full_pre)
+        act_pruned = ops.gemm_nt(A, B, epilogue=ops.N.EPI_GELU, aux_out=pruned_pre, bwd_rows=(grp, first))
+        none_pre = torch.full((M, Nn), 7.0, dtype=BF16, device="cuda")
+        ops.gemm_nt(A, B, epilogue=ops.N.EPI_GELU, aux_out=none_pre, bwd_rows=(grp, grp))
+        assert bool((none_pre == 7.0).all())
+    else:
+        full_pre, pruned_pre = torch.empty(M, Nn, dtype=BF16, device="cuda"), torch.full((M, Nn), 7.0, dtype=BF16, device="cuda")
+        act_full, act_pruned = torch.empty(M, Nn // 2, dtype=BF16, device="cuda"), torch.empty(M, Nn // 2, dtype=BF16, device="cuda")
+        ops.gemm_nt(A, B, out=full_pre, epilogue=ops.N.EPI_SWIGLU, aux_out=act_full)
+        ops.gemm_nt(A, B, out=pruned_pre, epilogue=ops.N.EPI_SWIGLU, aux_out=act_pruned, bwd_rows=(grp, first))
+    assert torch.equal(act_full, act_pruned)
+    assert torch.equal(pruned_pre[keep], full_pre[keep]) and bool((pruned_pre[~keep] == 7.0).all())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,F,K,tune", [(300, 96, 128, None), (2048, 1024, 256, None), (1024, 512, 128, (256, 256, 2, 8)),
                                         (1000, 320, 64, (128, 192, 2, 8))])
 def test_gemm_dswiglu_epilogue(ops, M, F, K, tune):
