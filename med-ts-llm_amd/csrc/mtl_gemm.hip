@@ -700,7 +700,7 @@ int tile_order(int tiles_m, int tiles_n, int bm, int bn, int per_cu, int64_t K, 
     // the sqrt rule: qkv 35.6 -> 34.2, two-k-group 21.1 -> 20.5, dGELU 33.1 -> 32.2, residual 36.0 -> 34.8, GELU 61.0 -> 59.9 us.
     // Doing it for only some of a layer's GEMMs made every kernel 3-6 % slower; giving the norm and attention kernels the same
     // row -> XCD ownership changed nothing (tools/ab build, 3 alternations), so the effect is not producer -> consumer L2 reuse.
-    if (tiles_m % 8 == 0 && !(rules_off() & 32)) return (tiles_m / 8 > 255 ? 255 : tiles_m / 8) | rotate | (1 << 9);
+    if (tiles_m % 8 == 0 && tiles_m / 8 <= 255 && !(rules_off() & 32)) return (tiles_m / 8) | rotate | (1 << 9);   // (rotation needs g == chunk rows)
     const double chunk = nt / 8.0;
     double g = std::sqrt(chunk * bn / bm);
     if (g < chunk / tiles_n) g = chunk / tiles_n;

@@ -538,6 +538,33 @@ def test_gemm_every_tile_configuration(ops, cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(128, 64, 2, 4), (128, 96, 2, 4), (128, 96, 2, 8), (128, 128, 2, 8), (128, 192, 2, 8), (256, 96, 3, 8), (256, 192, 2, 8),
+                                 (256, 256, 2, 8)])
+@pytest.mark.parametrize("tiles_m", [8, 16, 24])
+def test_gemm_tile_order_whole_rows_per_xcd(ops, cfg, tiles_m):
+    """grids with a multiple of 8 tile rows take the whole-rows-per-XCD order with the per-XCD column rotation (and, with two
+    k-groups, the k rotation): every tile must still be computed exactly once, for 1 .. 9 tile columns incl. a ragged last one"""
+    lib = ops.lib()
+    bm, bn = cfg[0], cfg[1]
+    M = tiles_m * bm - 5                                    # ragged last tile row, same number of tile rows
+    for tiles_n, K in ((1, 128), (3, 256), (5, 128), (9, 192)):
+        Nn = tiles_n * bn - (8 if tiles_n > 1 else 0)
+        if cfg == (128, 96, 2, 8):
+            if tiles_m * tiles_n > 256:
+                continue                                    # two k-groups: at most one tile per CU ...
+            K = 256                                         # ... and an even number (>= 4) of 64-wide k-tiles
+        A = torch.randn(M, K, generator=g(M + tiles_n)).to(BF16).cuda()
+        B = (torch.randn(Nn, K, generator=g(Nn)) * 0.2).to(BF16).cuda()
+        lib.mtl_gemm_tune(1, *cfg)
+        try:
+            out = ops.gemm_nt(A, B, out_dtype=F32)
+        finally:
+            lib.mtl_gemm_tune(1, 0, 0, 0, 0)
+        ref = A.double().cpu() @ B.double().cpu().t()
+        assert rel_err(out, ref) < 1e-5, (cfg, tiles_m, tiles_n)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,Nn,K", [(300, 260, 256), (515, 388, 384), (4096, 768, 768), (128, 96, 3072)])
 def test_gemm_two_k_groups(ops, M, Nn, K):
     """128x96 tile with two 4-wave k-groups (the configuration picked for grids of at most one tile per CU): same results as the
