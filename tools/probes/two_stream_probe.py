@@ -1,7 +1,7 @@
 """Probe (GPU box): frozen GPT-2-small stack forward + backward on B = 32 sequences of T = 256 — one stream vs the batch split in
 two halves on two streams (does one half's epilogue / prologue burst hide under the other half's main loops?)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from med_ts_llm_amd.models.backbone import FrozenBackbone, random_state_dict
