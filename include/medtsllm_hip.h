@@ -132,6 +132,8 @@ int mtl_cast_pad_f32_bf16(const float* src, int64_t ld_src, void* dst, int64_t l
                           int64_t R, int64_t Cc, void* stream);
 /* bf16 [R, Cc] (ld_src) -> bf16 [Cc, ld_dst] transpose, zero-padding cols >= R up to ld_dst. */
 int mtl_transpose_bf16(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t R, int64_t Cc, void* stream);
+/* the same, and colsum f32 [Cc] = column sums of src (zeroed inside): a Linear's dY^T for the dW GEMM and its bias gradient in one pass */
+int mtl_transpose_colsum_bf16(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, float* colsum, int64_t R, int64_t Cc, void* stream);
 /* elementwise casts of contiguous buffers */
 int mtl_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int mtl_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);

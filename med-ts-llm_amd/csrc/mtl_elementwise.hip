@@ -30,8 +30,9 @@ __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__
     }
 }
 
+template <bool COLSUM>
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, int64_t ld_src, bf16_t* __restrict__ dst,
-                                                             int64_t ld_dst, int64_t R, int64_t Cc) {
+                                                             int64_t ld_dst, int64_t R, int64_t Cc, float* __restrict__ colsum) {
     __shared__ bf16_t tile[64][66];
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -47,6 +48,14 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
         const int cc = ty * 16 + i;
         const int64_t c = c0 + cc, r = r0 + tx;
         if (c < Cc && r < ld_dst) dst[c * ld_dst + r] = tile[tx][cc];
+    }
+    if constexpr (COLSUM) {     // column sums of src from the staged tile (rows >= R are zero): the bias gradient of a Linear's dY
+        if (ty == 0 && c0 + tx < Cc) {
+            float sacc = 0.f;
+#pragma unroll 8
+            for (int rr = 0; rr < 64; ++rr) sacc += bf16_to_f32(tile[rr][tx]);
+            atomicAdd(colsum + c0 + tx, sacc);
+        }
     }
 }
 
@@ -240,8 +249,20 @@ extern "C" int mtl_transpose_bf16(const void* src, int64_t ld_src, void* dst, in
     if (!src || !dst || R <= 0 || Cc <= 0 || ld_dst < R) return MTL_ERR_ARG;
     const int64_t rmax = ld_dst > R ? ld_dst : R;
     dim3 grid((unsigned)((Cc + 63) / 64), (unsigned)((rmax + 63) / 64));
-    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst,
-                       R, Cc);
+    hipLaunchKernelGGL(transpose_bf16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst,
+                       R, Cc, (float*)nullptr);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+extern "C" int mtl_transpose_colsum_bf16(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, float* colsum, int64_t R, int64_t Cc,
+                                         void* stream) {
+    if (!src || !dst || !colsum || R <= 0 || Cc <= 0 || ld_dst < R) return MTL_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(colsum, 0, (size_t)Cc * sizeof(float), st) != hipSuccess) return MTL_ERR_LAUNCH;
+    const int64_t rows = ld_dst > R ? ld_dst : R;
+    dim3 grid((unsigned)((Cc + 63) / 64), (unsigned)((rows + 63) / 64));
+    hipLaunchKernelGGL(transpose_bf16_kernel<true>, grid, dim3(256), 0, st, (const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, R, Cc, colsum);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }

@@ -92,6 +92,7 @@ SIGNATURES = {
     "mtl_prof_read": (i32, [C.POINTER(i32), C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double), i32]),
     "mtl_cast_pad_f32_bf16": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, vp]),
     "mtl_transpose_bf16": (i32, [vp, i64, vp, i64, i64, i64, vp]),
+    "mtl_transpose_colsum_bf16": (i32, [vp, i64, vp, i64, vp, i64, i64, vp]),
     "mtl_cast_f32_to_bf16": (i32, [vp, vp, i64, vp]),
     "mtl_cast_bf16_to_f32": (i32, [vp, vp, i64, vp]),
     "mtl_colsum_bf16": (i32, [vp, i64, vp, i64, i64, vp]),

@@ -106,6 +106,17 @@ def transpose_bf16(src, ld_dst=None):
     return dst
 
 
+def transpose_colsum_bf16(src, ld_dst=None):
+    """transpose_bf16 plus the fp32 column sums of src, one pass over src (dY^T for the dW GEMM + the bias gradient)"""
+    _req(src.dtype == BF16 and src.dim() == 2 and src.stride(1) == 1, "transpose_colsum_bf16: bf16 2-D")
+    R, Cc = src.shape
+    ld_dst = R if ld_dst is None else ld_dst
+    dst = torch.empty((Cc, ld_dst), dtype=BF16, device=src.device)
+    sums = torch.empty(Cc, dtype=F32, device=src.device)
+    check(lib().mtl_transpose_colsum_bf16(ptr(src), src.stride(0), ptr(dst), ld_dst, ptr(sums), R, Cc, stream()), "mtl_transpose_colsum_bf16")
+    return dst, sums
+
+
 def to_bf16(x):
     x = x.contiguous()
     out = torch.empty(x.shape, dtype=BF16, device=x.device)
@@ -336,13 +347,18 @@ class LinearFn(torch.autograd.Function):
         dy2 = dy2.contiguous()
         dyp = dy2 if Np == Nn else torch.nn.functional.pad(dy2, (0, Np - Nn))
         dx = gemm_nt(dyp, wt).reshape(xshape) if ctx.needs_input_grad[0] else None
-        dW = None
+        dW = db = None
+        want_b = has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             Mp = pad64(M)
-            dyT = transpose_bf16(dy2, Mp)            # [N, Mp]
+            if want_b:
+                dyT, db = transpose_colsum_bf16(dy2, Mp)   # [N, Mp] and the bias gradient from the same pass over dy
+            else:
+                dyT = transpose_bf16(dy2, Mp)        # [N, Mp]
             xT = transpose_bf16(x2[:, :Kin] if Kin != Kx else x2, Mp)  # [Kin, Mp]
             dW = gemm_nt(dyT, xT, out_dtype=F32)     # [N, Kin] fp32
-        db = colsum(dy2) if (has_b and ctx.needs_input_grad[2]) else None
+        elif want_b:
+            db = colsum(dy2)
         return dx, dW, db
 
 

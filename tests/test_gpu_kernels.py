@@ -513,6 +513,15 @@ def test_attention_causal_dropout(ops, pdrop, resident):
 
 
 @pytest.mark.gpu
+def test_transpose_with_column_sums(ops):
+    for R, Cc, ld in [(300, 130, 320), (64, 64, 64), (4096, 1152, 4096), (37, 5, 64)]:
+        x = torch.randn(R, Cc, generator=g(R)).to(BF16).cuda()
+        t, sums = ops.transpose_colsum_bf16(x, ld)
+        assert torch.equal(t, ops.transpose_bf16(x, ld))
+        assert rel_err(sums, x.double().sum(0).cpu()) < 1e-5
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [(128, 64, 2, 4), (128, 96, 2, 4), (128, 96, 3, 4), (128, 128, 2, 8), (128, 128, 3, 8), (128, 128, 2, 4),
                                  (128, 192, 2, 8), (256, 128, 3, 16), (256, 128, 2, 16), (256, 192, 2, 8), (256, 96, 3, 8), (256, 96, 2, 8)])
 def test_gemm_every_tile_configuration(ops, cfg):
