@@ -122,6 +122,10 @@ double mtl_prof_calibrate(void* stream);
  *                              8 per-XCD k rotation, 16 balanced tile-group height)
  *   MTL_GEMM_FORCE="epi,N,bm,bn,stages,waves"  force one tile configuration for the launches of one epilogue and N */
 int mtl_gemm_tune(int mode, int bm, int bn, int stages, int waves);
+/* Host-only (no device call): the tile order the persistent GEMM would use for a grid of tiles_m x tiles_n tiles of bm x bn with
+ * per_cu resident workgroups per CU: bits 0-7 rows of a tile group, bit 8 per-XCD k rotation, bit 9 per-XCD column rotation
+ * (negative: error code). Lets the CPU test suite check that every order visits every tile exactly once. */
+int mtl_gemm_tile_order(int tiles_m, int tiles_n, int bm, int bn, int per_cu, int64_t K, int one_tile_per_wg);
 int mtl_prof_read(int* keys, int64_t* launches, double* total_ms, double* total_flops, int cap);
 
 /* ------------------------------------------------------------------ layout / cast helpers

@@ -881,6 +881,11 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int mtl_gemm_tile_order(int tiles_m, int tiles_n, int bm, int bn, int per_cu, int64_t K, int one_tile_per_wg) {
+    if (tiles_m <= 0 || tiles_n <= 0 || bm <= 0 || bn <= 0 || per_cu <= 0 || K <= 0) return MTL_ERR_ARG;
+    return tile_order(tiles_m, tiles_n, bm, bn, per_cu, K, one_tile_per_wg != 0);
+}
+
 extern "C" int mtl_gemm_tune(int mode, int bm, int bn, int stages, int waves) {
     if ((mode != 0 && mode != 1) || (bm != 0 && bm != 128 && bm != 256) || (bn != 0 && bn != 64 && bn != 128 && bn != 96 && bn != 192 && bn != 256) ||
         (stages != 0 && (stages < 2 || stages > 5)) || (waves != 0 && waves != 4 && waves != 8 && waves != 16))

@@ -89,6 +89,7 @@ SIGNATURES = {
     "mtl_prof_enable": (i32, [i32]),
     "mtl_prof_calibrate": (C.c_double, [vp]),
     "mtl_gemm_tune": (i32, [i32, i32, i32, i32, i32]),
+    "mtl_gemm_tile_order": (i32, [i32, i32, i32, i32, i32, i64, i32]),
     "mtl_prof_read": (i32, [C.POINTER(i32), C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double), i32]),
     "mtl_cast_pad_f32_bf16": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, vp]),
     "mtl_transpose_bf16": (i32, [vp, i64, vp, i64, i64, i64, vp]),

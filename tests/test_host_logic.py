@@ -113,6 +113,45 @@ def test_c_abi_exports_every_declared_symbol():
     assert b"alignment" in lib.mtl_strerror(-2)
 
 
+def test_gemm_tile_order_visits_every_tile_once():
+    """the persistent GEMM's work distribution (XCD chunks, tile groups, per-XCD column rotation: csrc/mtl_gemm.hip) restated on
+    the host for the orders mtl_gemm_tile_order() picks: every tile of every grid must be owned by exactly one workgroup"""
+    from med_ts_llm_amd.hip import _native
+    lib = _native.lib()
+    n_cu = 256
+    seen_rot = 0
+    for bm, bn in ((128, 64), (128, 96), (128, 192), (256, 96), (256, 192), (256, 256)):
+        for per_cu in (1, 2, 3):
+            for tiles_m in list(range(1, 20)) + [24, 32, 40, 64, 72, 128]:
+                for tiles_n in (1, 2, 3, 5, 8, 9, 12, 16, 24, 43):
+                    order = lib.mtl_gemm_tile_order(tiles_m, tiles_n, bm, bn, per_cu, 768, 0)
+                    assert order > 0
+                    g, col_rot = order & 0xff, bool(order & (1 << 9))
+                    seen_rot += col_rot
+                    nt = tiles_m * tiles_n
+                    nblk = min(nt, per_cu * n_cu)
+                    owned = []
+                    for bid in range(nblk):
+                        xcd, slot = bid & 7, bid >> 3
+                        xblocks = (nblk - xcd + 7) >> 3
+                        q, r8 = nt >> 3, nt & 7
+                        t0 = xcd * (q + 1) if xcd < r8 else r8 * (q + 1) + (xcd - r8) * q
+                        cnt = q + (1 if xcd < r8 else 0)
+                        t = t0 + slot
+                        while t < t0 + cnt:
+                            grp, rem = divmod(t, g * tiles_n)
+                            first_m = grp * g
+                            gm = min(tiles_m - first_m, g)
+                            tm, tn = first_m + rem % gm, rem // gm
+                            if col_rot:
+                                tn = (tn + ((xcd * tiles_n) >> 3)) % tiles_n
+                            owned.append(tm * tiles_n + tn)
+                            t += xblocks
+                    assert sorted(owned) == list(range(nt)), (bm, bn, per_cu, tiles_m, tiles_n, order)
+    assert seen_rot > 50            # the rotated orders were exercised
+    assert lib.mtl_gemm_tile_order(32, 8, 128, 96, 1, 3072, 1) & (1 << 8) and not lib.mtl_gemm_tile_order(32, 8, 128, 96, 1, 8192, 1) & (1 << 8)
+
+
 def test_optimisation_step_order_matches_reference_trajectory():
     """a10: forward -> loss -> backward -> Adam.step -> zero_grad on the oracle reproduces the REFERENCE trainer's
     per-step losses and final weights (golden from tasks.get_trainer(...).train() on a synthetic dataset)."""
