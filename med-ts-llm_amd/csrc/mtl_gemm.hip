@@ -146,7 +146,9 @@ __device__ __forceinline__ void epilogue4(const mtl_gemm_args& p, int64_t m, int
 // out as straight-line code. (With predicates every use sits in its own branch and hipcc waits vmcnt(0) in each, i.e.
 // every store waits for the previous store to complete, and the still-"pending" bias registers force a vmcnt(0) in
 // front of the next k-step's first ds_read, draining the LDS-DMA pipeline.)
-template <int EPI, int CDT, int NI, bool FULL>
+// PAIR (even NI): the B fragments of column tiles 2t / 2t+1 were read from LDS rows permuted so that a lane's 4 + 4 columns are the
+// 8 CONSECUTIVE columns n_first + 32t .. +7 (n_first includes 8*g, not 4*g): tile ni covers n_first + (ni/2)*32 + (ni%2)*4 + 0..3.
+template <int EPI, int CDT, int NI, bool FULL, bool PAIR = false>
 __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m_first, int64_t n_first, f32x4 (*acc)[4],
                                                const bool dword_stores) {
     // lane owns rows m_first + mi*16 (mi = 0..3) and columns n_first + ni*16 .. +3.  Edge tiles (!FULL) LOAD from
@@ -172,7 +174,7 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
     float4 b4[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-        const int64_t n = n_first + ni * 16;
+        const int64_t n = n_first + (PAIR ? (ni >> 1) * 32 + (ni & 1) * 4 : ni * 16);
         nok[ni] = FULL || n < p.N;  // vector path: N % 4 == 0, so the 4 columns are valid together
         ncol[ni] = nok[ni] ? n : p.N - 4;
         b4[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -181,6 +183,25 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) b4[ni] = *reinterpret_cast<const float4*>(p.bias + ncol[ni]);
     }
+    // bf16 outputs of a column-tile pair leave as ONE 16-byte store per lane (8 consecutive columns) when the rows are 16-B aligned
+    const bool wide_c = PAIR && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (p.ldc & 7) == 0;
+    const bool wide_a = PAIR && (reinterpret_cast<uintptr_t>(p.aux_out) & 15) == 0 && (p.ld_aux_out & 7) == 0;
+    auto put_bf16 = [&](bf16_t* base, int64_t ld, int mi, int ni, const u32x2& pk, bool ok, u32x2& hold, bool& hold_ok, bool wide) {
+        bf16_t* dst = base + crow[mi] * ld + ncol[ni];
+        if constexpr (!PAIR) {
+            if (ok) *reinterpret_cast<u32x2*>(dst) = pk;
+        } else if ((ni & 1) == 0) {
+            hold = pk; hold_ok = ok;
+        } else {
+            bf16_t* d0 = base + crow[mi] * ld + ncol[ni - 1];
+            if (wide && hold_ok && ok) {
+                *reinterpret_cast<u32x4*>(d0) = (u32x4){hold[0], hold[1], pk[0], pk[1]};
+            } else {
+                if (hold_ok) *reinterpret_cast<u32x2*>(d0) = hold;
+                if (ok) *reinterpret_cast<u32x2*>(dst) = pk;
+            }
+        }
+    };
     float4 res[EPI == MTL_EPI_RESID || EPI == MTL_EPI_ACCUM ? NI : 1][4];
     u32x2 hk[EPI == MTL_EPI_DGELU ? NI : 1][4];
     u32x4 gq[EPI == MTL_EPI_DSWIGLU ? NI : 1][4];        // saved (gate, up) pairs of the lane's 4 activation columns
@@ -199,7 +220,10 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
     // "pending" at the merge and costs a vmcnt(0) before every later ds_read; a compiler-visible wait here settles it.
     if constexpr (!FULL) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0) only (gfx9 encoding)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < 4; ++mi) {
+        u32x2 hold_c = {0u, 0u}, hold_a = {0u, 0u};
+        uint32_t hold_s = 0u;
+        bool hold_c_ok = false, hold_a_ok = false, hold_s_ok = false;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const bool ok = mok[mi] && nok[ni];
@@ -208,7 +232,7 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
                           acc[ni][mi][3] * p.alpha + b4[ni].w};
             if constexpr (EPI == MTL_EPI_GELU) {
                 const u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-                if (ok && bwd_ok[mi]) *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.aux_out) + crow[mi] * p.ld_aux_out + n) = pk;
+                put_bf16(reinterpret_cast<bf16_t*>(p.aux_out), p.ld_aux_out, mi, ni, pk, ok && bwd_ok[mi], hold_a, hold_a_ok, wide_a);
                 o[0] = gelu_new_f(__uint_as_float(pk[0] << 16)); o[1] = gelu_new_f(__uint_as_float(pk[0] & 0xffff0000u));
                 o[2] = gelu_new_f(__uint_as_float(pk[1] << 16)); o[3] = gelu_new_f(__uint_as_float(pk[1] & 0xffff0000u));
             } else if constexpr (EPI == MTL_EPI_RESID) {
@@ -243,7 +267,7 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
                 if (ok) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + crow[mi] * p.ldc + 2 * n) = outq;
             } else if constexpr (CDT == MTL_BF16) {
                 const u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-                if (ok && (EPI != MTL_EPI_SWIGLU || bwd_ok[mi])) *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + crow[mi] * p.ldc + n) = pk;
+                put_bf16(reinterpret_cast<bf16_t*>(p.C), p.ldc, mi, ni, pk, ok && (EPI != MTL_EPI_SWIGLU || bwd_ok[mi]), hold_c, hold_c_ok, wide_c);
                 if constexpr (EPI == MTL_EPI_SWIGLU) {
                     // columns (n .. n+3) = (gate_j, up_j, gate_j+1, up_j+1), j = n/2; the activation sees the bf16-rounded Linear
                     // outputs and silu's own output is a bf16 tensor before the product (HF:modeling_llama.py:176)
@@ -251,7 +275,21 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
                     const float g1 = __uint_as_float(pk[1] << 16), u1 = __uint_as_float(pk[1] & 0xffff0000u);
                     const float s0 = bf16_to_f32(f32_to_bf16(g0 * __builtin_amdgcn_rcpf(1.0f + __expf(-g0))));
                     const float s1 = bf16_to_f32(f32_to_bf16(g1 * __builtin_amdgcn_rcpf(1.0f + __expf(-g1))));
-                    if (ok) *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(p.aux_out) + crow[mi] * p.ld_aux_out + (n >> 1)) = pack_bf16x2(s0 * u0, s1 * u1);
+                    const uint32_t av = pack_bf16x2(s0 * u0, s1 * u1);      // 2 activation columns; a tile pair's 4 leave in one 8-byte store
+                    bf16_t* ad = reinterpret_cast<bf16_t*>(p.aux_out) + crow[mi] * p.ld_aux_out + (n >> 1);
+                    if constexpr (!PAIR) {
+                        if (ok) *reinterpret_cast<uint32_t*>(ad) = av;
+                    } else if ((ni & 1) == 0) {
+                        hold_s = av; hold_s_ok = ok;
+                    } else {
+                        bf16_t* a0 = reinterpret_cast<bf16_t*>(p.aux_out) + crow[mi] * p.ld_aux_out + (ncol[ni - 1] >> 1);
+                        if (hold_s_ok && ok && (reinterpret_cast<uintptr_t>(p.aux_out) & 7) == 0 && (p.ld_aux_out & 3) == 0) {
+                            *reinterpret_cast<u32x2*>(a0) = (u32x2){hold_s, av};
+                        } else {
+                            if (hold_s_ok) *reinterpret_cast<uint32_t*>(a0) = hold_s;
+                            if (ok) *reinterpret_cast<uint32_t*>(ad) = av;
+                        }
+                    }
                 }
             } else {
                 float* cp = reinterpret_cast<float*>(p.C) + crow[mi] * p.ldc + n;
@@ -273,17 +311,19 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
                 }
             }
         }
+    }
 }
 
 // column tiles are processed NCH at a time so that the prefetched auxiliary operands (residual: 4 float4 per column tile)
 // stay within the register budget of the wide wave tiles (64x96, 64x128 per wave); <= 4 column tiles go in one piece
-template <int EPI, int CDT, int NI, bool FULL>
+template <int EPI, int CDT, int NI, bool FULL, bool PAIR = false>
 __device__ __forceinline__ void epilogue_wave(const mtl_gemm_args& p, int64_t m_first, int64_t n_first, f32x4 (&acc)[NI][4],
                                               const bool dword_stores = false) {
     constexpr int NCH = NI > 4 ? 2 : NI;
     static_assert(NI % NCH == 0, "column tiles per wave must split evenly");
+    static_assert(!PAIR || NCH % 2 == 0, "paired column tiles stay inside one chunk");
 #pragma unroll
-    for (int c0 = 0; c0 < NI; c0 += NCH) epilogue_chunk<EPI, CDT, NCH, FULL>(p, m_first, n_first + c0 * 16, &acc[c0], dword_stores);
+    for (int c0 = 0; c0 < NI; c0 += NCH) epilogue_chunk<EPI, CDT, NCH, FULL, PAIR>(p, m_first, n_first + c0 * 16, &acc[c0], dword_stores);
 }
 
 // SPLIT: raw fp32 partial sums go to workspace slab [split][M][N]; epilogue runs in splitk_reduce_kernel.
@@ -424,6 +464,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const mtl_gemm_args p, 
 // swizzle of the 16-B chunk index inside a 128-B tile row: slot = (r&1)*8 + (c ^ (r>>1 & 7)) -> conflict-free
 // ds_read_b128 lane groups (SQ_LDS_BANK_CONFLICT == 0 measured).
 __device__ __forceinline__ int swz64(int row) { return (row >> 1) & 7; }
+// B tiles read in column pairs: fragment lane i = 4a + b reads LDS row 32t + 8a + 4*(ni & 1) + b, and this swizzle gives that lane the
+// same (row & 1, swizzle) = (i & 1, i >> 1) pair as swz64 gives lane i on row i: bank-for-bank the same conflict-free ds_read_b128
+__device__ __forceinline__ int swz_pair(int row) { return (((row >> 3) & 3) << 1) | ((row >> 1) & 1); }
 
 // grouped (GM rows at a time) tile order: consecutive linear ids form compact GM x n patches, so the workgroups that
 // run concurrently on one XCD stream the SAME few A/B panels through its 4 MiB L2 (measured: the flat row-major
@@ -460,6 +503,7 @@ __global__ __launch_bounds__(NW_ALL * 64) void gemm_nt_persist_kernel(const mtl_
     constexpr int WN = NW / WM;                // waves along N
     constexpr int WCOLS = BN_ / WN;            // columns per wave
     constexpr int NI = WCOLS / 16;             // 16-wide n tiles per wave
+    constexpr bool PAIR = NI % 2 == 0;         // column tiles read in pairs: a lane owns 8 consecutive output columns (epilogue_chunk)
     constexpr int CPR = BK_ / 8;               // 16-B chunks per tile row
     constexpr int ROWB = BK_ * 2;              // bytes per tile row
     constexpr int NA = BM_ * CPR / NT;         // 16-B staging slots per thread, A tile
@@ -518,7 +562,7 @@ __global__ __launch_bounds__(NW_ALL * 64) void gemm_nt_persist_kernel(const mtl_
         for (int i = 0; i < NB; ++i) {
             const int sl = i * NT + tid;
             const int rr = sl / CPR, pc = sl % CPR;
-            const int c = pc ^ swz64(rr);
+            const int c = pc ^ (PAIR ? swz_pair(rr) : swz64(rr));
             int64_t bn = n0 + rr; if (bn > p.N - 1) bn = p.N - 1;
             bsrc[i] = reinterpret_cast<const bf16_t*>(p.B) + bn * p.ldb + c * 8 + k0;
         }
@@ -555,17 +599,17 @@ __global__ __launch_bounds__(NW_ALL * 64) void gemm_nt_persist_kernel(const mtl_
             mtl_gemm_args q = p;
             q.C = reinterpret_cast<float*>(p.workspace) + (int64_t)slab * p.M * p.N;
             q.ldc = p.N; q.bias = nullptr; q.alpha = 1.f; q.c_group_rows = 0;
-            if (full) epilogue_wave<MTL_EPI_STORE, MTL_F32, NI, true>(q, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * 4, acc);
-            else epilogue_wave<MTL_EPI_STORE, MTL_F32, NI, false>(q, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * 4, acc);
+            if (full) epilogue_wave<MTL_EPI_STORE, MTL_F32, NI, true, PAIR>(q, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * (PAIR ? 8 : 4), acc);
+            else epilogue_wave<MTL_EPI_STORE, MTL_F32, NI, false, PAIR>(q, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * (PAIR ? 8 : 4), acc);
         } else {
             const bool dw = vec_ok_i == 0;     // fp32 plain store without bias into 4-B aligned rows (host guarantees the rest)
-            if (full) epilogue_wave<EPI, CDT, NI, true>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * 4, acc, dw);
-            else epilogue_wave<EPI, CDT, NI, false>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * 4, acc, dw);
+            if (full) epilogue_wave<EPI, CDT, NI, true, PAIR>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * (PAIR ? 8 : 4), acc, dw);
+            else epilogue_wave<EPI, CDT, NI, false, PAIR>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * (PAIR ? 8 : 4), acc, dw);
         }
     };
     const int sw = swz64(l15);                 // wave / mi / ni row offsets are multiples of 16: swz unchanged
     const int a_off = (wr * 64 + l15) * ROWB;
-    const int b_off = (wc * WCOLS + l15) * ROWB;
+    const int b_off = PAIR ? (wc * WCOLS + (l15 >> 2) * 8 + (l15 & 3)) * ROWB : (wc * WCOLS + l15) * ROWB;
 
     int s_i = 0, s_kt = 0, s_buf = 0;   // next (tile index, k-tile, ring slot) to stage
     int c_i = 0, c_kt = 0, c_buf = 0;   // being computed
@@ -613,7 +657,8 @@ __global__ __launch_bounds__(NW_ALL * 64) void gemm_nt_persist_kernel(const mtl_
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(la + a_off + mi * 16 * ROWB + pc16);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8*>(lb + b_off + ni * 16 * ROWB + pc16);
+            for (int ni = 0; ni < NI; ++ni)
+                bfr[ni] = *reinterpret_cast<const bf16x8*>(lb + b_off + (PAIR ? (ni >> 1) * 32 + (ni & 1) * 4 : ni * 16) * ROWB + pc16);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
