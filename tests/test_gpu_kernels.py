@@ -547,6 +547,41 @@ def test_gemm_every_tile_configuration(ops, cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(128, 64, 2, 4), (128, 96, 2, 4), (128, 128, 2, 8), (128, 192, 2, 8), (256, 128, 3, 16), (256, 192, 2, 8), (256, 256, 2, 8)])
+def test_gemm_bf16_epilogues_on_every_tile_configuration(ops, cfg):
+    """the bf16-output epilogues (plain, GELU + saved pre-activation, dGELU, SwiGLU, dSwiGLU) on ragged shapes for every tile
+    configuration: waves with an even number of column tiles store 8-column pairs (16-byte stores), odd ones 4-column quads,
+    edge tiles fall back to predicated narrow stores — all must equal the automatic configuration's result up to summation order"""
+    lib = ops.lib()
+    for (M, Nn, K) in [(300, 264, 128), (517, 392, 192), (130, 1032, 64)]:
+        A = torch.randn(M, K, generator=g(M)).to(BF16).cuda()
+        B = (torch.randn(Nn, K, generator=g(Nn)) * 0.2).to(BF16).cuda()
+        bias = torch.randn(Nn, generator=g(K)).cuda()
+        pre_in = torch.randn(M, Nn, generator=g(9)).to(BF16).cuda()
+        gu = torch.randn(M, 2 * Nn, generator=g(10)).to(BF16).cuda()
+
+        def run():
+            pre = torch.zeros(M, Nn, dtype=BF16, device="cuda")
+            act = ops.gemm_nt(A, B, bias=bias, epilogue=ops.N.EPI_GELU, aux_out=pre)
+            sact = torch.zeros(M, Nn // 2, dtype=BF16, device="cuda")
+            sgu = ops.gemm_nt(A, B, epilogue=ops.N.EPI_SWIGLU, aux_out=sact)
+            dgu = torch.zeros(M, 2 * Nn, dtype=BF16, device="cuda")
+            ops.gemm_nt(A, B, out=dgu, epilogue=ops.N.EPI_DSWIGLU, aux_in=gu)
+            return (ops.gemm_nt(A, B, bias=bias), act, pre, ops.gemm_nt(A, B, epilogue=ops.N.EPI_DGELU, aux_in=pre_in), sgu, sact, dgu)
+
+        ref = run()
+        lib.mtl_gemm_tune(1, *cfg)
+        try:
+            out = run()
+        finally:
+            lib.mtl_gemm_tune(1, 0, 0, 0, 0)
+        lin = A.double().cpu() @ B.double().cpu().t() + bias.double().cpu()
+        assert rel_err(out[0].float(), lin) < TOL_BF16
+        for a, b in zip(out, ref):
+            assert rel_err(a.float(), b.float().double().cpu()) < 2e-3, cfg
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [(128, 64, 2, 4), (128, 96, 2, 4), (128, 96, 2, 8), (128, 128, 2, 8), (128, 192, 2, 8), (256, 96, 3, 8), (256, 192, 2, 8),
                                  (256, 256, 2, 8)])
 @pytest.mark.parametrize("tiles_m", [8, 16, 24])
