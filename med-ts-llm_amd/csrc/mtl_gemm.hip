@@ -146,11 +146,13 @@ __device__ __forceinline__ void epilogue4(const mtl_gemm_args& p, int64_t m, int
 // out as straight-line code. (With predicates every use sits in its own branch and hipcc waits vmcnt(0) in each, i.e.
 // every store waits for the previous store to complete, and the still-"pending" bias registers force a vmcnt(0) in
 // front of the next k-step's first ds_read, draining the LDS-DMA pipeline.)
-// PAIR (even NI): the B fragments of column tiles 2t / 2t+1 were read from LDS rows permuted so that a lane's 4 + 4 columns are the
-// 8 CONSECUTIVE columns n_first + 32t .. +7 (n_first includes 8*g, not 4*g): tile ni covers n_first + (ni/2)*32 + (ni%2)*4 + 0..3.
+// PAIR: the B fragments of column tiles 2t / 2t+1 were read from LDS rows permuted so that a lane's 4 + 4 columns are the 8
+// CONSECUTIVE columns n_base + 32t + 8g .. +7: tile ni < NPT covers n_base + (ni/2)*32 + 8g + (ni%2)*4 + 0..3; an odd last tile
+// (ni >= NPT) keeps the plain layout n_base + 16 ni + 4g + 0..3. `g` = lane >> 4.
 template <int EPI, int CDT, int NI, bool FULL, bool PAIR = false>
-__device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m_first, int64_t n_first, f32x4 (*acc)[4],
+__device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m_first, int64_t n_base, const int g, f32x4 (*acc)[4],
                                                const bool dword_stores) {
+    constexpr int NPT = PAIR ? (NI & ~1) : 0;      // column tiles that come in pairs
     // lane owns rows m_first + mi*16 (mi = 0..3) and columns n_first + ni*16 .. +3.  Edge tiles (!FULL) LOAD from
     // clamped (always valid) addresses and predicate only the stores: no load result is ever consumed inside a branch.
     int64_t crow[4];
@@ -174,7 +176,7 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
     float4 b4[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-        const int64_t n = n_first + (PAIR ? (ni >> 1) * 32 + (ni & 1) * 4 : ni * 16);
+        const int64_t n = n_base + (ni < NPT ? (ni >> 1) * 32 + g * 8 + (ni & 1) * 4 : ni * 16 + g * 4);
         nok[ni] = FULL || n < p.N;  // vector path: N % 4 == 0, so the 4 columns are valid together
         ncol[ni] = nok[ni] ? n : p.N - 4;
         b4[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -188,7 +190,7 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
     const bool wide_a = PAIR && (reinterpret_cast<uintptr_t>(p.aux_out) & 15) == 0 && (p.ld_aux_out & 7) == 0;
     auto put_bf16 = [&](bf16_t* base, int64_t ld, int mi, int ni, const u32x2& pk, bool ok, u32x2& hold, bool& hold_ok, bool wide) {
         bf16_t* dst = base + crow[mi] * ld + ncol[ni];
-        if constexpr (!PAIR) {
+        if (!PAIR || ni >= NPT) {
             if (ok) *reinterpret_cast<u32x2*>(dst) = pk;
         } else if ((ni & 1) == 0) {
             hold = pk; hold_ok = ok;
@@ -277,7 +279,7 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
                     const float s1 = bf16_to_f32(f32_to_bf16(g1 * __builtin_amdgcn_rcpf(1.0f + __expf(-g1))));
                     const uint32_t av = pack_bf16x2(s0 * u0, s1 * u1);      // 2 activation columns; a tile pair's 4 leave in one 8-byte store
                     bf16_t* ad = reinterpret_cast<bf16_t*>(p.aux_out) + crow[mi] * p.ld_aux_out + (n >> 1);
-                    if constexpr (!PAIR) {
+                    if (!PAIR || ni >= NPT) {
                         if (ok) *reinterpret_cast<uint32_t*>(ad) = av;
                     } else if ((ni & 1) == 0) {
                         hold_s = av; hold_s_ok = ok;
@@ -317,13 +319,13 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
 // column tiles are processed NCH at a time so that the prefetched auxiliary operands (residual: 4 float4 per column tile)
 // stay within the register budget of the wide wave tiles (64x96, 64x128 per wave); <= 4 column tiles go in one piece
 template <int EPI, int CDT, int NI, bool FULL, bool PAIR = false>
-__device__ __forceinline__ void epilogue_wave(const mtl_gemm_args& p, int64_t m_first, int64_t n_first, f32x4 (&acc)[NI][4],
+__device__ __forceinline__ void epilogue_wave(const mtl_gemm_args& p, int64_t m_first, int64_t n_base, const int g, f32x4 (&acc)[NI][4],
                                               const bool dword_stores = false) {
     constexpr int NCH = NI > 4 ? 2 : NI;
     static_assert(NI % NCH == 0, "column tiles per wave must split evenly");
-    static_assert(!PAIR || NCH % 2 == 0, "paired column tiles stay inside one chunk");
+    static_assert(!PAIR || NCH == NI || NCH % 2 == 0, "paired column tiles stay inside one chunk");
 #pragma unroll
-    for (int c0 = 0; c0 < NI; c0 += NCH) epilogue_chunk<EPI, CDT, NCH, FULL, PAIR>(p, m_first, n_first + c0 * 16, &acc[c0], dword_stores);
+    for (int c0 = 0; c0 < NI; c0 += NCH) epilogue_chunk<EPI, CDT, NCH, FULL, PAIR>(p, m_first, n_base + c0 * 16, g, &acc[c0], dword_stores);
 }
 
 // SPLIT: raw fp32 partial sums go to workspace slab [split][M][N]; epilogue runs in splitk_reduce_kernel.
@@ -493,8 +495,18 @@ __device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int
 // halves of K, each with its own LDS ring (twice the LDS-DMA bytes in flight and two waves per SIMD, which a lone 4-wave
 // workgroup per CU lacks: M = B*n_grad backward GEMMs 46 -> ~30 us cold); group 1 hands its partial sums over through LDS.
 // Host guarantees one tile per workgroup and an even number of k-tiles.
+// waves per SIMD the launcher counts on (workgroups per CU by LDS x waves per workgroup / 4 SIMDs): told to the compiler so that an
+// epilogue change cannot silently push a kernel over an occupancy cliff (the 128x192 / 8-wave qkv kernel went 126 -> 136 VGPRs and
+// lost its second workgroup per CU: 38.5 -> 40.9 us)
+constexpr int persist_waves_per_simd(int bm, int bn, int stages, int nw_all, int ks) {
+    const int bn_lds = ((bn * 8 + (nw_all / ks) * 64 - 1) / ((nw_all / ks) * 64)) * ((nw_all / ks) * 64) / 8;
+    const int lds = ks * stages * (bm + bn_lds) * 128;
+    const int wgs = 160 * 1024 / lds < 1 ? 1 : 160 * 1024 / lds;
+    const int w = wgs * nw_all / 4;
+    return w < 1 ? 1 : (w > 4 ? 4 : w);        // (beyond 4 waves per SIMD nothing here is register-limited)
+}
 template <int EPI, int CDT, int BM_, int BN_, int STAGES, int NW_ALL, bool SPLIT = false, int KS = 1>
-__global__ __launch_bounds__(NW_ALL * 64) void gemm_nt_persist_kernel(const mtl_gemm_args p, const int vec_ok_i, const int tiles_m,
+__global__ __launch_bounds__(NW_ALL * 64, persist_waves_per_simd(BM_, BN_, STAGES, NW_ALL, KS)) void gemm_nt_persist_kernel(const mtl_gemm_args p, const int vec_ok_i, const int tiles_m,
                                                                  const int tiles_n, const int gm_all) {
     constexpr int BK_ = 64;
     constexpr int NW = NW_ALL / KS;            // waves per k-group (all tile geometry below is per group)
@@ -503,7 +515,8 @@ __global__ __launch_bounds__(NW_ALL * 64) void gemm_nt_persist_kernel(const mtl_
     constexpr int WN = NW / WM;                // waves along N
     constexpr int WCOLS = BN_ / WN;            // columns per wave
     constexpr int NI = WCOLS / 16;             // 16-wide n tiles per wave
-    constexpr bool PAIR = NI % 2 == 0;         // column tiles read in pairs: a lane owns 8 consecutive output columns (epilogue_chunk)
+    constexpr bool PAIR = NI >= 2;             // column tiles read in pairs: a lane owns 8 consecutive output columns (epilogue_chunk)
+    constexpr int NPT = PAIR ? (NI & ~1) : 0;  // an odd last tile keeps the plain layout
     constexpr int CPR = BK_ / 8;               // 16-B chunks per tile row
     constexpr int ROWB = BK_ * 2;              // bytes per tile row
     constexpr int NA = BM_ * CPR / NT;         // 16-B staging slots per thread, A tile
@@ -562,7 +575,8 @@ __global__ __launch_bounds__(NW_ALL * 64) void gemm_nt_persist_kernel(const mtl_
         for (int i = 0; i < NB; ++i) {
             const int sl = i * NT + tid;
             const int rr = sl / CPR, pc = sl % CPR;
-            const int c = pc ^ (PAIR ? swz_pair(rr) : swz64(rr));
+            const int loc = rr % WCOLS;            // row inside its wave's column block: the paired rows swizzle on it
+            const int c = pc ^ (loc < NPT * 16 ? swz_pair(loc) : swz64(rr));
             int64_t bn = n0 + rr; if (bn > p.N - 1) bn = p.N - 1;
             bsrc[i] = reinterpret_cast<const bf16_t*>(p.B) + bn * p.ldb + c * 8 + k0;
         }
@@ -599,17 +613,21 @@ __global__ __launch_bounds__(NW_ALL * 64) void gemm_nt_persist_kernel(const mtl_
             mtl_gemm_args q = p;
             q.C = reinterpret_cast<float*>(p.workspace) + (int64_t)slab * p.M * p.N;
             q.ldc = p.N; q.bias = nullptr; q.alpha = 1.f; q.c_group_rows = 0;
-            if (full) epilogue_wave<MTL_EPI_STORE, MTL_F32, NI, true, PAIR>(q, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * (PAIR ? 8 : 4), acc);
-            else epilogue_wave<MTL_EPI_STORE, MTL_F32, NI, false, PAIR>(q, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * (PAIR ? 8 : 4), acc);
+            if (full) epilogue_wave<MTL_EPI_STORE, MTL_F32, NI, true, PAIR>(q, m0 + wr * 64 + l15, n0 + wc * WCOLS, g, acc);
+            else epilogue_wave<MTL_EPI_STORE, MTL_F32, NI, false, PAIR>(q, m0 + wr * 64 + l15, n0 + wc * WCOLS, g, acc);
         } else {
             const bool dw = vec_ok_i == 0;     // fp32 plain store without bias into 4-B aligned rows (host guarantees the rest)
-            if (full) epilogue_wave<EPI, CDT, NI, true, PAIR>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * (PAIR ? 8 : 4), acc, dw);
-            else epilogue_wave<EPI, CDT, NI, false, PAIR>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS + g * (PAIR ? 8 : 4), acc, dw);
+            if (full) epilogue_wave<EPI, CDT, NI, true, PAIR>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS, g, acc, dw);
+            else epilogue_wave<EPI, CDT, NI, false, PAIR>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS, g, acc, dw);
         }
     };
     const int sw = swz64(l15);                 // wave / mi / ni row offsets are multiples of 16: swz unchanged
     const int a_off = (wr * 64 + l15) * ROWB;
-    const int b_off = PAIR ? (wc * WCOLS + (l15 >> 2) * 8 + (l15 & 3)) * ROWB : (wc * WCOLS + l15) * ROWB;
+    const int b_off = (wc * WCOLS + l15) * ROWB;                                     // plain layout (an odd last column tile)
+    const int b_off_pair = (wc * WCOLS + (l15 >> 2) * 8 + (l15 & 3)) * ROWB;         // paired column tiles
+    // the LDS-DMA swizzles the paired rows on the row inside the wave's block: for lane i = 4a + b that is (a << 1) | (b >> 1) = i >> 1
+    // = sw, so every lane keeps the (row & 1, swizzle) pair, i.e. the bank slot, it has in the plain layout (same pc16 for all tiles)
+    static_assert(WCOLS % 16 == 0, "wave column blocks start on 16-row boundaries");
 
     int s_i = 0, s_kt = 0, s_buf = 0;   // next (tile index, k-tile, ring slot) to stage
     int c_i = 0, c_kt = 0, c_buf = 0;   // being computed
@@ -658,7 +676,8 @@ __global__ __launch_bounds__(NW_ALL * 64) void gemm_nt_persist_kernel(const mtl_
             for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(la + a_off + mi * 16 * ROWB + pc16);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-                bfr[ni] = *reinterpret_cast<const bf16x8*>(lb + b_off + (PAIR ? (ni >> 1) * 32 + (ni & 1) * 4 : ni * 16) * ROWB + pc16);
+                bfr[ni] = ni < NPT ? *reinterpret_cast<const bf16x8*>(lb + b_off_pair + ((ni >> 1) * 32 + (ni & 1) * 4) * ROWB + pc16)
+                                   : *reinterpret_cast<const bf16x8*>(lb + b_off + ni * 16 * ROWB + pc16);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll

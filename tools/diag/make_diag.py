@@ -24,8 +24,8 @@ def sub(a, b, count=1):
 
 sub("            stage(s_buf, s_kt);\n            s_buf = (s_buf + 1 == STAGES) ? 0 : s_buf + 1;\n            if (++s_kt == nkt) { s_kt = 0; ++s_i; }\n        }\n        const char* la",
     "#ifndef DIAG_NOLOAD\n            stage(s_buf, s_kt);\n#endif\n            s_buf = (s_buf + 1 == STAGES) ? 0 : s_buf + 1;\n            if (++s_kt == nkt) { s_kt = 0; ++s_i; }\n        }\n        const char* la")
-sub("#pragma unroll\n        for (int ks = 0; ks < 2; ++ks) {\n            const int pc16 = ((ks * 4 + g) ^ sw) * 16;\n            bf16x8 af[4], bfr[NI];",
-    "#ifdef DIAG_NOCOMPUTE\n        if (p.alpha == 12345.f)\n#endif\n#pragma unroll\n        for (int ks = 0; ks < 2; ++ks) {\n            const int pc16 = ((ks * 4 + g) ^ sw) * 16;\n            bf16x8 af[4], bfr[NI];")
+sub("#pragma unroll\n        for (int ks = 0; ks < 2; ++ks) {\n            const int pc16 = ((ks * 4 + g) ^ sw) * 16;\n            bf16x8 af[4], bfr[NI]",
+    "#ifdef DIAG_NOCOMPUTE\n        if (p.alpha == 12345.f)\n#endif\n#pragma unroll\n        for (int ks = 0; ks < 2; ++ks) {\n            const int pc16 = ((ks * 4 + g) ^ sw) * 16;\n            bf16x8 af[4], bfr[NI]")
 sub("                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);\n        }\n        c_buf =",
     "#ifdef DIAG_NOMFMA\n                    { acc[ni][mi][0] += (float)af[mi][0] + (float)bfr[ni][0]; }\n#else\n                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);\n#endif\n        }\n        c_buf =")
 sub("__device__ __forceinline__ int swz64(int row) { return (row >> 1) & 7; }",
