@@ -90,23 +90,43 @@ def make_tokenizer(d, bos="<|endoftext|>", vocab=384):
     return fast
 
 
+def synth_table(rows, cols, salt, scale):
+    """Deterministic [rows, cols] fp32 table from integer hashing (numpy only): lets fixtures with 100 000-row tensors
+    (the vocabulary > 100 000 case) be REGENERATED on the test side instead of stored. Same function in tests/helpers.py."""
+    i = np.arange(rows, dtype=np.uint64)[:, None]
+    j = np.arange(cols, dtype=np.uint64)[None, :]
+    h = (i * np.uint64(2654435761) + j * np.uint64(40503) + np.uint64(salt * 97 + 1)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(2246822519)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(3266489917)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    return ((h.astype(np.float64) / 4294967296.0 - 0.5) * scale).astype(np.float32)
+
+
+BIG_VOCAB = 100_100
+SYNTH_EMBED = {"rows": BIG_VOCAB, "cols": 128, "salt": 1, "scale": 0.3}
+
+
 def make_backbone(kind, d, seed, vocab=512):
-    """Seeded random-init tiny backbone saved HF-style into directory d."""
+    """Seeded random-init tiny backbone saved HF-style into directory d. Shapes the HIP path accepts: head dims 32 / 64,
+    d_llm and FFN multiples of 64 (GPT-2 128 = 2 x 64; Llama MHA 128 = 2 x 64; Llama GQA 128 = 4 x 32 with 2 KV heads)."""
     import transformers
     torch.manual_seed(seed)
     if kind == "gpt2":
-        cfg = transformers.GPT2Config(vocab_size=vocab, n_positions=256, n_embd=64, n_layer=2, n_head=4,
+        cfg = transformers.GPT2Config(vocab_size=vocab, n_positions=256, n_embd=128, n_layer=2, n_head=2,
                                       bos_token_id=0, eos_token_id=0,
                                       resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0)  # train-mode dropouts off: parity needs determinism
         m = transformers.GPT2Model(cfg)
     elif kind == "llama":
-        cfg = transformers.LlamaConfig(vocab_size=vocab, hidden_size=64, intermediate_size=160,
-                                       num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4,
+        cfg = transformers.LlamaConfig(vocab_size=vocab, hidden_size=128, intermediate_size=192,
+                                       num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2,
                                        rope_theta=10000.0, rms_norm_eps=1e-5, max_position_embeddings=512,
                                        bos_token_id=0, eos_token_id=0, pad_token_id=None)
         m = transformers.LlamaModel(cfg)
-    elif kind == "llama_gqa":
-        cfg = transformers.LlamaConfig(vocab_size=vocab, hidden_size=64, intermediate_size=160,
+    elif kind in ("llama_gqa", "llama_gqa_bigvocab"):
+        # bigvocab: vocabulary > 100 000 -> the reference sub-samples 100 000 rows into a TRAINABLE parameter (R:models/medtsllm.py:220-222)
+        cfg = transformers.LlamaConfig(vocab_size=BIG_VOCAB if kind.endswith("bigvocab") else vocab, hidden_size=128, intermediate_size=192,
                                        num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
                                        rope_theta=500000.0, rms_norm_eps=1e-5, max_position_embeddings=512,
                                        bos_token_id=0, eos_token_id=0, pad_token_id=None)
@@ -125,6 +145,8 @@ def make_backbone(kind, d, seed, vocab=512):
                         p.copy_(0.05 * torch.randn(p.shape, generator=g))
                 else:
                     p.copy_(0.02 * torch.randn(p.shape, generator=g))
+            elif kind.endswith("bigvocab") and n == "embed_tokens.weight":
+                p.copy_(torch.from_numpy(synth_table(**SYNTH_EMBED)))
             else:
                 p.copy_(0.08 * torch.randn(p.shape, generator=g))
     m.save_pretrained(d)
@@ -139,8 +161,8 @@ class DS:
         self.task_description = None
 
 
-def base_config(llm_dir, task, L, pred, cov, down, prompting, dropout=0.0, d_model=8, d_ff=16, H=2,
-                num_tokens=32, patch_len=16, stride=8, llm_layers=-1, dtype="fp32"):
+def base_config(llm_dir, task, L, pred, cov, down, prompting, dropout=0.0, d_model=8, d_ff=64, H=2,
+                num_tokens=64, patch_len=16, stride=8, llm_layers=-1, dtype="fp32"):
     return {
         "DEBUG": True, "task": task, "model": "medtsllm", "history_len": L, "pred_len": pred,
         "training": {"dropout": dropout},
@@ -182,7 +204,27 @@ CASES = [
     # "examples" prompting: a (text, tensor[1, L_ex, C]) pair per sample is spliced into the prompt, the tensor goes through encode_ts
     ("gpt2_concat_fc_examples", "gpt2",  "forecasting",           2, 64,  3, 16,  "concat",      "linear",   PROMPT_EXAMPLES, 0),
     ("llama_add_semseg_examples", "llama", "semantic_segmentation", 2, 64, 3, 64, "add",         "linear",   PROMPT_EXAMPLES, 4),
+    # vocabulary > 100 000 (Llama-3's quirk): word_embeddings = 100 000 linspace-sampled rows, TRAINABLE; the 100 000-row tensors are
+    # formula-generated (synth_table) and their gradients are stored as norms + projections + strided samples (BIG_* below)
+    ("llamagqa_bigvocab_recon", "llama_gqa_bigvocab", "reconstruction", 2, 64, 2, 64, "concat",   "linear",   PROMPT_CONST, 0),
 ]
+
+SYNTH_MAPPING = {"rows": 64, "cols": 100_000, "salt": 2, "scale": 0.02}     # mapping_layer.weight of the bigvocab case
+BIG_STRIDE = 997                                                            # stored rows / columns of the 100 000-wide gradients
+
+
+def big_grad_summary(name, g):
+    """A 100 000-wide gradient as data small enough to commit: Frobenius norm, projections onto fixed synthetic vectors
+    along both axes, and every BIG_STRIDE-th slice along the long axis."""
+    g = g.detach().double().numpy()
+    long_axis = 0 if g.shape[0] >= g.shape[1] else 1
+    u = synth_table(1, g.shape[0], 11, 2.0)[0].astype(np.float64)
+    v = synth_table(1, g.shape[1], 12, 2.0)[0].astype(np.float64)
+    return {f"gradnorm.{name}": np.float64(np.linalg.norm(g)),
+            f"gradproj_rows.{name}": (g @ v).astype(np.float32),       # [rows]
+            f"gradproj_cols.{name}": (u @ g).astype(np.float32),       # [cols]
+            f"gradsample.{name}": np.take(g, np.arange(0, g.shape[long_axis], BIG_STRIDE), axis=long_axis).astype(np.float32)}
+
 
 
 def t2n(t):
@@ -198,6 +240,11 @@ def run_case(name, kind, task, B, L, C, pred, cov, down, prompting, n_classes, l
     torch.manual_seed(1234)
     model = ref_models.model_lookup["medtsllm"](cfg, ds)
     model = model.to("cpu", torch.float32)
+    big = kind.endswith("bigvocab")
+    if big:
+        assert model.word_embeddings.requires_grad and model.word_embeddings.shape[0] == 100_000
+        with torch.no_grad():
+            model.mapping_layer.weight.copy_(torch.from_numpy(synth_table(**SYNTH_MAPPING)))
 
     g = torch.Generator().manual_seed(99)
     x = torch.randn(B, L, C, generator=g) * torch.tensor([1.0, 2.5, 0.3][:C]) + torch.tensor([0.5, -1.0, 3.0][:C])
@@ -253,6 +300,9 @@ def run_case(name, kind, task, B, L, C, pred, cov, down, prompting, n_classes, l
     out["pred_train"] = t2n(pred_train)
     for n, p in model.named_parameters():
         if p.requires_grad:
+            if big and p.numel() > 1_000_000:       # regenerated by formula on the test side; gradient stored as a summary
+                out.update(big_grad_summary(n, p.grad))
+                continue
             out["param." + n] = t2n(p)
             out["grad." + n] = t2n(p.grad)
     out["revin_mean"] = t2n(model.normalize_layers.mean)
@@ -286,8 +336,10 @@ def run_case(name, kind, task, B, L, C, pred, cov, down, prompting, n_classes, l
     meta = {
         "name": name, "backbone": kind, "task": task, "B": B, "L": L, "C": C, "pred_len": pred,
         "covariate_mode": cov, "embedding_downsample_mode": down, "prompting": prompting,
-        "n_classes": n_classes, "d_model": 8, "d_ff": 16, "n_heads": 2, "num_tokens": 32,
+        "n_classes": n_classes, "d_model": cfg.models.timellm.d_model, "d_ff": cfg.models.timellm.d_ff,
+        "n_heads": cfg.models.timellm.n_heads, "num_tokens": cfg.models.timellm.num_tokens,
         "patch_len": 16, "stride": 8,
+        "synth": ({"embed_tokens.weight": SYNTH_EMBED, "mapping_layer.weight": SYNTH_MAPPING, "stride": BIG_STRIDE} if big else None),
         "dataset_description": ds.description,
         "descriptions": inputs.get("descriptions"),
         "prompts": prompts, "prompt_token_ids": tok_ids,
@@ -345,7 +397,7 @@ def run_trainer_golden(llm_dirs):
     cfgd = base_config(llm_dirs["gpt2"], "forecasting", 64, 16, "concat", "linear", PROMPT_FULL)
     cfgd.update({
         "data": {"dataset": "synthetic", "mode": "multivariate", "cols": "all", "normalize": True, "step": 8},
-        "training": {"epochs": 1, "batch_size": 4, "optimizer": "adam", "learning_rate": 1e-3, "dropout": 0.0,
+        "training": {"epochs": 2, "batch_size": 4, "optimizer": "adam", "learning_rate": 1e-3, "dropout": 0.0,
                      "loss": "mse", "eval_metric": "mse", "eval_metric_direction": "min"},
         "setup": {"seed": 0, "device": "cpu", "dtype": "fp32", "num_workers": 0, "logger": "print"},
         "datasets": {"synthetic": {}},
@@ -381,20 +433,25 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         setup_imports(tmp)
         llm_dirs, backbones = {}, {}
-        for i, kind in enumerate(["gpt2", "llama", "llama_gqa"]):
+        for i, kind in enumerate(["gpt2", "llama", "llama_gqa", "llama_gqa_bigvocab"]):
             d = str(Path(tmp) / f"llm_{kind}")
             os.makedirs(d)
             sd, cfgd = make_backbone(kind, d, seed=100 + i)
             make_tokenizer(d)
             llm_dirs[kind] = d
             backbones[kind] = sd
-            np.savez_compressed(OUT / f"backbone_{kind}.npz", **{k: t2n(v) for k, v in sd.items()})
+            np.savez_compressed(OUT / f"backbone_{kind}.npz", **{k: t2n(v) for k, v in sd.items()
+                                                                  if not (kind.endswith("bigvocab") and k == "embed_tokens.weight")})
             (OUT / f"backbone_{kind}.json").write_text(json.dumps(
                 {**{k: v for k, v in cfgd.items() if isinstance(v, (int, float, str, bool, type(None), list))},
                  **({"rope_theta": float((cfgd.get("rope_parameters") or {}).get("rope_theta", cfgd.get("rope_theta", 10000.0)))}
-                    if cfgd.get("model_type") == "llama" else {})}, indent=1))
+                    if cfgd.get("model_type") == "llama" else {}),
+                 **({"synth": {"embed_tokens.weight": SYNTH_EMBED}} if kind.endswith("bigvocab") else {})}, indent=1))
             # tokenizer fixture (data): copy tokenizer.json
-            (OUT / f"tokenizer_{kind}.json").write_text((Path(d) / "tokenizer.json").read_text())
+            if kind == "gpt2":      # one tokenizer fixture: the same corpus and trainer give byte-identical files for every backbone
+                (OUT / "tokenizer.json").write_text((Path(d) / "tokenizer.json").read_text())
+            else:
+                assert (Path(d) / "tokenizer.json").read_text() == (OUT / "tokenizer.json").read_text()
         only = sys.argv[1:] or None
         for case in CASES:
             if only and case[0] not in only:

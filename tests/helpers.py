@@ -11,7 +11,31 @@ CASES = [
     "gpt2_concat_fc", "gpt2_indep_recon", "gpt2_interleave_ad", "gpt2_uni_seg",
     "llama_concat_semseg", "llama_add_fc", "llama_wavg_fc", "llama_mergeend_fc", "llamagqa_concat_fc",
     "gpt2_concat_fc_examples", "llama_add_semseg_examples",     # "examples" prompting: a tensor part inside the prompt
+    "llamagqa_bigvocab_recon",                                  # vocabulary > 100 000: trainable sub-sampled word embeddings
 ]
+
+
+def synth_table(rows, cols, salt, scale):
+    """Deterministic [rows, cols] fp32 table from integer hashing — the same function tests/golden/make_golden.py used to FILL the
+    100 000-row tensors of the vocabulary > 100 000 fixture, so they are regenerated here instead of stored."""
+    i = np.arange(rows, dtype=np.uint64)[:, None]
+    j = np.arange(cols, dtype=np.uint64)[None, :]
+    h = (i * np.uint64(2654435761) + j * np.uint64(40503) + np.uint64(salt * 97 + 1)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(2246822519)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(3266489917)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    return ((h.astype(np.float64) / 4294967296.0 - 0.5) * scale).astype(np.float32)
+
+
+def big_grad_summary(g, stride):
+    """(norm, row projection, column projection, strided sample) of a 100 000-wide gradient, as make_golden.big_grad_summary"""
+    g = torch.as_tensor(g).detach().cpu().double().numpy()
+    long_axis = 0 if g.shape[0] >= g.shape[1] else 1
+    u = synth_table(1, g.shape[0], 11, 2.0)[0].astype(np.float64)
+    v = synth_table(1, g.shape[1], 12, 2.0)[0].astype(np.float64)
+    return (float(np.linalg.norm(g)), g @ v, u @ g, np.take(g, np.arange(0, g.shape[long_axis], stride), axis=long_axis))
 
 
 def prompt_parts_with_examples(meta, data):
@@ -42,6 +66,13 @@ def load_case(name):
     bcfg = json.loads((GOLDEN / f"backbone_{meta['backbone']}.json").read_text())
     zb = np.load(GOLDEN / f"backbone_{meta['backbone']}.npz")
     backbone = {k: torch.from_numpy(zb[k]) for k in zb.files}
+    for k, spec in (bcfg.get("synth") or {}).items():       # formula-generated tables (vocabulary > 100 000 fixture)
+        backbone[k] = torch.from_numpy(synth_table(**spec))
+    if meta.get("synth"):
+        data["param.mapping_layer.weight"] = synth_table(**meta["synth"]["mapping_layer.weight"])
+        emb = backbone["embed_tokens.weight"]
+        inds = torch.linspace(0, emb.shape[0] - 1, 100_000, dtype=torch.long)     # R:models/medtsllm.py:220-222
+        data["param.word_embeddings"] = emb[inds].numpy().copy()
     return meta, data, bcfg, backbone
 
 
@@ -102,8 +133,9 @@ class FakeDataset:
 
 
 def fixture_tokenizer(kind="gpt2"):
+    """the BPE tokenizer trained in-process by make_golden.py (the same file for every fixture backbone)"""
     from transformers import PreTrainedTokenizerFast
-    tok = PreTrainedTokenizerFast(tokenizer_file=str(GOLDEN / f"tokenizer_{kind}.json"), bos_token="<|endoftext|>",
+    tok = PreTrainedTokenizerFast(tokenizer_file=str(GOLDEN / "tokenizer.json"), bos_token="<|endoftext|>",
                                   eos_token="<|endoftext|>")
     tok.pad_token = tok.eos_token
     return tok

@@ -225,7 +225,7 @@ def _write_hf_dir(d, kind):
     sd = random_state_dict(cfg, seed=5, std=0.05)
     (d / "config.json").write_text(json.dumps(cfg))
     save_file({k: v.contiguous() for k, v in sd.items()}, str(d / "model.safetensors"))
-    shutil.copy(GOLDEN / "tokenizer_gpt2.json", d / "tokenizer.json")
+    shutil.copy(GOLDEN / "tokenizer.json", d / "tokenizer.json")
     (d / "tokenizer_config.json").write_text(json.dumps({"tokenizer_class": "PreTrainedTokenizerFast", "bos_token": "<|endoftext|>",
                                                          "eos_token": "<|endoftext|>"}))
 

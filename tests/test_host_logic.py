@@ -152,33 +152,96 @@ def test_gemm_tile_order_visits_every_tile_once():
     assert lib.mtl_gemm_tile_order(32, 8, 128, 96, 1, 3072, 1) & (1 << 8) and not lib.mtl_gemm_tile_order(32, 8, 128, 96, 1, 8192, 1) & (1 << 8)
 
 
-def test_optimisation_step_order_matches_reference_trajectory():
-    """a10: forward -> loss -> backward -> Adam.step -> zero_grad on the oracle reproduces the REFERENCE trainer's
-    per-step losses and final weights (golden from tasks.get_trainer(...).train() on a synthetic dataset)."""
-    from oracle import medtsllm_oracle as O
+def golden_trainer_setup(tmp_path, device, dtype, model_key="medtsllm"):
+    """Everything the product trainer needs to replay the reference trainer's golden run (tests/golden/make_golden.py
+    run_trainer_golden): an on-disk HF-format backbone directory (golden weights + fixture tokenizer), a registered dataset
+    that yields the golden batches in the golden order, and the reference run's config. -> (config, z)"""
+    import shutil
+    from safetensors.torch import save_file
+    from torch.utils.data import Dataset
+    from med_ts_llm_amd.tasks.synthetic import register_dataset
+    from med_ts_llm_amd.utils import dict_to_object
     z = np.load(GOLDEN / "trainer_gpt2_concat_fc.npz")
     meta, _, bcfg, backbone = load_case("gpt2_concat_fc")
-    tok = fixture_tokenizer("gpt2")
-    from med_ts_llm_amd.models import prompt as P
-    p = {k[len("init."):]: torch.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith("init.")}
-    opt = torch.optim.Adam(list(p.values()), lr=1e-3)
-    m = oracle_mcfg(meta)
-    losses = []
+    d = Path(tmp_path) / "llm_gpt2"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps(bcfg))
+    save_file({k: v.contiguous() for k, v in backbone.items()}, str(d / "model.safetensors"))
+    shutil.copy(GOLDEN / "tokenizer.json", d / "tokenizer.json")
+    (d / "tokenizer_config.json").write_text(json.dumps({"tokenizer_class": "PreTrainedTokenizerFast", "bos_token": "<|endoftext|>",
+                                                         "eos_token": "<|endoftext|>"}))
     n_batches = len([k for k in z.files if k.endswith(".x_enc")])
-    for i in range(n_batches):
-        x, y = torch.from_numpy(z[f"batch{i}.x_enc"]), torch.from_numpy(z[f"batch{i}.y"])
-        parts = P.build_prompt_parts({"x_enc": x}, meta["prompting"], meta["dataset_description"], meta["task_description"], tok.bos_token)
-        ids = [[tok(s, padding=False, truncation=False).input_ids for s in ps] for ps in parts]
-        pred = O.medtsllm_forward(x, p, backbone, bcfg, m, token_ids=ids, pad_token_id=tok.pad_token_id, training=True)
-        loss = torch.nn.functional.mse_loss(pred, y)
-        loss.backward()
-        opt.step()
-        opt.zero_grad()
-        losses.append(loss.item())
+    xs = torch.cat([torch.from_numpy(z[f"batch{i}.x_enc"]) for i in range(n_batches)])
+    ys = torch.cat([torch.from_numpy(z[f"batch{i}.y"]) for i in range(n_batches)])
+
+    class GoldenWindows(Dataset):
+        description, n_features, n_classes, task_description = meta["dataset_description"], meta["C"], 0, None
+
+        def __len__(self):
+            return xs.shape[0]
+
+        def __getitem__(self, i):
+            return {"x_enc": xs[i], "y": ys[i]}
+
+    register_dataset("golden_trainer", lambda config, split: GoldenWindows())
+    cfg = dict_to_object({
+        "DEBUG": True, "task": "forecasting", "model": model_key, "history_len": meta["L"], "pred_len": meta["pred_len"],
+        "data": {"dataset": "golden_trainer"},
+        "training": {"epochs": 2, "batch_size": 4, "optimizer": "adam", "learning_rate": 1e-3, "dropout": 0.0, "loss": "mse",
+                     "eval_metric": "loss", "eval_metric_direction": "min", "shuffle": False},
+        "tasks": {"segmentation": {"mode": "boundary-prediction"}},
+        "models": {"timellm": {
+            "d_model": meta["d_model"], "d_ff": meta["d_ff"], "n_heads": meta["n_heads"], "num_tokens": meta["num_tokens"],
+            "covariate_mode": "concat", "embedding_downsample_mode": "linear", "patching": {"patch_len": 16, "stride": 8},
+            "prompting": meta["prompting"],
+            "llm": {"enabled": True, "llm": str(d), "llm_layers": -1, "load_in_4bit": False, "load_in_8bit": False}}},
+        "setup": {"seed": 0, "device": device, "dtype": dtype, "num_workers": 0, "logger": "print", "quiet": True}})
+    return cfg, z, n_batches
+
+
+def load_golden_init(trainer, z):
+    """the reference trainer's initial trainable weights -> the product model (in place: optimiser / bf16 shadows keep their references)"""
+    sd = {k[len("init."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("init.")}
+    missing, unexpected = trainer.model.load_state_dict(sd, strict=False)
+    assert not unexpected and set(missing) <= {"word_embeddings"}, (missing, unexpected)
+
+
+def test_optimisation_step_order_matches_reference_trajectory(tmp_path):
+    """a10: the PRODUCT trainer — tasks.get_trainer(...).train(), i.e. BaseTask.train_step / prepare_batch / build_optimizer /
+    log_step — replays the REFERENCE trainer's golden run (8 Adam steps over 2 epochs) and must land on the reference's per-step
+    losses and final weights. The device math is swapped for the pinned oracle (the HIP model has no CPU path) by a model class
+    that keeps the product's constructor, parameter names and prompt builder; tests/test_gpu_golden.py runs the same replay with
+    the HIP model itself."""
+    from oracle import medtsllm_oracle as O
+    from med_ts_llm_amd.models import model_lookup
+    from med_ts_llm_amd.models.medtsllm import MedTsLLM
+    from med_ts_llm_amd.tasks import get_trainer
+    meta, _, bcfg, backbone = load_case("gpt2_concat_fc")
+    m = oracle_mcfg(meta)
+
+    class OracleMath(MedTsLLM):
+        def forward(self, inputs):
+            x = inputs["x_enc"]
+            tok = self._get_tokenizer()
+            ids = [[tok(s, padding=False, truncation=False).input_ids for s in ps] for ps in self.build_prompt(inputs)]
+            p = {n: t for n, t in self.named_parameters() if n != "word_embeddings"}
+            return O.medtsllm_forward(x, p, backbone, bcfg, m, token_ids=ids, pad_token_id=tok.pad_token_id, training=self.training)
+
+    model_lookup["medtsllm_oracle_math"] = OracleMath
+    try:
+        cfg, z, n_batches = golden_trainer_setup(tmp_path, "cpu", "fp32", "medtsllm_oracle_math")
+        trainer = get_trainer("DEBUG-golden", cfg)
+        load_golden_init(trainer, z)
+        trainer.train()
+    finally:
+        del model_lookup["medtsllm_oracle_math"]
+    losses = [h["train/loss"] for h in trainer.logger.history if "train/loss" in h]
     # importing the reference's tasks package sets torch.set_float32_matmul_precision("medium") (R:tasks/base.py:19-22),
     # so the golden trajectory itself carries ~3e-4 of reduced-precision CPU matmul noise; a wrong step order
     # (e.g. zero_grad before step, stale gradients) moves these numbers by O(1e-1).
+    assert len(losses) == 2 * n_batches == len(z["losses"])
     assert np.allclose(losses, z["losses"], rtol=1e-3, atol=1e-6), (losses, z["losses"])
+    p = dict(trainer.model.named_parameters())
     for k in z.files:
         if k.startswith("final."):
             name = k[len("final."):]
@@ -186,4 +249,4 @@ def test_optimisation_step_order_matches_reference_trajectory():
                 continue   # analytically-zero gradient: Adam normalises pure round-off noise into +-lr steps (not reproducible)
             moved = float(np.linalg.norm(z[k] - z["init." + name]))
             assert float((p[name].detach() - torch.from_numpy(z[k])).norm()) < 0.05 * moved + 1e-6, k
-    assert int(z["step_counter"]) == 4 * n_batches   # BaseTask.step advances by batch_size per step (R:tasks/base.py:217)
+    assert trainer.step == int(z["step_counter"]) == 4 * 2 * n_batches   # BaseTask.step advances by batch_size per step (R:tasks/base.py:217)

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import medtsllm_oracle as O
-from helpers import CASES, load_case, oracle_mcfg, golden_loss, rel_err, abs_err, GOLDEN, prompt_parts_with_examples
+from helpers import CASES, load_case, oracle_mcfg, golden_loss, rel_err, abs_err, GOLDEN, prompt_parts_with_examples, big_grad_summary
 
 TOL = 1e-5
 
@@ -43,8 +43,9 @@ def test_forward_backward_vs_reference(name):
     src = O.source_embeddings(we, p["mapping_layer.weight"], p["mapping_layer.bias"])
     assert rel_err(src, data["source_embeddings"]) < TOL
 
+    we_kw = {"word_emb": p["word_embeddings"]} if "word_embeddings" in p else {}      # trainable table (vocabulary > 100 000)
     pred, inter = O.medtsllm_forward(x, p, backbone, bcfg, m, token_ids=tok, pad_token_id=meta["pad_token_id"],
-                                     training=True, return_intermediates=True)
+                                     training=True, return_intermediates=True, **we_kw)
     assert rel_err(inter["llm_inputs_embeds"], data["llm_inputs_embeds"]) < TOL
     assert rel_err(O.backbone_forward(inter["llm_inputs_embeds"], backbone, bcfg), data["llm_last_hidden"]) < TOL
     assert pred.shape == data["pred_train"].shape
@@ -56,15 +57,23 @@ def test_forward_backward_vs_reference(name):
     for k, v in data.items():
         if k.startswith("grad."):
             n = k[len("grad."):]
-            if n == "word_embeddings":
-                continue
             g = p[n].grad
             assert g is not None, n
             # key_projection.bias has an analytically-zero gradient (softmax shift invariance): absolute floor
             assert abs_err(g, v) < 5e-5 * float(np.linalg.norm(v)) + 1e-7, (n, rel_err(g, v))
 
+    # 100 000-wide gradients (vocabulary > 100 000 fixture): norm, projections along both axes and strided samples
+    for k, v in data.items():
+        if k.startswith("gradnorm."):
+            n = k[len("gradnorm."):]
+            assert p[n].grad is not None, n
+            norm, prow, pcol, sample = big_grad_summary(p[n].grad, meta["synth"]["stride"])
+            assert abs(norm - float(v)) < 5e-5 * float(v), n
+            for got, want in ((prow, data["gradproj_rows." + n]), (pcol, data["gradproj_cols." + n]), (sample, data["gradsample." + n])):
+                assert abs_err(got, want) < 5e-5 * float(np.linalg.norm(want)) + 1e-7, (n, rel_err(got, want))
+
     with torch.no_grad():
-        pe_eval = O.medtsllm_forward(x, p, backbone, bcfg, m, token_ids=tok, pad_token_id=meta["pad_token_id"], training=False)
+        pe_eval = O.medtsllm_forward(x, p, backbone, bcfg, m, token_ids=tok, pad_token_id=meta["pad_token_id"], training=False, **we_kw)
     assert rel_err(pe_eval, data["pred_eval"]) < TOL
 
 

@@ -20,7 +20,7 @@ if rank == 0:
     d.mkdir(exist_ok=True)
     cfg = hf_cfg("gpt2"); sd = random_state_dict(cfg, seed=5, std=0.05)
     (d / "config.json").write_text(json.dumps(cfg)); save_file({k: v.contiguous() for k, v in sd.items()}, str(d / "model.safetensors"))
-    shutil.copy(GOLDEN / "tokenizer_gpt2.json", d / "tokenizer.json")
+    shutil.copy(GOLDEN / "tokenizer.json", d / "tokenizer.json")
 
 def source(config, split):
     g = np.random.default_rng({"train": 1, "val": 2, "test": 3}[split]); n = 400; t = np.arange(n, dtype=np.float32)
