@@ -1,21 +1,26 @@
 #!/usr/bin/env python3
 """bench.py — samples/s of the MedTsLLM fwd+bwd(+optimizer) hot path on N MI355X (one process per GPU).
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
-torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE from env). Rank 0 prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under torch.distributed.run
+(RANK / LOCAL_RANK / WORLD_SIZE from env) — or, when started WITHOUT a launcher, it re-runs itself under one. Rank 0 prints
+ONE JSON line.
 
-Workload (BASELINE.json metric, SURVEY.md §8d "M"): synthetic [B=32, L=1024, C=12] windows per GPU, patch 16/8 ->
-P=128, d_model=32, d_ff=128, 8 heads, 1024 prototype tokens, concat covariates, linear down-sample, forecasting
-pred_len=96, fixed 128-token prompt -> T=256, frozen GPT-2-small backbone (12 x 768, random init, bf16 operands,
-fp32 residual/statistics = the reference's dtype="mixed"), dropout 0. A step = forward + MSE loss + backward +
-[DP all-reduce] + Adam step + zero_grad. Weak scaling: per-GPU batch fixed at 32.
+Workload (BASELINE.json metric, SURVEY.md §8d "M"): synthetic [B=32, L=1024, C=12] windows per GPU, patch 16/8 -> P=128,
+d_model=32, d_ff=128, 8 heads, 1024 prototype tokens, concat covariates, linear down-sample, forecasting pred_len=96, fixed
+128-token prompt -> T=256, frozen GPT-2-small backbone (12 x 768, random init, bf16 operands, fp32 residual/statistics = the
+reference's dtype="mixed"), training.dropout 0.1 and GPT-2's own train-mode dropouts live, as the reference trains. A step =
+forward + MSE loss + backward + [DP all-reduce] + Adam step + zero_grad. Weak scaling: per-GPU batch fixed at 32.
 
 Extra objects on the JSON line:
-  roofline     the dominant kernel (bf16 MFMA GEMM instance with the largest total time): achieved TFLOP/s =
-               algorithmic 2MNK FLOPs / HIP-event duration per launch, measured in this process on the launch stream
-               in a profiled replay of the same steps right after the timed region (events off while timing `value`).
-  cpu_baseline the oracle (a plain-torch port of the reference math, pinned to reference goldens) timed on the host
-               cores, rank 0, N = 1 only, on a bounded sample of the same workload.
+  roofline      the dominant MFMA kernel (bf16 GEMM instance with the largest total time): achieved TFLOP/s = algorithmic 2MNK
+                FLOPs / kernel duration, measured in this process in a profiled replay of the same steps right after the timed
+                region: every launch carries its own start/stop event pair (kernel begin -> end on its stream, the duration
+                rocprofv3 --kernel-trace reports). `traffic`: HBM bytes per launch from the committed PMC passes of this workload,
+                null when they were taken with other kernel sources.
+  roofline_hbm  the same for the dominant HBM-bound kernel (norm family) against 8 TB/s
+  cpu_baseline  the oracle (a plain-torch port of the reference math, pinned to reference goldens) timed on the host cores,
+                rank 0, N = 1 only, on a bounded sample of the same workload (+ BASELINE.json configs[0], the ETTh1-shaped case)
+  configs       default run only: the same measurement for BASELINE.json configs[2] (Llama-2-7B backbone), 2 + 5 steps
 """
 import argparse
 import ctypes as C
@@ -48,12 +53,13 @@ WORKLOADS = {
     "llama2_7b_psm_B32_L2048_C25": (LLAMA2_7B, 32, 2048, 25, 2048, 128, "anomaly_detection"),
 }
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0            # HBM3E spec (6.29 TB/s is the measured achievable, same guide)
 
 
 def model_cfg(L, pred, task="forecasting"):
     return {
         "DEBUG": True, "task": task, "model": "medtsllm", "history_len": L, "pred_len": pred,
-        "training": {"dropout": 0.0}, "setup": {"dtype": "mixed"},
+        "training": {"dropout": 0.1}, "setup": {"dtype": "mixed"},     # every shipped reference config trains at 0.1 (configs/datasets/*.toml)
         "models": {"timellm": {
             "d_model": 32, "d_ff": 128, "n_heads": 8, "num_tokens": 1024, "covariate_mode": "concat",
             "embedding_downsample_mode": "linear", "patching": {"patch_len": 16, "stride": 8},
@@ -139,6 +145,7 @@ def cpu_baseline(hf_cfg, sd, L, C_, pred, n_tok, prompt_ids, max_seconds=30.0):
     # pick the thread count that runs this workload fastest (256 SMT threads are far slower than ~1 per core-complex)
     ncpu = os.cpu_count() or 1
     best = None
+    # (`cores` below = the threads actually used, `host_cores` = os.cpu_count() of the box)
     for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
         torch.set_num_threads(nt)
         if best is None:
@@ -156,7 +163,7 @@ def cpu_baseline(hf_cfg, sd, L, C_, pred, n_tok, prompt_ids, max_seconds=30.0):
         step()
         n += 1
     dt = (time.perf_counter() - t0) / n
-    return {"value": round(Bs / dt, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(Bs / dt, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(), "kind": "port",
             "sample": f"{n} timed fwd+bwd steps of B={Bs} windows [L={L}, C={C_}] (same model/shapes as the GPU workload, fp32, "
                       f"plain-torch oracle; optimizer step excluded), {dt:.2f} s/step",
             # measured once in the build container (8 cores, the only machine where both run): the real
@@ -164,66 +171,77 @@ def cpu_baseline(hf_cfg, sd, L, C_, pred, n_tok, prompt_ids, max_seconds=30.0):
             "reference_speed_over_port": 1.54}
 
 
-def read_prof(lib):
-    """per kernel instance (named exactly as rocprofv3 prints it): launches, total ms, total algorithmic FLOPs"""
-    cap = 64
-    keys = (C.c_int * cap)()
-    launches = (C.c_int64 * cap)()
-    ms = (C.c_double * cap)()
-    fl = (C.c_double * cap)()
-    n = lib.mtl_prof_read(keys, launches, ms, fl, cap)
-    rows = []
-    for i in range(n):
-        k = keys[i]
-        epi, cdt, split = (k & 0xff) // 4, ((k & 0xff) // 2) % 2, k & 1
-        if k & (1 << 8):
-            name = (f"gemm_nt_persist_kernel<{epi}, {cdt}, {256 if k & (1 << 15) else 128}, {256 if k & (1 << 18) else (64, 128, 96, 192)[(k >> 16) & 3]}, "
-                    f"{(k >> 12) & 7}, {(4, 8, 16)[(k >> 10) & 3]}, {'true' if split else 'false'}, {2 if k & (1 << 19) else 1}>")
-        else:
-            name = f"gemm_nt_kernel<{epi}, {cdt}, {'true' if split else 'false'}>"
-        rows.append({"kernel": name, "launches": int(launches[i]), "total_ms": ms[i], "flops": fl[i]})
-    return rows
+def csrc_sha16():
+    """hash of the kernel sources: PMC traffic tables are only valid for the library they were measured with"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(ROOT, "med-ts-llm_amd", "csrc", "*.h*")) + [os.path.join(ROOT, "include", "medtsllm_hip.h")]):
+        with open(fn, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json), or None."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this workload (profiles/pmc_traffic_<workload>.json, written
+    by tools/profile_round.sh from separate rocprofv3 --pmc runs), or None when there is no table for the CURRENT kernel sources."""
+    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
         table = json.load(f)
+    if table.get("_meta", {}).get("csrc_sha16") != csrc_sha16():
+        return None                      # stale: measured with other kernel sources
     return table.get(kernel)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="gpt2s_B32_L1024_C12", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--full-backward", action="store_true", help="also compute the (unused) prompt-row input gradients")
-    ap.add_argument("--replicate-mapping", action="store_true", help="DP: keep the mapping layer replicated (all-reduce its gradient)")
-    ap.add_argument("--no-llm-dropout", action="store_true", help="GPT-2: switch the frozen LLM's train-mode dropouts (0.1) off")
-    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the HIP multi-tensor Adam")
-    args = ap.parse_args()
+def roofline_objects(rows, workload):
+    """(roofline, roofline_hbm, all instances) from the launch profiler's rows: the dominant kernel of each family"""
+    def obj(r, peak, unit, scale):
+        per_launch_ms = r["total_ms"] / r["launches"]
+        achieved = r["work"] / (r["total_ms"] * 1e-3) / scale
+        return {"bound": "mfma" if r["kind"] == "flops" else "hbm", "kernel": r["kernel"], "achieved": round(achieved, 1), "peak": peak, "unit": unit,
+                "frac": round(achieved / peak, 4), "traffic": pmc_traffic(workload, r["kernel"]), "launches": r["launches"],
+                "avg_launch_us": round(per_launch_ms * 1e3, 2), "min_launch_us": round(r["min_ms"] * 1e3, 2),
+                ("flops_per_launch" if r["kind"] == "flops" else "algorithmic_bytes_per_launch"): r["work"] / r["launches"],
+                "timing": "per-dispatch start/stop events (hipExtLaunchKernelGGL) on the launch stream: kernel begin -> end, as rocprofv3 --kernel-trace reports it"}
+    mf = [r for r in rows if r["kind"] == "flops" and r["kernel"].startswith("gemm")]
+    hb = [r for r in rows if r["kind"] == "bytes" and r["kernel"].startswith("norm")]
+    roof = obj(max(mf, key=lambda r: r["total_ms"]), MFMA_BF16_PEAK_TFLOPS, "TFLOP/s", 1e12) if mf else None
+    roof_hbm = obj(max(hb, key=lambda r: r["total_ms"]), HBM_PEAK_GBS, "GB/s", 1e9) if hb else None
+    inst = [{"kernel": r["kernel"], "launches": r["launches"], "avg_us": round(r["total_ms"] / r["launches"] * 1e3, 2),
+             **({"tflops": round(r["work"] / (r["total_ms"] * 1e-3) / 1e12, 1)} if r["kind"] == "flops" else
+                {"gbs": round(r["work"] / (r["total_ms"] * 1e-3) / 1e9, 1)})} for r in sorted(rows, key=lambda r: -r["total_ms"])]
+    return roof, roof_hbm, inst
 
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: re-run under torch.distributed.run, one rank per GPU. With fewer GPUs than
+    ranks (a 1-GPU test box) the ranks share devices over gloo, since RCCL refuses two ranks per GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if torch.cuda.is_available() and torch.cuda.device_count() < args.gpus:
+        env.setdefault("MTL_DIST_BACKEND", "gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline):
+    """one bench line (dict, rank 0; None elsewhere) for WORKLOADS[name]: `warmup` untimed steps, then exactly `steps` timed steps
+    bracketed by barrier + synchronize on both sides, MAX over ranks; then (outside the timed region) a profiled replay."""
     from med_ts_llm_amd import parallel
     from med_ts_llm_amd.hip import _native
     from med_ts_llm_amd.models import model_lookup
     from med_ts_llm_amd.models.backbone import random_state_dict
     from med_ts_llm_amd.utils import dict_to_object
-
-    rank, world, local_rank = parallel.init_from_env("cuda")
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
-    device = torch.device("cuda", local_rank % torch.cuda.device_count())   # (ranks may share a GPU only in the gloo DP test)
-    torch.cuda.set_device(device)
-
-    hf_cfg, B, L, C_, pred, n_tok, task = WORKLOADS[args.workload]
+    rank, world, device = ctx
+    hf_cfg, B, L, C_, pred, n_tok, task = WORKLOADS[name]
     big = hf_cfg["model_type"] == "llama"
     sd = random_state_dict(hf_cfg, seed=0, std=0.02, device=device if big else "cpu", dtype=torch.bfloat16 if big else torch.float32)
     torch.manual_seed(0)
@@ -248,8 +266,6 @@ def main():
     loss_fn = torch.nn.MSELoss() if task != "semantic_segmentation" else torch.nn.CrossEntropyLoss()
     batches = [make_batch(B, L, C_, pred, 1000 + rank * 97 + i, device, task) for i in range(4)]
 
-    opt_events = None    # set during the profiled replay: optimiser time is reported separately
-
     def step(i):
         inputs = batches[i % len(batches)]
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=True):
@@ -258,18 +274,11 @@ def main():
         loss.backward()
         if sync is not None:
             sync()
-        if opt_events is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            opt.step()
-            e1.record()
-            opt_events.append((e0, e1))
-        else:
-            opt.step()
+        opt.step()
         opt.zero_grad()
         return loss
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
 
     def fence():
@@ -280,7 +289,7 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         loss = step(i)
     fence()
     elapsed = time.perf_counter() - t0
@@ -290,61 +299,103 @@ def main():
         elapsed = float(t.item())
     final_loss = float(loss.item())
 
-    roofline, optimizer_ms = None, None
-    if not args.no_roofline:
-        # profiled replay (outside the timed region). EVERY rank replays the steps — they contain collectives — but only
-        # rank 0 brackets its GEMM launches with events.
+    roofline = roofline_hbm = instances = optimizer_ms = None
+    if want_roofline:
+        # profiled replay (outside the timed region). EVERY rank replays the steps — they contain collectives — but only rank 0
+        # records: each GEMM / attention / norm / optimiser launch carries its own start/stop event pair
         lib = _native.lib()
+        n_replay = min(steps, 5)
         if rank == 0:
             lib.mtl_prof_enable(1)
-        opt_events = []
-        for i in range(min(args.steps, 5)):
+        for i in range(n_replay):
             step(i)
         torch.cuda.synchronize()
-        optimizer_ms = sum(a.elapsed_time(b) for a, b in opt_events) / max(len(opt_events), 1)
-        opt_events = None
-        rows = read_prof(lib) if rank == 0 else []
+        rows = _native.prof_rows() if rank == 0 else []
         lib.mtl_prof_enable(0)
         if rows:
-            gap_ms = lib.mtl_prof_calibrate(C.c_void_p(torch.cuda.current_stream().cuda_stream))   # empty event bracket
-            for r in rows:
-                r["total_ms"] = max(r["total_ms"] - gap_ms * r["launches"], 1e-9)
-            dom = max(rows, key=lambda r: r["total_ms"])
-            per_launch_ms = dom["total_ms"] / dom["launches"]
-            achieved = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom["kernel"]),
-                        "launches": dom["launches"], "avg_launch_us": round(per_launch_ms * 1e3, 2),
-                        "flops_per_launch": dom["flops"] / dom["launches"], "event_bracket_overhead_us": round(gap_ms * 1e3, 2),
-                        "all_gemm_instances": [{"kernel": r["kernel"], "launches": r["launches"], "avg_us": round(r["total_ms"] / r["launches"] * 1e3, 2),
-                                                "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 1)} for r in rows]}
+            roofline, roofline_hbm, instances = roofline_objects(rows, name)
+            adam = [r for r in rows if r["kernel"].startswith("adam")]
+            optimizer_ms = sum(r["total_ms"] for r in adam) / n_replay if adam else None
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not big:
+    if rank == 0 and world == 1 and want_cpu and not big:
         cpu = cpu_baseline(hf_cfg, sd, L, C_, pred, n_tok, prompt_ids[0].tolist())
+        if name == "gpt2s_B32_L1024_C12":     # BASELINE.json configs[0]: the reference's CPU-runnable case, timed beside the metric workload
+            _, _, L1, C1, pred1, n_tok1, _ = WORKLOADS["gpt2s_etth1_B32_L512_C7"]
+            cpu["configs"] = [dict(cpu_baseline(hf_cfg, sd, L1, C1, pred1, n_tok1, prompt_ids[0].tolist(), max_seconds=20.0),
+                                   workload="gpt2s_etth1_B32_L512_C7 (BASELINE.json configs[0]: ETTh1-shaped [B, 512, 7] forecasting, GPT-2-small, CPU fp32)")]
 
+    out = None
     if rank == 0:
         P = (L + 8 - 16) // 8 + 1
         T = n_tok + P
         fl, fl_exec = flops_per_step(hf_cfg, B, T, P, C_, pred * (C_ if task != "semantic_segmentation" else 4), min(hf_cfg["vocab_size"], 100_000))
         if args.full_backward:
             fl_exec = fl
-        value = B * world * args.steps / elapsed
+        value = B * world * steps / elapsed
         out = {
             "metric": "samples/sec (1024-step, 12-ch windows) through MedTsLLM fwd+bwd", "value": round(value, 2), "unit": "samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: [B={B}/GPU, L={L}, C={C_}] windows, P={P}, prompt {n_tok} tok -> T={T}, "
-                                   f"frozen {args.workload.split('_B32')[0] if big else 'GPT-2-small'} (random init) backbone, concat covariates, {task} pred_len={pred}, "
+            "config": {"workload": f"{name}: [B={B}/GPU, L={L}, C={C_}] windows, P={P}, prompt {n_tok} tok -> T={T}, "
+                                   f"frozen {name.split('_')[0] + '-' + name.split('_')[1] if big else 'GPT-2-small'} (random init) backbone, concat covariates, "
+                                   f"{task} pred_len={pred}, training.dropout=0.1 (patch-embedding + reprogramming-attention dropout live"
+                                   f"{', GPT-2 embd/attn/resid dropouts live' if (not big and not args.no_llm_dropout) else ''}), "
                                    f"step = fwd+loss+bwd+{'allreduce+' if world > 1 else ''}Adam", "global_batch": B * world,
                        "parallelism": f"dp{world}" + (" (mapping layer row-sharded)" if sharded else "")},
+            "per_gpu_samples_per_s": round(value / world, 2),
+            "dist_backend": (dist.get_backend() if world > 1 else None),
             "final_loss": final_loss,
             "backward": "full (incl. unused prompt-row input gradients)" if args.full_backward else
                         "exact dead-gradient elimination: prompt rows never depend on a trainable parameter, their input gradient is not computed",
             "algorithmic_tflop_per_step_per_gpu": round(fl / 1e12, 3), "executed_tflop_per_step_per_gpu": round(fl_exec / 1e12, 3),
-            "step_mfma_frac": round(fl_exec / (elapsed / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-            "optimizer_ms_per_step": optimizer_ms, "roofline": roofline, "cpu_baseline": cpu,
+            "step_mfma_frac": round(fl_exec / (elapsed / steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "step_mfma_frac_algorithmic": round(fl / (elapsed / steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "optimizer_ms_per_step": optimizer_ms, "roofline": roofline, "roofline_hbm": roofline_hbm, "kernel_instances": instances,
+            "cpu_baseline": cpu,
         }
+    del model, opt, sync, batches, sd, params
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="gpt2s_B32_L1024_C12", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the Llama-2-7B line that the default run attaches as configs[]")
+    ap.add_argument("--full-backward", action="store_true", help="also compute the (unused) prompt-row input gradients")
+    ap.add_argument("--replicate-mapping", action="store_true", help="DP: keep the mapping layer replicated (all-reduce its gradient)")
+    ap.add_argument("--no-llm-dropout", action="store_true", help="GPT-2: switch the frozen LLM's train-mode dropouts (0.1) off")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the HIP multi-tensor Adam")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args)
+
+    from med_ts_llm_amd import parallel
+    rank, world, local_rank = parallel.init_from_env("cuda")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())   # (ranks share a GPU only over gloo on a box with fewer GPUs)
+    torch.cuda.set_device(device)
+    ctx = (rank, world, device)
+
+    out = run_workload(args.workload, args, ctx, args.steps, args.warmup, not args.no_cpu_baseline, not args.no_roofline)
+    if args.workload == "gpt2s_B32_L1024_C12" and not args.no_extra_configs:
+        # BASELINE.json configs[2] (LUDB-shaped semantic segmentation on a frozen Llama-2-7B) on the same GPUs, right after the headline
+        # workload's timed region: the configuration where the backbone GEMMs are large enough for the >= 40 % MFMA target
+        extra = run_workload("llama2_7b_semseg_B32_L1024_C12", args, ctx, steps=5, warmup=2, want_cpu=False, want_roofline=not args.no_roofline)
+        if rank == 0:
+            extra["metric"] = "samples/sec ([B, 1024, 12] windows, Llama-2-7B frozen backbone) through MedTsLLM fwd+bwd"
+            out["configs"] = [extra]
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

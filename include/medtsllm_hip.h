@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MTL_ABI_VERSION 4
+#define MTL_ABI_VERSION 5
 
 enum { MTL_OK = 0, MTL_ERR_ARG = -1, MTL_ERR_ALIGN = -2, MTL_ERR_UNSUPPORTED = -3, MTL_ERR_LAUNCH = -4,
        MTL_ERR_WORKSPACE = -5 };
@@ -104,13 +104,20 @@ typedef struct {
 } mtl_gemm_args;
 size_t mtl_gemm_workspace_bytes(int64_t M, int64_t N, int split_k);
 int mtl_gemm_nt(const mtl_gemm_args* args, void* stream);
-/* Measurement aid (bench.py roofline leg; off by default, no effect on results): while enabled every GEMM launch is
- * bracketed by HIP events on its launch stream. mtl_prof_read aggregates per kernel instance
- * key: bits 0-7 = epilogue*4 + c_dtype*2 + (split_k > 1); bit 8 = persistent kernel, bit 9 = 128-wide tile (else 64),
- * bits 10-11 = waves (0: 4, 1: 8, 2: 16), bits 12-14 = LDS stages, bit 15 = 256-row tile (else 128), bits 16-17 = tile width (0: 64, 1: 128, 2: 96, 3: 192), bit 18 = 256-wide tile, bit 19 = two k-groups: launches, total ms, total algorithmic FLOPs (2*M*N*K).
- * mtl_prof_calibrate returns the duration (ms) of an empty event bracket on `stream` (fixed per-launch overhead). */
+/* Measurement aid (bench.py's roofline legs; off by default, no effect on results): while enabled, every GEMM, attention, norm and
+ * optimiser launch carries its own start / stop event pair (hipExtLaunchKernelGGL), whose elapsed time is the kernel's begin -> end
+ * on the device — what rocprofv3 --kernel-trace reports for the same dispatch. mtl_prof_read aggregates per kernel instance:
+ * `name` as rocprofv3 prints it (without the anonymous-namespace prefix and the parameter list), launches, total / min / max
+ * duration, and the launches' ALGORITHMIC work: FLOPs (kind 0: 2*M*N*K for a GEMM, full-rectangle 4*T*T*d convention for
+ * attention) or HBM bytes (kind 1). Enabling clears the records. Not to be read concurrently with launches. */
+typedef struct mtl_prof_row {
+    char name[128];
+    int32_t kind;            /* 0: total_work in FLOPs (MFMA family); 1: in bytes (HBM family) */
+    int64_t launches;
+    double total_ms, min_ms, max_ms, total_work;
+} mtl_prof_row;
 int mtl_prof_enable(int on);
-double mtl_prof_calibrate(void* stream);
+int mtl_prof_read(mtl_prof_row* rows, int cap);
 /* Experiment knob for A/B runs: mode 0 = one output tile per workgroup, 1 = persistent flat-K (default);
  * bm / bn = tile rows (128, 256) / columns (64, 96, 128, 192, 256), stages = LDS ring depth (2, 3), waves per workgroup (4, 8, 16);
  * 0 = automatic. Instantiated combinations: 128x64/4w/{2,3}, 128x96/4w/{2,3}, 128x96/8w/2 (two k-groups; needs at most one tile
@@ -126,7 +133,6 @@ int mtl_gemm_tune(int mode, int bm, int bn, int stages, int waves);
  * per_cu resident workgroups per CU: bits 0-7 rows of a tile group, bit 8 per-XCD k rotation, bit 9 per-XCD column rotation
  * (negative: error code). Lets the CPU test suite check that every order visits every tile exactly once. */
 int mtl_gemm_tile_order(int tiles_m, int tiles_n, int bm, int bn, int per_cu, int64_t K, int one_tile_per_wg);
-int mtl_prof_read(int* keys, int64_t* launches, double* total_ms, double* total_flops, int cap);
 
 /* ------------------------------------------------------------------ layout / cast helpers
  * f32 [R, Cc] (ld_src) -> bf16 [R, ld_dst] zero-padding cols >= Cc; optionally also the transpose

@@ -15,6 +15,7 @@
 // (row stride D+8 bf16: conflict-free 16-B fragment reads), fp32 online softmax.
 #include "mtl_common.h"
 
+#include <cstdio>
 #include <mutex>
 
 namespace {
@@ -257,7 +258,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
     }
     dl = rows_sum(dl);
     const int64_t stat_idx = (b * f.Hq + h) * (f.stat_stride ? f.stat_stride : f.Tq) + qrow;
-    if (g == 0 && q_valid) a.delta[stat_idx] = dl;
     const float c = f.scale * LOG2E;
     const float lse2 = f.lse[stat_idx] * LOG2E;   // exp(s*scale - lse) == exp2(s*c - lse2)
     const uint32_t drop_thr = DROP ? drop_threshold(f.dropout_p) : 0u;
@@ -275,6 +275,48 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
         k_end = lim < f.Tk ? lim : f.Tk;
     }
     const int64_t wave_qmax = ((q0 + 15 < f.Tq - 1) ? q0 + 15 : f.Tq - 1) + coff;
+
+    if (!CAUSAL) {
+        // CONSISTENT delta for the (unmasked) reprogramming attention: delta_q = sum_s p_qs * dP_qs from the very p and dP the main loop
+        // uses, so that sum_s dS_qs = 0 holds to fp32 round-off, as it does in an unfused softmax backward. dO . O with the bf16-rounded
+        // O is the same number only to ~2^-9, and with near-uniform probabilities over the vocabulary prototypes (keys that share a
+        // large common component) the resulting ~1e-3 * delta * sum_s p_s K_s is a coherent error along the mean key: measured on the
+        // reference goldens it doubled the error of dQ (query-projection / patch-embedding gradients 2-3 % instead of 1 %).
+        // One extra pass over K and V (S and dP MFMAs only); the causal self-attention kernels keep dO . O.
+        float acc = 0.f;
+        for (int64_t kc0 = 0; kc0 < k_end; kc0 += KC) {
+            __syncthreads();
+            load_tile<D>(ktile, K, f.k_ts, kc0, f.Tk);
+            load_tile<D>(vtile, V, f.v_ts, kc0, f.Tk);
+            __syncthreads();
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int64_t kb = kc0 + sub * 32;
+                if (kb >= k_end) continue;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    const bf16_t* kr = ktile + (sub * 32 + t * 16 + l15) * LDT + g * 8;
+                    const bf16_t* vr = vtile + (sub * 32 + t * 16 + l15) * LDT + g * 8;
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kr + ks * 32), qf[ks], s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(vr + ks * 32), dof[ks], dp, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t key = kb + t * 16 + g * 4 + r;
+                        const float p = key >= f.Tk ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse2);
+                        float dpv = dp[r];
+                        if (DROP) dpv = drop_hash(f.dropout_seed, bh, (uint32_t)(qrow + coff), (uint32_t)key) >= drop_thr ? dpv * drop_scale : 0.f;
+                        acc += p * dpv;
+                    }
+                }
+            }
+        }
+        dl = rows_sum(acc);
+    }
+    if (g == 0 && q_valid) a.delta[stat_idx] = dl;
 
     for (int64_t kc0 = 0; kc0 < k_end; kc0 += KC) {
         __syncthreads();
@@ -884,21 +926,24 @@ extern "C" int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream) {
     const int rc = check_fwd(*a);
     if (rc != MTL_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
+    // algorithmic FLOPs, full-rectangle convention: S = Q K^T and O = P V, 2 * Tq * Tk * D each per head
+    const double fl_fwd = 4.0 * (double)a->B * a->Hq * a->Tq * a->Tk * a->D;
+    (void)fl_fwd;
     if (resident_ok(*a, a->Tk)) {
         const size_t lds = 2 * pad32(a->Tk) * (a->D + 8) * 2;
         const int npairs = (int)(((a->Tq + 15) / 16 + 1) / 2);
         if (a->D == 64 && a->dropout_p > 0.f) {
             static std::once_flag once; std::call_once(once, [&] { set_lds(attn_fwd_res_kernel<64, 8, true>, kLdsBudget); });
-            hipLaunchKernelGGL((attn_fwd_res_kernel<64, 8, true>), dim3((unsigned)((npairs + 7) / 8), (unsigned)a->Hq, (unsigned)a->B), dim3(512), lds, st, *a);
+            MTL_LAUNCH("attn_fwd_res_kernel<64, 8, true>", fl_fwd, 0, (attn_fwd_res_kernel<64, 8, true>), dim3((unsigned)((npairs + 7) / 8), (unsigned)a->Hq, (unsigned)a->B), dim3(512), lds, st, *a);
         } else if (a->D == 128 && a->dropout_p > 0.f) {
             static std::once_flag once; std::call_once(once, [&] { set_lds(attn_fwd_res_kernel<128, 8, true>, kLdsBudget); });
-            hipLaunchKernelGGL((attn_fwd_res_kernel<128, 8, true>), dim3((unsigned)((npairs + 7) / 8), (unsigned)a->Hq, (unsigned)a->B), dim3(512), lds, st, *a);
+            MTL_LAUNCH("attn_fwd_res_kernel<128, 8, true>", fl_fwd, 0, (attn_fwd_res_kernel<128, 8, true>), dim3((unsigned)((npairs + 7) / 8), (unsigned)a->Hq, (unsigned)a->B), dim3(512), lds, st, *a);
         } else if (a->D == 64) {
             static std::once_flag once; std::call_once(once, [&] { set_lds(attn_fwd_res_kernel<64, 8>, kLdsBudget); });
-            hipLaunchKernelGGL((attn_fwd_res_kernel<64, 8>), dim3((unsigned)((npairs + 7) / 8), (unsigned)a->Hq, (unsigned)a->B), dim3(512), lds, st, *a);
+            MTL_LAUNCH("attn_fwd_res_kernel<64, 8, false>", fl_fwd, 0, (attn_fwd_res_kernel<64, 8>), dim3((unsigned)((npairs + 7) / 8), (unsigned)a->Hq, (unsigned)a->B), dim3(512), lds, st, *a);
         } else {
             static std::once_flag once; std::call_once(once, [&] { set_lds(attn_fwd_res_kernel<128, 8>, kLdsBudget); });
-            hipLaunchKernelGGL((attn_fwd_res_kernel<128, 8>), dim3((unsigned)((npairs + 7) / 8), (unsigned)a->Hq, (unsigned)a->B), dim3(512), lds, st, *a);
+            MTL_LAUNCH("attn_fwd_res_kernel<128, 8, false>", fl_fwd, 0, (attn_fwd_res_kernel<128, 8>), dim3((unsigned)((npairs + 7) / 8), (unsigned)a->Hq, (unsigned)a->B), dim3(512), lds, st, *a);
         }
         MTL_CHECK_LAUNCH();
         return MTL_OK;
@@ -906,11 +951,11 @@ extern "C" int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream) {
     const dim3 grid((unsigned)((a->Tq + 63) / 64), (unsigned)a->Hq, (unsigned)a->B), block(256);
     const bool drop = a->dropout_p > 0.f;
     if (drop && a->dropout_p >= 1.f) return MTL_ERR_UNSUPPORTED;
-#define MTL_FWD(DD)                                                                                        \
-    if (a->causal && drop) hipLaunchKernelGGL((attn_fwd_kernel<DD, true, true>), grid, block, 0, st, *a);  \
-    else if (a->causal) hipLaunchKernelGGL((attn_fwd_kernel<DD, true, false>), grid, block, 0, st, *a);    \
-    else if (drop) hipLaunchKernelGGL((attn_fwd_kernel<DD, false, true>), grid, block, 0, st, *a);         \
-    else hipLaunchKernelGGL((attn_fwd_kernel<DD, false, false>), grid, block, 0, st, *a)
+#define MTL_FWD(DD)                                                                                                                        \
+    if (a->causal && drop) MTL_LAUNCH("attn_fwd_kernel<" #DD ", true, true>", fl_fwd, 0, (attn_fwd_kernel<DD, true, true>), grid, block, 0, st, *a);   \
+    else if (a->causal) MTL_LAUNCH("attn_fwd_kernel<" #DD ", true, false>", fl_fwd, 0, (attn_fwd_kernel<DD, true, false>), grid, block, 0, st, *a);    \
+    else if (drop) MTL_LAUNCH("attn_fwd_kernel<" #DD ", false, true>", fl_fwd, 0, (attn_fwd_kernel<DD, false, true>), grid, block, 0, st, *a);        \
+    else MTL_LAUNCH("attn_fwd_kernel<" #DD ", false, false>", fl_fwd, 0, (attn_fwd_kernel<DD, false, false>), grid, block, 0, st, *a)
     if (a->D == 32) { MTL_FWD(32); } else if (a->D == 64) { MTL_FWD(64); } else { MTL_FWD(128); }
 #undef MTL_FWD
     MTL_CHECK_LAUNCH();
@@ -928,6 +973,10 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
     for (int64_t s : sts) if (s % 4 != 0) return MTL_ERR_ALIGN;
     if (a->do_ts % 8 != 0 || a->do_hs % 8 != 0 || a->do_bs % 8 != 0 || ((uintptr_t)a->dout % 16)) return MTL_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
+    // algorithmic FLOPs of the backward = 2 x forward (dV = P^T dO, dP = dO V^T, dQ = dS K, dK = dS^T Q; the recomputation of S is
+    // not counted), split evenly over the dQ kernel (dP, dQ) and the dK/dV kernel (dV, dK)
+    const double fl_half = 4.0 * (double)f.B * f.Hq * f.Tq * f.Tk * f.D;
+    (void)fl_half;
     if (resident_ok(f, f.Tk) && resident_ok(f, f.Tq)) {
         if (a->kv_row0 < 0 || a->kv_row0 >= f.Tk) return MTL_ERR_ARG;
         const size_t lds_q = 2 * pad32(f.Tk) * (f.D + 8) * 2;
@@ -936,23 +985,23 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
         if (f.dropout_p > 0.f && f.D == 64) {
             static std::once_flag once;
             std::call_once(once, [&] { set_lds(attn_bwd_dq_res_kernel<64, 8, true>, kLdsBudget); set_lds(attn_bwd_dkv_res_kernel<64, 4, true>, kLdsBudget); });
-            hipLaunchKernelGGL((attn_bwd_dq_res_kernel<64, 8, true>), dim3((unsigned)((npq + 7) / 8), (unsigned)f.Hq, (unsigned)f.B), dim3(512), lds_q, st, *a);
-            hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<64, 4, true>), dim3((unsigned)((npk + 3) / 4), (unsigned)f.Hkv, (unsigned)f.B), dim3(256), lds_k, st, *a);
+            MTL_LAUNCH("attn_bwd_dq_res_kernel<64, 8, true>", fl_half, 0, (attn_bwd_dq_res_kernel<64, 8, true>), dim3((unsigned)((npq + 7) / 8), (unsigned)f.Hq, (unsigned)f.B), dim3(512), lds_q, st, *a);
+            MTL_LAUNCH("attn_bwd_dkv_res_kernel<64, 4, true>", fl_half, 0, (attn_bwd_dkv_res_kernel<64, 4, true>), dim3((unsigned)((npk + 3) / 4), (unsigned)f.Hkv, (unsigned)f.B), dim3(256), lds_k, st, *a);
         } else if (f.dropout_p > 0.f) {
             static std::once_flag once;
             std::call_once(once, [&] { set_lds(attn_bwd_dq_res_kernel<128, 8, true>, kLdsBudget); set_lds(attn_bwd_dkv_res_kernel<128, 4, true>, kLdsBudget); });
-            hipLaunchKernelGGL((attn_bwd_dq_res_kernel<128, 8, true>), dim3((unsigned)((npq + 7) / 8), (unsigned)f.Hq, (unsigned)f.B), dim3(512), lds_q, st, *a);
-            hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<128, 4, true>), dim3((unsigned)((npk + 3) / 4), (unsigned)f.Hkv, (unsigned)f.B), dim3(256), lds_k, st, *a);
+            MTL_LAUNCH("attn_bwd_dq_res_kernel<128, 8, true>", fl_half, 0, (attn_bwd_dq_res_kernel<128, 8, true>), dim3((unsigned)((npq + 7) / 8), (unsigned)f.Hq, (unsigned)f.B), dim3(512), lds_q, st, *a);
+            MTL_LAUNCH("attn_bwd_dkv_res_kernel<128, 4, true>", fl_half, 0, (attn_bwd_dkv_res_kernel<128, 4, true>), dim3((unsigned)((npk + 3) / 4), (unsigned)f.Hkv, (unsigned)f.B), dim3(256), lds_k, st, *a);
         } else if (f.D == 64) {
             static std::once_flag once;
             std::call_once(once, [&] { set_lds(attn_bwd_dq_res_kernel<64, 8>, kLdsBudget); set_lds(attn_bwd_dkv_res_kernel<64, 4>, kLdsBudget); });
-            hipLaunchKernelGGL((attn_bwd_dq_res_kernel<64, 8>), dim3((unsigned)((npq + 7) / 8), (unsigned)f.Hq, (unsigned)f.B), dim3(512), lds_q, st, *a);
-            hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<64, 4>), dim3((unsigned)((npk + 3) / 4), (unsigned)f.Hkv, (unsigned)f.B), dim3(256), lds_k, st, *a);
+            MTL_LAUNCH("attn_bwd_dq_res_kernel<64, 8, false>", fl_half, 0, (attn_bwd_dq_res_kernel<64, 8>), dim3((unsigned)((npq + 7) / 8), (unsigned)f.Hq, (unsigned)f.B), dim3(512), lds_q, st, *a);
+            MTL_LAUNCH("attn_bwd_dkv_res_kernel<64, 4, false>", fl_half, 0, (attn_bwd_dkv_res_kernel<64, 4>), dim3((unsigned)((npk + 3) / 4), (unsigned)f.Hkv, (unsigned)f.B), dim3(256), lds_k, st, *a);
         } else {
             static std::once_flag once;
             std::call_once(once, [&] { set_lds(attn_bwd_dq_res_kernel<128, 8>, kLdsBudget); set_lds(attn_bwd_dkv_res_kernel<128, 4>, kLdsBudget); });
-            hipLaunchKernelGGL((attn_bwd_dq_res_kernel<128, 8>), dim3((unsigned)((npq + 7) / 8), (unsigned)f.Hq, (unsigned)f.B), dim3(512), lds_q, st, *a);
-            hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<128, 4>), dim3((unsigned)((npk + 3) / 4), (unsigned)f.Hkv, (unsigned)f.B), dim3(256), lds_k, st, *a);
+            MTL_LAUNCH("attn_bwd_dq_res_kernel<128, 8, false>", fl_half, 0, (attn_bwd_dq_res_kernel<128, 8>), dim3((unsigned)((npq + 7) / 8), (unsigned)f.Hq, (unsigned)f.B), dim3(512), lds_q, st, *a);
+            MTL_LAUNCH("attn_bwd_dkv_res_kernel<128, 4, false>", fl_half, 0, (attn_bwd_dkv_res_kernel<128, 4>), dim3((unsigned)((npk + 3) / 4), (unsigned)f.Hkv, (unsigned)f.B), dim3(256), lds_k, st, *a);
         }
         MTL_CHECK_LAUNCH();
         return MTL_OK;
@@ -972,17 +1021,17 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
     if (drop && f.dropout_p >= 1.f) return MTL_ERR_UNSUPPORTED;
 #define MTL_BWD(DD)                                                                                        \
     if (f.causal && drop) {                                                                                \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, true, true>), gq, block, 0, st, *a);                    \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<DD, true, true>), gk, block, 0, st, *a);                   \
+        MTL_LAUNCH("attn_bwd_dq_kernel<" #DD ", true, true>", fl_half, 0, (attn_bwd_dq_kernel<DD, true, true>), gq, block, 0, st, *a);                    \
+        MTL_LAUNCH("attn_bwd_dkv_kernel<" #DD ", true, true>", fl_half, 0, (attn_bwd_dkv_kernel<DD, true, true>), gk, block, 0, st, *a);                   \
     } else if (f.causal) {                                                                                 \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, true, false>), gq, block, 0, st, *a);                   \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<DD, true, false>), gk, block, 0, st, *a);                  \
+        MTL_LAUNCH("attn_bwd_dq_kernel<" #DD ", true, false>", fl_half, 0, (attn_bwd_dq_kernel<DD, true, false>), gq, block, 0, st, *a);                   \
+        MTL_LAUNCH("attn_bwd_dkv_kernel<" #DD ", true, false>", fl_half, 0, (attn_bwd_dkv_kernel<DD, true, false>), gk, block, 0, st, *a);                  \
     } else if (drop) {                                                                                     \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, false, true>), gq, block, 0, st, *a);                   \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<DD, false, true>), gk, block, 0, st, *a);                  \
+        MTL_LAUNCH("attn_bwd_dq_kernel<" #DD ", false, true>", fl_half, 0, (attn_bwd_dq_kernel<DD, false, true>), gq, block, 0, st, *a);                   \
+        MTL_LAUNCH("attn_bwd_dkv_kernel<" #DD ", false, true>", fl_half, 0, (attn_bwd_dkv_kernel<DD, false, true>), gk, block, 0, st, *a);                  \
     } else {                                                                                               \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, false, false>), gq, block, 0, st, *a);                  \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<DD, false, false>), gk, block, 0, st, *a);                 \
+        MTL_LAUNCH("attn_bwd_dq_kernel<" #DD ", false, false>", fl_half, 0, (attn_bwd_dq_kernel<DD, false, false>), gq, block, 0, st, *a);                  \
+        MTL_LAUNCH("attn_bwd_dkv_kernel<" #DD ", false, false>", fl_half, 0, (attn_bwd_dkv_kernel<DD, false, false>), gk, block, 0, st, *a);                 \
     }
     if (f.D == 32) { MTL_BWD(32) } else if (f.D == 64) { MTL_BWD(64) } else { MTL_BWD(128) }
 #undef MTL_BWD

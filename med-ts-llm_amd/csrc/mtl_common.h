@@ -2,6 +2,7 @@
 // CDNA4-only code (wave64, MFMA, LDS-DMA); there is deliberately no other backend.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/medtsllm_hip.h"
@@ -77,4 +78,27 @@ __host__ __device__ __forceinline__ uint32_t drop_site_seed(uint32_t seed, int l
     do {                                                     \
         hipError_t e__ = hipGetLastError();                  \
         if (e__ != hipSuccess) return MTL_ERR_LAUNCH;        \
+    } while (0)
+
+// ---------------------------------------------------------------- optional launch profiler (bench.py's roofline legs)
+// Off by default: one relaxed flag test per launch. While on (mtl_prof_enable), a launch goes through hipExtLaunchKernelGGL with
+// its own start / stop event pair: their elapsed time is the kernel's begin -> end on the device — the duration rocprofv3
+// --kernel-trace reports for the same dispatch — with no launch gap inside, so nothing has to be calibrated away.
+// `name` is the kernel as rocprofv3 prints it (without the anonymous-namespace prefix and the parameter list); `work` is the
+// launch's ALGORITHMIC work: FLOPs (kind 0, MFMA family) or HBM bytes (kind 1, HBM family). Defined in mtl_gemm.hip.
+namespace mtlprof {
+bool enabled();
+bool begin(hipEvent_t* e0, hipEvent_t* e1);
+void end(hipEvent_t e0, hipEvent_t e1, const char* name, double work, int kind);
+}  // namespace mtlprof
+
+#define MTL_LAUNCH(NAME, WORK, KIND, KERNEL, GRID, BLOCK, LDS, ST, ...)                                    \
+    do {                                                                                                   \
+        hipEvent_t pe0__, pe1__;                                                                           \
+        if (mtlprof::enabled() && mtlprof::begin(&pe0__, &pe1__)) {                                        \
+            hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, ST, pe0__, pe1__, 0, __VA_ARGS__);             \
+            mtlprof::end(pe0__, pe1__, NAME, WORK, KIND);                                                  \
+        } else {                                                                                           \
+            hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, ST, __VA_ARGS__);                                 \
+        }                                                                                                  \
     } while (0)

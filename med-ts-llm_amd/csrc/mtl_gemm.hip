@@ -13,22 +13,23 @@
 //   * split-K (fp32 slabs + reduce kernel) for the batch-independent mapping GEMM (M=1024, N=d_llm, K=V).
 #include "mtl_common.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
 namespace {
 
-// ---------------------------------------------------------------- optional launch profiler (bench.py roofline leg)
-// When enabled, every GEMM launch is bracketed by two HIP events on the launch stream; mtl_prof_read() then
-// reports, per kernel instance (epilogue, c_dtype, split), launches / total ms / total algorithmic FLOPs.
-// Disabled by default: zero cost on the product path (one relaxed flag test per launch).
-struct ProfRec { hipEvent_t e0, e1; int key; double flops; };
+// ---------------------------------------------------------------- launch profiler state (interface: mtl_common.h)
+struct ProfRec { hipEvent_t e0, e1; int slot; };
+struct ProfSlot { char name[128]; int kind; int64_t launches; double work; };
 struct Profiler {
     std::mutex mu;
-    bool on = false;
+    std::atomic<bool> on{false};
     std::vector<ProfRec> recs;
+    std::vector<ProfSlot> slots;
 };
 Profiler& prof() { static Profiler p; return p; }
 
@@ -792,28 +793,8 @@ template <int EPI, int CDT>
 int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
     const int tiles_m = (int)((p.M + BM - 1) / BM), tiles_n = (int)((p.N + BN - 1) / BN);
     const int S = p.split_k > 1 ? p.split_k : 1;
-    Profiler& pf = prof();
-    ProfRec rec;
-    bool recording = false;
-    if (pf.on) {
-        std::lock_guard<std::mutex> lk(pf.mu);
-        if (pf.on && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess) {
-            rec.key = EPI * 4 + CDT * 2 + (S > 1 ? 1 : 0);   // variant bits are OR-ed in below once the tile shape is chosen
-            rec.flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
-            recording = true;
-            (void)hipEventRecord(rec.e0, st);
-        }
-    }
-    struct Closer {
-        Profiler& pf; ProfRec& rec; bool& recording; hipStream_t st;
-        ~Closer() {
-            if (recording) {
-                (void)hipEventRecord(rec.e1, st);
-                std::lock_guard<std::mutex> lk(pf.mu);
-                pf.recs.push_back(rec);
-            }
-        }
-    } closer{pf, rec, recording, st};
+    const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
+    char kname[128];
     // the persistent kernel has the wave-level epilogue only: 16-B aligned rows, or (plain fp32 store, no bias) dword stores
     const bool dword_ok = EPI == MTL_EPI_STORE && CDT == MTL_F32 && !p.bias && aligned(p.C, 4) && p.c_group_rows == 0;
     if (S == 1 && tuning().mode == 1 && (vec_ok || dword_ok) && p.N >= 4) {
@@ -876,21 +857,20 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         const size_t lds = (size_t)ks * stages * (bm + bn_lds) * BK * 2;
         const int per_cu = (int)(160 * 1024 / lds) < 1 ? 1 : (int)(160 * 1024 / lds);
         const int grid = nt < per_cu * ncu ? nt : per_cu * ncu;
-        if (recording) rec.key |= (1 << 8) | ((bn == 128 ? 1 : 0) << 9) | ((nw == 8 ? 1 : (nw == 16 ? 2 : 0)) << 10) | (stages << 12) | ((bm == 256 ? 1 : 0) << 15) |
-                                      ((bn == 96 ? 2 : (bn == 192 ? 3 : (bn == 128 ? 1 : 0))) << 16) | ((bn == 256 ? 1 : 0) << 18);
 #define MTL_PERSIST(BMV, BNV, STV, NWV)                                                                                \
     do {                                                                                                               \
         auto kfn = gemm_nt_persist_kernel<EPI, CDT, BMV, BNV, STV, NWV>;                                               \
         static std::once_flag once;                                                                                    \
         std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(NWV * 64), lds, st, p, vec_ok, tm, tn, tile_order(tm, tn, bm, bn, per_cu, p.K)); \
+        snprintf(kname, sizeof kname, "gemm_nt_persist_kernel<%d, %d, %d, %d, %d, %d, false, 1>", EPI, CDT, BMV, BNV, STV, NWV); \
+        MTL_LAUNCH(kname, flops, 0, kfn, dim3(grid), dim3(NWV * 64), lds, st, p, vec_ok, tm, tn, tile_order(tm, tn, bm, bn, per_cu, p.K)); \
     } while (0)
         if (ks == 2) {
             auto kfn = gemm_nt_persist_kernel<EPI, CDT, 128, 96, 2, 8, false, 2>;
             static std::once_flag once;
             std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-            if (recording) rec.key |= 1 << 19;
-            hipLaunchKernelGGL(kfn, dim3(nt), dim3(512), lds, st, p, vec_ok, tm, tn, tile_order(tm, tn, bm, bn, 1, p.K, true));
+            snprintf(kname, sizeof kname, "gemm_nt_persist_kernel<%d, %d, 128, 96, 2, 8, false, 2>", EPI, CDT);
+            MTL_LAUNCH(kname, flops, 0, kfn, dim3(nt), dim3(512), lds, st, p, vec_ok, tm, tn, tile_order(tm, tn, bm, bn, 1, p.K, true));
         } else if (bm == 256 && bn == 128 && nw == 16 && stages == 3) MTL_PERSIST(256, 128, 3, 16);
         else if (bm == 256 && bn == 128 && nw == 16 && stages == 2) MTL_PERSIST(256, 128, 2, 16);
         else if (bm == 128 && bn == 128 && nw == 8 && stages == 2) MTL_PERSIST(128, 128, 2, 8);
@@ -909,7 +889,8 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
 #undef MTL_PERSIST
     } else if (S == 1) {
         if (EPI == MTL_EPI_SWIGLU || EPI == MTL_EPI_DSWIGLU) return MTL_ERR_UNSUPPORTED;      // the fused activation lives in the wave-level epilogue only
-        hipLaunchKernelGGL((gemm_nt_kernel<EPI, CDT, false>), dim3(tiles_m * tiles_n, 1), dim3(256), 0, st, p, vec_ok);
+        snprintf(kname, sizeof kname, "gemm_nt_kernel<%d, %d, false>", EPI, CDT);
+        MTL_LAUNCH(kname, flops, 0, (gemm_nt_kernel<EPI, CDT, false>), dim3(tiles_m * tiles_n, 1), dim3(256), 0, st, p, vec_ok);
     } else {
         const int ws_vec = (p.N % 4 == 0) && aligned(p.workspace, 16);
         const int nkt_total = (int)(p.K / BK);
@@ -925,8 +906,8 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
                 auto kfn = gemm_nt_persist_kernel<MTL_EPI_STORE, MTL_F32, BMV, BNV, STV, NWV, true>;
                 static std::once_flag once;
                 std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-                if (recording) rec.key |= (1 << 8) | (1 << 10) | (STV << 12) | ((BNV == 192 ? 3 : 1) << 16) | ((BMV == 256 ? 1 : 0) << 15);
-                hipLaunchKernelGGL(kfn, dim3(grid), dim3(NWV * 64), lds, st, p, S, tm, tn, tile_order(tm, tn, BMV, BNV, per_cu, p.K));
+                snprintf(kname, sizeof kname, "gemm_nt_persist_kernel<0, 0, %d, %d, %d, %d, true, 1>", BMV, BNV, STV, NWV);
+                MTL_LAUNCH(kname, flops, 0, kfn, dim3(grid), dim3(NWV * 64), lds, st, p, S, tm, tn, tile_order(tm, tn, BMV, BNV, per_cu, p.K));
             };
             using I128 = std::integral_constant<int, 128>; using I192 = std::integral_constant<int, 192>; using I256 = std::integral_constant<int, 256>;
             // operands of a split GEMM stream from HBM (K is huge): the fewest operand bytes per FLOP wins (256x192 when it still
@@ -935,9 +916,14 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
             else if (p.N % 192 == 0) go(I128{}, I192{});
             else go(I128{}, I128{});
         } else
-        hipLaunchKernelGGL((gemm_nt_kernel<EPI, CDT, true>), dim3(tiles_m * tiles_n, S), dim3(256), 0, st, p, ws_vec);
+        {
+            snprintf(kname, sizeof kname, "gemm_nt_kernel<%d, %d, true>", EPI, CDT);
+            MTL_LAUNCH(kname, flops, 0, (gemm_nt_kernel<EPI, CDT, true>), dim3(tiles_m * tiles_n, S), dim3(256), 0, st, p, ws_vec);
+        }
         const int64_t items = p.M * ((p.N + 3) / 4);
-        hipLaunchKernelGGL((splitk_reduce_kernel<EPI, CDT>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, p, S, vec_ok);
+        snprintf(kname, sizeof kname, "splitk_reduce_kernel<%d, %d>", EPI, CDT);
+        MTL_LAUNCH(kname, (double)S * p.M * p.N * 4.0 + (double)p.M * p.N * (CDT == MTL_BF16 ? 2.0 : 4.0), 1, (splitk_reduce_kernel<EPI, CDT>),
+                   dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, p, S, vec_ok);
     }
     MTL_CHECK_LAUNCH();
     return MTL_OK;
@@ -962,49 +948,66 @@ extern "C" int mtl_gemm_tune(int mode, int bm, int bn, int stages, int waves) {
     return MTL_OK;
 }
 
-// average duration (ms) of an EMPTY event bracket on `stream`: the fixed cost included in every bracketed launch
-extern "C" double mtl_prof_calibrate(void* stream) {
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int n = 64;
-    double tot = 0;
-    int ok = 0;
-    for (int i = 0; i < n; ++i) {
-        hipEvent_t e0, e1;
-        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) continue;
-        (void)hipEventRecord(e0, st);
-        (void)hipEventRecord(e1, st);
-        float ms = 0.f;
-        if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { tot += ms; ++ok; }
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-    }
-    return ok ? tot / ok : 0.0;
+namespace mtlprof {
+bool enabled() { return prof().on.load(std::memory_order_relaxed); }
+bool begin(hipEvent_t* e0, hipEvent_t* e1) {
+    if (hipEventCreate(e0) != hipSuccess) return false;
+    if (hipEventCreate(e1) != hipSuccess) { (void)hipEventDestroy(*e0); return false; }
+    return true;
 }
+void end(hipEvent_t e0, hipEvent_t e1, const char* name, double work, int kind) {
+    Profiler& pf = prof();
+    std::lock_guard<std::mutex> lk(pf.mu);
+    int slot = -1;
+    for (size_t i = 0; i < pf.slots.size(); ++i)
+        if (strncmp(pf.slots[i].name, name, sizeof pf.slots[i].name) == 0) { slot = (int)i; break; }
+    if (slot < 0) {
+        ProfSlot sl = {};
+        strncpy(sl.name, name, sizeof sl.name - 1);
+        sl.kind = kind;
+        pf.slots.push_back(sl);
+        slot = (int)pf.slots.size() - 1;
+    }
+    pf.slots[slot].launches += 1;
+    pf.slots[slot].work += work;
+    pf.recs.push_back(ProfRec{e0, e1, slot});
+}
+}  // namespace mtlprof
 
 extern "C" int mtl_prof_enable(int on) {
     Profiler& pf = prof();
     std::lock_guard<std::mutex> lk(pf.mu);
-    pf.on = on != 0;
+    pf.on.store(on != 0);
     if (on) {
         for (auto& r : pf.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
         pf.recs.clear();
+        pf.slots.clear();
     }
     return MTL_OK;
 }
 
-// fills up to `cap` rows of (key, launches, total_ms, total_flops); returns the number of rows. Synchronises the events.
-extern "C" int mtl_prof_read(int* keys, int64_t* launches, double* total_ms, double* total_flops, int cap) {
+// fills up to `cap` rows, one per kernel instance launched since mtl_prof_enable(1); returns the number of instances.
+// Synchronises the recorded events (call after the work has been enqueued; do not call concurrently with launches).
+extern "C" int mtl_prof_read(mtl_prof_row* rows, int cap) {
+    if (!rows || cap <= 0) return MTL_ERR_ARG;
     Profiler& pf = prof();
     std::lock_guard<std::mutex> lk(pf.mu);
-    int n = 0;
+    const int n = (int)pf.slots.size() < cap ? (int)pf.slots.size() : cap;
+    for (int i = 0; i < n; ++i) {
+        memset(&rows[i], 0, sizeof rows[i]);
+        memcpy(rows[i].name, pf.slots[i].name, sizeof rows[i].name);
+        rows[i].kind = pf.slots[i].kind;
+        rows[i].launches = pf.slots[i].launches;
+        rows[i].total_work = pf.slots[i].work;
+        rows[i].min_ms = 1e30;
+    }
     for (auto& r : pf.recs) {
-        if (hipEventSynchronize(r.e1) != hipSuccess) continue;
+        if (r.slot >= n) continue;
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
-        int i = 0;
-        for (; i < n; ++i) if (keys[i] == r.key) break;
-        if (i == n) { if (n >= cap) continue; keys[n] = r.key; launches[n] = 0; total_ms[n] = 0; total_flops[n] = 0; ++n; }
-        launches[i] += 1; total_ms[i] += ms; total_flops[i] += r.flops;
+        if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) { rows[r.slot].launches -= 1; continue; }
+        rows[r.slot].total_ms += ms;
+        if (ms < rows[r.slot].min_ms) rows[r.slot].min_ms = ms;
+        if (ms > rows[r.slot].max_ms) rows[r.slot].max_ms = ms;
     }
     return n;
 }

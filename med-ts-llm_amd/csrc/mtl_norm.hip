@@ -4,6 +4,8 @@
 // loads), statistics by wave shuffles in fp32, bf16x4 (8 B/lane) stores. Algorithmic bytes per row:
 // fwd 4d (read) + 2d (write); bwd 2d (dy) + 4d (x) + 4d (dres in) + 4d (+2d) (dres out).
 #include "mtl_common.h"
+
+#include <cstdio>
 #include <type_traits>
 
 namespace {
@@ -163,12 +165,15 @@ extern "C" int mtl_norm_fwd(const float* x, const float* gamma, const float* bet
     const dim3 grid((unsigned)((M + 3) / 4)), block(256);
     auto go = [&](auto nv) -> int {
         constexpr int NV = decltype(nv)::value;
+        char kname[64];
+        snprintf(kname, sizeof kname, "norm_fwd_kernel<%d, %s>", NV, rms ? "true" : "false");
+        const double bytes = (double)M * d * (4 + 2) + (stats ? (double)M * 8 : 0.0);      // fp32 row in, bf16 row out, 2 statistics
         if (rms)
-            hipLaunchKernelGGL((norm_fwd_kernel<NV, true>), grid, block, 0, st, x, gamma, beta, (bf16_t*)y, ld_y, stats, M, (int)d,
-                               eps, group_rows, group_stride, row_offset);
+            MTL_LAUNCH(kname, bytes, 1, (norm_fwd_kernel<NV, true>), grid, block, 0, st, x, gamma, beta, (bf16_t*)y, ld_y, stats, M, (int)d,
+                       eps, group_rows, group_stride, row_offset);
         else
-            hipLaunchKernelGGL((norm_fwd_kernel<NV, false>), grid, block, 0, st, x, gamma, beta, (bf16_t*)y, ld_y, stats, M, (int)d,
-                               eps, group_rows, group_stride, row_offset);
+            MTL_LAUNCH(kname, bytes, 1, (norm_fwd_kernel<NV, false>), grid, block, 0, st, x, gamma, beta, (bf16_t*)y, ld_y, stats, M, (int)d,
+                       eps, group_rows, group_stride, row_offset);
         MTL_CHECK_LAUNCH();
         return MTL_OK;
     };
@@ -185,12 +190,16 @@ extern "C" int mtl_norm_bwd(const void* dy, int64_t ld_dy, const float* x, const
     const dim3 grid((unsigned)((M + 3) / 4)), block(256);
     auto go = [&](auto nv) -> int {
         constexpr int NV = decltype(nv)::value;
+        char kname[64];
+        snprintf(kname, sizeof kname, "norm_bwd_kernel<%d, %s>", NV, rms ? "true" : "false");
+        // bf16 dy + fp32 x in (+ fp32 incoming residual gradient), fp32 residual gradient out (+ its bf16 copy)
+        const double bytes = (double)M * d * (2 + 4 + (dres_in ? 4 : 0) + 4 + (dres_out_bf16 ? 2 : 0)) + (double)M * 8;
         if (rms)
-            hipLaunchKernelGGL((norm_bwd_kernel<NV, true>), grid, block, 0, st, (const bf16_t*)dy, ld_dy, x, gamma, stats, dres_in,
-                               dres_out, (bf16_t*)dres_out_bf16, M, (int)d, group_rows, group_stride, row_offset, stats_physical, bf16_drop_p, bf16_drop_seed);
+            MTL_LAUNCH(kname, bytes, 1, (norm_bwd_kernel<NV, true>), grid, block, 0, st, (const bf16_t*)dy, ld_dy, x, gamma, stats, dres_in,
+                       dres_out, (bf16_t*)dres_out_bf16, M, (int)d, group_rows, group_stride, row_offset, stats_physical, bf16_drop_p, bf16_drop_seed);
         else
-            hipLaunchKernelGGL((norm_bwd_kernel<NV, false>), grid, block, 0, st, (const bf16_t*)dy, ld_dy, x, gamma, stats, dres_in,
-                               dres_out, (bf16_t*)dres_out_bf16, M, (int)d, group_rows, group_stride, row_offset, stats_physical, bf16_drop_p, bf16_drop_seed);
+            MTL_LAUNCH(kname, bytes, 1, (norm_bwd_kernel<NV, false>), grid, block, 0, st, (const bf16_t*)dy, ld_dy, x, gamma, stats, dres_in,
+                       dres_out, (bf16_t*)dres_out_bf16, M, (int)d, group_rows, group_stride, row_offset, stats_physical, bf16_drop_p, bf16_drop_seed);
         MTL_CHECK_LAUNCH();
         return MTL_OK;
     };

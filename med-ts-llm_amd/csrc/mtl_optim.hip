@@ -94,11 +94,12 @@ extern "C" int mtl_adam_step(const mtl_adam_tensor* tensors, int count, float lr
     h.lr = lr; h.beta1 = beta1; h.beta2 = beta2; h.eps = eps; h.wd = weight_decay; h.decoupled = decoupled;
     h.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     h.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-    for (int i0 = 0; i0 < count; i0 += MAX_T) {
+    for (int i = 0; i < count;) {       // one launch per table of up to MAX_T non-empty tensors; `i` carries across tables
         AdamTable tab;
         tab.count = 0;
         int blocks = 0;
-        for (int i = i0; i < count && tab.count < MAX_T; ++i) {
+        double bytes = 0;
+        for (; i < count && tab.count < MAX_T; ++i) {
             const mtl_adam_tensor& t = tensors[i];
             if (t.n == 0) continue;
             if (!t.p || !t.g || !t.m || !t.v || t.n < 0) return MTL_ERR_ARG;
@@ -106,11 +107,12 @@ extern "C" int mtl_adam_step(const mtl_adam_tensor* tensors, int count, float lr
             tab.t[tab.count] = t;
             tab.first_block[tab.count] = blocks;
             blocks += (int)((t.n + CHUNK - 1) / CHUNK);
+            bytes += (double)t.n * (28.0 + (t.shadow ? 2.0 : 0.0));      // p, g, m, v read; p, m, v written (+ bf16 shadow)
             ++tab.count;
         }
         tab.first_block[tab.count] = blocks;
         if (blocks == 0) continue;
-        hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(THREADS), 0, st, tab, h);
+        MTL_LAUNCH("adam_multi_kernel", bytes, 1, adam_multi_kernel, dim3(blocks), dim3(THREADS), 0, st, tab, h);
         MTL_CHECK_LAUNCH();
     }
     return MTL_OK;

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("MTL_LIB_PATH") or os.path.join(_HERE, "libmedtsllm_hi
 MTL_F32, MTL_BF16 = 0, 1
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM, EPI_SWIGLU, EPI_DSWIGLU = 0, 1, 2, 3, 4, 5, 6
 ARCH_GPT2, ARCH_LLAMA = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 i64, vp, f32, i32 = C.c_int64, C.c_void_p, C.c_float, C.c_int
 
@@ -30,6 +30,11 @@ class GemmArgs(C.Structure):
                 ("bias", vp), ("epilogue", i32), ("aux_in", vp), ("ld_aux_in", i64), ("aux_out", vp), ("ld_aux_out", i64),
                 ("alpha", f32), ("split_k", i32), ("workspace", vp), ("workspace_bytes", C.c_size_t),
                 ("drop_p", f32), ("drop_seed", C.c_uint32), ("bwd_group_rows", i64), ("bwd_first_row", i64)]
+
+
+class ProfRow(C.Structure):
+    _fields_ = [("name", C.c_char * 128), ("kind", C.c_int32), ("launches", i64), ("total_ms", C.c_double), ("min_ms", C.c_double),
+                ("max_ms", C.c_double), ("total_work", C.c_double)]
 
 
 class BackboneDropout(C.Structure):
@@ -87,10 +92,9 @@ SIGNATURES = {
     "mtl_gemm_workspace_bytes": (C.c_size_t, [i64, i64, i32]),
     "mtl_gemm_nt": (i32, [C.POINTER(GemmArgs), vp]),
     "mtl_prof_enable": (i32, [i32]),
-    "mtl_prof_calibrate": (C.c_double, [vp]),
     "mtl_gemm_tune": (i32, [i32, i32, i32, i32, i32]),
     "mtl_gemm_tile_order": (i32, [i32, i32, i32, i32, i32, i64, i32]),
-    "mtl_prof_read": (i32, [C.POINTER(i32), C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double), i32]),
+    "mtl_prof_read": (i32, [C.POINTER(ProfRow), i32]),
     "mtl_cast_pad_f32_bf16": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, vp]),
     "mtl_transpose_bf16": (i32, [vp, i64, vp, i64, i64, i64, vp]),
     "mtl_transpose_colsum_bf16": (i32, [vp, i64, vp, i64, vp, i64, i64, vp]),
@@ -138,6 +142,17 @@ def lib():
             raise MtlError(f"ABI mismatch: library {l.mtl_abi_version()} vs binding {ABI_VERSION}")
         _lib = l
     return _lib
+
+
+def prof_rows(cap=256):
+    """launch-profiler records since mtl_prof_enable(1): [{kernel, kind ('flops' | 'bytes'), launches, total_ms, min_ms, max_ms, work}]"""
+    rows = (ProfRow * cap)()
+    n = lib().mtl_prof_read(rows, cap)
+    if n < 0:
+        check(n, "mtl_prof_read")
+    return [{"kernel": rows[i].name.decode(), "kind": "flops" if rows[i].kind == 0 else "bytes", "launches": int(rows[i].launches),
+             "total_ms": rows[i].total_ms, "min_ms": rows[i].min_ms, "max_ms": rows[i].max_ms, "work": rows[i].total_work}
+            for i in range(n) if rows[i].launches > 0]
 
 
 def check(code, what=""):

@@ -131,6 +131,18 @@ class MedTsLLM(nn.Module):
         self._id_cache = {}
         self.prune_dead_prompt_grads = True   # exact: skips gradients nobody consumes (set False for the full dh0)
         self.fixed_prompt_ids = None   # int32 [1 or B, n_tok]: synthetic-benchmark prompt (no tokenizer files needed)
+        self.debug_tap = None          # dict -> stage tensors (and, after backward, their gradients as "grad:<name>") for parity tests
+
+    def _tap(self, name, t):
+        """parity-test probe: no-op unless `debug_tap` is a dict. The i-th tensor tapped under `name` in a forward (encode_ts runs
+        twice with "examples" prompting) is stored as "name@i", its gradient after backward as "grad:name@i"; "name" is the latest."""
+        tap = self.debug_tap
+        if tap is not None:
+            key = f"{name}@{sum(1 for k in tap if k.startswith(name + '@'))}"
+            tap[key] = tap[name] = t.detach()
+            if t.requires_grad:
+                t.register_hook(lambda g, k=key: tap.__setitem__("grad:" + k, g.detach()))
+        return t
 
     # ------------------------------------------------------------------ construction (a11)
     def _setup_llm(self, backbone_state):
@@ -339,6 +351,7 @@ class MedTsLLM(nn.Module):
         rl = self.reprogramming_layer
         tokens, mean, stdev = PatchTokenizeFn.apply(x_enc, self.patch_embedding.value_embedding.tokenConv.weight,
                                                     self.patch_len, self.stride, concat)
+        self._tap("tokens", tokens)
         if self.training and self.dropout > 0:
             tokens = F.dropout(tokens, self.dropout, True)
         if self.word_embeddings.requires_grad:
@@ -351,22 +364,23 @@ class MedTsLLM(nn.Module):
                 from ..parallel import AllGatherRows
                 rank, world, _, _, group = self._map_shard
                 source = AllGatherRows.apply(source, rank, world, group)
-        q = LinearFn.apply(tokens, rl.query_projection.weight, rl.query_projection.bias)
-        k = LinearFn.apply(source, rl.key_projection.weight, rl.key_projection.bias)
-        v = LinearFn.apply(source, rl.value_projection.weight, rl.value_projection.bias)
+        self._tap("source", source)
+        q = self._tap("q", LinearFn.apply(tokens, rl.query_projection.weight, rl.query_projection.bias))
+        k = self._tap("k", LinearFn.apply(source, rl.key_projection.weight, rl.key_projection.bias))
+        v = self._tap("v", LinearFn.apply(source, rl.value_projection.weight, rl.value_projection.bias))
         if self.training and self.dropout > 0:   # A = dropout(softmax(.)), R:models/medtsllm.py:588 (own RNG stream)
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
             a = CrossAttnFn.apply(q, k, v, self.n_attention_heads, self.d_ff, float(self.dropout), seed)
         else:
             a = CrossAttnFn.apply(q, k, v, self.n_attention_heads, self.d_ff)
-        enc = LinearFn.apply(a, rl.out_projection.weight, rl.out_projection.bias)     # [B', P, d_llm]
+        enc = self._tap("reprog", LinearFn.apply(a, rl.out_projection.weight, rl.out_projection.bias))     # [B', P, d_llm]
         n_patches, d_llm = enc.shape[1], self.d_llm
         cm = self.covariate_mode
         if cm == "add":
             enc = enc.reshape(bs, C, n_patches, d_llm).float().mean(dim=1).to(BF16)
         elif cm == "weighted-average":
-            enc = enc.reshape(bs, C, n_patches, d_llm).permute(0, 2, 3, 1).float()
-            enc = F.linear(enc, self.feature_weighting.weight, self.feature_weighting.bias).squeeze(-1).to(BF16)
+            enc = self._tap("fw_in", enc.reshape(bs, C, n_patches, d_llm).permute(0, 2, 3, 1).float())
+            enc = self._tap("fw_out", F.linear(enc, self.feature_weighting.weight, self.feature_weighting.bias)).squeeze(-1).to(BF16)
         elif cm == "interleave":
             enc = enc.reshape(bs, C, -1, d_llm).permute(0, 2, 1, 3).reshape(bs, -1, d_llm)
         return enc, mean, stdev
@@ -404,24 +418,25 @@ class MedTsLLM(nn.Module):
                 h0 = EmbdDropoutFn.apply(h0, c["embd_pdrop"], seed ^ 0x5bd1e995)
             if c["attn_pdrop"] > 0 or c["resid_pdrop"] > 0:
                 drop = (c["attn_pdrop"], c["resid_pdrop"], seed)
-        dec = BackboneFn.apply(h0, bb, self.n_patches, n_grad, drop)   # [B', n_patches, d_llm] (final norm on the consumed rows only)
+        self._tap("h0", h0)
+        dec = self._tap("dec", BackboneFn.apply(h0, bb, self.n_patches, n_grad, drop))   # [B', n_patches, d_llm] (final norm on the consumed rows only)
         mode = self.embedding_downsample_mode
         if mode == "truncate":
             dec = dec[:, :, :self.d_ff]
         elif mode == "linear":
-            dec = LinearFn.apply(dec, self.embedding_downsample_layer.weight, self.embedding_downsample_layer.bias)
+            dec = self._tap("down", LinearFn.apply(dec, self.embedding_downsample_layer.weight, self.embedding_downsample_layer.bias))
         else:
             dec = dec.reshape(dec.shape[0], self.n_patches, self.d_ff, -1).float().mean(dim=-1).to(BF16)
         head_in = dec.permute(0, 2, 1).reshape(dec.shape[0], -1)       # feature index = f * P + p (R:models/medtsllm.py:366,549)
         kp = pad64(head_in.shape[1])
         if kp != head_in.shape[1]:
             head_in = F.pad(head_in, (0, kp - head_in.shape[1]))
-        out = LinearFn.apply(head_in.contiguous(), self.output_projection.linear.weight, self.output_projection.linear.bias)
+        out = self._tap("head", LinearFn.apply(head_in.contiguous(), self.output_projection.linear.weight, self.output_projection.linear.bias))
         if cm == "independent":
             out = out.float().view(bs, C, self.pred_len, self.n_outputs_per_step).mean(dim=1)
         elif cm == "merge-end":
-            out = out.float().view(bs, C, self.pred_len, self.n_outputs_per_step).permute(0, 2, 3, 1).reshape(bs, self.pred_len, -1)
-            out = F.linear(out, self.feature_weighting.weight, self.feature_weighting.bias)
+            out = self._tap("fw_in", out.float().view(bs, C, self.pred_len, self.n_outputs_per_step).permute(0, 2, 3, 1).reshape(bs, self.pred_len, -1))
+            out = self._tap("fw_out", F.linear(out, self.feature_weighting.weight, self.feature_weighting.bias))
         else:
             out = out.view(bs, self.pred_len, self.n_outputs_per_step)
         if self.task in FORECAST_LIKE:

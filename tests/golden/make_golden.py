@@ -310,6 +310,27 @@ def run_case(name, kind, task, B, L, C, pred, cov, down, prompting, n_classes, l
     for k, v in rec.items():
         out[k] = t2n(v)
 
+    # ---- the reference's OWN dtype="mixed" run of the same step (fp32 weights, bf16 autocast around forward + loss, as its
+    # train loop does: R:tasks/forecasting.py:22-26): its deviation from the fp32 run above is the yardstick of the end-to-end
+    # parity bar (HIP error <= 1.5 x this). Stored as error norms only.
+    fp32 = {"pred_train": pred_train.detach().clone(), "loss": loss.detach().clone(), **{k: v.clone() for k, v in rec.items()},
+            **{"grad." + n: p.grad.detach().clone() for n, p in model.named_parameters() if p.requires_grad}}
+    model.zero_grad()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        pred_m = model(inputs)
+        if task == "semantic_segmentation":
+            loss_m = torch.nn.functional.cross_entropy(pred_m.permute(0, 2, 1), tgt)
+        elif task == "segmentation":
+            loss_m = torch.nn.functional.binary_cross_entropy_with_logits(pred_m, tgt)
+        else:
+            loss_m = torch.nn.functional.mse_loss(pred_m, tgt)
+    loss_m.backward()
+    mixed = {"pred_train": pred_m.detach(), "loss": loss_m.detach(), **rec,
+             **{"grad." + n: p.grad.detach() for n, p in model.named_parameters() if p.requires_grad}}
+    for k, v in fp32.items():
+        out["selferr." + k] = np.float64((mixed[k].double() - v.double()).norm().item())
+    model.zero_grad()
+
     # ---- eval-mode forward
     model.eval()
     with torch.no_grad():

@@ -1,8 +1,12 @@
 """GPU parity tests (run with -m gpu on an MI355X): every HIP kernel, through the C-ABI, against the oracle /
 a plain torch fp32 statement of the same op on the SAME bf16-rounded inputs.
 
-Tolerances (norm-wise relative): fp32 outputs of bf16-input GEMMs 2e-5 (accumulation order only);
-bf16 outputs 4e-3 (one bf16 rounding, 2^-9 per element); integer maps bit-exact.
+Tolerances (norm-wise relative; SURVEY.md 8c ladder L2, <= 1e-3-class per rounding): fp32 outputs of bf16-input GEMMs 2e-5
+(accumulation order only); bf16 outputs of one fp32 computation 2e-3 (ONE bf16 rounding: at most 2^-9 = 1.95e-3 per element,
+1.1-1.6e-3 norm-wise); attention forward 3e-3 (the probabilities are rounded to bf16 before P.V, then the output is); attention
+backward 5e-3 (bf16 P, dS, dO operands and the bf16-rounded O inside delta: three to four roundings); integer maps bit-exact.
+Every comparison's measured error is logged per source line to gpurun_out/kernel_parity_floor.json (largest value per line),
+which is how the bars above were set (profiles/r02_kernel_parity_floor.json).
 """
 import math
 
@@ -11,12 +15,40 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import rel_err, GOLDEN, load_case
+import json
+import os
+import sys
+
+import helpers
+from helpers import GOLDEN, load_case
 
 pytestmark = pytest.mark.gpu
 
 BF16, F32 = torch.bfloat16, torch.float32
-TOL_F32, TOL_BF16 = 2e-5, 4e-3
+TOL_F32, TOL_BF16, TOL_ATTN_FWD, TOL_ATTN_BWD = 2e-5, 2e-3, 3e-3, 5e-3
+
+_FLOOR = {}
+
+
+def rel_err(a, b):
+    """helpers.rel_err + a log of the largest error seen per calling line"""
+    e = helpers.rel_err(a, b)
+    f = sys._getframe(1)
+    key = f"{f.f_code.co_name}:{f.f_lineno}"
+    _FLOOR[key] = max(_FLOOR.get(key, 0.0), e)
+    return e
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_floor():
+    yield
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "kernel_parity_floor.json"), "w") as fh:
+            json.dump(dict(sorted(_FLOOR.items())), fh, indent=1)
+    except OSError:
+        pass
 
 
 @pytest.fixture(scope="module")
@@ -132,12 +164,12 @@ def test_attention_self(ops, B, T, Hq, Hkv, D, causal):
     ref = ref_attention(qf, kf, vf, Hq, Hkv, D, scale, causal)
     ref.backward(do.float())
     o, lse = ops.attention_fwd(dev(q), dev(k), dev(v), Hq, Hkv, D, scale, causal)
-    assert rel_err(o.float(), ref) < TOL_BF16
+    assert rel_err(o.float(), ref) < TOL_ATTN_FWD
     dq, dk, dv = ops.attention_bwd(dev(q), dev(k), dev(v), o, lse, dev(do), Hq, Hkv, D, scale, causal)
-    # backward consumes the bf16-rounded O (for delta) and bf16 P/dS operands: 1e-2 norm-wise
-    assert rel_err(dq.float(), qf.grad) < 1e-2
-    assert rel_err(dk.float(), kf.grad) < 1e-2
-    assert rel_err(dv.float(), vf.grad) < 1e-2
+    # backward consumes the bf16-rounded O (for delta) and bf16 P/dS operands
+    assert rel_err(dq.float(), qf.grad) < TOL_ATTN_BWD
+    assert rel_err(dk.float(), kf.grad) < TOL_ATTN_BWD
+    assert rel_err(dv.float(), vf.grad) < TOL_ATTN_BWD
 
 
 @pytest.mark.parametrize("B,T,Hq,Hkv,D", [(2, 173, 4, 4, 64), (2, 256, 4, 2, 128), (1, 40, 2, 1, 64)])
@@ -160,7 +192,7 @@ def test_attention_chunked_equals_resident(ops, B, T, Hq, Hkv, D):
     for a, b in zip(res[0], res[1]):
         assert rel_err(a.float(), b.float()) < 5e-3
     ref = ref_attention(q.float().cpu(), k.float().cpu(), v.float().cpu(), Hq, Hkv, D, scale, True)
-    assert rel_err(res[0][0].float(), ref) < TOL_BF16 and rel_err(res[1][0].float(), ref) < TOL_BF16
+    assert rel_err(res[0][0].float(), ref) < TOL_ATTN_FWD and rel_err(res[1][0].float(), ref) < TOL_ATTN_FWD
 
 
 def test_attention_fused_qkv_views(ops):
@@ -173,7 +205,7 @@ def test_attention_fused_qkv_views(ops):
     o, _ = ops.attention_fwd(q, k, v, Hq, Hkv, D, scale, True)
     ref = ref_attention(qkv[..., : Hq * D].float(), qkv[..., Hq * D: (Hq + Hkv) * D].float(), qkv[..., (Hq + Hkv) * D:].float(),
                         Hq, Hkv, D, scale, True)
-    assert rel_err(o.float(), ref) < TOL_BF16
+    assert rel_err(o.float(), ref) < TOL_ATTN_FWD
 
 
 @pytest.mark.parametrize("B,L,S,H,E", [(2, 8, 32, 2, 32), (3, 20, 1024, 8, 128), (2, 128, 200, 2, 64)])
@@ -190,11 +222,11 @@ def test_attention_cross_shared_kv(ops, B, L, S, H, E):
     ref = torch.einsum("bhls,she->blhe", A, vf.view(S, H, E)).reshape(B, L, H * E)
     ref.backward(do.float())
     o, lse = ops.attention_fwd(dev(q), dev(k), dev(v), H, H, E, scale, False, shared_kv=True)
-    assert rel_err(o.float(), ref) < TOL_BF16
+    assert rel_err(o.float(), ref) < TOL_ATTN_FWD
     dq, dk, dv = ops.attention_bwd(dev(q), dev(k), dev(v), o, lse, dev(do), H, H, E, scale, False, shared_kv=True)
-    assert rel_err(dq.float(), qf.grad) < 1e-2
-    assert rel_err(dk.float(), kf.grad) < 1e-2
-    assert rel_err(dv.float(), vf.grad) < 1e-2
+    assert rel_err(dq.float(), qf.grad) < TOL_ATTN_BWD
+    assert rel_err(dk.float(), kf.grad) < TOL_ATTN_BWD
+    assert rel_err(dv.float(), vf.grad) < TOL_ATTN_BWD
 
 
 def _drop_hash(seed, bh, q, key):
@@ -230,11 +262,11 @@ def test_attention_cross_dropout(ops, pdrop):
     ref = torch.einsum("bhls,she->blhe", A, vf.view(S, H, E)).reshape(B, L, H * E)
     ref.backward(do.float())
     o, lse = ops.attention_fwd(dev(q), dev(k), dev(v), H, H, E, scale, False, shared_kv=True, dropout=(pdrop, seed))
-    assert rel_err(o.float(), ref) < TOL_BF16
+    assert rel_err(o.float(), ref) < TOL_ATTN_FWD
     dq, dk, dv = ops.attention_bwd(dev(q), dev(k), dev(v), o, lse, dev(do), H, H, E, scale, False, shared_kv=True, dropout=(pdrop, seed))
-    assert rel_err(dq.float(), qf.grad) < 1e-2
-    assert rel_err(dk.float(), kf.grad) < 1e-2
-    assert rel_err(dv.float(), vf.grad) < 1e-2
+    assert rel_err(dq.float(), qf.grad) < TOL_ATTN_BWD
+    assert rel_err(dk.float(), kf.grad) < TOL_ATTN_BWD
+    assert rel_err(dv.float(), vf.grad) < TOL_ATTN_BWD
 
 
 def test_attention_online_softmax_rescale(ops):
@@ -247,7 +279,7 @@ def test_attention_online_softmax_rescale(ops):
     q, k, v = q.to(BF16), k.to(BF16), v.to(BF16)
     ref = ref_attention(q.double(), k.double(), v.double(), H, H, D, 1 / math.sqrt(D), False)
     o, _ = ops.attention_fwd(dev(q), dev(k), dev(v), H, H, D, 1 / math.sqrt(D), False)
-    assert rel_err(o.float(), ref) < TOL_BF16
+    assert rel_err(o.float(), ref) < TOL_ATTN_FWD
 
 
 # ------------------------------------------------------------------------------------------------ norms
@@ -435,7 +467,7 @@ def test_gemm_split_k_paths(ops, M, Nn, K, S):
     split = ops.gemm_nt(A, B, bias=bias, out_dtype=F32, split_k=S)
     assert rel_err(one, ref) < 2e-5 and rel_err(split, ref) < 2e-5
     splitb = ops.gemm_nt(A, B, bias=bias, split_k=S)
-    assert splitb.dtype == BF16 and rel_err(splitb.float(), ref) < 4e-3
+    assert splitb.dtype == BF16 and rel_err(splitb.float(), ref) < TOL_BF16
 
 
 @pytest.mark.gpu
@@ -508,8 +540,8 @@ def test_attention_causal_dropout(ops, pdrop, resident):
         dq, dk, dv = ops.attention_bwd(dev(q), dev(k), dev(v), o, lse, dev(do), H, H, D, scale, True, dropout=(pdrop, seed))
     finally:
         ops.lib().mtl_attention_tune(1)
-    assert rel_err(o.float(), ref) < TOL_BF16
-    assert rel_err(dq.float(), qf.grad) < 1e-2 and rel_err(dk.float(), kf.grad) < 1e-2 and rel_err(dv.float(), vf.grad) < 1e-2
+    assert rel_err(o.float(), ref) < TOL_ATTN_FWD
+    assert rel_err(dq.float(), qf.grad) < TOL_ATTN_BWD and rel_err(dk.float(), kf.grad) < TOL_ATTN_BWD and rel_err(dv.float(), vf.grad) < TOL_ATTN_BWD
 
 
 @pytest.mark.gpu

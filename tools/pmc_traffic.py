@@ -31,7 +31,18 @@ def clean(kn):
     return kn.split("(")[0]
 
 
-def main(tag, out):
+def csrc_sha16():
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(root, "med-ts-llm_amd", "csrc", "*.h*")) + [os.path.join(root, "include", "medtsllm_hip.h")]):
+        with open(fn, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def main(tag, out, workload=""):
     f = glob.glob(f"gpurun_out/pmc_{tag}_fetch/**/*.db", recursive=True)
     w = glob.glob(f"gpurun_out/pmc_{tag}_write/**/*.db", recursive=True)
     fetch = per_kernel(f[0], "FETCH_SIZE") if f else {}
@@ -43,9 +54,12 @@ def main(tag, out):
         rd, wr = 2.0 * fk * 1024.0, wk * 1024.0
         res[clean(kn)] = {"hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr, "dispatches": n}
         lines.append(f"{rd / 1e6:12.2f} MB read (2x FETCH_SIZE) {wr / 1e6:12.2f} MB written  per launch over {n:5d} launches  {clean(kn)[:110]}")
+    # bench.py only trusts a table measured with the kernel sources it runs (same hash as bench.csrc_sha16)
+    res["_meta"] = {"csrc_sha16": csrc_sha16(), "workload": workload, "tag": tag,
+                    "method": "separate rocprofv3 --pmc passes (FETCH_SIZE x2 x 1024 B, WRITE_SIZE x 1024 B), mean per launch"}
     json.dump(res, open(out, "w"), indent=1)
     print("\n".join(lines[:40]))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "")
