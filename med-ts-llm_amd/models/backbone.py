@@ -44,11 +44,27 @@ def load_hf_dir(path):
     return cfg, sd
 
 
+def _reject(what):
+    raise NotImplementedError(f"backbone config option {what} changes the arithmetic and is not implemented by the HIP path "
+                              "(loading it anyway would silently compute something else than HF does)")
+
+
 def normalise_config(cfg):
-    """Common view over GPT2Config / LlamaConfig json (SURVEY.md Appendix B constants)."""
+    """Common view over GPT2Config / LlamaConfig json (SURVEY.md Appendix B constants). Options that change the numerics and
+    that the kernels do not implement are REJECTED rather than ignored (the reference gets them applied by HF AutoModel)."""
     mt = cfg["model_type"]
     if mt == "gpt2":
         d, H = cfg["n_embd"], cfg["n_head"]
+        if cfg.get("activation_function", "gelu_new") != "gelu_new":
+            _reject(f"activation_function={cfg['activation_function']!r} (gelu_new only)")
+        if cfg.get("scale_attn_by_inverse_layer_idx", False):
+            _reject("scale_attn_by_inverse_layer_idx=true")
+        if cfg.get("reorder_and_upcast_attn", False):
+            _reject("reorder_and_upcast_attn=true")
+        if not cfg.get("scale_attn_weights", True):
+            _reject("scale_attn_weights=false")
+        if cfg.get("add_cross_attention", False):
+            _reject("add_cross_attention=true")
         return dict(arch="gpt2", n_layers=cfg["n_layer"], d=d, n_heads=H, n_kv_heads=H, head_dim=d // H,
                     ffn=cfg.get("n_inner") or 4 * d, eps=cfg.get("layer_norm_epsilon", 1e-5), vocab=cfg["vocab_size"],
                     n_positions=cfg.get("n_positions", 1024),
@@ -57,9 +73,21 @@ def normalise_config(cfg):
                     resid_pdrop=float(cfg.get("resid_pdrop", 0.1)))
     if mt == "llama":
         d, H = cfg["hidden_size"], cfg["num_attention_heads"]
+        rp = cfg.get("rope_parameters") or {}
         theta = cfg.get("rope_theta")
         if theta is None:
-            theta = (cfg.get("rope_parameters") or {}).get("rope_theta", 10000.0)
+            theta = rp.get("rope_theta", 10000.0)
+        scaling = cfg.get("rope_scaling") or ({k: v for k, v in rp.items() if k != "rope_theta"} if rp.get("rope_type", "default") != "default" else None)
+        if scaling and scaling.get("rope_type", scaling.get("type", "default")) != "default":
+            _reject(f"rope_scaling={scaling!r} (Llama-3.1-style frequency scaling; plain RoPE only)")
+        if cfg.get("attention_bias", False):
+            _reject("attention_bias=true")
+        if cfg.get("mlp_bias", False):
+            _reject("mlp_bias=true")
+        if cfg.get("hidden_act", "silu") != "silu":
+            _reject(f"hidden_act={cfg['hidden_act']!r} (silu only)")
+        if float(cfg.get("attention_dropout", 0.0) or 0.0) != 0.0:
+            _reject("attention_dropout > 0")
         return dict(arch="llama", n_layers=cfg["num_hidden_layers"], d=d, n_heads=H,
                     n_kv_heads=cfg.get("num_key_value_heads") or H, head_dim=cfg.get("head_dim") or d // H,
                     ffn=cfg["intermediate_size"], eps=cfg.get("rms_norm_eps", 1e-6), vocab=cfg["vocab_size"],

@@ -277,6 +277,9 @@ class MedTsLLM(nn.Module):
         R:datasets/ecg.py:139-166) a dict(emb [B, P_ex, d_llm], pos [B]) describing where each sample's example
         embeddings replace the placeholder (pad) tokens that reserve their rows in `ids`."""
         if self.fixed_prompt_ids is not None:
+            if not getattr(self, "_fixed_ids_checked", None) is self.fixed_prompt_ids:
+                self._check_ids(self.fixed_prompt_ids.tolist())
+                self._fixed_ids_checked = self.fixed_prompt_ids
             return self.fixed_prompt_ids.to(device=device, dtype=torch.int32), None
         prompts = self.build_prompt(inputs)
         if len(prompts[0]) == 0:
@@ -312,7 +315,17 @@ class MedTsLLM(nn.Module):
             rows = P.left_pad_ids(id_lists, tok.pad_token_id)
             if all(r == rows[0] for r in rows):
                 rows = rows[:1]                       # one shared prompt: the kernel broadcasts it
+        self._check_ids(rows)
         return torch.tensor(rows, dtype=torch.int32, device=device), splice
+
+    def _check_ids(self, rows):
+        """prompt token ids index the frozen embedding table inside a kernel that cannot raise: range-check them on the host (the
+        reference's nn.Embedding raises an IndexError here, e.g. for a '[PAD]' token added beyond an un-resized table)"""
+        V = self._hf_state["wte.weight" if "wte.weight" in self._hf_state else "embed_tokens.weight"].shape[0]
+        lo = min(min(r) for r in rows)
+        hi = max(max(r) for r in rows)
+        if lo < 0 or hi >= V:
+            raise IndexError(f"prompt token id out of range: ids span [{lo}, {hi}], the embedding table has {V} rows")
 
     # ------------------------------------------------------------------ forward
     def forward(self, inputs):

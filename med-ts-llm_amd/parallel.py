@@ -30,6 +30,15 @@ def init_from_env(device_type="cuda"):
     return rank, world, local_rank
 
 
+def broadcast_object(obj, src=0, group=None):
+    """rank `src`'s picklable object on every rank (control decisions that gate collectives must agree across ranks)"""
+    if not dist.is_initialized() or dist.get_world_size(group) <= 1:
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src, group=group)
+    return box[0]
+
+
 def shard_range(n, rank, world):
     """contiguous equal row range [r0, r1) of `n` rows owned by `rank` (n % world == 0)"""
     assert n % world == 0, (n, world)
@@ -106,7 +115,7 @@ class FlatGradAllReduce:
 
     def _arm(self):
         for b in self.buckets:
-            b["pending"], b["handle"], b["packed"] = len(b["items"]), None, set()
+            b["pending"], b["handle"], b["packed"], b["dirty"] = len(b["items"]), None, set(), False
 
     def _launch(self, b):
         b["handle"] = dist.all_reduce(self.flat[b["start"]:b["start"] + b["n"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -115,7 +124,10 @@ class FlatGradAllReduce:
     def _on_grad(self, p):
         b, view = self._where[id(p)]
         if b["handle"] is not None or id(p) in b["packed"]:
-            return                       # a second backward before sync(): handled by the pack in __call__
+            # a second backward before sync() (gradient accumulation): p.grad now holds MORE than what was packed / sent.
+            # The bucket is repacked from the accumulated p.grad and reduced again in __call__.
+            b["dirty"] = True
+            return
         view.copy_(p.grad)
         b["packed"].add(id(p))
         b["pending"] -= 1
@@ -127,6 +139,10 @@ class FlatGradAllReduce:
         if self.world <= 1:
             return
         for b in self.buckets:           # whatever the hooks did not launch (no hooks, unused parameters, ...)
+            if b["dirty"]:               # gradients accumulated after the bucket was packed: the in-flight result is stale
+                if b["handle"] is not None:
+                    b["handle"].wait()
+                b["handle"], b["packed"] = None, set()
             if b["handle"] is None:
                 for p, view in b["items"]:
                     if id(p) not in b["packed"]:

@@ -256,7 +256,12 @@ class BaseTask(ABC):
         self.logger.save_state("latest")
         metric = "val/" + self.config.training.eval_metric
         d = self.config.training.eval_metric_direction
-        if metric in scores and ((d == "min" and scores[metric] < self.best_score) or (d == "max" and scores[metric] > self.best_score)):
+        better = metric in scores and ((d == "min" and scores[metric] < self.best_score) or (d == "max" and scores[metric] > self.best_score))
+        if self.world_size > 1:
+            # save_state is a collective when the mapping layer is row-sharded (state_dict gathers the rows): every rank must take
+            # the same branch, so rank 0's comparison decides (each rank scores the validation split itself; 1 ulp would do)
+            better = parallel.broadcast_object(bool(better), src=0)
+        if better:
             self.best_score = scores[metric]
             if self.config.training.get("save_best", True):
                 self.logger.save_state("best")

@@ -166,3 +166,41 @@ def test_overlapped_bucketed_allreduce_two_steps():
         p_.join(120)
         assert p_.exitcode == 0
     assert dict(q.get(timeout=5) for _ in range(2)) == {0: True, 1: True}
+
+
+# ---- gradient accumulation: two backwards before one sync() (the hooks have already sent the first micro-batch's buckets)
+def _accum_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from med_ts_llm_amd import parallel
+    parallel.init_from_env("cpu")
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    ref.load_state_dict(model.state_dict())
+    sync = parallel.FlatGradAllReduce(model.parameters(), bucket_elems=16)
+    ok = True
+    for step in range(2):                       # two optimiser steps of two micro-batches each
+        for micro in range(2):
+            g = torch.Generator().manual_seed(100 + 10 * step + micro)
+            batch = {"x_enc": torch.randn(8, 6, generator=g), "y": torch.randn(8, 3, generator=g)}
+            shard = parallel.shard_batch(batch, rank, world)
+            torch.nn.functional.mse_loss(model(shard["x_enc"]), shard["y"]).backward()
+            torch.nn.functional.mse_loss(ref(batch["x_enc"]), batch["y"]).backward()        # accumulates over the two micro-batches
+        sync()
+        ok = ok and all(torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6) for a, b in zip(model.parameters(), ref.parameters()))
+        model.zero_grad(), ref.zero_grad()
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_gradient_accumulation_before_sync_is_not_dropped():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_accum_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    for p_ in procs:
+        p_.join(120)
+        assert p_.exitcode == 0
+    assert dict(q.get(timeout=5) for _ in range(2)) == {0: True, 1: True}

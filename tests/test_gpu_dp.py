@@ -106,12 +106,19 @@ def test_two_rank_dp_step_matches_single_process():
     assert abs(float(losses2[0]) - loss) < 2e-3 * abs(loss), (losses2, loss)
     assert abs(float(losses2[1]) - loss2) < 5e-3 * abs(loss2), (losses2, loss2)
     assert loss2 < loss
+    params = dict(model.named_parameters())
+    worst = {}
     for k, g1 in grads1.items():
         g1, g2 = g1.cpu().float(), torch.from_numpy(grads2[k])
-        err = float((g1 - g2).norm() / (g1.norm() + 1e-12))
-        # two half batches vs one full batch: bf16 rounding of different partial sums; cancellation-prone gradients get the loose bar
-        loose = k in ("reprogramming_layer.key_projection.bias", "reprogramming_layer.query_projection.bias", "mapping_layer.bias")
-        assert err < (0.5 if loose else 3e-2), (k, err)
+        # analytically-zero gradients (key bias: softmax shift invariance) are compared on an absolute scale
+        scale = max(float(g1.norm()), 1e-3 * float(params[k].detach().norm()) + 1e-6)
+        worst[k] = float((g1 - g2).norm()) / scale
+    print("\n2-rank DP vs single process, per-gradient relative difference:", {k: round(v, 5) for k, v in worst.items()})
+    for k, err in worst.items():
+        # two half batches vs one full batch: the bf16 roundings fall on different partial sums (a few 1e-3 on the large weights);
+        # gradients with few elements that are sums with cancellation (bias vectors) see that noise amplified
+        small = grads1[k].numel() < 4096
+        assert err < (1e-1 if small else 3e-2), (k, err)
     assert set(sd1) == set(sd2)
     for k in sd1:
         assert tuple(sd1[k].shape) == sd2[k], k

@@ -454,6 +454,26 @@ def test_hip_adam_matches_torch(ops, wd, decoupled):
 
 
 @pytest.mark.gpu
+def test_hip_adam_many_tensors_with_empty_ones(ops):
+    """more tensors than one kernel table holds (24), with zero-element parameters in between: every tensor gets exactly ONE
+    update per step (the table loop used to restart 24 entries after the previous table's FIRST tensor, so an empty tensor
+    inside a table made the tensors after it step twice)"""
+    from med_ts_llm_amd.hip.optim import HipAdam
+    g = torch.Generator().manual_seed(5)
+    shapes = [(7, 3)] * 10 + [(0,)] + [(5,)] * 12 + [(0, 4)] + [(9, 2)] * 9 + [(33,)] * 20
+    ref_p = [torch.randn(s, generator=g).cuda().requires_grad_() for s in shapes]
+    our_p = [p.detach().clone().requires_grad_() for p in ref_p]
+    ref, ours = torch.optim.Adam(ref_p, lr=1e-2), HipAdam(our_p, lr=1e-2)
+    for step in range(3):
+        for a, b in zip(ref_p, our_p):
+            gr = torch.randn(a.shape, generator=g).cuda()
+            a.grad, b.grad = gr.clone(), gr.clone()
+        ref.step(), ours.step()
+        for i, (a, b) in enumerate(zip(ref_p, our_p)):
+            torch.testing.assert_close(b, a, rtol=2e-6, atol=2e-7, msg=lambda m, i=i: f"tensor {i} {shapes[i]}: {m}")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,Nn,K,S", [(1024, 768, 64 * 32, 16), (200, 132, 64 * 8, 4), (128, 64, 64 * 6, 4)])
 def test_gemm_split_k_paths(ops, M, Nn, K, S):
     """split-K through the persistent work-item kernel (k-steps divisible by S) and through the classic one (not

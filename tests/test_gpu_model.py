@@ -151,13 +151,13 @@ def test_full_model_fwd_bwd(kind, task, B, L, C, pred, cov, down, prompt_on):
         e_hip = float((t.grad.cpu().float() - gref).norm()) / scale
         e_ref = float((p16[n].grad.detach().float() - gref).norm()) / scale
         print(f"   grad {n:55s} hip {e_hip:.3e}  reference-mixed {e_ref:.3e}")
-        # sums with heavy cancellation (|sum| ~ 1e-3 of the L1 mass: biases fed by sign-alternating gradients, the
-        # 1 x C feature-weighting, and the analytically-zero key bias) amplify ANY bf16-level perturbation of the
-        # incoming gradient by ~sqrt(N); measured on MI355X (tools/parity_cancellation_evidence.py) the deviation is the random projection of a
-        # 1e-2 norm-wise error, not a bias. They get a loose absolute bar; every large weight keeps the tight one.
-        loose = n.endswith("key_projection.bias") or n.startswith("feature_weighting") or n == "mapping_layer.bias" \
-            or n.endswith("query_projection.bias")
-        if e_hip > (max(0.5, 1.5 * e_ref) if loose else 1.5 * max(e_ref, 1e-2)):
+        # bar: 1.5 x the reference-mixed arithmetic's own error on this tensor (floor 1e-2). Gradients with few elements — bias
+        # vectors, the 1 x C feature weighting (sums with cancellation; the key bias is analytically zero and is scaled
+        # absolutely above) — are projections of the upstream noise onto a handful of directions: the ratio of two such error
+        # samples scatters, they get 3 x (tests/test_gpu_golden.py pins the same family exactly against the fp64 reduction of the
+        # HIP path's own upstream gradient, and bounds the scatter by an aggregate criterion).
+        small = t.numel() < 4096
+        if e_hip > (3.0 if small else 1.5) * max(e_ref, 1e-2):
             bad[n] = (e_hip, e_ref)
     assert not bad, bad
 

@@ -250,3 +250,35 @@ def test_optimisation_step_order_matches_reference_trajectory(tmp_path):
             moved = float(np.linalg.norm(z[k] - z["init." + name]))
             assert float((p[name].detach() - torch.from_numpy(z[k])).norm()) < 0.05 * moved + 1e-6, k
     assert trainer.step == int(z["step_counter"]) == 4 * 2 * n_batches   # BaseTask.step advances by batch_size per step (R:tasks/base.py:217)
+
+
+def test_backbone_config_options_that_change_numerics_are_rejected():
+    """a checkpoint whose config asks for arithmetic the kernels do not implement must not load silently (HF would apply it)"""
+    from med_ts_llm_amd.models.backbone import normalise_config
+    llama = {"model_type": "llama", "vocab_size": 512, "hidden_size": 128, "intermediate_size": 192, "num_hidden_layers": 2,
+             "num_attention_heads": 2, "num_key_value_heads": 2, "rms_norm_eps": 1e-5, "rope_theta": 10000.0}
+    gpt2 = {"model_type": "gpt2", "vocab_size": 512, "n_positions": 256, "n_embd": 128, "n_layer": 2, "n_head": 2}
+    assert normalise_config(llama)["rope_theta"] == 10000.0 and normalise_config(gpt2)["ffn"] == 512
+    assert normalise_config({**llama, "rope_scaling": None, "attention_bias": False, "mlp_bias": False, "hidden_act": "silu"})["arch"] == "llama"
+    for bad in ({"rope_scaling": {"rope_type": "llama3", "factor": 8.0}}, {"rope_scaling": {"type": "linear", "factor": 2.0}},
+                {"rope_parameters": {"rope_type": "llama3", "rope_theta": 500000.0, "factor": 8.0}},
+                {"attention_bias": True}, {"mlp_bias": True}, {"hidden_act": "gelu"}, {"attention_dropout": 0.1}):
+        with pytest.raises(NotImplementedError):
+            normalise_config({**llama, **bad})
+    for bad in ({"activation_function": "gelu"}, {"scale_attn_by_inverse_layer_idx": True}, {"reorder_and_upcast_attn": True},
+                {"scale_attn_weights": False}):
+        with pytest.raises(NotImplementedError):
+            normalise_config({**gpt2, **bad})
+
+
+def test_prompt_token_ids_are_range_checked_on_the_host():
+    """the assembly kernel gathers embedding rows by id and cannot raise: out-of-range ids (a '[PAD]' token beyond an un-resized
+    table, bad fixed_prompt_ids) are refused before the launch, like nn.Embedding's IndexError in the reference"""
+    model, meta, data = _model("gpt2_concat_fc")
+    model._check_ids([[0, 5, 511]])
+    for rows in ([[0, 512]], [[-1, 3]]):
+        with pytest.raises(IndexError):
+            model._check_ids(rows)
+    model.fixed_prompt_ids = torch.tensor([[1, 2, 9999]], dtype=torch.int32)
+    with pytest.raises(IndexError):
+        model._prompt_ids({"x_enc": torch.zeros(1, 64, 3)}, torch.device("cpu"))
