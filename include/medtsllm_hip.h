@@ -42,15 +42,17 @@ const char* mtl_strerror(int code);
  *   out      bf16; concat==0: [B*C, P, ld_out] (cols >= d_patch zero-filled up to ld_out)
  *                  concat==1: [B, P, ld_out]   (col = c*d_patch + o; cols >= C*d_patch zero-filled)
  *   mean, stdev  f32 [B, C]  (stdev = sqrt(biased var + eps), as RevIN stores them for the de-norm)
- * P = (L + stride - patch_len)/stride + 1 (== R:models/medtsllm.py:52 for the supported L). */
+ * P = (L + stride - patch_len)/stride + 1 (== R:models/medtsllm.py:52 for the supported L).
+ * drop_p > 0: PatchEmbedding's train-mode dropout (R:models/layers/embed.py:197) on the conv output, with the library's counter
+ * mask of (drop_seed, row of `out`, column of `out`); the backward takes the same pair and regenerates it. */
 int mtl_patch_tokenize_fwd(const float* x, const float* conv_w, void* out, float* mean, float* stdev,
                            int64_t B, int64_t L, int64_t C, int64_t patch_len, int64_t stride, int64_t d_patch,
-                           int64_t ld_out, int concat, float eps, void* stream);
+                           int64_t ld_out, int concat, float eps, float drop_p, uint32_t drop_seed, void* stream);
 /* dW of the token conv (x_enc needs no gradient; RevIN statistics are detached in the reference).
  *   dout  bf16, same layout as `out`;  partial f32 [B*C, d_patch*patch_len*3] workspace;  dw f32 [d_patch, patch_len, 3] */
 int mtl_patch_tokenize_bwd(const float* x, const float* mean, const float* stdev, const void* dout, float* partial,
                            float* dw, int64_t B, int64_t L, int64_t C, int64_t patch_len, int64_t stride,
-                           int64_t d_patch, int64_t ld_out, int concat, void* stream);
+                           int64_t d_patch, int64_t ld_out, int concat, float drop_p, uint32_t drop_seed, void* stream);
 /* int32 [P, patch_len] source-index map idx[p][j] = min(p*stride + j, L-1), produced by the SAME device
  * function the tokeniser uses (bit-exact parity target). */
 int mtl_patch_index_map(int32_t* idx, int64_t L, int64_t patch_len, int64_t stride, void* stream);

@@ -21,6 +21,12 @@
 namespace {
 
 constexpr int KC = 64;  // keys (or queries, in the dK/dV kernel) per LDS chunk
+#ifndef MTL_CONSISTENT_DELTA
+#define MTL_CONSISTENT_DELTA 0     // causal self-attention: 0 = delta = dO . O with the bf16-rounded forward output (measured: the consistent
+                                   // form changes nothing there — tools/diag_bias.py: the stack's input gradient is unbiased and on par
+                                   // with the reference's mixed mode — and costs two more MFMA groups); the reprogramming attention
+                                   // (unmasked, near-uniform probabilities over shared keys) always uses the consistent form
+#endif
 
 // reductions across the four 16-lane rows of a wave (lanes with equal lane & 15) without touching the LDS crossbar:
 // v_permlane16_swap / v_permlane32_swap exchange whole rows / halves in one VALU instruction (ds_bpermute costs an LDS
@@ -123,8 +129,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a
     const float c = a.scale * LOG2E;
     float m_run = NEG_BIG, l_run = 0.f;
     const uint32_t drop_thr = DROP ? drop_threshold(a.dropout_p) : 0u;
-    const float drop_scale = DROP ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
-    const uint32_t bh = (uint32_t)(b * a.Hq + h);
+    const float drop_scale = DROP ? drop_scale_of(drop_thr) : 1.0f;
+    const uint32_t dbase = DROP ? drop_base(a.dropout_seed, (uint32_t)(b * a.Hq + h)) : 0u;
 
     // causal: key visible to query q iff key <= q + causal_off (causal_off = Tk - Tq aligns the diagonal bottom-right)
     const int64_t coff = a.causal_off;
@@ -191,13 +197,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a
                 m_run = m_new;
             }
             l_run += psum;
-            if (DROP) {
+            if (DROP) {   // a lane's keys kb + t*16 + g*4 + {0,1,2,3} are two whole pairs: one mask word per pair
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const uint32_t key = (uint32_t)(kb + t * 16 + g * 4 + r);
-                        p[t][r] = drop_hash(a.dropout_seed, bh, (uint32_t)(qrow + coff), key) >= drop_thr ? p[t][r] * drop_scale : 0.f;   // absolute query index
+                    for (int r = 0; r < 4; r += 2) {
+                        const uint32_t w = drop_word(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4 + r) >> 1);   // absolute query index
+                        p[t][r] = (w & 0xffffu) >= drop_thr ? p[t][r] * drop_scale : 0.f;
+                        p[t][r + 1] = (w >> 16) >= drop_thr ? p[t][r + 1] * drop_scale : 0.f;
                     }
             }
             const bf16x8 pf = pack8(p[0], p[1]);
@@ -261,8 +268,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
     const float c = f.scale * LOG2E;
     const float lse2 = f.lse[stat_idx] * LOG2E;   // exp(s*scale - lse) == exp2(s*c - lse2)
     const uint32_t drop_thr = DROP ? drop_threshold(f.dropout_p) : 0u;
-    const float drop_scale = DROP ? 1.0f / (1.0f - f.dropout_p) : 1.0f;
-    const uint32_t bh = (uint32_t)(b * f.Hq + h);
+    const float drop_scale = DROP ? drop_scale_of(drop_thr) : 1.0f;
+    const uint32_t dbase = DROP ? drop_base(f.dropout_seed, (uint32_t)(b * f.Hq + h)) : 0u;
 
     f32x4 dq[NDT];
 #pragma unroll
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
     }
     const int64_t wave_qmax = ((q0 + 15 < f.Tq - 1) ? q0 + 15 : f.Tq - 1) + coff;
 
-    if (!CAUSAL) {
+    if (!CAUSAL || MTL_CONSISTENT_DELTA) {
         // CONSISTENT delta for the (unmasked) reprogramming attention: delta_q = sum_s p_qs * dP_qs from the very p and dP the main loop
         // uses, so that sum_s dS_qs = 0 holds to fp32 round-off, as it does in an unfused softmax backward. dO . O with the bf16-rounded
         // O is the same number only to ~2^-9, and with near-uniform probabilities over the vocabulary prototypes (keys that share a
@@ -303,12 +310,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
                         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kr + ks * 32), qf[ks], s, 0, 0, 0);
                         dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(vr + ks * 32), dof[ks], dp, 0, 0, 0);
                     }
+                    uint32_t dw[2] = {0u, 0u};      // mask words of the lane's two key pairs
+                    if (DROP) {
+                        dw[0] = drop_word(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4) >> 1);
+                        dw[1] = drop_word(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4 + 2) >> 1);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int64_t key = kb + t * 16 + g * 4 + r;
-                        const float p = key >= f.Tk ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse2);
+                        const float p = (key >= f.Tk || (CAUSAL && key > qrow + coff)) ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse2);
                         float dpv = dp[r];
-                        if (DROP) dpv = drop_hash(f.dropout_seed, bh, (uint32_t)(qrow + coff), (uint32_t)key) >= drop_thr ? dpv * drop_scale : 0.f;
+                        if (DROP) dpv = drop_field(dw[r >> 1], (uint32_t)r) >= drop_thr ? dpv * drop_scale : 0.f;
                         acc += p * dpv;
                     }
                 }
@@ -339,13 +351,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
                     s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kr + ks * 32), qf[ks], s, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(vr + ks * 32), dof[ks], dp, 0, 0, 0);
                 }
+                uint32_t dw[2] = {0u, 0u};      // mask words of the lane's two key pairs
+                if (DROP) {
+                    dw[0] = drop_word(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4) >> 1);
+                    dw[1] = drop_word(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4 + 2) >> 1);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t key = kb + t * 16 + g * 4 + r;
                     const bool masked = key >= f.Tk || (CAUSAL && key > qrow + coff);
                     const float p = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse2);
                     float dpv = dp[r];
-                    if (DROP) dpv = drop_hash(f.dropout_seed, bh, (uint32_t)(qrow + coff), (uint32_t)key) >= drop_thr ? dpv * drop_scale : 0.f;
+                    if (DROP) dpv = drop_field(dw[r >> 1], (uint32_t)r) >= drop_thr ? dpv * drop_scale : 0.f;
                     ds[t][r] = p * (dpv - dl);
                 }
             }
@@ -394,7 +411,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const mtl_attn_bwd_ar
 
     const float c = f.scale * LOG2E;
     const uint32_t drop_thr = DROP ? drop_threshold(f.dropout_p) : 0u;
-    const float drop_scale = DROP ? 1.0f / (1.0f - f.dropout_p) : 1.0f;
+    const float drop_scale = DROP ? drop_scale_of(drop_thr) : 1.0f;
     f32x4 dk[NDT], dv[NDT];
 #pragma unroll
     for (int i = 0; i < NDT; ++i) {
@@ -413,6 +430,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const mtl_attn_bwd_ar
         }
         for (int hg = 0; hg < group; ++hg) {
             const int64_t h = hk * group + hg;
+            const uint32_t dbase_h = DROP ? drop_base(f.dropout_seed, (uint32_t)(b * f.Hq + h)) : 0u;
             const bf16_t* Q = reinterpret_cast<const bf16_t*>(f.q) + b * f.q_bs + h * f.q_hs;
             const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dout) + b * a.do_bs + h * a.do_hs;
             const int64_t stat0 = (b * f.Hq + h) * (f.stat_stride ? f.stat_stride : f.Tq);
@@ -452,7 +470,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const mtl_attn_bwd_ar
                             const bool masked = q >= f.Tq || (CAUSAL && krow > q + coff);
                             const float pv = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse_s[ql]);
                             float keep = 1.0f;
-                            if (DROP) keep = drop_hash(f.dropout_seed, (uint32_t)(b * f.Hq + h), (uint32_t)(q + coff), (uint32_t)krow) >= drop_thr ? drop_scale : 0.f;
+                            if (DROP) keep = drop_keep(dbase_h, (uint32_t)(q + coff), (uint32_t)krow, drop_thr) ? drop_scale : 0.f;
                             p[t][r] = pv * keep;                               // feeds dV = (dropped P)^T dO
                             ds[t][r] = pv * (dp[r] * keep - delta_s[ql]);      // feeds dK
                         }
@@ -567,9 +585,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fw
     load_rows_pair<D, NW * 64, 4>(ktile, reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + hk * a.k_hs, a.k_ts,
                                   vtile, reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + hk * a.v_hs, a.v_ts, a.Tk);
     __syncthreads();
-    const uint32_t bh = (uint32_t)(b * a.Hq + h);
+    const uint32_t dbase = DROP ? drop_base(a.dropout_seed, (uint32_t)(b * a.Hq + h)) : 0u;
     const uint32_t drop_thr = DROP ? drop_threshold(a.dropout_p) : 0u;
-    const float drop_scale = DROP ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
+    const float drop_scale = DROP ? drop_scale_of(drop_thr) : 1.0f;
     const float c = a.scale * LOG2E;
     const int64_t coff = a.causal_off;
     const int nt = (int)((a.Tq + 15) / 16), npairs = (nt + 1) / 2;
@@ -637,12 +655,15 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fw
                 m_run = m_new;
             }
             l_run += psum;
-            if (DROP) {   // attn_pdrop: the normaliser keeps the undropped sum, the P.V operand carries the mask
+            if (DROP) {   // attn_pdrop: the normaliser keeps the undropped sum, the P.V operand carries the mask (one word per key pair)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        p[t][r] = drop_hash(a.dropout_seed, bh, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4 + r)) >= drop_thr ? p[t][r] * drop_scale : 0.f;
+                    for (int r = 0; r < 4; r += 2) {
+                        const uint32_t w = drop_word(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4 + r) >> 1);
+                        p[t][r] = (w & 0xffffu) >= drop_thr ? p[t][r] * drop_scale : 0.f;
+                        p[t][r + 1] = (w >> 16) >= drop_thr ? p[t][r + 1] * drop_scale : 0.f;
+                    }
             }
             const bf16x8 pf = pack8(p[0], p[1]);
             const int ra = (int)(kb + g * 4), rb = (int)(kb + 16 + g * 4);   // rows >= Tk are zero-filled and carry p == 0
@@ -681,9 +702,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn
     load_rows_pair<D, NW * 64, 4>(ktile, reinterpret_cast<const bf16_t*>(f.k) + b * f.k_bs + hk * f.k_hs, f.k_ts,
                                   vtile, reinterpret_cast<const bf16_t*>(f.v) + b * f.v_bs + hk * f.v_hs, f.v_ts, f.Tk);
     __syncthreads();
-    const uint32_t bh = (uint32_t)(b * f.Hq + h);
+    const uint32_t dbase = DROP ? drop_base(f.dropout_seed, (uint32_t)(b * f.Hq + h)) : 0u;
     const uint32_t drop_thr = DROP ? drop_threshold(f.dropout_p) : 0u;
-    const float drop_scale = DROP ? 1.0f / (1.0f - f.dropout_p) : 1.0f;
+    const float drop_scale = DROP ? drop_scale_of(drop_thr) : 1.0f;
     const float c = f.scale * LOG2E;
     const int64_t coff = f.causal_off;
     const int nt = (int)((f.Tq + 15) / 16), npairs = (nt + 1) / 2;
@@ -713,13 +734,46 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn
         }
         dl = rows_sum(dl);
         const int64_t stat_idx = (b * f.Hq + h) * (f.stat_stride ? f.stat_stride : f.Tq) + qrow;
-        if (g == 0 && q_valid) a.delta[stat_idx] = dl;
         const float lse2 = f.lse[stat_idx] * LOG2E;
         f32x4 dq[NDT];
 #pragma unroll
         for (int i = 0; i < NDT; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int64_t wave_qmax = ((q0 + 15 < f.Tq - 1) ? q0 + 15 : f.Tq - 1) + coff;
         const int64_t k_end = (wave_qmax + 1 < f.Tk) ? wave_qmax + 1 : f.Tk;
+        if (MTL_CONSISTENT_DELTA) {
+            // delta_q = sum_s p_qs * dP_qs from the very p and dP of the main loop (see attn_bwd_dq_kernel): sum_s dS_qs = 0 to fp32
+            // round-off. K and V are already resident in LDS, so the extra pass costs S and dP MFMAs only.
+            float acc = 0.f;
+            for (int64_t kb = 0; kb < k_end; kb += 32) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    const bf16_t* kr = ktile + (kb + t * 16 + l15) * LDT + g * 8;
+                    const bf16_t* vr = vtile + (kb + t * 16 + l15) * LDT + g * 8;
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kr + ks * 32), qf[ks], s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(vr + ks * 32), dof[ks], dp, 0, 0, 0);
+                    }
+                    uint32_t dw[2] = {0u, 0u};
+                    if (DROP) {
+                        dw[0] = drop_word(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4) >> 1);
+                        dw[1] = drop_word(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4 + 2) >> 1);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t key = kb + t * 16 + g * 4 + r;
+                        const bool masked = key >= f.Tk || key > qrow + coff;
+                        const float pv = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse2);
+                        float dpv = dp[r];
+                        if (DROP) dpv = drop_field(dw[r >> 1], (uint32_t)r) >= drop_thr ? dpv * drop_scale : 0.f;
+                        acc += pv * dpv;
+                    }
+                }
+            }
+            dl = rows_sum(acc);
+        }
+        if (g == 0 && q_valid) a.delta[stat_idx] = dl;
         for (int64_t kb = 0; kb < k_end; kb += 32) {
             float ds[2][4];
 #pragma unroll
@@ -732,13 +786,18 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn
                     s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kr + ks * 32), qf[ks], s, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(vr + ks * 32), dof[ks], dp, 0, 0, 0);
                 }
+                uint32_t dw[2] = {0u, 0u};      // mask words of the lane's two key pairs
+                if (DROP) {
+                    dw[0] = drop_word(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4) >> 1);
+                    dw[1] = drop_word(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4 + 2) >> 1);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t key = kb + t * 16 + g * 4 + r;
                     const bool masked = key >= f.Tk || key > qrow + coff;
                     const float pv = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse2);
                     float dpv = dp[r];
-                    if (DROP) dpv = drop_hash(f.dropout_seed, bh, (uint32_t)(qrow + coff), (uint32_t)key) >= drop_thr ? dpv * drop_scale : 0.f;
+                    if (DROP) dpv = drop_field(dw[r >> 1], (uint32_t)r) >= drop_thr ? dpv * drop_scale : 0.f;
                     ds[t][r] = pv * (dpv - dl);
                 }
             }
@@ -775,7 +834,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(const mtl_att
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
     const int64_t b = blockIdx.z, hk = blockIdx.y;
     const uint32_t drop_thr = DROP ? drop_threshold(f.dropout_p) : 0u;
-    const float drop_scale = DROP ? 1.0f / (1.0f - f.dropout_p) : 1.0f;
+    const float drop_scale = DROP ? drop_scale_of(drop_thr) : 1.0f;
     const int group = (int)(f.Hq / f.Hkv);
     const float c = f.scale * LOG2E;
     const int64_t coff = f.causal_off;
@@ -807,6 +866,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(const mtl_att
         }
 #pragma unroll 1
         for (int hg = 0; hg < group; ++hg) {
+            const uint32_t dbase_h = DROP ? drop_base(f.dropout_seed, (uint32_t)(b * f.Hq + hk * group + hg)) : 0u;
             if (half == 0 || group > 1) {
                 const int64_t h = hk * group + hg;
                 const int64_t stat0 = (b * f.Hq + h) * (f.stat_stride ? f.stat_stride : f.Tq);
@@ -840,7 +900,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(const mtl_att
                         const bool masked = q >= f.Tq || krow > q + coff;
                         const float pv = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse_s[q]);
                         float keep = 1.0f;
-                        if (DROP) keep = drop_hash(f.dropout_seed, (uint32_t)(b * f.Hq + hk * group + hg), (uint32_t)(q + coff), (uint32_t)krow) >= drop_thr ? drop_scale : 0.f;
+                        if (DROP) keep = drop_keep(dbase_h, (uint32_t)(q + coff), (uint32_t)krow, drop_thr) ? drop_scale : 0.f;
                         p[t][r] = pv * keep;                               // feeds dV = (dropped P)^T dO
                         ds[t][r] = pv * (dp[r] * keep - delta_s[q]);       // feeds dK
                     }

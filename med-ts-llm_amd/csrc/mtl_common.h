@@ -59,16 +59,36 @@ __device__ __forceinline__ float dgelu_new_f(float x) {
     return s + x * s * (1.0f - s) * (2.0f * k0 * (1.0f + 3.0f * k1 * x2));
 }
 
-// dropout: counter-based keep mask, a pure function of (seed, a, b, c) so that a backward kernel regenerates exactly the
-// forward's mask; tests replicate the hash on the host. Attention: (seed, batch*head, query, key); matrices: (seed, 0, row, col).
-__device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint32_t bh, uint32_t q, uint32_t key) {
-    uint32_t h = seed ^ (bh * 0x9E3779B1u);
-    h = (h ^ (q * 0x85EBCA77u)) * 0xC2B2AE3Du;
-    h = (h ^ (h >> 15) ^ (key * 0x27D4EB2Fu)) * 0x165667B1u;
-    h ^= h >> 13; h *= 0x85EBCA6Bu; h ^= h >> 16;
+// dropout: counter-based keep mask, a pure function of (seed, stream, a, b) so that a backward kernel regenerates exactly the
+// forward's mask; tests replicate it on the host (tests/helpers.py). Attention: stream = batch*head, (a, b) = (query, key);
+// matrices: stream = 0, (a, b) = (row, column).
+// Cost matters: the mask is evaluated for every attention probability in four kernels per layer. One WORD carries the decisions of
+// the element PAIR (a, 2*pair) / (a, 2*pair + 1) as two uniform 16-bit fields, and the per-element mixing uses only full-rate
+// 24-bit multiply-adds (v_mad_u32_u24) — 32-bit integer multiplies are quarter rate on CDNA: 13 VALU issue slots per pair instead
+// of ~30 per element for the murmur-style hash this replaces (attention forward 23.8 -> see profiles/r02_dropout_hash_ab.txt).
+// A keep threshold is a 16-bit number: the effective rate is thr / 65536 (p = 0.1 -> 0.09999), and the kept values are scaled by
+// the EXACT 1 / (1 - thr / 65536), so the mask is unbiased. a, pair < 2^24 (beyond that the pattern repeats).
+__host__ __device__ __forceinline__ uint32_t drop_base(uint32_t seed, uint32_t stream) {   // wave-uniform: scalar unit, once per kernel
+    uint32_t a = seed ^ (stream * 0x9E3779B1u);
+    a ^= a >> 16; a *= 0x85EBCA6Bu; a ^= a >> 13; a *= 0xC2B2AE35u; a ^= a >> 16;
+    return a;
+}
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }
+__device__ __forceinline__ uint32_t drop_word(uint32_t base, uint32_t a, uint32_t pair) {
+    uint32_t h = mad24(a, 0x9E3779u, base) ^ __umul24(pair, 0x85EBCBu);
+    h ^= h >> 15; h = mad24(h, 0xC2B2AFu, h >> 24);
+    h ^= h >> 13; h = mad24(h, 0x27D4EBu, h >> 24);
+    h ^= h >> 16;
     return h;
 }
-__host__ __device__ __forceinline__ uint32_t drop_threshold(float p) { return (uint32_t)fminf(p * 4294967296.0f, 4294967040.0f); }
+// the 16-bit field of element b (its pair's word given): keep iff field >= threshold
+__device__ __forceinline__ uint32_t drop_field(uint32_t word, uint32_t b) { return (b & 1u) ? word >> 16 : word & 0xffffu; }
+__device__ __forceinline__ bool drop_keep(uint32_t base, uint32_t a, uint32_t b, uint32_t thr) { return drop_field(drop_word(base, a, b >> 1), b) >= thr; }
+__host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
+    const float t = p * 65536.0f;
+    return t >= 65535.0f ? 65535u : (t <= 0.f ? 0u : (uint32_t)t);
+}
+__host__ __device__ __forceinline__ float drop_scale_of(uint32_t thr) { return 65536.0f / (float)(65536u - thr); }
 // seed of layer i's k-th dropout site (k = 0 attention probabilities, 1 attention-branch residual, 2 MLP-branch residual)
 __host__ __device__ __forceinline__ uint32_t drop_site_seed(uint32_t seed, int layer, int k) {
     return seed ^ (0x9E3779B9u * (uint32_t)(3 * layer + k + 1));

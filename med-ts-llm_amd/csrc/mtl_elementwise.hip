@@ -362,10 +362,10 @@ __global__ __launch_bounds__(256) void dropout_f32_kernel(const float* x, float*
         const int64_t row = i / (d / 4);
         const int c = (int)(i - row * (d / 4)) * 4;
         float4 v = *reinterpret_cast<const float4*>(x + row * d + c);
-        v.x = drop_hash(seed, 0u, (uint32_t)row, (uint32_t)c) >= thr ? v.x * scale : 0.f;
-        v.y = drop_hash(seed, 0u, (uint32_t)row, (uint32_t)(c + 1)) >= thr ? v.y * scale : 0.f;
-        v.z = drop_hash(seed, 0u, (uint32_t)row, (uint32_t)(c + 2)) >= thr ? v.z * scale : 0.f;
-        v.w = drop_hash(seed, 0u, (uint32_t)row, (uint32_t)(c + 3)) >= thr ? v.w * scale : 0.f;
+        const uint32_t dbase = drop_base(seed, 0u);
+        const uint32_t w0 = drop_word(dbase, (uint32_t)row, (uint32_t)c >> 1), w1 = drop_word(dbase, (uint32_t)row, ((uint32_t)c >> 1) + 1u);
+        v.x = (w0 & 0xffffu) >= thr ? v.x * scale : 0.f; v.y = (w0 >> 16) >= thr ? v.y * scale : 0.f;
+        v.z = (w1 & 0xffffu) >= thr ? v.z * scale : 0.f; v.w = (w1 >> 16) >= thr ? v.w * scale : 0.f;
         *reinterpret_cast<float4*>(y + row * d + c) = v;
     }
 }
@@ -377,7 +377,7 @@ extern "C" int mtl_dropout_f32(const float* x, float* y, int64_t M, int64_t d, f
     const int64_t nq = M * (d / 4);
     const unsigned blocks = (unsigned)((nq + 255) / 256 < 8192 ? (nq + 255) / 256 : 8192);
     hipLaunchKernelGGL(dropout_f32_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y, M, (int)d,
-                       drop_threshold(p), 1.0f / (1.0f - p), seed);
+                       drop_threshold(p), drop_scale_of(drop_threshold(p)), seed);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }

@@ -83,10 +83,10 @@ __device__ __forceinline__ void epilogue4(const mtl_gemm_args& p, int64_t m, int
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = bf16_to_f32(f32_to_bf16(o[e]));
         if (p.drop_p > 0.f) {   // resid_pdrop: same (seed, physical row, column) hash as epilogue_wave
-            const uint32_t thr = drop_threshold(p.drop_p);
-            const float sc = 1.0f / (1.0f - p.drop_p);
+            const uint32_t thr = drop_threshold(p.drop_p), dbase = drop_base(p.drop_seed, 0u);
+            const float sc = drop_scale_of(thr);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = drop_hash(p.drop_seed, 0u, (uint32_t)crow, (uint32_t)(n + e)) >= thr ? o[e] * sc : 0.f;
+            for (int e = 0; e < 4; ++e) o[e] = drop_keep(dbase, (uint32_t)crow, (uint32_t)(n + e), thr) ? o[e] * sc : 0.f;
         }
         if (vec_ok) {
             const float4 r4 = *reinterpret_cast<const float4*>(r);
@@ -243,10 +243,12 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
                 float v[4] = {__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u), __uint_as_float(pk[1] << 16),
                               __uint_as_float(pk[1] & 0xffff0000u)};
                 if (p.drop_p > 0.f) {                                                      // resid_pdrop (uniform branch)
-                    const uint32_t thr = drop_threshold(p.drop_p);
-                    const float sc = 1.0f / (1.0f - p.drop_p);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = drop_hash(p.drop_seed, 0u, (uint32_t)crow[mi], (uint32_t)(n + e)) >= thr ? v[e] * sc : 0.f;
+                    // the lane's 4 columns n .. n+3 (n % 4 == 0) are two whole pairs: one mask word each
+                    const uint32_t thr = drop_threshold(p.drop_p), dbase = drop_base(p.drop_seed, 0u);
+                    const float sc = drop_scale_of(thr);
+                    const uint32_t w0 = drop_word(dbase, (uint32_t)crow[mi], (uint32_t)n >> 1), w1 = drop_word(dbase, (uint32_t)crow[mi], ((uint32_t)n >> 1) + 1u);
+                    v[0] = (w0 & 0xffffu) >= thr ? v[0] * sc : 0.f; v[1] = (w0 >> 16) >= thr ? v[1] * sc : 0.f;
+                    v[2] = (w1 & 0xffffu) >= thr ? v[2] * sc : 0.f; v[3] = (w1 >> 16) >= thr ? v[3] * sc : 0.f;
                 }
                 o[0] = res[ni][mi].x + v[0]; o[1] = res[ni][mi].y + v[1]; o[2] = res[ni][mi].z + v[2]; o[3] = res[ni][mi].w + v[3];
             } else if constexpr (EPI == MTL_EPI_DGELU) {

@@ -127,12 +127,11 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict_
             *reinterpret_cast<float4*>(dres_out + prow * (int64_t)d + c) = o;
             if (dres_out_bf16) {
                 if (drop_p > 0.f) {   // gradient entering a residual branch whose forward output was dropped with this mask
-                    const uint32_t thr = drop_threshold(drop_p);
-                    const float sc = 1.0f / (1.0f - drop_p);
-                    o.x = drop_hash(drop_seed, 0u, (uint32_t)prow, (uint32_t)c) >= thr ? o.x * sc : 0.f;
-                    o.y = drop_hash(drop_seed, 0u, (uint32_t)prow, (uint32_t)(c + 1)) >= thr ? o.y * sc : 0.f;
-                    o.z = drop_hash(drop_seed, 0u, (uint32_t)prow, (uint32_t)(c + 2)) >= thr ? o.z * sc : 0.f;
-                    o.w = drop_hash(drop_seed, 0u, (uint32_t)prow, (uint32_t)(c + 3)) >= thr ? o.w * sc : 0.f;
+                    const uint32_t thr = drop_threshold(drop_p), dbase = drop_base(drop_seed, 0u);
+                    const float sc = drop_scale_of(thr);
+                    const uint32_t w0 = drop_word(dbase, (uint32_t)prow, (uint32_t)c >> 1), w1 = drop_word(dbase, (uint32_t)prow, ((uint32_t)c >> 1) + 1u);   // c % 4 == 0
+                    o.x = (w0 & 0xffffu) >= thr ? o.x * sc : 0.f; o.y = (w0 >> 16) >= thr ? o.y * sc : 0.f;
+                    o.z = (w1 & 0xffffu) >= thr ? o.z * sc : 0.f; o.w = (w1 >> 16) >= thr ? o.w * sc : 0.f;
                 }
                 u32x2 pk = {pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w)};
                 *reinterpret_cast<u32x2*>(dres_out_bf16 + prow * (int64_t)d + c) = pk;

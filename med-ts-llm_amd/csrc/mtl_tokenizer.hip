@@ -32,7 +32,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 __global__ __launch_bounds__(256) void tokenize_fwd_kernel(const float* __restrict__ x, const float* __restrict__ conv_w,
                                                            bf16_t* __restrict__ out, float* __restrict__ mean_out,
                                                            float* __restrict__ stdev_out, int L, int C, int patch_len, int stride,
-                                                           int d_patch, int P, int64_t ld_out, int concat, float eps) {
+                                                           int d_patch, int P, int64_t ld_out, int concat, float eps, uint32_t drop_thr, uint32_t drop_seed) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xn = lds;
     float* w = lds + L;
@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void tokenize_fwd_kernel(const float* __restri
             const float* wk = w + o * patch_len * 3 + k;
             for (int j = 0; j < patch_len; ++j) acc += wk[j * 3] * xn[patch_src_index(pp, j, L, stride)];
         }
+        if (drop_thr) acc = drop_keep(drop_base(drop_seed, 0u), (uint32_t)(row0 + p), (uint32_t)(col0 + o), drop_thr) ? acc * drop_scale_of(drop_thr) : 0.f;
         out[(row0 + p) * ld_out + col0 + o] = f32_to_bf16(acc);
     }
     // zero the K-padding columns of this series' rows (GEMM operands are padded to K % 64 == 0)
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void tokenize_fwd_kernel(const float* __restri
 __global__ __launch_bounds__(256) void tokenize_fwd_fast_kernel(const float* __restrict__ x, const float* __restrict__ conv_w,
                                                                 bf16_t* __restrict__ out, float* __restrict__ mean_out,
                                                                 float* __restrict__ stdev_out, int L, int C, int stride, int d_patch,
-                                                                int P, int64_t ld_out, int concat, float eps) {
+                                                                int P, int64_t ld_out, int concat, float eps, uint32_t drop_thr, uint32_t drop_seed) {
     constexpr int PL = 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xp = lds;
@@ -144,6 +145,8 @@ __global__ __launch_bounds__(256) void tokenize_fwd_fast_kernel(const float* __r
                 acc += w[k][j4 * 4] * v.x + w[k][j4 * 4 + 1] * v.y + w[k][j4 * 4 + 2] * v.z + w[k][j4 * 4 + 3] * v.w;
             }
         }
+        // PatchEmbedding's dropout (R:models/layers/embed.py:197), mask indexed by the element's position in `out`
+        if (drop_thr) acc = drop_keep(drop_base(drop_seed, 0u), (uint32_t)(row0 + p), (uint32_t)(col0 + o), drop_thr) ? acc * drop_scale_of(drop_thr) : 0.f;
         out[(row0 + p) * ld_out + col0 + o] = f32_to_bf16(acc);
     }
     const int used = concat ? C * d_patch : d_patch;
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void tokenize_fwd_fast_kernel(const float* __r
 __global__ __launch_bounds__(256) void tokenize_bwd_kernel(const float* __restrict__ x, const float* __restrict__ mean_in,
                                                            const float* __restrict__ stdev_in, const bf16_t* __restrict__ dout,
                                                            float* __restrict__ partial, int L, int C, int patch_len, int stride,
-                                                           int d_patch, int P, int64_t ld_out, int concat) {
+                                                           int d_patch, int P, int64_t ld_out, int concat, uint32_t drop_thr, uint32_t drop_seed) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xn = lds;
     const int bc = blockIdx.x, b = bc / C, c = bc % C;
@@ -169,7 +172,11 @@ __global__ __launch_bounds__(256) void tokenize_bwd_kernel(const float* __restri
     float* dt = lds + L;
     const int64_t row0 = concat ? (int64_t)b * P : (int64_t)bc * P;
     const int col0 = concat ? c * d_patch : 0;
-    for (int e = tid; e < P * d_patch; e += 256) dt[e] = bf16_to_f32(dout[(row0 + e / d_patch) * ld_out + col0 + e % d_patch]);
+    for (int e = tid; e < P * d_patch; e += 256) {
+        float v = bf16_to_f32(dout[(row0 + e / d_patch) * ld_out + col0 + e % d_patch]);
+        if (drop_thr) v = drop_keep(drop_base(drop_seed, 0u), (uint32_t)(row0 + e / d_patch), (uint32_t)(col0 + e % d_patch), drop_thr) ? v * drop_scale_of(drop_thr) : 0.f;
+        dt[e] = v;      // gradient through the forward's dropout mask
+    }
     __syncthreads();
     const int nw = d_patch * patch_len * 3;
     // consecutive threads -> consecutive output channels o (conflict-free dt reads, broadcast xn reads)
@@ -212,16 +219,18 @@ extern "C" int mtl_patch_index_map(int32_t* idx, int64_t L, int64_t patch_len, i
 
 extern "C" int mtl_patch_tokenize_fwd(const float* x, const float* conv_w, void* out, float* mean, float* stdev, int64_t B, int64_t L,
                                       int64_t C, int64_t patch_len, int64_t stride, int64_t d_patch, int64_t ld_out, int concat,
-                                      float eps, void* stream) {
+                                      float eps, float drop_p, uint32_t drop_seed, void* stream) {
     if (!x || !conv_w || !out || !mean || !stdev || B <= 0 || C <= 0 || L < patch_len || patch_len <= 0 || stride <= 0 || d_patch <= 0)
         return MTL_ERR_ARG;
+    if (drop_p < 0.f || drop_p >= 1.f) return MTL_ERR_ARG;
+    const uint32_t drop_thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
     const int P = (int)((L + stride - patch_len) / stride + 1);
     if (ld_out < (concat ? C * d_patch : d_patch)) return MTL_ERR_ARG;
     if (patch_len == 16 && stride % 4 == 0 && d_patch <= 256 && 256 % d_patch == 0) {
         const size_t fast_bytes = (size_t)(((L + stride + 3) & ~3) + 4) * sizeof(float);
         if (fast_bytes <= 64 * 1024) {
             hipLaunchKernelGGL(tokenize_fwd_fast_kernel, dim3((unsigned)(B * C)), dim3(256), fast_bytes, (hipStream_t)stream, x, conv_w,
-                               (bf16_t*)out, mean, stdev, (int)L, (int)C, (int)stride, (int)d_patch, P, ld_out, concat, eps);
+                               (bf16_t*)out, mean, stdev, (int)L, (int)C, (int)stride, (int)d_patch, P, ld_out, concat, eps, drop_thr, drop_seed);
             MTL_CHECK_LAUNCH();
             return MTL_OK;
         }
@@ -229,21 +238,23 @@ extern "C" int mtl_patch_tokenize_fwd(const float* x, const float* conv_w, void*
     const size_t lds_bytes = (size_t)(L + d_patch * patch_len * 3 + 4) * sizeof(float);
     if (lds_bytes > 64 * 1024) return MTL_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(tokenize_fwd_kernel, dim3((unsigned)(B * C)), dim3(256), lds_bytes, (hipStream_t)stream, x, conv_w, (bf16_t*)out,
-                       mean, stdev, (int)L, (int)C, (int)patch_len, (int)stride, (int)d_patch, P, ld_out, concat, eps);
+                       mean, stdev, (int)L, (int)C, (int)patch_len, (int)stride, (int)d_patch, P, ld_out, concat, eps, drop_thr, drop_seed);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
 
 extern "C" int mtl_patch_tokenize_bwd(const float* x, const float* mean, const float* stdev, const void* dout, float* partial, float* dw,
                                       int64_t B, int64_t L, int64_t C, int64_t patch_len, int64_t stride, int64_t d_patch,
-                                      int64_t ld_out, int concat, void* stream) {
+                                      int64_t ld_out, int concat, float drop_p, uint32_t drop_seed, void* stream) {
     if (!x || !mean || !stdev || !dout || !partial || !dw || B <= 0 || C <= 0 || L < patch_len) return MTL_ERR_ARG;
+    if (drop_p < 0.f || drop_p >= 1.f) return MTL_ERR_ARG;
+    const uint32_t drop_thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
     const int P = (int)((L + stride - patch_len) / stride + 1);
     const size_t lds_bytes = (size_t)(L + P * d_patch) * sizeof(float);
     if (lds_bytes > 64 * 1024) return MTL_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(tokenize_bwd_kernel, dim3((unsigned)(B * C)), dim3(256), lds_bytes, st, x, mean, stdev, (const bf16_t*)dout, partial,
-                       (int)L, (int)C, (int)patch_len, (int)stride, (int)d_patch, P, ld_out, concat);
+                       (int)L, (int)C, (int)patch_len, (int)stride, (int)d_patch, P, ld_out, concat, drop_thr, drop_seed);
     const int nw = (int)(d_patch * patch_len * 3);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((nw + 63) / 64), dim3(256), 0, st, partial, dw, (int)(B * C), nw);
     MTL_CHECK_LAUNCH();

@@ -85,8 +85,8 @@ class BackboneWeights(C.Structure):
 SIGNATURES = {
     "mtl_abi_version": (i32, []),
     "mtl_strerror": (C.c_char_p, [i32]),
-    "mtl_patch_tokenize_fwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, f32, vp]),
-    "mtl_patch_tokenize_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, vp]),
+    "mtl_patch_tokenize_fwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, f32, f32, C.c_uint32, vp]),
+    "mtl_patch_tokenize_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, f32, C.c_uint32, vp]),
     "mtl_patch_index_map": (i32, [vp, i64, i64, i64, vp]),
     "mtl_revin_denorm": (i32, [vp, vp, vp, vp, i64, i64, i64, vp]),
     "mtl_gemm_workspace_bytes": (C.c_size_t, [i64, i64, i32]),

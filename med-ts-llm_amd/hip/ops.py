@@ -145,7 +145,7 @@ def patch_index_map(L, patch_len, stride, device):
     return idx
 
 
-def patch_tokenize_fwd(x, conv_w, patch_len, stride, concat, eps=1e-5):
+def patch_tokenize_fwd(x, conv_w, patch_len, stride, concat, eps=1e-5, drop=(0.0, 0)):
     B, L, Cc = x.shape
     d_patch = conv_w.shape[0]
     P = (L + stride - patch_len) // stride + 1
@@ -156,18 +156,18 @@ def patch_tokenize_fwd(x, conv_w, patch_len, stride, concat, eps=1e-5):
     mean = torch.empty((B, Cc), dtype=F32, device=x.device)
     stdev = torch.empty((B, Cc), dtype=F32, device=x.device)
     check(lib().mtl_patch_tokenize_fwd(ptr(x), ptr(conv_w), ptr(out), ptr(mean), ptr(stdev), B, L, Cc, patch_len, stride,
-                                       d_patch, ld, 1 if concat else 0, eps, stream()), "mtl_patch_tokenize_fwd")
+                                       d_patch, ld, 1 if concat else 0, eps, float(drop[0]), int(drop[1]) & 0xFFFFFFFF, stream()), "mtl_patch_tokenize_fwd")
     return out, mean, stdev
 
 
-def patch_tokenize_bwd(x, mean, stdev, dout, conv_w_shape, patch_len, stride, concat):
+def patch_tokenize_bwd(x, mean, stdev, dout, conv_w_shape, patch_len, stride, concat, drop=(0.0, 0)):
     B, L, Cc = x.shape
     d_patch = conv_w_shape[0]
     nw = d_patch * patch_len * 3
     partial = torch.empty((B * Cc, nw), dtype=F32, device=x.device)
     dw = torch.empty(conv_w_shape, dtype=F32, device=x.device)
     check(lib().mtl_patch_tokenize_bwd(ptr(x), ptr(mean), ptr(stdev), ptr(dout), ptr(partial), ptr(dw), B, L, Cc, patch_len,
-                                       stride, d_patch, dout.shape[-1], 1 if concat else 0, stream()), "mtl_patch_tokenize_bwd")
+                                       stride, d_patch, dout.shape[-1], 1 if concat else 0, float(drop[0]), int(drop[1]) & 0xFFFFFFFF, stream()), "mtl_patch_tokenize_bwd")
     return dw
 
 
@@ -296,21 +296,22 @@ class PatchTokenizeFn(torch.autograd.Function):
     """(x_enc f32 [B,L,C], conv_w) -> (tokens bf16 [B or B*C, P, K64], mean [B,C], stdev [B,C]).  a1-a4."""
 
     @staticmethod
-    def forward(ctx, x, conv_w, patch_len, stride, concat):
+    def forward(ctx, x, conv_w, patch_len, stride, concat, drop_p=0.0, drop_seed=0):
+        """drop_p > 0: PatchEmbedding's train-mode dropout fused into the kernel (counter mask of (seed, row, column))"""
         x = x.contiguous().float()
         w = conv_w.detach().contiguous().float()
-        out, mean, stdev = patch_tokenize_fwd(x, w, patch_len, stride, concat)
+        out, mean, stdev = patch_tokenize_fwd(x, w, patch_len, stride, concat, drop=(drop_p, drop_seed))
         ctx.save_for_backward(x, mean, stdev)
-        ctx.meta = (tuple(conv_w.shape), patch_len, stride, concat)
+        ctx.meta = (tuple(conv_w.shape), patch_len, stride, concat, (drop_p, drop_seed))
         ctx.mark_non_differentiable(mean, stdev)
         return out, mean, stdev
 
     @staticmethod
     def backward(ctx, dout, _dm, _ds):
         x, mean, stdev = ctx.saved_tensors
-        shape, patch_len, stride, concat = ctx.meta
-        dw = patch_tokenize_bwd(x, mean, stdev, dout.contiguous(), shape, patch_len, stride, concat)
-        return None, dw, None, None, None
+        shape, patch_len, stride, concat, drop = ctx.meta
+        dw = patch_tokenize_bwd(x, mean, stdev, dout.contiguous(), shape, patch_len, stride, concat, drop=drop)
+        return None, dw, None, None, None, None, None
 
 
 class LinearFn(torch.autograd.Function):

@@ -362,11 +362,13 @@ class MedTsLLM(nn.Module):
         assert C == self.n_features
         concat = self.covariate_mode == "concat"
         rl = self.reprogramming_layer
+        # training.dropout: one host seed per encode, split over the two sites (patch embedding R:models/layers/embed.py:197, attention
+        # probabilities R:models/medtsllm.py:588); drawn from the host torch RNG, so no device sync
+        drop_on = self.training and self.dropout > 0
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if drop_on else 0
         tokens, mean, stdev = PatchTokenizeFn.apply(x_enc, self.patch_embedding.value_embedding.tokenConv.weight,
-                                                    self.patch_len, self.stride, concat)
+                                                    self.patch_len, self.stride, concat, float(self.dropout) if drop_on else 0.0, seed ^ 0x2545F491)
         self._tap("tokens", tokens)
-        if self.training and self.dropout > 0:
-            tokens = F.dropout(tokens, self.dropout, True)
         if self.word_embeddings.requires_grad:
             source = MappingTrainableFn.apply(self.mapping_layer.weight, self.mapping_layer.bias, self.word_embeddings, self._map_split_k)
         else:
@@ -381,8 +383,7 @@ class MedTsLLM(nn.Module):
         q = self._tap("q", LinearFn.apply(tokens, rl.query_projection.weight, rl.query_projection.bias))
         k = self._tap("k", LinearFn.apply(source, rl.key_projection.weight, rl.key_projection.bias))
         v = self._tap("v", LinearFn.apply(source, rl.value_projection.weight, rl.value_projection.bias))
-        if self.training and self.dropout > 0:   # A = dropout(softmax(.)), R:models/medtsllm.py:588 (own RNG stream)
-            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        if drop_on:   # A = dropout(softmax(.)), R:models/medtsllm.py:588
             a = CrossAttnFn.apply(q, k, v, self.n_attention_heads, self.d_ff, float(self.dropout), seed)
         else:
             a = CrossAttnFn.apply(q, k, v, self.n_attention_heads, self.d_ff)

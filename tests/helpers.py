@@ -141,24 +141,46 @@ def fixture_tokenizer(kind="gpt2"):
     return tok
 
 
-# ----------------------------------------------------------------------------- host replicas of the library's dropout hash
-def drop_hash(seed, bh, q, key):
-    """drop_hash() of csrc/mtl_common.h in uint32 arithmetic on numpy arrays / ints"""
-    import numpy as np
-    M = np.uint64(0xFFFFFFFF)
-    seed, bh, q, key = (np.asarray(v, dtype=np.uint64) for v in (seed, bh, q, key))
-    h = (seed ^ ((bh * np.uint64(0x9E3779B1)) & M)) & M
-    h = ((h ^ ((q * np.uint64(0x85EBCA77)) & M)) * np.uint64(0xC2B2AE3D)) & M
-    h = ((h ^ (h >> np.uint64(15)) ^ ((key * np.uint64(0x27D4EB2F)) & M)) * np.uint64(0x165667B1)) & M
-    h ^= h >> np.uint64(13)
-    h = (h * np.uint64(0x85EBCA6B)) & M
-    h ^= h >> np.uint64(16)
-    return h
+# ----------------------------------------------------------------------------- host replicas of the library's dropout mask
+def _drop_base(seed, stream):
+    """drop_base() of csrc/mtl_common.h in uint32 arithmetic on numpy arrays / ints"""
+    M, u = np.uint64(0xFFFFFFFF), np.uint64
+    seed, stream = np.asarray(seed, dtype=np.uint64), np.asarray(stream, dtype=np.uint64)
+    a = (seed ^ ((stream * u(0x9E3779B1)) & M)) & M
+    a ^= a >> u(16)
+    a = (a * u(0x85EBCA6B)) & M
+    a ^= a >> u(13)
+    a = (a * u(0xC2B2AE35)) & M
+    a ^= a >> u(16)
+    return a
+
+
+def _mad24(a, b, c):
+    M, u = np.uint64(0xFFFFFFFF), np.uint64
+    return (((a & u(0xFFFFFF)) * (u(b) & u(0xFFFFFF))) + c) & M
+
+
+def drop_u16(seed, stream, a, b):
+    """the 16-bit mask field of element (stream, a, b): drop_field(drop_word(drop_base(seed, stream), a, b >> 1), b) of mtl_common.h"""
+    M, u = np.uint64(0xFFFFFFFF), np.uint64
+    a, b = np.asarray(a, dtype=np.uint64), np.asarray(b, dtype=np.uint64)
+    h = (_mad24(a, 0x9E3779, _drop_base(seed, stream)) ^ _mad24(b >> u(1), 0x85EBCB, u(0))) & M
+    h ^= h >> u(15)
+    h = _mad24(h, 0xC2B2AF, h >> u(24))
+    h ^= h >> u(13)
+    h = _mad24(h, 0x27D4EB, h >> u(24))
+    h ^= h >> u(16)
+    return np.where((b & u(1)) == 1, h >> u(16), h & u(0xFFFF))
 
 
 def drop_threshold(p):
-    import numpy as np
-    return min(int(np.float32(p) * np.float32(4294967296.0)), 4294967040)
+    t = np.float32(p) * np.float32(65536.0)
+    return 65535 if t >= 65535 else (0 if t <= 0 else int(t))
+
+
+def drop_scale(p):
+    """the library scales kept values by the EXACT inverse keep rate of its 16-bit threshold"""
+    return float(np.float32(65536.0) / np.float32(65536 - drop_threshold(p)))
 
 
 def drop_site_seed(seed, layer, k):
@@ -166,15 +188,48 @@ def drop_site_seed(seed, layer, k):
 
 
 def drop_mult_matrix(seed, p, rows, cols):
-    """[rows, cols] multipliers keep / (1 - p) of the (seed, 0, row, col) mask (GEMM resid / norm-bwd / embd dropout)"""
-    import numpy as np
+    """[rows, cols] multipliers keep * scale of the (seed, 0, row, col) mask (GEMM resid / norm-bwd / embd dropout)"""
     r, c = np.meshgrid(np.arange(rows, dtype=np.uint64), np.arange(cols, dtype=np.uint64), indexing="ij")
-    keep = drop_hash(seed, 0, r, c) >= drop_threshold(p)
-    return torch.from_numpy(keep.astype(np.float32)) / (1.0 - float(np.float32(p)))
+    keep = drop_u16(seed, 0, r, c) >= drop_threshold(p)
+    return torch.from_numpy(keep.astype(np.float32)) * drop_scale(p)
 
 
 def drop_mult_attention(seed, p, B, H, Tq, Tk):
-    import numpy as np
     bh, q, k = np.meshgrid(np.arange(B * H, dtype=np.uint64), np.arange(Tq, dtype=np.uint64), np.arange(Tk, dtype=np.uint64), indexing="ij")
-    keep = drop_hash(seed, bh, q, k) >= drop_threshold(p)
-    return torch.from_numpy(keep.astype(np.float32).reshape(B, H, Tq, Tk)) / (1.0 - float(np.float32(p)))
+    keep = drop_u16(seed, bh, q, k) >= drop_threshold(p)
+    return torch.from_numpy(keep.astype(np.float32).reshape(B, H, Tq, Tk)) * drop_scale(p)
+
+
+# ----------------------------------------------------------------------------- gradients that are sums with cancellation
+def cancellation_checks(tap, grads, floor):
+    """For the gradients that are contractions of an upstream gradient A with a layer input X over many rows — bias vectors
+    (X = ones) and the tiny feature-weighting layer — returns (exact, cond):
+      exact[name] = (error of the returned gradient against the fp64 contraction of the HIP path's OWN upstream gradient, L1 mass)
+      cond[name]  = floor * |A|_F * |X|_F / sqrt(rows): what a relative perturbation `floor` of A's elements moves the sum by,
+                    however small the (cancelled) sum itself is — the absolute error allowance on that gradient.
+    `tap` = MedTsLLM.debug_tap after backward (the i-th tensor tapped under a name is "name@i", its gradient "grad:name@i")."""
+    def up(name):
+        gs = [tap[k] for k in sorted(tap) if k.startswith(f"grad:{name}@")]
+        return torch.cat([g.double().cpu().reshape(-1, g.shape[-1]) for g in gs], dim=0)
+
+    exact, cond = {}, {}
+
+    def add(pname, want64, mass, allowance):
+        e = float((grads[pname].detach().cpu().double().flatten() - want64.flatten()).norm())
+        exact[pname], cond[pname] = (e, mass), allowance
+
+    rl = "reprogramming_layer."
+    for pname, tname in ((rl + "query_projection.bias", "q"), (rl + "key_projection.bias", "k"), (rl + "value_projection.bias", "v"),
+                         (rl + "out_projection.bias", "reprog"), ("embedding_downsample_layer.bias", "down"), ("output_projection.linear.bias", "head")):
+        if pname in grads and any(k.startswith(f"grad:{tname}@") for k in tap):
+            dy = up(tname)
+            add(pname, dy.sum(0), float(dy.abs().sum(0).norm()), floor * float(dy.norm()))
+    if any(k.startswith("grad:source@") for k in tap):
+        ds = sum(tap[k].double().cpu() for k in tap if k.startswith("grad:source@"))
+        add("mapping_layer.bias", ds.sum(1), float(ds.abs().sum(1).norm()), floor * float(ds.norm()))
+    if "feature_weighting.weight" in grads:
+        x = torch.cat([tap[k].double().cpu().reshape(-1, tap[k].shape[-1]) for k in sorted(tap) if k.startswith("fw_in@")], dim=0)
+        dy = up("fw_out")
+        add("feature_weighting.weight", dy.t() @ x, float((dy.abs().t() @ x.abs()).norm()), floor * float(dy.norm()) * float(x.norm()) / x.shape[0] ** 0.5)
+        add("feature_weighting.bias", dy.sum(0), float(dy.abs().sum(0).norm()), floor * float(dy.norm()))
+    return exact, cond

@@ -100,7 +100,9 @@ def test_full_size_pruned_backward_equals_full_backward(model):
     # between two equally valid tile configurations of the SAME full backward (tools/grad_noise.py,
     # profiles/r01_grad_noise_floor.txt) is 1e-3 .. 9e-3 per tensor, 1.9e-2 on the key bias, whose exact gradient is zero
     # (softmax is invariant to a shift of every score of a row). A pruning bug (wrong rows) shows up as O(1).
+    params = dict(model.named_parameters())
     for n in gp:
-        scale = float(gf[n].norm()) + 1e-12
-        tol = 5e-2 if n.endswith("key_projection.bias") else 2.5e-2
-        assert float((gp[n] - gf[n]).norm()) / scale < tol, n
+        # the key bias' exact gradient is zero (softmax shift invariance; with the consistent delta of the attention backward it
+        # comes out at 1e-8, pure round-off): compare it — like every analytically-small gradient — on an absolute scale
+        scale = max(float(gf[n].norm()), 1e-3 * float(params[n].detach().norm()) + 1e-6)
+        assert float((gp[n] - gf[n]).norm()) / scale < 2.5e-2, n

@@ -24,7 +24,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import CASES, load_case, rel_err, golden_loss, fixture_tokenizer, big_grad_summary
+from helpers import CASES, load_case, rel_err, golden_loss, fixture_tokenizer, big_grad_summary, cancellation_checks
 
 pytestmark = pytest.mark.gpu
 BF16 = torch.bfloat16
@@ -156,36 +156,11 @@ def test_hip_model_vs_reference_golden(name):
     # sqrt(rows) (X = ones for a bias) however small the sum itself is — the key bias sums to exactly zero analytically. Such a
     # gradient is therefore (1) pinned EXACTLY against the fp64 reduction of the HIP path's own upstream gradient, and (2) compared
     # with the reference on the scale of that upstream mass instead of on the scale of the cancelled result.
-    def exact(n, got, want64, mass):
-        e = float((got.detach().cpu().double().flatten() - want64.flatten()).norm())
+    exact, cond = cancellation_checks(tap, grads, GRAD_FLOOR)
+    for n, (e, mass) in exact.items():
         report["exact:" + n] = (e / (mass + 1e-30), 2e-5)
         if not e <= 2e-5 * mass + 1e-9:
             failures.append(("exact:" + n, e / (mass + 1e-30), 2e-5))
-
-    def up(name):        # upstream gradient rows of every tensor tapped under `name` (encode_ts runs twice with "examples" prompting)
-        gs = [tap[k] for k in sorted(tap) if k.startswith(f"grad:{name}@")]
-        return torch.cat([g.double().cpu().reshape(-1, g.shape[-1]) for g in gs], dim=0)
-
-    cond = {}          # parameter name -> GRAD_FLOOR-level error allowance from the upstream mass
-    rl = "reprogramming_layer."
-    sums = [(rl + "query_projection.bias", "q"), (rl + "key_projection.bias", "k"), (rl + "value_projection.bias", "v"),
-            (rl + "out_projection.bias", "reprog"), ("embedding_downsample_layer.bias", "down"), ("output_projection.linear.bias", "head")]
-    for pname, tname in sums:
-        if pname not in grads:
-            continue
-        dy = up(tname)
-        exact(pname, grads[pname], dy.sum(0), float(dy.abs().sum(0).norm()))
-        cond[pname] = GRAD_FLOOR * float(dy.norm())
-    ds = sum(tap[k].double().cpu() for k in tap if k.startswith("grad:source@"))
-    exact("mapping_layer.bias", grads["mapping_layer.bias"], ds.sum(1), float(ds.abs().sum(1).norm()))
-    cond["mapping_layer.bias"] = GRAD_FLOOR * float(ds.norm())
-    if "feature_weighting.weight" in grads:
-        x = torch.cat([tap[k].double().cpu().reshape(-1, tap[k].shape[-1]) for k in sorted(tap) if k.startswith("fw_in@")], dim=0)
-        dy = up("fw_out")
-        exact("feature_weighting.weight", grads["feature_weighting.weight"], dy.t() @ x, float((dy.abs().t() @ x.abs()).norm()))
-        exact("feature_weighting.bias", grads["feature_weighting.bias"], dy.sum(0), float(dy.abs().sum(0).norm()))
-        cond["feature_weighting.weight"] = GRAD_FLOOR * float(dy.norm()) * float(x.norm()) / x.shape[0] ** 0.5
-        cond["feature_weighting.bias"] = GRAD_FLOOR * float(dy.norm())
 
     n_checked = 0
     for k in data:

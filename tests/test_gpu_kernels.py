@@ -229,18 +229,6 @@ def test_attention_cross_shared_kv(ops, B, L, S, H, E):
     assert rel_err(dv.float(), vf.grad) < TOL_ATTN_BWD
 
 
-def _drop_hash(seed, bh, q, key):
-    """host replica of drop_hash() in csrc/mtl_attention.hip (uint32 arithmetic)"""
-    M = 0xFFFFFFFF
-    h = (seed ^ ((bh * 0x9E3779B1) & M)) & M
-    h = ((h ^ ((q * 0x85EBCA77) & M)) * 0xC2B2AE3D) & M
-    h = ((h ^ (h >> 15) ^ ((key * 0x27D4EB2F) & M)) * 0x165667B1) & M
-    h ^= h >> 13
-    h = (h * 0x85EBCA6B) & M
-    h ^= h >> 16
-    return h
-
-
 @pytest.mark.parametrize("pdrop", [0.1, 0.5])
 def test_attention_cross_dropout(ops, pdrop):
     """A = dropout(softmax(.)) (R:models/medtsllm.py:588): the kernel's counter-based keep mask is replicated on the host,
@@ -251,11 +239,8 @@ def test_attention_cross_dropout(ops, pdrop):
     v = torch.randn(S, H * E, generator=g(3)).to(BF16)
     do = torch.randn(B, L, H * E, generator=g(4)).to(BF16)
     scale = 1.0 / math.sqrt(E)
-    thr = min(int(np.float32(pdrop) * np.float32(4294967296.0)), 4294967040)
-    bh, qq, kk = np.meshgrid(np.arange(B * H, dtype=np.uint64), np.arange(L, dtype=np.uint64), np.arange(S, dtype=np.uint64), indexing="ij")
-    keep = (_drop_hash(seed, bh, qq, kk) >= thr)
-    assert abs(keep.mean() - (1 - pdrop)) < 0.02
-    keep = torch.from_numpy(keep.reshape(B, H, L, S)).float() / (1.0 - float(np.float32(pdrop)))
+    keep = helpers.drop_mult_attention(seed, pdrop, B, H, L, S)            # host replica of the library's mask, keep * scale
+    assert abs(float((keep > 0).float().mean()) - (1 - pdrop)) < 0.02
     qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
     scores = torch.einsum("blhe,she->bhls", qf.view(B, L, H, E), kf.view(S, H, E))
     A = torch.softmax(scale * scores, dim=-1) * keep
@@ -363,6 +348,22 @@ def test_patch_tokenizer(ops, B, L, C, pl, st, dm, concat):
     dpad[..., :width] = dout
     dw = ops.patch_tokenize_bwd(dev(x), m, s, dev(dpad), tuple(w.shape), pl, st, concat)
     assert rel_err(dw, wf.grad) < 1e-5
+    # PatchEmbedding's train-mode dropout fused into both kernels: the counter mask of (seed, row of out, column of out),
+    # replicated on the host and handed to the reference as an explicit multiplier
+    pd, seed = 0.25, 424242
+    rows = out.shape[0] * out.shape[1]
+    mult = helpers.drop_mult_matrix(seed, pd, rows, out.shape[-1]).view(out.shape)[..., :width]
+    assert abs(float((mult > 0).float().mean()) - (1 - pd)) < 0.05
+    wf2 = w.clone().requires_grad_(True)
+    ref2 = O.patch_embed(O.revin_norm(x, mean, stdev), wf2, pl, st)
+    if concat:
+        ref2 = ref2.reshape(B, C, P, dm).permute(0, 2, 1, 3).reshape(B, P, C * dm)
+    ref2 = ref2 * mult
+    out2, _, _ = ops.patch_tokenize_fwd(dev(x), dev(w), pl, st, concat, drop=(pd, seed))
+    assert rel_err(out2[..., :width].float(), ref2) < TOL_BF16 and torch.all(out2[..., width:] == 0)
+    ref2.backward(dout.float())
+    dw2 = ops.patch_tokenize_bwd(dev(x), m, s, dev(dpad), tuple(w.shape), pl, st, concat, drop=(pd, seed))
+    assert rel_err(dw2, wf2.grad) < 1e-5
 
 
 # ------------------------------------------------------------------------------------------------ elementwise / layout
