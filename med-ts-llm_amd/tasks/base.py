@@ -4,10 +4,14 @@
     prepare_batch (H2D + cast) -> autocast(bf16) iff dtype == "mixed" -> model(inputs) -> loss -> backward
     -> [DP: one flat all-reduce of the trainable grads] -> optimizer.step -> zero_grad -> log_step(loss.item())
 
-Only what drives the hot path is built: device/dtype resolution, loaders, model/optimizer/loss construction,
-checkpoint surface. Eval stitching / metrics / wandb / tensorboard are out of scope (SURVEY.md §8 "next" rank 1).
+What drives the hot path is built: device/dtype resolution, loaders, model/optimizer/scheduler/loss construction, fine-tuning from
+a pre-trained run (two parameter groups + frozen / warm-up epochs), the checkpoint surface incl. optimiser state, the pre-emption
+hook, resume from a run directory. wandb / tensorboard sinks are out of scope.
 """
+import json
 import os
+import signal
+import threading
 from abc import ABC, abstractmethod
 from datetime import datetime
 from pathlib import Path
@@ -23,15 +27,27 @@ from .. import parallel
 from .synthetic import get_dataset
 
 
+def logdir_base(config):
+    """R:loggers/base_logger.py:14-17 — config.paths.logdir, else outputs/logs under the working directory"""
+    paths = config.get("paths", {}) if hasattr(config, "get") else {}
+    base = paths.get("logdir") if hasattr(paths, "get") else None
+    return Path(base or "outputs/logs")
+
+
 class PrintLogger:
-    """Minimal sink with the reference logger's surface (log_scores / save_state / log_end); rank 0 only."""
+    """Minimal sink with the reference logger's surface (log_scores / save_state / log_end); rank 0 only. Writes what
+    R:loggers/base_logger.py writes: <logdir>/<run_id>/config.json on a new run and checkpoints/<name>.pt — the reference's
+    fields plus `optimizer` (the reference omits the optimiser state, so a resumed run restarts Adam's moments)."""
 
     def __init__(self, trainer, config, newrun=True):
         self.trainer, self.config = trainer, config
         self.debug = bool(config.get("DEBUG", False))
-        base = config.get("paths", {}).get("logdir") if hasattr(config.get("paths", {}), "get") else None
-        self.logdir = Path(base or "outputs/logs") / trainer.run_id
+        self.logdir = logdir_base(config) / trainer.run_id
         self.history = []
+        if newrun and not self.debug and trainer.rank == 0:
+            self.logdir.mkdir(parents=True, exist_ok=True)
+            with open(self.logdir / "config.json", "w") as f:
+                json.dump(config.to_dict(), f, indent="\t")
 
     def log_scores(self, scores):
         self.history.append(dict(scores))
@@ -39,16 +55,18 @@ class PrintLogger:
             print(" ".join(f"{k}={v:.6g}" if isinstance(v, float) else f"{k}={v}" for k, v in scores.items()))
 
     def save_state(self, name):
-        """Checkpoint format of R:loggers/base_logger.py:29-40 (model.state_dict() is already filtered)."""
+        """Checkpoint format of R:loggers/base_logger.py:29-40 (model.state_dict() is already filtered) + the optimiser state."""
         if self.debug:
             return
-        model_state = self.trainer.model.state_dict()    # a collective when the mapping layer is row-sharded: all ranks
+        # collectives when the mapping layer is row-sharded (the rows and their Adam moments are gathered): every rank takes part
+        model_state = self.trainer.model.state_dict()
+        optim_state = self.trainer.optimizer_state()
         if self.trainer.rank != 0:
             return
         d = self.logdir / "checkpoints"
         d.mkdir(parents=True, exist_ok=True)
         torch.save({"run_id": self.trainer.run_id, "epoch": self.trainer.epoch, "step": self.trainer.step,
-                    "datetime": datetime.now().isoformat(), "model": model_state}, d / f"{name}.pt")
+                    "datetime": datetime.now().isoformat(), "model": model_state, "optimizer": optim_state}, d / f"{name}.pt")
 
     def log_end(self):
         pass
@@ -69,7 +87,7 @@ class BaseTask(ABC):
         self.build_datasets()
         self.build_dataloaders()
         self.model = self.build_model().to(self.device, self.dtype)
-        self.finetuning = False
+        self.load_pretrained()
         if self.world_size > 1:     # identical initial weights on every rank (seeded above), rank-specific dropout streams from here on
             torch.manual_seed(self.config.setup.seed + 7919 * (self.rank + 1))
         if self.world_size > 1 and self.config.setup.get("shard_mapping", True) and hasattr(self.model, "shard_mapping_layer"):
@@ -82,6 +100,8 @@ class BaseTask(ABC):
         metric_dir = self.config.training.eval_metric_direction
         self.best_score = float("inf") if metric_dir == "min" else float("-inf")
         self.logger = PrintLogger(self, self.config, self.newrun)
+        if threading.current_thread() is threading.main_thread() and hasattr(signal, "SIGUSR1"):
+            signal.signal(signal.SIGUSR1, self.handle_termination)       # pre-emption notice: R:tasks/base.py:55
 
     # ---- construction (R:tasks/base.py:81-108,157-198,248-275)
     def build_model(self):
@@ -89,8 +109,26 @@ class BaseTask(ABC):
         assert self.task in self.model.supported_tasks, f"{self.task} not supported by {self.config.model}"
         return self.model
 
+    def load_pretrained(self):
+        """R:tasks/base.py:143-155 — fine-tuning from a pre-trained run: its checkpoint's trainable front / back end minus the output
+        head is loaded into the model (MedTsLLM.load_pretrained); `loaded_params` then get their own optimiser group."""
+        if "finetuning" not in self.config or not self.config.finetuning.enabled:
+            self.finetuning = False
+            return
+        assert hasattr(self.model, "load_pretrained"), "Only TimeLLM / MedTsLLM support finetuning"      # (R: config.model == "timellm")
+        cfg = self.config.finetuning
+        self.finetuning = True
+        path = logdir_base(self.config) / cfg.pretrained_id / "checkpoints" / f"{cfg.pretrained_ckpt}.pt"
+        saved_state = torch.load(path, map_location="cpu")["model"]
+        self.loaded_params = self.model.load_pretrained(saved_state)
+
     def build_optimizer(self):
-        params = [p for p in self.model.parameters() if p.requires_grad]
+        if self.finetuning:      # R:tasks/base.py:88-91: group 0 = the new parameters, group 1 = the pre-trained ones (own LR schedule)
+            named = list(self.model.named_parameters())
+            params = [{"params": [p for n, p in named if n not in self.loaded_params and p.requires_grad]},
+                      {"params": [p for n, p in named if n in self.loaded_params]}]
+        else:
+            params = [p for p in self.model.parameters() if p.requires_grad]
         lr = self.config.training.learning_rate
         opt = self.config.training.optimizer
         if self.device.type == "cuda" and opt in ("adam", "adamw"):
@@ -111,9 +149,62 @@ class BaseTask(ABC):
 
     def build_scheduler(self):
         st = self.config.training.get("lr_scheduler")
-        if st in (None, "none", "constant"):
+        if st not in (None, "none", "constant"):
+            raise ValueError(f"Invalid scheduler selection: {st}")
+        if not self.finetuning:
             return optim.lr_scheduler.StepLR(self.optimizer, step_size=1, gamma=1)
-        raise ValueError(f"Invalid scheduler selection: {st}")
+        # R:tasks/base.py:118-139: per-epoch LR factor of the PRE-TRAINED group — frozen (0) for the first epochs, or a linear warm-up
+        # from warmup_factor to 1; the new parameters always train at the full rate. (The reference's own guard reads
+        # `assert not (frozen > 0) and (warmup > 0)`, which by precedence also rejects every frozen-epochs run; the evident intent —
+        # the two are mutually exclusive — is what is enforced here.)
+        cfg = self.config.finetuning
+        frozen, warm = int(cfg.get("frozen_epochs", 0)), int(cfg.get("warmup_epochs", 0))
+        assert not (frozen > 0 and warm > 0), "Frozen epochs and warmup epochs are mutually exclusive"
+        if frozen > 0:
+            return optim.lr_scheduler.LambdaLR(self.optimizer, [lambda _: 1.0, lambda epoch: 0.0 if epoch < frozen else 1.0])
+        if warm > 0:
+            factors = torch.linspace(float(cfg.warmup_factor), 1.0, warm)
+            return optim.lr_scheduler.LambdaLR(self.optimizer, [lambda _: 1.0, lambda epoch: factors[epoch].item() if epoch < warm else 1.0])
+        return optim.lr_scheduler.StepLR(self.optimizer, step_size=1, gamma=1)
+
+    # ---- optimiser state in checkpoints, keyed by parameter NAME so that it survives a changed parameter order
+    def optimizer_state(self):
+        named = {id(p): n for n, p in self.model.named_parameters()}
+        shard = getattr(self.model, "_map_shard", None)
+        out = {"type": type(self.optimizer).__name__, "state": {}, "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.optimizer.param_groups],
+               "group_of": {}}
+        for gi, g in enumerate(self.optimizer.param_groups):
+            for p in g["params"]:
+                out["group_of"][named[id(p)]] = gi
+        for p, st in self.optimizer.state.items():
+            rec = {}
+            for k, v in st.items():
+                if torch.is_tensor(v) and v.dim() > 0 and shard is not None and getattr(p, "_dp_sharded", False):
+                    v = parallel.gather_rows(v, shard[1], shard[4])              # row-sharded mapping layer: full moments, like the weights
+                rec[k] = v.detach().cpu() if torch.is_tensor(v) else v
+            out["state"][named[id(p)]] = rec
+        return out
+
+    def load_optimizer_state(self, saved):
+        if not saved or saved.get("type") != type(self.optimizer).__name__:
+            return False
+        by_name = dict(self.model.named_parameters())
+        shard = getattr(self.model, "_map_shard", None)
+        for g, sg in zip(self.optimizer.param_groups, saved["param_groups"]):
+            g.update({k: v for k, v in sg.items() if k in g and k != "params"})
+        for n, rec in saved["state"].items():
+            p = by_name.get(n)
+            if p is None:
+                continue
+            st = {}
+            for k, v in rec.items():
+                if torch.is_tensor(v) and v.dim() > 0:
+                    if shard is not None and getattr(p, "_dp_sharded", False) and v.shape[0] != p.shape[0]:
+                        v = v[shard[2]:shard[3]]
+                    v = v.to(device=p.device, dtype=p.dtype if v.is_floating_point() else v.dtype).contiguous().clone()
+                st[k] = v
+            self.optimizer.state[p] = st
+        return True
 
     def build_datasets(self):
         self.train_dataset = get_dataset(self.config, "train")
@@ -251,7 +342,8 @@ class BaseTask(ABC):
 
     def log_epoch(self, scores={}, **kw):
         lrs = self.scheduler.get_last_lr()
-        scores = {**scores, **kw, **({"train/lr": lrs[0]} if len(lrs) == 1 else {})}
+        lrs = {"train/lr": lrs[0]} if len(lrs) == 1 else ({"train/lr": lrs[0], "train/finetune_lr": lrs[1]} if len(lrs) == 2 else {})
+        scores = {**scores, **kw, **lrs}
         self.logger.log_scores(scores)
         self.logger.save_state("latest")
         metric = "val/" + self.config.training.eval_metric
@@ -268,12 +360,37 @@ class BaseTask(ABC):
         if self.epoch < self.config.training.epochs:
             self.epoch += 1
 
+    def handle_termination(self, signum, frame):
+        """R:tasks/base.py:277-281 — SIGUSR1 (a scheduler's pre-emption notice): checkpoint "latest", close the logger, exit"""
+        print("Interrupted!")
+        self.logger.save_state("latest")
+        self.log_end()
+        raise SystemExit(0)
+
     @classmethod
-    def from_run_id(cls, run_id, config, ckpt="latest", basepath="outputs/logs"):
-        """R:tasks/base.py:283-306 (the config object is passed in; TOML parsing is the CLI's job)."""
+    def from_run_id(cls, run_id, cfg=None, ckpt="latest", basepath=None):
+        """R:tasks/base.py:283-306: rebuild the trainer of a finished / interrupted run from its log directory — the config the
+        run was started with (config.json; config.toml when a TOML reader is importable), overridden by `cfg` (a dict or a config
+        object) — and load its checkpoint: model, epoch, step, and (ours) the optimiser state."""
+        from ..utils import dict_to_object
+        if cfg is not None and hasattr(cfg, "to_dict"):
+            cfg = cfg.to_dict()
+        base = Path(basepath) if basepath is not None else logdir_base(dict_to_object(cfg or {}))
+        rundir = base / run_id
+        if (rundir / "config.json").exists():
+            with open(rundir / "config.json") as f:
+                config = json.load(f)
+        elif (rundir / "config.toml").exists():
+            import tomli
+            with open(rundir / "config.toml", "rb") as f:
+                config = tomli.load(f)
+        else:
+            config = {}
+        config = dict_to_object({**config, **(cfg or {})})
         trainer = cls(run_id, config, newrun=False)
-        state = torch.load(Path(basepath) / run_id / f"checkpoints/{ckpt or 'latest'}.pt")
+        state = torch.load(rundir / f"checkpoints/{ckpt or 'latest'}.pt", map_location="cpu")
         _, unexpected = trainer.model.load_state_dict(state["model"], strict=False)
         assert not unexpected, f"Unexpected keys in model state: {unexpected}"
         trainer.epoch, trainer.step = state["epoch"], state["step"]
+        trainer.load_optimizer_state(state.get("optimizer"))
         return trainer

@@ -76,10 +76,6 @@ class ForecastTask(_StitchedEval, BaseTask):
         return preds.cpu(), targets.cpu()
 
 
-class PretrainingTask(ForecastTask):
-    pass
-
-
 class ReconstructionTask(_StitchedEval, BaseTask):
     def build_loss(self):
         return _regression_loss(self.config.training.loss)
@@ -107,6 +103,33 @@ class ReconstructionTask(_StitchedEval, BaseTask):
         (preds, targets), _ = self._stitch_recon(dataloader)
         assert not preds.isnan().any() and not targets.isnan().any()
         return preds.cpu(), targets.cpu()
+
+
+class PretrainingTask(ReconstructionTask):
+    """R:tasks/pretraining.py: reconstruction over a MIX of datasets — every split is a `MixedWindows` over the component datasets
+    (each built as a plain reconstruction dataset of its own name), batches mix windows of all of them, channel counts are
+    brought to one width by tiling / truncation. The component names come from `tasks.pretraining.datasets` (default: the
+    reference's hard-coded four); each must be registered with the dataset registry (tasks/windows.register_series)."""
+    DEFAULT_DATASETS = ("ECG", "ventilator", "bidmc", "ludb")
+
+    def __init__(self, run_id, config, newrun=True):
+        super().__init__(run_id, config, newrun)
+        self.task = "pretraining"
+
+    def build_datasets(self):
+        from .synthetic import get_dataset
+        from .windows import MixedWindows
+        tc = self.config.tasks.pretraining
+        names = list(tc.get("datasets", self.DEFAULT_DATASETS))
+        parts = {"train": {}, "val": {}, "test": {}}
+        for name in names:      # (component order = the order of the reference's loop: it decides the RNG draws of the subsets)
+            cfg = self.config.copy()
+            cfg.data.dataset = name
+            cfg.task = "reconstruction"
+            for split in parts:
+                parts[split][name] = get_dataset(cfg, split)
+        mk = lambda split: MixedWindows(parts[split], downsample_pct=tc.downsample_pct, n_features=tc.n_features)
+        self.train_dataset, self.val_dataset, self.test_dataset = mk("train"), mk("val"), mk("test")
 
 
 class AnomalyDetectionTask(ReconstructionTask):

@@ -238,3 +238,77 @@ def test_product_trainer_replays_reference_trajectory_on_gpu(tmp_path):
     print("final weights, distance to the reference's / distance moved:", {k: round(v, 4) for k, v in worst.items()})
     assert max(worst.values()) < 0.10, worst
     assert trainer.step == int(z["step_counter"])
+
+
+def _gpu_losses_close(tr, z, rtol=1.5e-2):
+    losses = np.array([h["train/loss"] for h in tr.logger.history if "train/loss" in h])
+    print("\nloss trajectory  hip:", np.round(losses, 5).tolist(), "\n            reference:", np.round(z["losses"], 5).tolist())
+    assert len(losses) == len(z["losses"]) and np.allclose(losses, z["losses"], rtol=rtol, atol=1e-5), (losses, z["losses"])
+
+
+def test_pretraining_trainer_replays_reference_on_gpu(tmp_path):
+    """R:tasks/pretraining.py on the device: the mixed-dataset windows the reference drew, through the HIP model + HipAdam in bf16 mixed
+    mode: the reference's (fp32) per-step losses within 1.5 %, final weights within the mixed-precision ladder"""
+    import test_datasets_trainer as T
+    from med_ts_llm_amd.tasks import get_trainer
+    G = (dict(np.load(T.GOLDEN / "datasets.npz")), json.loads((T.GOLDEN / "datasets.json").read_text()))
+    z = np.load(T.GOLDEN / "trainer_pretraining.npz")
+    T.register_part_sources(G)
+    tr = get_trainer("DEBUG-pretrain-gpu", T.pretraining_config(tmp_path, device="cuda", dtype="mixed"))
+    assert tr.device.type == "cuda" and tr.task == "pretraining" and type(tr.optimizer).__name__ == "HipAdam"
+    for j, inds in enumerate(tr.train_dataset.dataset_inds):
+        assert np.array_equal(inds.numpy(), z[f"mix.inds{j}"])
+    T._load_init(tr, z)
+    tr.train()
+    _gpu_losses_close(tr, z)
+    T._check_final(tr, z, tol_each=0.25, tol_all=0.10)
+
+
+def test_finetuning_trainer_replays_reference_on_gpu(tmp_path):
+    """R:tasks/base.py:88-91,118-155 on the device: pre-trained front end + fresh head, two HipAdam parameter groups, warm-up schedule"""
+    import test_datasets_trainer as T
+    from med_ts_llm_amd.tasks import get_trainer
+    G = (dict(np.load(T.GOLDEN / "datasets.npz")), json.loads((T.GOLDEN / "datasets.json").read_text()))
+    z = np.load(T.GOLDEN / "trainer_finetune.npz")
+    meta = json.loads((T.GOLDEN / "trainer_finetune.json").read_text())
+    T.register_part_sources(G)
+    T.write_pretrained_checkpoint(tmp_path, z)
+    tr = get_trainer("DEBUG-finetune-gpu", T.finetune_config(tmp_path, device="cuda", dtype="mixed"))
+    assert tr.finetuning and tr.loaded_params == meta["loaded_params"] and type(tr.optimizer).__name__ == "HipAdam"
+    named = {id(p): n for n, p in tr.model.named_parameters()}
+    assert [[named[id(p)] for p in g["params"]] for g in tr.optimizer.param_groups] == meta["groups"]
+    T._load_init(tr, z)
+    lrs = []
+    orig = tr.log_epoch
+    tr.log_epoch = lambda scores={}, **kw: (lrs.append(list(tr.scheduler.get_last_lr())), orig(scores, **kw))[1]
+    tr.train()
+    assert np.allclose(lrs, z["lrs"], rtol=1e-6)
+    _gpu_losses_close(tr, z)
+    T._check_final(tr, z, tol_each=0.25, tol_all=0.10)
+
+
+def test_resume_restores_hip_adam_state_on_gpu(tmp_path):
+    """checkpoint -> from_run_id -> one more epoch == an uninterrupted run, with HipAdam's moments travelling through the checkpoint"""
+    import test_datasets_trainer as T
+    from med_ts_llm_amd.tasks import get_trainer, task_lookup
+    G = (dict(np.load(T.GOLDEN / "datasets.npz")), json.loads((T.GOLDEN / "datasets.json").read_text()))
+    T.register_part_sources(G)
+    llm = T._golden_backbone_dir(tmp_path)
+
+    def cfg(epochs):
+        return T.base_cfg("reconstruction", "bidmc", llm_dir=llm, epochs=epochs,
+                          extra={"DEBUG": False, "paths": {"logdir": str(tmp_path / "logs")},
+                                 "setup": {"seed": 0, "device": "cuda", "dtype": "mixed", "num_workers": 0, "logger": "print", "quiet": True}})
+    full = get_trainer("run-full", cfg(2))
+    init = {k: v.detach().clone() for k, v in full.model.state_dict().items()}
+    full.train()
+    part = get_trainer("run-part", cfg(1))
+    part.model.load_state_dict(init, strict=False)
+    part.train()
+    resumed = task_lookup["reconstruction"].from_run_id("run-part", cfg={"training": cfg(2).training.to_dict()}, basepath=str(tmp_path / "logs"))
+    assert type(resumed.optimizer).__name__ == "HipAdam" and all(int(st["step"]) == 2 for st in resumed.optimizer.state.values())
+    resumed.config.training.epochs = 1
+    resumed.train()
+    for (n, a), (_, b) in zip(full.model.named_parameters(), resumed.model.named_parameters()):
+        if a.requires_grad:
+            assert torch.equal(a, b), n          # same kernels, same inputs, same moments: bit-identical

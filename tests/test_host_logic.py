@@ -156,20 +156,13 @@ def golden_trainer_setup(tmp_path, device, dtype, model_key="medtsllm"):
     """Everything the product trainer needs to replay the reference trainer's golden run (tests/golden/make_golden.py
     run_trainer_golden): an on-disk HF-format backbone directory (golden weights + fixture tokenizer), a registered dataset
     that yields the golden batches in the golden order, and the reference run's config. -> (config, z)"""
-    import shutil
-    from safetensors.torch import save_file
     from torch.utils.data import Dataset
+    from helpers import write_hf_dir
     from med_ts_llm_amd.tasks.synthetic import register_dataset
     from med_ts_llm_amd.utils import dict_to_object
     z = np.load(GOLDEN / "trainer_gpt2_concat_fc.npz")
     meta, _, bcfg, backbone = load_case("gpt2_concat_fc")
-    d = Path(tmp_path) / "llm_gpt2"
-    d.mkdir()
-    (d / "config.json").write_text(json.dumps(bcfg))
-    save_file({k: v.contiguous() for k, v in backbone.items()}, str(d / "model.safetensors"))
-    shutil.copy(GOLDEN / "tokenizer.json", d / "tokenizer.json")
-    (d / "tokenizer_config.json").write_text(json.dumps({"tokenizer_class": "PreTrainedTokenizerFast", "bos_token": "<|endoftext|>",
-                                                         "eos_token": "<|endoftext|>"}))
+    d = write_hf_dir(Path(tmp_path) / "llm_gpt2", bcfg, backbone)
     n_batches = len([k for k in z.files if k.endswith(".x_enc")])
     xs = torch.cat([torch.from_numpy(z[f"batch{i}.x_enc"]) for i in range(n_batches)])
     ys = torch.cat([torch.from_numpy(z[f"batch{i}.y"]) for i in range(n_batches)])
@@ -212,29 +205,17 @@ def test_optimisation_step_order_matches_reference_trajectory(tmp_path):
     losses and final weights. The device math is swapped for the pinned oracle (the HIP model has no CPU path) by a model class
     that keeps the product's constructor, parameter names and prompt builder; tests/test_gpu_golden.py runs the same replay with
     the HIP model itself."""
-    from oracle import medtsllm_oracle as O
     from med_ts_llm_amd.models import model_lookup
-    from med_ts_llm_amd.models.medtsllm import MedTsLLM
     from med_ts_llm_amd.tasks import get_trainer
-    meta, _, bcfg, backbone = load_case("gpt2_concat_fc")
-    m = oracle_mcfg(meta)
-
-    class OracleMath(MedTsLLM):
-        def forward(self, inputs):
-            x = inputs["x_enc"]
-            tok = self._get_tokenizer()
-            ids = [[tok(s, padding=False, truncation=False).input_ids for s in ps] for ps in self.build_prompt(inputs)]
-            p = {n: t for n, t in self.named_parameters() if n != "word_embeddings"}
-            return O.medtsllm_forward(x, p, backbone, bcfg, m, token_ids=ids, pad_token_id=tok.pad_token_id, training=self.training)
-
-    model_lookup["medtsllm_oracle_math"] = OracleMath
+    from helpers import register_oracle_math_model
+    key = register_oracle_math_model()
     try:
-        cfg, z, n_batches = golden_trainer_setup(tmp_path, "cpu", "fp32", "medtsllm_oracle_math")
+        cfg, z, n_batches = golden_trainer_setup(tmp_path, "cpu", "fp32", key)
         trainer = get_trainer("DEBUG-golden", cfg)
         load_golden_init(trainer, z)
         trainer.train()
     finally:
-        del model_lookup["medtsllm_oracle_math"]
+        del model_lookup[key]
     losses = [h["train/loss"] for h in trainer.logger.history if "train/loss" in h]
     # importing the reference's tasks package sets torch.set_float32_matmul_precision("medium") (R:tasks/base.py:19-22),
     # so the golden trajectory itself carries ~3e-4 of reduced-precision CPU matmul noise; a wrong step order

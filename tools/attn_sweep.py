@@ -31,7 +31,8 @@ def run(B, T, H, D, drop, n=30):
     return {r["kernel"].split("<")[0].replace("attn_", ""): r["total_ms"] / r["launches"] * 1e3 for r in rows}
 
 
-for B, T, H, D in [(32, 256, 12, 64), (32, 128, 12, 64), (32, 64, 12, 64), (16, 256, 12, 64), (8, 256, 12, 64), (64, 256, 12, 64), (32, 256, 32, 128), (32, 256, 6, 64)]:
+SHAPES = [(32, 256, 12, 64), (32, 256, 32, 128)] if len(sys.argv) > 1 else [(32, 256, 12, 64), (32, 128, 12, 64), (32, 64, 12, 64), (16, 256, 12, 64), (8, 256, 12, 64), (64, 256, 12, 64), (32, 256, 32, 128), (32, 256, 6, 64)]
+for B, T, H, D in SHAPES:
     for drop in ((0.0, 0), (0.1, 7)):
         r = run(B, T, H, D, drop)
         print(f"B={B:3d} T={T:4d} H={H:3d} D={D:4d} drop={drop[0]}: " + "  ".join(f"{k} {v:7.2f} us" for k, v in r.items()), flush=True)
