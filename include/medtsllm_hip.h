@@ -136,6 +136,21 @@ int mtl_gemm_tune(int mode, int bm, int bn, int stages, int waves);
  * (negative: error code). Lets the CPU test suite check that every order visits every tile exactly once. */
 int mtl_gemm_tile_order(int tiles_m, int tiles_n, int bm, int bn, int per_cu, int64_t K, int one_tile_per_wg);
 
+/* ------------------------------------------------------------------ prompt input statistics (a6 / f2)
+ * Replaces the five reductions + rFFT autocorrelation of `build_input_stats_prompt` / `calcute_lags` (R:models/medtsllm.py:476-481,
+ * 530-538) and their five `.tolist()` syncs: per sample and selected channel the minimum, maximum, LOWER median (torch.median) and
+ * trend (1 if the summed first differences are > 0), and per sample the top `n_lags` lags of the channel-mean circular
+ * autocorrelation, evaluated directly (exactly symmetric; ties towards the smaller lag — the reference's order inside a twin pair
+ * lag / L - lag is FFT round-off noise).
+ *   x          f32 [B, L, C]
+ *   channel    >= 0: that channel only (n_channels = 1);  -1: all C channels (statistics per channel, lags of the channel mean)
+ *   out_stats  f32 [B, n_channels, 4] = (min, max, median, trend)
+ *   out_lags   f32 [B, n_lags]  (integers, exact in fp32)
+ * out_stats and out_lags may be the two halves of one buffer, so that ONE device-to-host copy fetches everything. */
+size_t mtl_input_stats_workspace_bytes(int64_t B, int64_t L, int64_t n_channels);
+int mtl_input_stats(const float* x, float* out_stats, float* out_lags, void* workspace, size_t workspace_bytes, int64_t B, int64_t L,
+                    int64_t C, int64_t channel, int64_t n_lags, void* stream);
+
 /* ------------------------------------------------------------------ layout / cast helpers
  * f32 [R, Cc] (ld_src) -> bf16 [R, ld_dst] zero-padding cols >= Cc; optionally also the transpose
  * dst_t bf16 [Cc, ld_dst_t] (zero-padded cols >= R). Used once per step on trainable fp32 master weights

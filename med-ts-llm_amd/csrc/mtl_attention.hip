@@ -603,20 +603,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fw
         bf16x8 qf[NKS];
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + qrow * a.q_ts + ks * 32 + g * 8);
+        f32x4 o[NDT];
+#pragma unroll
+        for (int i = 0; i < NDT; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float m_run = NEG_BIG, l_run = 0.f;
+        const int64_t wave_qmin = q0 + coff;
         const int64_t wave_qmax = ((q0 + 15 < a.Tq - 1) ? q0 + 15 : a.Tq - 1) + coff;
         const int64_t k_end = (wave_qmax + 1 < a.Tk) ? wave_qmax + 1 : a.Tk;
-        // TWO independent online-softmax chains per query tile: chain 0 takes the even 32-key slabs, chain 1 the odd ones, merged
-        // at the end. One slab is a serial dependency chain (S MFMAs -> max -> exp -> pack -> P.V MFMAs -> rescale) of ~1 us under
-        // load, and with 2-4 waves per SIMD that latency, not issue or MFMA throughput, set the kernel's time (tools/attn_sweep.py:
-        // ~9 us per resident workgroup, flat in everything but the number of slabs). The slab body is branch-free (mask by select,
-        // rescale unconditionally) so that both chains sit in ONE basic block and the scheduler interleaves them.
-        float m_c[2] = {NEG_BIG, NEG_BIG}, l_c[2] = {0.f, 0.f};
-        f32x4 o_c[2][NDT];
-#pragma unroll
-        for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-            for (int i = 0; i < NDT; ++i) o_c[ch][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        auto slab = [&](const int64_t kb, float& m_run, float& l_run, f32x4 (&o)[NDT]) {
+        for (int64_t kb = 0; kb < k_end; kb += 32) {
             f32x4 s[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -627,16 +621,24 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fw
                     s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kr + ks * 32), qf[ks], s[t], 0, 0, 0);
             }
             float p[2][4];
+            const bool need_mask = (kb + 32 > a.Tk) || (kb + 31 > wave_qmin);
+            if (need_mask) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t key = kb + t * 16 + g * 4 + r;
-                    p[t][r] = (key >= a.Tk || key > qrow + coff) ? NEG_BIG : s[t][r] * c;
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t key = kb + t * 16 + g * 4 + r;
+                        p[t][r] = (key >= a.Tk || key > qrow + coff) ? NEG_BIG : s[t][r] * c;
+                    }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p[t][r] = s[t][r] * c;
+            }
             float mx = fmaxf(fmaxf(fmaxf(p[0][0], p[0][1]), fmaxf(p[0][2], p[0][3])), fmaxf(fmaxf(p[1][0], p[1][1]), fmaxf(p[1][2], p[1][3])));
             mx = rows_max(mx);
-            const float m_new = fmaxf(m_run, mx);      // (key 0 is visible to every query: a chain's first slab always has a finite max)
+            const float m_new = fmaxf(m_run, mx);
             float psum = 0.f;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -645,11 +647,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fw
                     p[t][r] = __builtin_amdgcn_exp2f(p[t][r] - m_new);
                     psum += p[t][r];
                 }
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            l_run = l_run * alpha + psum;
+            if (__any(m_new != m_run)) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                l_run *= alpha;
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
-            m_run = m_new;
+                for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
+                m_run = m_new;
+            }
+            l_run += psum;
             if (DROP) {   // attn_pdrop: the normaliser keeps the undropped sum, the P.V operand carries the mask (one word per key pair)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
@@ -667,20 +672,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fw
                 const bf16x8 vt = gather_col(vtile, LDT, ra, rb, dt * 16, l15);
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pf, o[dt], 0, 0, 0);
             }
-        };
-        int64_t kb = 0;
-        for (; kb + 32 < k_end; kb += 64) {
-            slab(kb, m_c[0], l_c[0], o_c[0]);
-            slab(kb + 32, m_c[1], l_c[1], o_c[1]);
         }
-        if (kb < k_end) slab(kb, m_c[0], l_c[0], o_c[0]);
-        // merge the chains (an unused chain has m = NEG_BIG, l = 0, o = 0: its factor is exp2(NEG_BIG - m) = 0)
-        const float m_run = fmaxf(m_c[0], m_c[1]);
-        const float f0 = __builtin_amdgcn_exp2f(m_c[0] - m_run), f1 = __builtin_amdgcn_exp2f(m_c[1] - m_run);
-        float l_run = l_c[0] * f0 + l_c[1] * f1;
-        f32x4 o[NDT];
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) o[dt] = o_c[0][dt] * f0 + o_c[1][dt] * f1;
         l_run = rows_sum(l_run);
         if (q_valid) {
             const float inv_l = 1.0f / l_run;
@@ -782,7 +774,6 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn
             dl = rows_sum(acc);
         }
         if (g == 0 && q_valid) a.delta[stat_idx] = dl;
-#pragma unroll 2
         for (int64_t kb = 0; kb < k_end; kb += 32) {
             float ds[2][4];
 #pragma unroll
@@ -891,7 +882,6 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(const mtl_att
             if (!tile_on) continue;
             // first query that can see key k0: q + coff >= k0
             const int64_t qs = k0 > coff ? ((k0 - coff) / 32) * 32 : 0;
-#pragma unroll 2
             for (int64_t qb = qs; qb < f.Tq; qb += 32) {
                 float p[2][4], ds[2][4];
 #pragma unroll

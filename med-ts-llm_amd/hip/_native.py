@@ -114,6 +114,8 @@ SIGNATURES = {
     "mtl_swiglu_fwd": (i32, [vp, vp, i64, i64, vp]),
     "mtl_swiglu_bwd": (i32, [vp, vp, vp, i64, i64, vp]),
     "mtl_assemble_llm_input": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, vp]),
+    "mtl_input_stats_workspace_bytes": (C.c_size_t, [i64, i64, i64]),
+    "mtl_input_stats": (i32, [vp, vp, vp, vp, C.c_size_t, i64, i64, i64, i64, i64, vp]),
     "mtl_backbone_saved_bytes": (C.c_size_t, [C.POINTER(BackboneWeights), i64, i64]),
     "mtl_backbone_work_bytes": (C.c_size_t, [C.POINTER(BackboneWeights), i64, i64]),
     "mtl_backbone_fwd": (i32, [C.POINTER(BackboneWeights), vp, vp, vp, vp, i64, i64, i64, i64, C.POINTER(BackboneDropout), vp]),

@@ -180,6 +180,20 @@ def revin_denorm(y, mean, stdev):
     return out
 
 
+def input_stats(x, channel, n_lags):
+    """x f32 [B, L, C] on the device -> ONE packed f32 [B, n_ch * 4 + n_lags] tensor: per selected channel (min, max, median, trend),
+    then the top-n_lags autocorrelation lags; channel = -1 selects every channel (mtl_input_stats)."""
+    x = x.contiguous().float()
+    B, L, Cc = x.shape
+    n_ch = Cc if channel < 0 else 1
+    packed = torch.empty((2, B, max(n_ch * 4, n_lags)), dtype=F32, device=x.device)       # [0]: stats rows, [1]: lag rows
+    nbytes = lib().mtl_input_stats_workspace_bytes(B, L, n_ch)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    stats, lags = packed[0].reshape(-1)[: B * n_ch * 4], packed[1].reshape(-1)[: B * n_lags]
+    check(lib().mtl_input_stats(ptr(x), ptr(stats), ptr(lags), ptr(ws), nbytes, B, L, Cc, channel, n_lags, stream()), "mtl_input_stats")
+    return stats.view(B, n_ch, 4), lags.view(B, n_lags), packed
+
+
 def _attn_fwd_args(q, k, v, o, lse, B, Hq, Hkv, Tq, Tk, D, scale, causal, qs, ks, vs, os_, dropout=(0.0, 0)):
     a = N.AttnFwdArgs()
     a.dropout_p, a.dropout_seed = float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF

@@ -63,13 +63,29 @@ def input_stats_prompts(x_enc, input_stats_dim, input_stats_select="all", n_lags
     else:
         insert, s = f"feature {input_stats_dim}", ""
         xs = xs[:, :, input_stats_dim]
-    with torch.no_grad():
-        # one packed D2H copy (= one stream sync) instead of the reference's five .tolist() calls; float64 holds every
-        # value exactly (fp32/bf16 statistics, 0/1 trends, integer lags), so the formatted strings are unchanged
-        per_feature = xs.ndim == 3
-        cols = [torch.min(xs, dim=1).values, torch.max(xs, dim=1).values, torch.median(xs.float(), dim=1).values,
-                (xs.diff(dim=1).sum(dim=1) > 0), calc_lags(xs.float(), n_lags)]
-        packed = torch.cat([c.reshape(xs.size(0), -1).double() for c in cols], dim=1).tolist()
+    per_feature = xs.ndim == 3
+    if x_enc.is_cuda:
+        # device path: two launches of the library's statistics kernels (csrc/mtl_stats.hip), ONE packed device-to-host copy — the
+        # reference runs five reductions + an rFFT round trip and five .tolist() syncs. Values are fp32, exactly representable in
+        # the float64 list; lags are integers. (The autocorrelation is symmetric: inside a twin pair lag / L - lag the reference's
+        # order is FFT round-off noise; the kernel's tie rule is "smaller lag first".)
+        from ..hip import ops
+        full = x_enc.detach()
+        full = full.unsqueeze(-1) if full.ndim == 2 else full
+        ch = -1 if input_stats_dim == "all" else int(input_stats_dim)
+        stats, lags, packed_dev = ops.input_stats(full, ch, n_lags)
+        host = packed_dev.cpu()                                   # the one sync of the prompt path
+        B_, n_ch = stats.shape[0], stats.shape[1]
+        st = host[0].reshape(-1)[: B_ * n_ch * 4].view(B_, n_ch, 4).double()
+        lg = host[1].reshape(-1)[: B_ * n_lags].view(B_, n_lags).double()
+        packed = torch.cat([st[:, :, 0], st[:, :, 1], st[:, :, 2], st[:, :, 3], lg], dim=1).tolist()
+    else:
+        with torch.no_grad():
+            # one packed D2H copy (= one stream sync) instead of the reference's five .tolist() calls; float64 holds every
+            # value exactly (fp32/bf16 statistics, 0/1 trends, integer lags), so the formatted strings are unchanged
+            cols = [torch.min(xs, dim=1).values, torch.max(xs, dim=1).values, torch.median(xs.float(), dim=1).values,
+                    (xs.diff(dim=1).sum(dim=1) > 0), calc_lags(xs.float(), n_lags)]
+            packed = torch.cat([c.reshape(xs.size(0), -1).double() for c in cols], dim=1).tolist()
     C = xs.size(2) if per_feature else 1
 
     def unpack(row, i, as_bool=False):

@@ -73,7 +73,8 @@ def canonical_prompts(prompts, L):
 
     def canon(part):
         def sub(m):
-            return "lags are " + str([min(int(k), L - int(k)) for k in m.group(1).split(",")])
+            n = 2 * (L // 2)        # length of irfft's default output
+            return "lags are " + str([min(int(k), n - int(k)) for k in m.group(1).split(",")])
         return re.sub(r"lags are \[([0-9, ]+)\]", sub, part)
     return [[canon(p) for p in ps] for ps in prompts]
 

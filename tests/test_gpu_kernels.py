@@ -366,6 +366,46 @@ def test_patch_tokenizer(ops, B, L, C, pl, st, dm, concat):
     assert rel_err(dw2, wf2.grad) < 1e-5
 
 
+# ------------------------------------------------------------------------------------------------ prompt input statistics (a6 / f2)
+def _twin(lags, L):
+    """lags -> twin-pair ids min(k, n - k), n = 2 * (L // 2) = the length of irfft's default output: the autocorrelation sequence is
+    symmetric, the order inside a pair is round-off noise"""
+    n = 2 * (L // 2)
+    return np.minimum(np.asarray(lags), n - np.asarray(lags))
+
+
+def test_input_stats_vs_reference_goldens(ops):
+    """device-computed statistics against the REFERENCE's golden lags (tests/golden/stats.npz: calcute_lags outputs of the real
+    reference) and against torch's min / max / median / trend on the same tensor: values exact, lags equal as twin-pair ids"""
+    z = np.load(GOLDEN / "stats.npz")
+    x = torch.from_numpy(z["x"])                       # [2, 96, 3]
+    B, L, C = x.shape
+    st, lg, _ = ops.input_stats(dev(x), -1, 5)         # all channels: lags of the channel mean (reference: calcute_lags on [B, L, C])
+    assert np.array_equal(_twin(lg.cpu().numpy().astype(np.int64), L), _twin(z["lags_3d"], L))
+    st1, lg1, _ = ops.input_stats(dev(x), 1, 5)        # one channel (reference: calcute_lags on x[:, :, 1])
+    assert np.array_equal(_twin(lg1.cpu().numpy().astype(np.int64), L), _twin(z["lags_2d"], L))
+    for stats, xs in ((st, x), (st1, x[:, :, 1:2])):
+        s = stats.cpu()
+        assert torch.equal(s[:, :, 0], xs.min(dim=1).values) and torch.equal(s[:, :, 1], xs.max(dim=1).values)
+        assert torch.equal(s[:, :, 2], xs.median(dim=1).values)                      # LOWER median, like torch.median
+        assert torch.equal(s[:, :, 3] > 0, xs.diff(dim=1).sum(dim=1) > 0)
+    # sizes of the metric workload, odd lengths, ties in the data (repeated values -> the median's rank window is wide)
+    for (B, L, C) in ((4, 1024, 12), (3, 101, 2), (2, 64, 1)):
+        x = torch.randn(B, L, C, generator=g(L)) + torch.linspace(-1, 1, L)[None, :, None] * torch.tensor([1.0, -1.0] * 6)[:C]
+        x[:, 7::7, 0] = x[:, 3:4, 0]            # repeated values (not at t = 0: the trend is the sign of x[L-1] - x[0] up to round-off)
+        st, lg, _ = ops.input_stats(dev(x), -1, 5)
+        s = st.cpu()
+        assert torch.equal(s[:, :, 0], x.min(dim=1).values) and torch.equal(s[:, :, 1], x.max(dim=1).values)
+        assert torch.equal(s[:, :, 2], x.median(dim=1).values)
+        assert torch.equal(s[:, :, 3] > 0, x.diff(dim=1).sum(dim=1) > 0)
+        from med_ts_llm_amd.models.prompt import calc_lags
+        ref = calc_lags(x, 5).numpy()
+        # compare as SETS of twin ids per sample against the FFT-based reference: values one ulp apart may swap neighbouring ranks
+        # of DIFFERENT pairs only if the pairs' correlations tie to ~1e-6, which random data does not produce
+        assert np.array_equal(_twin(lg.cpu().numpy().astype(np.int64), L), _twin(ref, L)), (lg, ref)
+        assert lg[:, 0].eq(0).all()                                               # lag 0 always ranks first
+
+
 # ------------------------------------------------------------------------------------------------ elementwise / layout
 def test_cast_transpose_colsum(ops):
     src = torch.randn(70, 50, generator=g(1))
