@@ -68,6 +68,18 @@ CASES = [
 
 @pytest.mark.parametrize("kind,task,B,L,C,pred,cov,down,prompt_on", CASES)
 def test_full_model_fwd_bwd(kind, task, B, L, C, pred, cov, down, prompt_on):
+    _check_full_model(kind, task, B, L, C, pred, cov, down, prompt_on)
+
+
+def test_psm_shaped_anomaly_detection_vs_oracle():
+    """BASELINE.json configs[3] at a checkable size: anomaly detection (reconstruction) on a Llama MHA backbone, concat covariates with
+    C = 25 channels -> a concat width of 25 * 32 = 800 that is NOT a multiple of 64 (padded to 832 for the query GEMM), the front-end
+    dimensions of the benchmark (d_model 32, d_ff 128, 8 heads, 1024 prototypes), a text prompt, and a wide flatten head
+    (128 * 64 -> 512 * 25 = 12 800 outputs). Forward, every gradient and the eval output against the fp32 oracle."""
+    _check_full_model("llama", "anomaly_detection", 2, 512, 25, 512, "concat", "linear", True, d_model=32, d_ff=128, H=8, num_tokens=1024)
+
+
+def _check_full_model(kind, task, B, L, C, pred, cov, down, prompt_on, d_model=8, d_ff=64, H=2, num_tokens=64):
     from med_ts_llm_amd.models import model_lookup
     from med_ts_llm_amd.models.backbone import random_state_dict
     from med_ts_llm_amd.utils import dict_to_object
@@ -80,7 +92,7 @@ def test_full_model_fwd_bwd(kind, task, B, L, C, pred, cov, down, prompt_on):
     prompting = {"dataset": prompt_on, "task": prompt_on, "clip": False, "input_stats": prompt_on, "examples": ex_on,
                  "input_stats_dim": 0, "input_stats_select": "all"}
     n_classes = 4 if task == "semantic_segmentation" else 0
-    config = dict_to_object(model_config(task, L, pred, cov, down, prompting))
+    config = dict_to_object(model_config(task, L, pred, cov, down, prompting, d_model=d_model, d_ff=d_ff, H=H, num_tokens=num_tokens))
     torch.manual_seed(11)
     model = model_lookup["medtsllm"](config, FakeDataset(C, n_classes), backbone_state=(cfg, sd))
     model.tokenizer = fixture_tokenizer()
@@ -92,7 +104,7 @@ def test_full_model_fwd_bwd(kind, task, B, L, C, pred, cov, down, prompt_on):
     model = model.to("cuda")
     model.train()
     g = torch.Generator().manual_seed(13)
-    x = torch.randn(B, L, C, generator=g) * torch.tensor([1.0, 2.5, 0.3][:C]) + torch.tensor([0.5, -1.0, 3.0][:C])
+    x = torch.randn(B, L, C, generator=g) * torch.tensor(([1.0, 2.5, 0.3] * 9)[:C]) + torch.tensor(([0.5, -1.0, 3.0] * 9)[:C])
     inputs = {"x_enc": x.cuda()}
     if ex_on:
         ex = torch.randn(B, 40, C, generator=g) * 0.7 + 0.2
@@ -112,7 +124,7 @@ def test_full_model_fwd_bwd(kind, task, B, L, C, pred, cov, down, prompt_on):
         # both sides see byte-identical prompts (CPU vs GPU FFT round-off can reorder near-tied top-k lags)
         parts = model.build_prompt(inputs)
         tok_ids = [[model.tokenizer(s, padding=False, truncation=False).input_ids if isinstance(s, str) else s.cpu() for s in ps] for ps in parts]
-    meta = {"task": task, "pred_len": pred, "patch_len": 16, "stride": 8, "n_heads": 2, "d_ff": 64, "covariate_mode": cov,
+    meta = {"task": task, "pred_len": pred, "patch_len": 16, "stride": 8, "n_heads": H, "d_ff": d_ff, "covariate_mode": cov,
             "embedding_downsample_mode": down, "n_classes": n_classes, "C": C}
     m = oracle_mcfg(meta)
     ref = O.medtsllm_forward(x, p, sd, cfg, m, token_ids=tok_ids, pad_token_id=model.tokenizer.pad_token_id, training=True, **we_kw)
