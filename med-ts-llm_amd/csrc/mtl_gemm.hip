@@ -325,10 +325,11 @@ template <int EPI, int CDT, int NI, bool FULL, bool PAIR = false>
 __device__ __forceinline__ void epilogue_wave(const mtl_gemm_args& p, int64_t m_first, int64_t n_base, const int g, f32x4 (&acc)[NI][4],
                                               const bool dword_stores = false) {
     constexpr int NCH = NI > 4 ? 2 : NI;
-    static_assert(NI % NCH == 0, "column tiles per wave must split evenly");
+    constexpr int NEVEN = NI - NI % NCH;       // an odd count (NI = 9: 64 x 144 per wave) ends with ONE unpaired column tile
     static_assert(!PAIR || NCH == NI || NCH % 2 == 0, "paired column tiles stay inside one chunk");
 #pragma unroll
-    for (int c0 = 0; c0 < NI; c0 += NCH) epilogue_chunk<EPI, CDT, NCH, FULL, PAIR>(p, m_first, n_base + c0 * 16, g, &acc[c0], dword_stores);
+    for (int c0 = 0; c0 < NEVEN; c0 += NCH) epilogue_chunk<EPI, CDT, NCH, FULL, PAIR>(p, m_first, n_base + c0 * 16, g, &acc[c0], dword_stores);
+    if constexpr (NEVEN < NI) epilogue_chunk<EPI, CDT, NI - NEVEN, FULL, false>(p, m_first, n_base + NEVEN * 16, g, &acc[NEVEN], dword_stores);
 }
 
 // SPLIT: raw fp32 partial sums go to workspace slab [split][M][N]; epilogue runs in splitk_reduce_kernel.
