@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MTL_ABI_VERSION 5
+#define MTL_ABI_VERSION 6
 
 enum { MTL_OK = 0, MTL_ERR_ARG = -1, MTL_ERR_ALIGN = -2, MTL_ERR_UNSUPPORTED = -3, MTL_ERR_LAUNCH = -4,
        MTL_ERR_WORKSPACE = -5 };
@@ -105,6 +105,9 @@ typedef struct {
     int64_t bwd_group_rows, bwd_first_row;
 } mtl_gemm_args;
 size_t mtl_gemm_workspace_bytes(int64_t M, int64_t N, int split_k);
+/* split_k the library would pick for a problem: > 1 only for few output tiles with a long K (the flatten head, small weight
+ * gradients), where it spreads the K range over the idle CUs; the caller allocates the workspace and passes it in mtl_gemm_args. */
+int mtl_gemm_auto_split_k(int64_t M, int64_t N, int64_t K, int epilogue);
 int mtl_gemm_nt(const mtl_gemm_args* args, void* stream);
 /* Measurement aid (bench.py's roofline legs; off by default, no effect on results): while enabled, every GEMM, attention, norm and
  * optimiser launch carries its own start / stop event pair (hipExtLaunchKernelGGL), whose elapsed time is the kernel's begin -> end

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
 // One workgroup per (64-key tile, kv head, batch or ALL batches when K/V are batch-shared); loops over the query
 // heads of the GQA group and over 64-query chunks. Lane owns key = lane & 15 of its wave's 16 keys.
 template <int D, bool CAUSAL, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const mtl_attn_bwd_args a) {
+__global__ __launch_bounds__(256, D >= 128 ? 2 : 1) void attn_bwd_dkv_kernel(const mtl_attn_bwd_args a) {
     constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
     __shared__ __attribute__((aligned(16))) bf16_t qtile[KC * LDT];
     __shared__ __attribute__((aligned(16))) bf16_t dotile[KC * LDT];

@@ -12,6 +12,7 @@
 //     in its private L2.
 //   * split-K (fp32 slabs + reduce kernel) for the batch-independent mapping GEMM (M=1024, N=d_llm, K=V).
 #include "mtl_common.h"
+#include <cstdarg>
 
 #include <atomic>
 #include <cmath>
@@ -727,8 +728,21 @@ __global__ void splitk_reduce_kernel(const mtl_gemm_args p, const int S, const i
     const float* w = reinterpret_cast<const float*>(p.workspace) + m * p.N + n;
     const int nvalid = (p.N - n) >= 4 ? 4 : (int)(p.N - n);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < S; ++s) {
-        const float* ws = w + (int64_t)s * p.M * p.N;
+    const int64_t slab = p.M * p.N;
+    int s = 0;
+    if (p.N % 4 == 0 && (reinterpret_cast<uintptr_t>(p.workspace) & 15) == 0) {
+        // four slabs' loads in flight per round (a serial load -> add chain costs one memory round trip per slab: 17 us for the
+        // 32-slab flatten-head reduction of 37 k outputs); the summation order stays slab 0, 1, 2, ...
+        for (; s + 4 <= S; s += 4) {
+            f32x4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const f32x4*>(w + (int64_t)(s + u) * slab);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v += t[u];
+        }
+    }
+    for (; s < S; ++s) {
+        const float* ws = w + (int64_t)s * slab;
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (e < nvalid) v[e] += ws[e];
     }
@@ -790,6 +804,16 @@ int num_cus() {
         t.num_cu = n;
     }
     return t.num_cu;
+}
+
+// kernel name of a launch for the profiler; MTL_PROF_SHAPES=1 appends the problem size (per-shape rows: tools/gemm_shapes.py)
+__attribute__((format(printf, 4, 5))) void kname_shape(char* buf, size_t cap, const mtl_gemm_args& p, const char* fmt, ...) {
+    static const bool shapes = getenv("MTL_PROF_SHAPES") && atoi(getenv("MTL_PROF_SHAPES")) != 0;
+    va_list ap;
+    va_start(ap, fmt);
+    const int n = vsnprintf(buf, cap, fmt, ap);
+    va_end(ap);
+    if (shapes && n > 0 && (size_t)n < cap) snprintf(buf + n, cap - n, " [%lldx%lldx%lld]", (long long)p.M, (long long)p.N, (long long)p.K);
 }
 
 template <int EPI, int CDT>
@@ -865,14 +889,14 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
         auto kfn = gemm_nt_persist_kernel<EPI, CDT, BMV, BNV, STV, NWV>;                                               \
         static std::once_flag once;                                                                                    \
         std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
-        snprintf(kname, sizeof kname, "gemm_nt_persist_kernel<%d, %d, %d, %d, %d, %d, false, 1>", EPI, CDT, BMV, BNV, STV, NWV); \
+        kname_shape(kname, sizeof kname, p, "gemm_nt_persist_kernel<%d, %d, %d, %d, %d, %d, false, 1>", EPI, CDT, BMV, BNV, STV, NWV); \
         MTL_LAUNCH(kname, flops, 0, kfn, dim3(grid), dim3(NWV * 64), lds, st, p, vec_ok, tm, tn, tile_order(tm, tn, bm, bn, per_cu, p.K)); \
     } while (0)
         if (ks == 2) {
             auto kfn = gemm_nt_persist_kernel<EPI, CDT, 128, 96, 2, 8, false, 2>;
             static std::once_flag once;
             std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-            snprintf(kname, sizeof kname, "gemm_nt_persist_kernel<%d, %d, 128, 96, 2, 8, false, 2>", EPI, CDT);
+            kname_shape(kname, sizeof kname, p, "gemm_nt_persist_kernel<%d, %d, 128, 96, 2, 8, false, 2>", EPI, CDT);
             MTL_LAUNCH(kname, flops, 0, kfn, dim3(nt), dim3(512), lds, st, p, vec_ok, tm, tn, tile_order(tm, tn, bm, bn, 1, p.K, true));
         } else if (bm == 256 && bn == 128 && nw == 16 && stages == 3) MTL_PERSIST(256, 128, 3, 16);
         else if (bm == 256 && bn == 128 && nw == 16 && stages == 2) MTL_PERSIST(256, 128, 2, 16);
@@ -892,7 +916,7 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
 #undef MTL_PERSIST
     } else if (S == 1) {
         if (EPI == MTL_EPI_SWIGLU || EPI == MTL_EPI_DSWIGLU) return MTL_ERR_UNSUPPORTED;      // the fused activation lives in the wave-level epilogue only
-        snprintf(kname, sizeof kname, "gemm_nt_kernel<%d, %d, false>", EPI, CDT);
+        kname_shape(kname, sizeof kname, p, "gemm_nt_kernel<%d, %d, false>", EPI, CDT);
         MTL_LAUNCH(kname, flops, 0, (gemm_nt_kernel<EPI, CDT, false>), dim3(tiles_m * tiles_n, 1), dim3(256), 0, st, p, vec_ok);
     } else {
         const int ws_vec = (p.N % 4 == 0) && aligned(p.workspace, 16);
@@ -909,7 +933,7 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
                 auto kfn = gemm_nt_persist_kernel<MTL_EPI_STORE, MTL_F32, BMV, BNV, STV, NWV, true>;
                 static std::once_flag once;
                 std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-                snprintf(kname, sizeof kname, "gemm_nt_persist_kernel<0, 0, %d, %d, %d, %d, true, 1>", BMV, BNV, STV, NWV);
+                kname_shape(kname, sizeof kname, p, "gemm_nt_persist_kernel<0, 0, %d, %d, %d, %d, true, 1>", BMV, BNV, STV, NWV);
                 MTL_LAUNCH(kname, flops, 0, kfn, dim3(grid), dim3(NWV * 64), lds, st, p, S, tm, tn, tile_order(tm, tn, BMV, BNV, per_cu, p.K));
             };
             using I128 = std::integral_constant<int, 128>; using I192 = std::integral_constant<int, 192>; using I256 = std::integral_constant<int, 256>;
@@ -920,11 +944,11 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
             else go(I128{}, I128{});
         } else
         {
-            snprintf(kname, sizeof kname, "gemm_nt_kernel<%d, %d, true>", EPI, CDT);
+            kname_shape(kname, sizeof kname, p, "gemm_nt_kernel<%d, %d, true>", EPI, CDT);
             MTL_LAUNCH(kname, flops, 0, (gemm_nt_kernel<EPI, CDT, true>), dim3(tiles_m * tiles_n, S), dim3(256), 0, st, p, ws_vec);
         }
         const int64_t items = p.M * ((p.N + 3) / 4);
-        snprintf(kname, sizeof kname, "splitk_reduce_kernel<%d, %d>", EPI, CDT);
+        kname_shape(kname, sizeof kname, p, "splitk_reduce_kernel<%d, %d>", EPI, CDT);
         MTL_LAUNCH(kname, (double)S * p.M * p.N * 4.0 + (double)p.M * p.N * (CDT == MTL_BF16 ? 2.0 : 4.0), 1, (splitk_reduce_kernel<EPI, CDT>),
                    dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, p, S, vec_ok);
     }
@@ -1017,6 +1041,20 @@ extern "C" int mtl_prof_read(mtl_prof_row* rows, int cap) {
 
 extern "C" size_t mtl_gemm_workspace_bytes(int64_t M, int64_t N, int split_k) {
     return split_k > 1 ? (size_t)split_k * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+// Few output tiles and a long K (the flatten head: [B, d_ff*P] x [pred*C, d_ff*P]^T = 12 tiles of 128x96 with 256 k-steps each, 131 us on
+// 12 CUs; the weight gradients of the small projections): split K so that about one work item per CU exists. 1 = do not split.
+extern "C" int mtl_gemm_auto_split_k(int64_t M, int64_t N, int64_t K, int epilogue) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % BK != 0) return 1;
+    if (epilogue == MTL_EPI_ACCUM || epilogue == MTL_EPI_SWIGLU || epilogue == MTL_EPI_DSWIGLU || N % 4 != 0) return 1;
+    const int64_t nkt = K / BK, bn = N % 192 == 0 ? 192 : 128;
+    const int64_t tiles = ((M + 127) / 128) * ((N + bn - 1) / bn);
+    const int ncu = num_cus();
+    if (tiles * 4 > ncu || nkt < 32) return 1;
+    int s = 1;
+    while (s * 2 <= 32 && (int64_t)s * 2 * tiles <= ncu && nkt / (s * 2) >= 8 && nkt % (s * 2) == 0) s *= 2;
+    return s;
 }
 
 extern "C" int mtl_gemm_nt(const mtl_gemm_args* a, void* stream) {

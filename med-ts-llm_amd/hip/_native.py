@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("MTL_LIB_PATH") or os.path.join(_HERE, "libmedtsllm_hi
 MTL_F32, MTL_BF16 = 0, 1
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM, EPI_SWIGLU, EPI_DSWIGLU = 0, 1, 2, 3, 4, 5, 6
 ARCH_GPT2, ARCH_LLAMA = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 i64, vp, f32, i32 = C.c_int64, C.c_void_p, C.c_float, C.c_int
 
@@ -90,6 +90,7 @@ SIGNATURES = {
     "mtl_patch_index_map": (i32, [vp, i64, i64, i64, vp]),
     "mtl_revin_denorm": (i32, [vp, vp, vp, vp, i64, i64, i64, vp]),
     "mtl_gemm_workspace_bytes": (C.c_size_t, [i64, i64, i32]),
+    "mtl_gemm_auto_split_k": (i32, [i64, i64, i64, i32]),
     "mtl_gemm_nt": (i32, [C.POINTER(GemmArgs), vp]),
     "mtl_prof_enable": (i32, [i32]),
     "mtl_gemm_tune": (i32, [i32, i32, i32, i32, i32]),

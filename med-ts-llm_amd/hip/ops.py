@@ -46,8 +46,9 @@ def _req(cond, msg):
 
 # =============================================================================================== raw wrappers
 def gemm_nt(A, B, out=None, out_dtype=BF16, bias=None, epilogue=N.EPI_STORE, aux_in=None, aux_out=None, alpha=1.0,
-            split_k=1, M=None, a_rows=None, c_rows=None, drop=(0.0, 0), bwd_rows=None):
-    """C[M,N] = epi(alpha * A[M,K] @ B[N,K]^T + bias). A, B bf16 with unit inner stride, K % 64 == 0."""
+            split_k=0, M=None, a_rows=None, c_rows=None, drop=(0.0, 0), bwd_rows=None):
+    """C[M,N] = epi(alpha * A[M,K] @ B[N,K]^T + bias). A, B bf16 with unit inner stride, K % 64 == 0.
+    split_k = 0: the library's own choice (mtl_gemm_auto_split_k: > 1 only for few output tiles with a long K)."""
     _req(A.dtype == BF16 and B.dtype == BF16 and A.dim() == 2 and B.dim() == 2, "gemm_nt: bf16 2-D operands")
     _req(A.stride(1) == 1 and B.stride(1) == 1 and A.shape[1] == B.shape[1], "gemm_nt: K mismatch / inner stride")
     K, Nn = A.shape[1], B.shape[0]
@@ -68,6 +69,8 @@ def gemm_nt(A, B, out=None, out_dtype=BF16, bias=None, epilogue=N.EPI_STORE, aux
         g.aux_in, g.ld_aux_in = aux_in.data_ptr(), aux_in.stride(0)
     if aux_out is not None:
         g.aux_out, g.ld_aux_out = aux_out.data_ptr(), aux_out.stride(0)
+    if split_k == 0:
+        split_k = lib().mtl_gemm_auto_split_k(M, Nn, K, epilogue)
     g.alpha, g.split_k = alpha, split_k
     g.drop_p, g.drop_seed = float(drop[0]), int(drop[1]) & 0xFFFFFFFF      # MTL_EPI_RESID only (resid_pdrop)
     if bwd_rows is not None:       # GELU / SWIGLU: (group_rows, first_row) of the rows whose backward-only output is stored
