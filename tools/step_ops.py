@@ -45,7 +45,7 @@ def main():
         step()
     torch.cuda.synchronize()
     from torch.profiler import profile, ProfilerActivity
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
         step()
         torch.cuda.synchronize()
     rows = []
@@ -72,6 +72,14 @@ def main():
     print("\ndevice kernels in the step: %d launches, %.1f us" % (sum(c for _, c in kern.values()), sum(t for t, _ in kern.values())))
     for n, (t, c) in sorted(kern.items(), key=lambda kv: -kv[1][0])[:60]:
         print(f"{t:9.1f} us  x{c:<3d} {n}")
+
+
+    print("\nATen ops by self device time (with shapes and the Python frame that issued them):")
+    ka = prof.key_averages(group_by_input_shape=True, group_by_stack_n=4)
+    rows2 = [k for k in ka if k.key.startswith("aten::") and k.self_device_time_total > 0]
+    for k in sorted(rows2, key=lambda k: -k.self_device_time_total)[:45]:
+        frames = [f for f in (k.stack or []) if "med-ts-llm_amd" in f or "bench.py" in f or "step_ops" in f]
+        print(f"{k.self_device_time_total:9.1f} us  x{k.count:<3d} {k.key:26s} {str(k.input_shapes)[:70]:70s} {frames[0][-70:] if frames else ''}")
 
 
 if __name__ == "__main__":
