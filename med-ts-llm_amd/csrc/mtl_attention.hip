@@ -200,12 +200,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a
             if (DROP) {   // a lane's keys kb + t*16 + g*4 + {0,1,2,3} are two whole pairs: one mask word per pair
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; r += 2) {
-                        const uint32_t w = drop_word(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4 + r) >> 1);   // absolute query index
-                        p[t][r] = (w & 0xffffu) >= drop_thr ? p[t][r] * drop_scale : 0.f;
-                        p[t][r + 1] = (w >> 16) >= drop_thr ? p[t][r + 1] * drop_scale : 0.f;
-                    }
+                {
+                    const uint2 w = drop_quad(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4) >> 2);   // absolute query index
+                    p[t][0] = (w.x & 0xffffu) >= drop_thr ? p[t][0] * drop_scale : 0.f;
+                    p[t][1] = (w.x >> 16) >= drop_thr ? p[t][1] * drop_scale : 0.f;
+                    p[t][2] = (w.y & 0xffffu) >= drop_thr ? p[t][2] * drop_scale : 0.f;
+                    p[t][3] = (w.y >> 16) >= drop_thr ? p[t][3] * drop_scale : 0.f;
+                }
             }
             const bf16x8 pf = pack8(p[0], p[1]);
 #pragma unroll
@@ -310,17 +311,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
                         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kr + ks * 32), qf[ks], s, 0, 0, 0);
                         dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(vr + ks * 32), dof[ks], dp, 0, 0, 0);
                     }
-                    uint32_t dw[2] = {0u, 0u};      // mask words of the lane's two key pairs
-                    if (DROP) {
-                        dw[0] = drop_word(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4) >> 1);
-                        dw[1] = drop_word(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4 + 2) >> 1);
-                    }
+                    uint2 dw = make_uint2(0u, 0u);      // mask words of the lane's four keys
+                    if (DROP) dw = drop_quad(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4) >> 2);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int64_t key = kb + t * 16 + g * 4 + r;
                         const float p = (key >= f.Tk || (CAUSAL && key > qrow + coff)) ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse2);
                         float dpv = dp[r];
-                        if (DROP) dpv = drop_field(dw[r >> 1], (uint32_t)r) >= drop_thr ? dpv * drop_scale : 0.f;
+                        if (DROP) dpv = drop_field(dw, (uint32_t)r) >= drop_thr ? dpv * drop_scale : 0.f;
                         acc += p * dpv;
                     }
                 }
@@ -351,18 +349,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
                     s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kr + ks * 32), qf[ks], s, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(vr + ks * 32), dof[ks], dp, 0, 0, 0);
                 }
-                uint32_t dw[2] = {0u, 0u};      // mask words of the lane's two key pairs
-                if (DROP) {
-                    dw[0] = drop_word(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4) >> 1);
-                    dw[1] = drop_word(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4 + 2) >> 1);
-                }
+                uint2 dw = make_uint2(0u, 0u);      // mask words of the lane's four keys
+                if (DROP) dw = drop_quad(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4) >> 2);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t key = kb + t * 16 + g * 4 + r;
                     const bool masked = key >= f.Tk || (CAUSAL && key > qrow + coff);
                     const float p = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse2);
                     float dpv = dp[r];
-                    if (DROP) dpv = drop_field(dw[r >> 1], (uint32_t)r) >= drop_thr ? dpv * drop_scale : 0.f;
+                    if (DROP) dpv = drop_field(dw, (uint32_t)r) >= drop_thr ? dpv * drop_scale : 0.f;
                     ds[t][r] = p * (dpv - dl);
                 }
             }
@@ -658,12 +653,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fw
             if (DROP) {   // attn_pdrop: the normaliser keeps the undropped sum, the P.V operand carries the mask (one word per key pair)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; r += 2) {
-                        const uint32_t w = drop_word(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4 + r) >> 1);
-                        p[t][r] = (w & 0xffffu) >= drop_thr ? p[t][r] * drop_scale : 0.f;
-                        p[t][r + 1] = (w >> 16) >= drop_thr ? p[t][r + 1] * drop_scale : 0.f;
-                    }
+                {
+                    const uint2 w = drop_quad(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4) >> 2);   // absolute query index
+                    p[t][0] = (w.x & 0xffffu) >= drop_thr ? p[t][0] * drop_scale : 0.f;
+                    p[t][1] = (w.x >> 16) >= drop_thr ? p[t][1] * drop_scale : 0.f;
+                    p[t][2] = (w.y & 0xffffu) >= drop_thr ? p[t][2] * drop_scale : 0.f;
+                    p[t][3] = (w.y >> 16) >= drop_thr ? p[t][3] * drop_scale : 0.f;
+                }
             }
             const bf16x8 pf = pack8(p[0], p[1]);
             const int ra = (int)(kb + g * 4), rb = (int)(kb + 16 + g * 4);   // rows >= Tk are zero-filled and carry p == 0
@@ -755,18 +751,15 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn
                         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kr + ks * 32), qf[ks], s, 0, 0, 0);
                         dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(vr + ks * 32), dof[ks], dp, 0, 0, 0);
                     }
-                    uint32_t dw[2] = {0u, 0u};
-                    if (DROP) {
-                        dw[0] = drop_word(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4) >> 1);
-                        dw[1] = drop_word(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4 + 2) >> 1);
-                    }
+                    uint2 dw = make_uint2(0u, 0u);      // mask words of the lane's four keys
+                    if (DROP) dw = drop_quad(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4) >> 2);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int64_t key = kb + t * 16 + g * 4 + r;
                         const bool masked = key >= f.Tk || key > qrow + coff;
                         const float pv = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse2);
                         float dpv = dp[r];
-                        if (DROP) dpv = drop_field(dw[r >> 1], (uint32_t)r) >= drop_thr ? dpv * drop_scale : 0.f;
+                        if (DROP) dpv = drop_field(dw, (uint32_t)r) >= drop_thr ? dpv * drop_scale : 0.f;
                         acc += pv * dpv;
                     }
                 }
@@ -786,18 +779,15 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn
                     s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kr + ks * 32), qf[ks], s, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(vr + ks * 32), dof[ks], dp, 0, 0, 0);
                 }
-                uint32_t dw[2] = {0u, 0u};      // mask words of the lane's two key pairs
-                if (DROP) {
-                    dw[0] = drop_word(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4) >> 1);
-                    dw[1] = drop_word(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4 + 2) >> 1);
-                }
+                uint2 dw = make_uint2(0u, 0u);      // mask words of the lane's four keys
+                if (DROP) dw = drop_quad(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4) >> 2);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t key = kb + t * 16 + g * 4 + r;
                     const bool masked = key >= f.Tk || key > qrow + coff;
                     const float pv = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse2);
                     float dpv = dp[r];
-                    if (DROP) dpv = drop_field(dw[r >> 1], (uint32_t)r) >= drop_thr ? dpv * drop_scale : 0.f;
+                    if (DROP) dpv = drop_field(dw, (uint32_t)r) >= drop_thr ? dpv * drop_scale : 0.f;
                     ds[t][r] = pv * (dpv - dl);
                 }
             }

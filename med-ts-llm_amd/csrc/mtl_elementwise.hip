@@ -363,7 +363,8 @@ __global__ __launch_bounds__(256) void dropout_f32_kernel(const float* x, float*
         const int c = (int)(i - row * (d / 4)) * 4;
         float4 v = *reinterpret_cast<const float4*>(x + row * d + c);
         const uint32_t dbase = drop_base(seed, 0u);
-        const uint32_t w0 = drop_word(dbase, (uint32_t)row, (uint32_t)c >> 1), w1 = drop_word(dbase, (uint32_t)row, ((uint32_t)c >> 1) + 1u);
+        const uint2 wq = drop_quad(dbase, (uint32_t)row, (uint32_t)c >> 2);
+                        const uint32_t w0 = wq.x, w1 = wq.y;
         v.x = (w0 & 0xffffu) >= thr ? v.x * scale : 0.f; v.y = (w0 >> 16) >= thr ? v.y * scale : 0.f;
         v.z = (w1 & 0xffffu) >= thr ? v.z * scale : 0.f; v.w = (w1 >> 16) >= thr ? v.w * scale : 0.f;
         *reinterpret_cast<float4*>(y + row * d + c) = v;

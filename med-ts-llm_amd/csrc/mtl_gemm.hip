@@ -247,7 +247,8 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
                     // the lane's 4 columns n .. n+3 (n % 4 == 0) are two whole pairs: one mask word each
                     const uint32_t thr = drop_threshold(p.drop_p), dbase = drop_base(p.drop_seed, 0u);
                     const float sc = drop_scale_of(thr);
-                    const uint32_t w0 = drop_word(dbase, (uint32_t)crow[mi], (uint32_t)n >> 1), w1 = drop_word(dbase, (uint32_t)crow[mi], ((uint32_t)n >> 1) + 1u);
+                    const uint2 wq = drop_quad(dbase, (uint32_t)crow[mi], (uint32_t)n >> 2);
+                        const uint32_t w0 = wq.x, w1 = wq.y;
                     v[0] = (w0 & 0xffffu) >= thr ? v[0] * sc : 0.f; v[1] = (w0 >> 16) >= thr ? v[1] * sc : 0.f;
                     v[2] = (w1 & 0xffffu) >= thr ? v[2] * sc : 0.f; v[3] = (w1 >> 16) >= thr ? v[3] * sc : 0.f;
                 }

@@ -129,7 +129,8 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict_
                 if (drop_p > 0.f) {   // gradient entering a residual branch whose forward output was dropped with this mask
                     const uint32_t thr = drop_threshold(drop_p), dbase = drop_base(drop_seed, 0u);
                     const float sc = drop_scale_of(thr);
-                    const uint32_t w0 = drop_word(dbase, (uint32_t)prow, (uint32_t)c >> 1), w1 = drop_word(dbase, (uint32_t)prow, ((uint32_t)c >> 1) + 1u);   // c % 4 == 0
+                    const uint2 wq = drop_quad(dbase, (uint32_t)prow, (uint32_t)c >> 2);
+                        const uint32_t w0 = wq.x, w1 = wq.y;   // c % 4 == 0
                     o.x = (w0 & 0xffffu) >= thr ? o.x * sc : 0.f; o.y = (w0 >> 16) >= thr ? o.y * sc : 0.f;
                     o.z = (w1 & 0xffffu) >= thr ? o.z * sc : 0.f; o.w = (w1 >> 16) >= thr ? o.w * sc : 0.f;
                 }

@@ -161,16 +161,17 @@ def _mad24(a, b, c):
 
 
 def drop_u16(seed, stream, a, b):
-    """the 16-bit mask field of element (stream, a, b): drop_field(drop_word(drop_base(seed, stream), a, b >> 1), b) of mtl_common.h"""
+    """the 16-bit mask field of element (stream, a, b): drop_field(drop_quad(drop_base(seed, stream), a, b >> 2), b) of mtl_common.h"""
     M, u = np.uint64(0xFFFFFFFF), np.uint64
     a, b = np.asarray(a, dtype=np.uint64), np.asarray(b, dtype=np.uint64)
-    h = (_mad24(a, 0x9E3779, _drop_base(seed, stream)) ^ _mad24(b >> u(1), 0x85EBCB, u(0))) & M
+    h = (_mad24(a, 0x9E3779, _drop_base(seed, stream)) ^ _mad24(b >> u(2), 0x85EBCB, u(0))) & M
     h ^= h >> u(15)
     h = _mad24(h, 0xC2B2AF, h >> u(24))
     h ^= h >> u(13)
-    h = _mad24(h, 0x27D4EB, h >> u(24))
-    h ^= h >> u(16)
-    return np.where((b & u(1)) == 1, h >> u(16), h & u(0xFFFF))
+    g = _mad24(h, 0x27D4EB, h >> u(8))
+    g ^= g >> u(15)
+    w = np.where((b & u(2)) == 0, h, g)
+    return np.where((b & u(1)) == 1, w >> u(16), w & u(0xFFFF))
 
 
 def drop_threshold(p):

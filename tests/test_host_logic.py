@@ -263,3 +263,33 @@ def test_prompt_token_ids_are_range_checked_on_the_host():
     model.fixed_prompt_ids = torch.tensor([[1, 2, 9999]], dtype=torch.int32)
     with pytest.raises(IndexError):
         model._prompt_ids({"x_enc": torch.zeros(1, 64, 3)}, torch.device("cpu"))
+
+
+def test_dropout_mask_function_statistics():
+    """the counter-based dropout mask (csrc/mtl_common.h::drop_quad, replicated in helpers.drop_u16): keep rate at the nominal 1 - p,
+    no correlation between neighbouring elements / rows / streams, uniform 16-bit fields — on the index patterns the kernels use
+    (a [rows, cols] matrix; [B*H, Tq, Tk] attention probabilities)"""
+    import numpy as np
+    from helpers import drop_u16, drop_threshold
+    thr = drop_threshold(0.1)
+    for seed in (1, 777, 123456789):
+        r, c = np.meshgrid(np.arange(2048, dtype=np.uint64), np.arange(768, dtype=np.uint64), indexing="ij")
+        keep = (drop_u16(seed, 0, r, c) >= thr).astype(np.float64)
+        assert abs(keep.mean() - 0.9) < 1.5e-3
+        z = keep - keep.mean()
+        for sh in (1, 2, 3, 4, 8):
+            assert abs((z[:, :-sh] * z[:, sh:]).mean() / z.var()) < 4e-3, ("col", sh)
+            assert abs((z[:-sh, :] * z[sh:, :]).mean() / z.var()) < 4e-3, ("row", sh)
+        # row / column keep rates scatter like independent Bernoulli draws
+        assert 0.9 < keep.mean(1).std() / np.sqrt(0.09 / 768) < 1.1 and 0.9 < keep.mean(0).std() / np.sqrt(0.09 / 2048) < 1.1
+        bh, q, k = np.meshgrid(np.arange(24, dtype=np.uint64), np.arange(128, dtype=np.uint64), np.arange(256, dtype=np.uint64), indexing="ij")
+        k3 = (drop_u16(seed, bh, q, k) >= thr).astype(np.float64)
+        z3 = k3 - k3.mean()
+        assert abs(k3.mean() - 0.9) < 1.5e-3
+        assert abs((z3[:-1] * z3[1:]).mean() / z3.var()) < 4e-3            # the same (q, k) of neighbouring heads
+    r, c = np.meshgrid(np.arange(1024, dtype=np.uint64), np.arange(1024, dtype=np.uint64), indexing="ij")
+    v = drop_u16(99, 0, r, c).astype(np.int64)
+    for byte in (v >> 8, v & 255):
+        hist = np.bincount(byte.ravel(), minlength=256)
+        e = byte.size / 256
+        assert ((hist - e) ** 2 / e).sum() / 255 < 1.5                     # chi-square per degree of freedom
