@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a
 
     // causal: key visible to query q iff key <= q + causal_off (causal_off = Tk - Tq aligns the diagonal bottom-right)
     const int64_t coff = a.causal_off;
+    const int klim = (int)((CAUSAL && qrow + coff < a.Tk - 1) ? qrow + coff : a.Tk - 1);   // last visible key of the lane's query
     int64_t k_end = a.Tk;
     if (CAUSAL) {
         const int64_t lim = (qblk0 + 64 < a.Tq ? qblk0 + 64 : a.Tq) + coff;  // keys <= last query of the block
@@ -169,8 +170,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int64_t key = kb + t * 16 + g * 4 + r;
-                        p[t][r] = (key >= a.Tk || (CAUSAL && key > qrow + coff)) ? NEG_BIG : s[t][r] * c;
+                        p[t][r] = ((int)kb + t * 16 + g * 4 + r > klim) ? NEG_BIG : s[t][r] * c;
                     }
             } else {
 #pragma unroll
@@ -277,6 +277,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
     for (int i = 0; i < NDT; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int64_t coff = f.causal_off;
+    const int klim = (int)((CAUSAL && qrow + coff < f.Tk - 1) ? qrow + coff : f.Tk - 1);   // last visible key of the lane's query
     int64_t k_end = f.Tk;
     if (CAUSAL) {
         const int64_t lim = (qblk0 + 64 < f.Tq ? qblk0 + 64 : f.Tq) + coff;
@@ -315,8 +316,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
                     if (DROP) dw = drop_quad(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4) >> 2);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int64_t key = kb + t * 16 + g * 4 + r;
-                        const float p = (key >= f.Tk || (CAUSAL && key > qrow + coff)) ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse2);
+                        const float p = ((int)kb + t * 16 + g * 4 + r > klim) ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse2);
                         float dpv = dp[r];
                         if (DROP) dpv = drop_field(dw, (uint32_t)r) >= drop_thr ? dpv * drop_scale : 0.f;
                         acc += p * dpv;
@@ -353,8 +353,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
                 if (DROP) dw = drop_quad(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4) >> 2);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int64_t key = kb + t * 16 + g * 4 + r;
-                    const bool masked = key >= f.Tk || (CAUSAL && key > qrow + coff);
+                    const bool masked = (int)kb + t * 16 + g * 4 + r > klim;
                     const float p = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse2);
                     float dpv = dp[r];
                     if (DROP) dpv = drop_field(dw, (uint32_t)r) >= drop_thr ? dpv * drop_scale : 0.f;
@@ -402,6 +401,9 @@ __global__ __launch_bounds__(256, D >= 128 ? 2 : 1) void attn_bwd_dkv_kernel(con
     const int64_t k0 = kblk0 + wave * 16;
     int64_t krow = k0 + l15;
     const bool k_valid = krow < f.Tk;
+    const int qhi = (int)f.Tq - 1, qlo = CAUSAL ? (int)(krow - coff) : 0;      // queries that see the lane's key
+    const int64_t key_u = krow;                       // (unclamped: the mask words are exchanged inside lane quads, also by lanes past the last key)
+    const bool quad_ok = (k0 & 3) == 0;               // the four keys of a lane quad share their mask quad
     if (krow > f.Tk - 1) krow = f.Tk - 1;
 
     const float c = f.scale * LOG2E;
@@ -458,14 +460,23 @@ __global__ __launch_bounds__(256, D >= 128 ? 2 : 1) void attn_bwd_dkv_kernel(con
                             s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(qr + ks * 32), kf[ks], s, 0, 0, 0);
                             dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(dr + ks * 32), vf[ks], dp, 0, 0, 0);
                         }
+                        uint32_t fld[4] = {0xffffu, 0xffffu, 0xffffu, 0xffffu};
+                        if (DROP) {
+                            const uint32_t a0 = (uint32_t)((int)qc0 + sub * 32 + t * 16 + g * 4 + (int)coff);
+                            if (quad_ok) drop_fields_shared(dbase_h, a0, (uint32_t)key_u, fld);
+                            else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) fld[r] = drop_field(drop_quad(dbase_h, a0 + r, (uint32_t)krow >> 2), (uint32_t)krow);
+                            }
+                        }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int ql = sub * 32 + t * 16 + g * 4 + r;
-                            const int64_t q = qc0 + ql;
-                            const bool masked = q >= f.Tq || (CAUSAL && krow > q + coff);
+                            const int q = (int)qc0 + ql;
+                            const bool masked = q > qhi || q < qlo;
                             const float pv = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse_s[ql]);
                             float keep = 1.0f;
-                            if (DROP) keep = drop_keep(dbase_h, (uint32_t)(q + coff), (uint32_t)krow, drop_thr) ? drop_scale : 0.f;
+                            if (DROP) keep = fld[r] >= drop_thr ? drop_scale : 0.f;
                             p[t][r] = pv * keep;                               // feeds dV = (dropped P)^T dO
                             ds[t][r] = pv * (dp[r] * keep - delta_s[ql]);      // feeds dK
                         }
@@ -595,6 +606,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fw
         int64_t qrow = q0 + l15;
         const bool q_valid = qrow < a.Tq;
         if (qrow > a.Tq - 1) qrow = a.Tq - 1;
+        const int klim = (int)(qrow + coff < a.Tk - 1 ? qrow + coff : a.Tk - 1);
         bf16x8 qf[NKS];
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + qrow * a.q_ts + ks * 32 + g * 8);
@@ -622,8 +634,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fw
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int64_t key = kb + t * 16 + g * 4 + r;
-                        p[t][r] = (key >= a.Tk || key > qrow + coff) ? NEG_BIG : s[t][r] * c;
+                        p[t][r] = ((int)kb + t * 16 + g * 4 + r > klim) ? NEG_BIG : s[t][r] * c;
                     }
             } else {
 #pragma unroll
@@ -713,6 +724,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn
         int64_t qrow = q0 + l15;
         const bool q_valid = qrow < f.Tq;
         if (qrow > f.Tq - 1) qrow = f.Tq - 1;
+        const int klim = (int)(qrow + coff < f.Tk - 1 ? qrow + coff : f.Tk - 1);
         bf16x8 qf[NKS], dof[NKS];
         float dl = 0.f;
 #pragma unroll
@@ -755,8 +767,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn
                     if (DROP) dw = drop_quad(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4) >> 2);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int64_t key = kb + t * 16 + g * 4 + r;
-                        const bool masked = key >= f.Tk || key > qrow + coff;
+                        const bool masked = (int)kb + t * 16 + g * 4 + r > klim;
                         const float pv = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse2);
                         float dpv = dp[r];
                         if (DROP) dpv = drop_field(dw, (uint32_t)r) >= drop_thr ? dpv * drop_scale : 0.f;
@@ -783,8 +794,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn
                 if (DROP) dw = drop_quad(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4) >> 2);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int64_t key = kb + t * 16 + g * 4 + r;
-                    const bool masked = key >= f.Tk || key > qrow + coff;
+                    const bool masked = (int)kb + t * 16 + g * 4 + r > klim;
                     const float pv = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse2);
                     float dpv = dp[r];
                     if (DROP) dpv = drop_field(dw, (uint32_t)r) >= drop_thr ? dpv * drop_scale : 0.f;
@@ -841,6 +851,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(const mtl_att
         const bool tile_on = active && !(half == 1 && tile == pi);
         const int64_t k0 = a.kv_row0 + (int64_t)(tile_on ? tile : 0) * 16;
         const int64_t krow = k0 + l15;
+        const int qhi = (int)f.Tq - 1, qlo = (int)(krow - coff);      // queries that see the lane's key
+        const bool quad_ok = (k0 & 3) == 0;           // the four keys of a lane quad share their mask quad
         const int64_t krc = krow > f.Tk - 1 ? f.Tk - 1 : krow;
         bf16x8 kf[NKS], vf[NKS];
 #pragma unroll
@@ -884,13 +896,22 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(const mtl_att
                         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(qr + ks * 32), kf[ks], s, 0, 0, 0);
                         dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(dr + ks * 32), vf[ks], dp, 0, 0, 0);
                     }
+                    uint32_t fld[4] = {0xffffu, 0xffffu, 0xffffu, 0xffffu};
+                    if (DROP) {
+                        const uint32_t a0 = (uint32_t)((int)qb + t * 16 + g * 4 + (int)coff);
+                        if (quad_ok) drop_fields_shared(dbase_h, a0, (uint32_t)krow, fld);
+                        else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) fld[r] = drop_field(drop_quad(dbase_h, a0 + r, (uint32_t)krow >> 2), (uint32_t)krow);
+                        }
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int64_t q = qb + t * 16 + g * 4 + r;
-                        const bool masked = q >= f.Tq || krow > q + coff;
+                        const int q = (int)qb + t * 16 + g * 4 + r;
+                        const bool masked = q > qhi || q < qlo;
                         const float pv = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse_s[q]);
                         float keep = 1.0f;
-                        if (DROP) keep = drop_keep(dbase_h, (uint32_t)(q + coff), (uint32_t)krow, drop_thr) ? drop_scale : 0.f;
+                        if (DROP) keep = fld[r] >= drop_thr ? drop_scale : 0.f;
                         p[t][r] = pv * keep;                               // feeds dV = (dropped P)^T dO
                         ds[t][r] = pv * (dp[r] * keep - delta_s[q]);       // feeds dK
                     }

@@ -92,6 +92,28 @@ __device__ __forceinline__ uint32_t drop_field(uint2 words, uint32_t b) {
     return (b & 1u) ? w >> 16 : w & 0xffffu;
 }
 __device__ __forceinline__ bool drop_keep(uint32_t base, uint32_t a, uint32_t b, uint32_t thr) { return drop_field(drop_quad(base, a, b >> 2), b) >= thr; }
+// dK/dV kernels: a lane owns ONE key and meets four consecutive queries (rows a0 .. a0 + 3) per tile, and the four lanes of a DPP
+// quad (keys 4j .. 4j + 3, key0 % 4 == 0) meet the SAME queries: lane m hashes row a0 + m once and the quad exchanges the word pairs
+// with quad_perm broadcasts (12 + 8 operations per four elements instead of 4 x 12). fields[r] = the lane's 16-bit field of row a0 + r.
+template <int R>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {      // the value lane R of the caller's DPP quad holds
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, R * 0x55, 0xf, 0xf, false);
+}
+__device__ __forceinline__ void drop_fields_shared(uint32_t base, uint32_t a0, uint32_t key, uint32_t (&fields)[4]) {
+    const uint2 w = drop_quad(base, a0 + (key & 3u), key >> 2);
+    const uint32_t shift = (key & 1u) * 16u;
+    const uint32_t pick_y = 0u - ((key >> 1) & 1u);      // all-ones where the lane's field lives in .y. Bitwise select, NOT `?:`: the compiler
+                                                        // turns a lane-dependent choice between two DPP reads into a branch, and a DPP read
+                                                        // under a partial EXEC mask returns 0 for the lanes parked in the other arm
+                                                        // (tools/probes/dpp_quad.hip)
+#define MTL_QUAD_FIELD(R)                                                     \
+    do {                                                                      \
+        const uint32_t x = quad_bcast<R>(w.x), y = quad_bcast<R>(w.y);        \
+        fields[R] = ((x ^ ((x ^ y) & pick_y)) >> shift) & 0xffffu;            \
+    } while (0)
+    MTL_QUAD_FIELD(0); MTL_QUAD_FIELD(1); MTL_QUAD_FIELD(2); MTL_QUAD_FIELD(3);
+#undef MTL_QUAD_FIELD
+}
 __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
     const float t = p * 65536.0f;
     return t >= 65535.0f ? 65535u : (t <= 0.f ? 0u : (uint32_t)t);
