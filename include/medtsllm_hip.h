@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MTL_ABI_VERSION 6
+#define MTL_ABI_VERSION 7
 
 enum { MTL_OK = 0, MTL_ERR_ARG = -1, MTL_ERR_ALIGN = -2, MTL_ERR_UNSUPPORTED = -3, MTL_ERR_LAUNCH = -4,
        MTL_ERR_WORKSPACE = -5 };
@@ -109,6 +109,26 @@ size_t mtl_gemm_workspace_bytes(int64_t M, int64_t N, int split_k);
  * gradients), where it spreads the K range over the idle CUs; the caller allocates the workspace and passes it in mtl_gemm_args. */
 int mtl_gemm_auto_split_k(int64_t M, int64_t N, int64_t K, int epilogue);
 int mtl_gemm_nt(const mtl_gemm_args* args, void* stream);
+/* Transposed-operand GEMM: C[M, N] = alpha * sum_k A(m, k) B(n, k) with either operand stored K-MAJOR. The backward of the trainable
+ * Linear layers (R:models/medtsllm.py:358,550,571-573,579) runs on what the forward already holds, without transposed copies:
+ *     dW[n, k] = sum_m dY[m, n] X[m, k]      a_trans = b_trans = 1 (A = dY [rows, n], B = X [rows, k]); a_colsum = the bias gradient
+ *     dX[m, k] = sum_n dY[m, n] W[n, k]      b_trans = 1 (B = W [n, k])
+ * a_trans = 0: A is bf16 [M, K] (lda = row stride, K % 8 == 0); 1: bf16 [K, M] (lda >= M rounded up to 8). Same for B / N.
+ * lda, ldb % 8 == 0, A / B 16-byte aligned. C f32 or bf16 [M, N]. At least one operand must be K-major (else: mtl_gemm_nt).
+ * split_k > 1: the contraction is cut into split_k ranges, fp32 partial slabs in `workspace` (mtl_gemm_xt_workspace_bytes), summed
+ * in a fixed order by a second kernel — deterministic. */
+typedef struct {
+    const void* A; int64_t lda; int a_trans;
+    const void* B; int64_t ldb; int b_trans;
+    void* C; int64_t ldc; int c_dtype;
+    int64_t M, N, K;
+    float alpha;
+    float* a_colsum;                 /* optional f32 [M]: sum_k A(m, k); a_trans = 1 only                    */
+    int split_k; void* workspace; size_t workspace_bytes;
+} mtl_gemm_xt_args;
+size_t mtl_gemm_xt_workspace_bytes(int64_t M, int64_t N, int split_k);
+int mtl_gemm_xt_auto_split_k(int64_t M, int64_t N, int64_t K);
+int mtl_gemm_xt(const mtl_gemm_xt_args* args, void* stream);
 /* Measurement aid (bench.py's roofline legs; off by default, no effect on results): while enabled, every GEMM, attention, norm and
  * optimiser launch carries its own start / stop event pair (hipExtLaunchKernelGGL), whose elapsed time is the kernel's begin -> end
  * on the device — what rocprofv3 --kernel-trace reports for the same dispatch. mtl_prof_read aggregates per kernel instance:

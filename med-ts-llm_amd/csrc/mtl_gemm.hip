@@ -750,6 +750,184 @@ __global__ void splitk_reduce_kernel(const mtl_gemm_args p, const int S, const i
     epilogue4<EPI, CDT>(p, m, n, v, vec_ok_i != 0);
 }
 
+// =============================================================================================== transposed-operand GEMM (mtl_gemm_xt)
+// C[M, N] = alpha * sum_k A(m, k) B(n, k) where either operand may be stored K-MAJOR ([K, M] / [K, N] row-major): the weight-gradient
+// and input-gradient GEMMs of the trainable Linear layers, whose operands are what the forward already holds —
+//     dW[n, k] = sum_m dY[m, n] X[m, k]      both operands K-major (the contraction runs over their rows)
+//     dX[m, k] = sum_n dY[m, n] W[n, k]      B = W K-major
+// — so that no transposed copy of dY, X or W is ever written. A K-major tile is staged row-major ([64 k][128 + 16]) and its MFMA
+// fragments come from the hardware transpose read (ds_read_b64_tr_b16: two 8-byte reads give a lane the 8 contraction values of its
+// output row); a K-contiguous tile is staged [128][64 + 8] and read with one ds_read_b128, as in the NT kernels. Both paddings make
+// the reads conflict-free (row strides of 72 / 36 dwords). 128 x 128 tile, 4 waves (2 x 2, 64 x 64 each), 64-deep k-steps, the next step's
+// global loads in flight during the MFMAs, two workgroups per CU. Small problems by construction (trainable projections): no persistence, split over
+// the contraction (grid.y) for parallelism, partial slabs reduced by xt_reduce_kernel. a_colsum (A K-major): sum_k A(m, k) — the bias
+// gradient falls out of the dY tiles the weight-gradient GEMM loads anyway.
+typedef __attribute__((ext_vector_type(4))) short xt_s16x4;
+typedef __attribute__((address_space(3))) xt_s16x4 xt_lds_s16x4;
+__device__ __forceinline__ bf16x8 xt_frag_t(const bf16_t* tile, int ldt, int r0, int c0, int l15) {     // rows r0..r0+7 of column c0 + l15
+    const int off = (l15 >> 2) * ldt + c0 + (l15 & 3) * 4;
+    union { bf16x8 v; xt_s16x4 h[2]; } f;
+    f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((xt_lds_s16x4*)(tile + r0 * ldt + off));
+    f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((xt_lds_s16x4*)(tile + (r0 + 4) * ldt + off));
+    return f.v;
+}
+
+struct xt_args {
+    const bf16_t* A; int64_t lda; const bf16_t* B; int64_t ldb; void* C; int64_t ldc;
+    int64_t M, N, K; float alpha; float* a_colsum; float* ws; int S;
+};
+
+template <bool AT, bool BT, int CDT>
+__global__ __launch_bounds__(256, 2) void gemm_xt_kernel(const xt_args p) {
+    constexpr int TM = 128, KC = 64, LDN = KC + 8, LDT = TM + 16, NCH = TM * KC / 8 / 256;      // 4 chunks per operand per thread per step
+    constexpr int A_EL = AT ? KC * LDT : TM * LDN, B_EL = BT ? KC * LDT : TM * LDN;
+    __shared__ __attribute__((aligned(16))) bf16_t sa[2][A_EL];
+    __shared__ __attribute__((aligned(16))) bf16_t sb[2][B_EL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles_n = (int)((p.N + TM - 1) / TM);
+    const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * TM, n0 = (int64_t)(blockIdx.x % tiles_n) * TM;
+    const int s = blockIdx.y;
+    const int64_t per = ((p.K + (int64_t)p.S * KC - 1) / ((int64_t)p.S * KC)) * KC;
+    const int64_t k_begin = s * per, k_end = k_begin + per < p.K ? k_begin + per : p.K;
+
+    // global -> register staging, one k-step ahead of the MFMAs
+    auto fetch = [&](const bf16_t* src, int64_t ld, bool trans, int64_t r0, int64_t rows, int64_t k0, u32x4 (&v)[NCH]) __attribute__((always_inline)) {
+        // every load is issued unconditionally from a clamped (always valid) address and zeroed afterwards: a load inside a branch
+        // ends with a full vmcnt(0) wait at the merge, which serialises the chunks (measured: 2.5 us per k-step)
+        bool ok[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = tid + i * 256;
+            int64_t r, k;
+            if (trans) { k = k0 + idx / 16; r = r0 + (idx % 16) * 8; }      // [K, rows]: 8 consecutive rows-dimension elements of contraction row k
+            else { r = r0 + idx / 8; k = k0 + (idx % 8) * 8; }              // [rows, K]: 8 consecutive contraction elements of one row
+            ok[i] = k < k_end && r < rows;
+            const int64_t kc = k < k_end ? k : 0, rc = r < rows ? r : 0;
+            v[i] = *reinterpret_cast<const u32x4*>(trans ? src + kc * ld + rc : src + rc * ld + kc);
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+            if (!ok[i]) v[i] = (u32x4){0u, 0u, 0u, 0u};
+    };
+    auto stash = [&](bf16_t* tile, bool trans, const u32x4 (&v)[NCH]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = tid + i * 256;
+            if (trans) *reinterpret_cast<u32x4*>(tile + (idx / 16) * LDT + (idx % 16) * 8) = v[i];
+            else *reinterpret_cast<u32x4*>(tile + (idx / 8) * LDN + (idx % 8) * 8) = v[i];
+        }
+    };
+    f32x4 acc[4][4];      // [nj][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool want_cs = AT && p.a_colsum != nullptr && n0 == 0;
+    // TWO k-steps of look-ahead (64 KB of loads in flight per workgroup): with one, a step lasts as long as a load round trip
+    u32x4 va[2][NCH], vb[2][NCH];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        fetch(p.A, p.lda, AT, m0, p.M, k_begin + d * KC, va[d]);      // (rows past k_end load zeros)
+        fetch(p.B, p.ldb, BT, n0, p.N, k_begin + d * KC, vb[d]);
+    }
+    auto step = [&](const int64_t k0, const int buf, u32x4 (&ra)[NCH], u32x4 (&rb)[NCH]) __attribute__((always_inline)) {
+        stash(sa[buf], AT, ra);
+        stash(sb[buf], BT, rb);
+        if (want_cs) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    csum[2 * e] += __uint_as_float(ra[i][e] << 16);
+                    csum[2 * e + 1] += __uint_as_float(ra[i][e] & 0xffff0000u);
+                }
+        }
+        __syncthreads();                              // (this buffer was last read before the previous barrier)
+        fetch(p.A, p.lda, AT, m0, p.M, k0 + 2 * KC, ra);
+        fetch(p.B, p.ldb, BT, n0, p.N, k0 + 2 * KC, rb);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (AT) af[i] = xt_frag_t(sa[buf], LDT, ks * 32 + g * 8, wr * 64 + i * 16, l15);
+                else af[i] = *reinterpret_cast<const bf16x8*>(sa[buf] + (wr * 64 + i * 16 + l15) * LDN + ks * 32 + g * 8);
+                if (BT) bfr[i] = xt_frag_t(sb[buf], LDT, ks * 32 + g * 8, wc * 64 + i * 16, l15);
+                else bfr[i] = *reinterpret_cast<const bf16x8*>(sb[buf] + (wc * 64 + i * 16 + l15) * LDN + ks * 32 + g * 8);
+            }
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[nj][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nj], af[mi], acc[nj][mi], 0, 0, 0);
+        }
+    };
+    for (int64_t k0 = k_begin; k0 < k_end; k0 += 2 * KC) {
+        step(k0, 0, va[0], vb[0]);
+        if (k0 + KC < k_end) step(k0 + KC, 1, va[1], vb[1]);
+    }
+    // lane owns row m0 + wr*64 + mi*16 + l15 and the four columns n0 + wc*64 + nj*16 + g*4 .. +3
+    const bool vec = (p.N % 4 == 0) && (p.ldc % 4 == 0);
+    float* slab = p.S > 1 ? p.ws + (int64_t)s * p.M * p.N : nullptr;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int64_t m = m0 + wr * 64 + mi * 16 + l15;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) {
+            const int64_t n = n0 + wc * 64 + nj * 16 + g * 4;
+            if (n >= p.N) continue;
+            const f32x4 v = acc[nj][mi];
+            if (slab) {
+                if (vec) *reinterpret_cast<f32x4*>(slab + m * p.N + n) = v;
+                else for (int e = 0; e < 4; ++e) if (n + e < p.N) slab[m * p.N + n + e] = v[e];
+            } else if (CDT == MTL_F32) {
+                float* cp = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
+                if (vec && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0) *reinterpret_cast<f32x4*>(cp) = v * p.alpha;
+                else for (int e = 0; e < 4; ++e) if (n + e < p.N) cp[e] = v[e] * p.alpha;
+            } else {
+                bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n;
+                if (vec && (reinterpret_cast<uintptr_t>(p.C) & 7) == 0) *reinterpret_cast<u32x2*>(cp) = (u32x2){pack_bf16x2(v[0] * p.alpha, v[1] * p.alpha), pack_bf16x2(v[2] * p.alpha, v[3] * p.alpha)};
+                else for (int e = 0; e < 4; ++e) if (n + e < p.N) cp[e] = f32_to_bf16(v[e] * p.alpha);
+            }
+        }
+    }
+    if (want_cs) {         // column chunk (tid % 16) * 8 of the tile, summed over the 16 threads that share it (fixed order)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(&sa[0][0]);       // [16][128] floats = 8 KB <= sizeof(sa)
+        static_assert(sizeof(sa) >= 16 * 128 * sizeof(float), "column-sum scratch");
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(tid / 16) * 128 + (tid % 16) * 8 + e] = csum[e];
+        __syncthreads();
+        if (tid < 128 && m0 + tid < p.M) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += red[r * 128 + tid];
+            if (p.S > 1) p.ws[(int64_t)p.S * p.M * p.N + (int64_t)s * p.M + m0 + tid] = t;
+            else p.a_colsum[m0 + tid] = t;
+        }
+    }
+}
+
+// sums the split slabs (fixed order) into C and the column-sum partials into a_colsum
+template <int CDT>
+__global__ void xt_reduce_kernel(const xt_args p) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, mn = p.M * p.N;
+    if (idx < mn) {
+        float v = 0.f;
+        for (int s = 0; s < p.S; ++s) v += p.ws[(int64_t)s * mn + idx];
+        const int64_t m = idx / p.N, n = idx - m * p.N;
+        if (CDT == MTL_F32) reinterpret_cast<float*>(p.C)[m * p.ldc + n] = v * p.alpha;
+        else reinterpret_cast<bf16_t*>(p.C)[m * p.ldc + n] = f32_to_bf16(v * p.alpha);
+    } else if (p.a_colsum && idx - mn < p.M) {
+        float v = 0.f;
+        for (int s = 0; s < p.S; ++s) v += p.ws[(int64_t)p.S * mn + (int64_t)s * p.M + (idx - mn)];
+        p.a_colsum[idx - mn] = v;
+    }
+}
+
+
 // Tile order of a launch, packed into the kernel's `gm_all` argument: bits 0-7 the rows g of a tile group (tile_coords), bit 8 the
 // per-XCD k rotation, bit 9 the per-XCD column rotation. Each XCD walks a contiguous chunk of ~tiles/8 ids = g rows x (chunk/g) columns of tiles.
 // * Short chunks (at most ~2 rounds of the XCD's resident workgroups; every GPT-2-small GEMM): g = sqrt(chunk*BN/BM) (at least
@@ -958,6 +1136,62 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" size_t mtl_gemm_xt_workspace_bytes(int64_t M, int64_t N, int split_k) {
+    return split_k > 1 ? (size_t)split_k * ((size_t)M * (size_t)N + (size_t)M) * sizeof(float) : 0;
+}
+
+extern "C" int mtl_gemm_xt_auto_split_k(int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 1;
+    const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128), ksteps = (K + 63) / 64;
+    const int ncu = num_cus();
+    if (tiles * 4 > ncu) return 1;                        // (a second pass over the output costs more than the idle CUs)
+    int s = 1;
+    while (s * 2 <= 64 && (int64_t)s * 2 * tiles <= 2 * ncu && ksteps / (s * 2) >= 4) s *= 2;      // two workgroups fit a CU
+    return s;
+}
+
+extern "C" int mtl_gemm_xt(const mtl_gemm_xt_args* a, void* stream) {
+    if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return MTL_ERR_ARG;
+    if (a->c_dtype != MTL_F32 && a->c_dtype != MTL_BF16) return MTL_ERR_ARG;
+    if (!a->a_trans && !a->b_trans) return MTL_ERR_ARG;                      // (that is mtl_gemm_nt's problem)
+    // 16-byte chunks: along K for a K-contiguous operand, along M / N for a K-major one
+    if (a->lda % 8 != 0 || a->ldb % 8 != 0 || !aligned(a->A, 16) || !aligned(a->B, 16)) return MTL_ERR_ALIGN;
+    if ((!a->a_trans || !a->b_trans) && a->K % 8 != 0) return MTL_ERR_ALIGN;
+    if ((a->a_trans && a->lda < ((a->M + 7) & ~(int64_t)7)) || (a->b_trans && a->ldb < ((a->N + 7) & ~(int64_t)7))) return MTL_ERR_ARG;
+    if (a->a_colsum && !a->a_trans) return MTL_ERR_ARG;
+    const int S = a->split_k > 1 ? a->split_k : 1;
+    if (S > 1 && (!a->workspace || a->workspace_bytes < mtl_gemm_xt_workspace_bytes(a->M, a->N, S))) return MTL_ERR_WORKSPACE;
+    if (S > (a->K + 63) / 64) return MTL_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    xt_args p = {reinterpret_cast<const bf16_t*>(a->A), a->lda, reinterpret_cast<const bf16_t*>(a->B), a->ldb, a->C, a->ldc,
+                 a->M, a->N, a->K, a->alpha, a->a_colsum, reinterpret_cast<float*>(a->workspace), S};
+    const dim3 grid((unsigned)(((a->M + 127) / 128) * ((a->N + 127) / 128)), (unsigned)S), block(256);
+    const double flops = 2.0 * (double)a->M * (double)a->N * (double)a->K;
+    char kname[96];
+    {
+        static const bool shapes = getenv("MTL_PROF_SHAPES") && atoi(getenv("MTL_PROF_SHAPES")) != 0;
+        const int n = snprintf(kname, sizeof kname, "gemm_xt_kernel<%d, %d, %d>", a->a_trans ? 1 : 0, a->b_trans ? 1 : 0, S > 1 ? MTL_F32 : a->c_dtype);
+        if (shapes && n > 0) snprintf(kname + n, sizeof kname - n, " [%lldx%lldx%lld /%d]", (long long)a->M, (long long)a->N, (long long)a->K, S);
+    }
+#define MTL_XT(AT, BT)                                                                                                   \
+    do {                                                                                                                 \
+        if (S > 1 || a->c_dtype == MTL_F32) MTL_LAUNCH(kname, flops, 0, (gemm_xt_kernel<AT, BT, MTL_F32>), grid, block, 0, st, p);   \
+        else MTL_LAUNCH(kname, flops, 0, (gemm_xt_kernel<AT, BT, MTL_BF16>), grid, block, 0, st, p);                    \
+    } while (0)
+    if (a->a_trans && a->b_trans) MTL_XT(true, true);
+    else if (a->a_trans) MTL_XT(true, false);
+    else MTL_XT(false, true);
+#undef MTL_XT
+    if (S > 1) {
+        const int64_t items = a->M * a->N + (a->a_colsum ? a->M : 0);
+        const double bytes = (double)S * a->M * a->N * 4.0 + (double)a->M * a->N * (a->c_dtype == MTL_BF16 ? 2.0 : 4.0);
+        if (a->c_dtype == MTL_F32) MTL_LAUNCH("xt_reduce_kernel<0>", bytes, 1, (xt_reduce_kernel<MTL_F32>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, p);
+        else MTL_LAUNCH("xt_reduce_kernel<1>", bytes, 1, (xt_reduce_kernel<MTL_BF16>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, p);
+    }
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
 
 extern "C" int mtl_gemm_tile_order(int tiles_m, int tiles_n, int bm, int bn, int per_cu, int64_t K, int one_tile_per_wg) {
     if (tiles_m <= 0 || tiles_n <= 0 || bm <= 0 || bn <= 0 || per_cu <= 0 || K <= 0) return MTL_ERR_ARG;

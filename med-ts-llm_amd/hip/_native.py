@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("MTL_LIB_PATH") or os.path.join(_HERE, "libmedtsllm_hi
 MTL_F32, MTL_BF16 = 0, 1
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM, EPI_SWIGLU, EPI_DSWIGLU = 0, 1, 2, 3, 4, 5, 6
 ARCH_GPT2, ARCH_LLAMA = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 i64, vp, f32, i32 = C.c_int64, C.c_void_p, C.c_float, C.c_int
 
@@ -30,6 +30,12 @@ class GemmArgs(C.Structure):
                 ("bias", vp), ("epilogue", i32), ("aux_in", vp), ("ld_aux_in", i64), ("aux_out", vp), ("ld_aux_out", i64),
                 ("alpha", f32), ("split_k", i32), ("workspace", vp), ("workspace_bytes", C.c_size_t),
                 ("drop_p", f32), ("drop_seed", C.c_uint32), ("bwd_group_rows", i64), ("bwd_first_row", i64)]
+
+
+class GemmXtArgs(C.Structure):
+    _fields_ = [("A", vp), ("lda", i64), ("a_trans", i32), ("B", vp), ("ldb", i64), ("b_trans", i32), ("C", vp), ("ldc", i64), ("c_dtype", i32),
+                ("M", i64), ("N", i64), ("K", i64), ("alpha", f32), ("a_colsum", vp), ("split_k", i32), ("workspace", vp),
+                ("workspace_bytes", C.c_size_t)]
 
 
 class ProfRow(C.Structure):
@@ -91,6 +97,9 @@ SIGNATURES = {
     "mtl_revin_denorm": (i32, [vp, vp, vp, vp, i64, i64, i64, vp]),
     "mtl_gemm_workspace_bytes": (C.c_size_t, [i64, i64, i32]),
     "mtl_gemm_auto_split_k": (i32, [i64, i64, i64, i32]),
+    "mtl_gemm_xt_workspace_bytes": (C.c_size_t, [i64, i64, i32]),
+    "mtl_gemm_xt_auto_split_k": (i32, [i64, i64, i64]),
+    "mtl_gemm_xt": (i32, [C.POINTER(GemmXtArgs), vp]),
     "mtl_gemm_nt": (i32, [C.POINTER(GemmArgs), vp]),
     "mtl_prof_enable": (i32, [i32]),
     "mtl_gemm_tune": (i32, [i32, i32, i32, i32, i32]),

@@ -6,6 +6,7 @@ a kernel that failed to load — `_native.lib()` raises instead.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -82,6 +83,35 @@ def gemm_nt(A, B, out=None, out_dtype=BF16, bias=None, epilogue=N.EPI_STORE, aux
         g.workspace, g.workspace_bytes = ws.data_ptr(), nbytes
     check(lib().mtl_gemm_nt(C.byref(g), stream()), "mtl_gemm_nt")
     return out
+
+
+def gemm_xt(A, B, a_trans=False, b_trans=False, out_dtype=BF16, alpha=1.0, want_colsum=False, split_k=0):
+    """C[M, N] = alpha * sum_k A(m, k) B(n, k) with K-MAJOR operands where flagged: A is [M, K] (a_trans False) or [K, M] (True),
+    B is [N, K] or [K, N]; rows contiguous, row strides % 8 == 0. want_colsum (a_trans only): also returns sum_k A(m, k) as f32 [M].
+    The backward GEMMs of the trainable Linear layers (no transposed copies): see mtl_gemm_xt in include/medtsllm_hip.h."""
+    _req(A.dtype == BF16 and B.dtype == BF16 and A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1, "gemm_xt: bf16 2-D row-major operands")
+    _req(a_trans or b_trans, "gemm_xt: at least one K-major operand (else gemm_nt)")
+    K, M = (A.shape[0], A.shape[1]) if a_trans else (A.shape[1], A.shape[0])
+    Kb, Nn = (B.shape[0], B.shape[1]) if b_trans else (B.shape[1], B.shape[0])
+    _req(K == Kb, "gemm_xt: K mismatch")
+    out = torch.empty((M, Nn), dtype=out_dtype, device=A.device)
+    g = N.GemmXtArgs()
+    g.A, g.lda, g.a_trans = A.data_ptr(), A.stride(0), int(a_trans)
+    g.B, g.ldb, g.b_trans = B.data_ptr(), B.stride(0), int(b_trans)
+    g.C, g.ldc, g.c_dtype = out.data_ptr(), out.stride(0), _dt(out)
+    g.M, g.N, g.K, g.alpha = M, Nn, K, alpha
+    cs = torch.empty((M,), dtype=F32, device=A.device) if want_colsum else None
+    g.a_colsum = cs.data_ptr() if cs is not None else None
+    if split_k == 0:
+        split_k = lib().mtl_gemm_xt_auto_split_k(M, Nn, K)
+    g.split_k = split_k
+    ws = None
+    if split_k > 1:
+        nbytes = lib().mtl_gemm_xt_workspace_bytes(M, Nn, split_k)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=A.device)
+        g.workspace, g.workspace_bytes = ws.data_ptr(), nbytes
+    check(lib().mtl_gemm_xt(C.byref(g), stream()), "mtl_gemm_xt")
+    return (out, cs) if want_colsum else out
 
 
 def cast_pad(src, ld_dst=None, want_t=False, ld_dst_t=None, dst=None, dst_t=None):
@@ -331,9 +361,14 @@ class PatchTokenizeFn(torch.autograd.Function):
         return None, dw, None, None, None, None, None
 
 
+_LINEAR_XT = os.environ.get("MTL_LINEAR_XT", "1") != "0"      # A/B knob: 0 = backward through explicit transposes + NT GEMMs
+
+
 class LinearFn(torch.autograd.Function):
     """y = x @ W^T + b with bf16 MFMA GEMMs. x bf16 [..., Kx] (Kx % 64 == 0, Kx >= W.shape[1], extra cols zero);
-    W f32 [N, Kin] master weight (cast to bf16 per call, as autocast does); y bf16 [..., N]."""
+    W f32 [N, Kin] master weight (cast to bf16 per call, as autocast does); y bf16 [..., N].
+    Backward on what the forward holds (mtl_gemm_xt): dX = dY . W with W read K-major, dW = dY^T . X with both operands K-major and
+    the bias gradient as the column sums of the dY tiles that GEMM loads — no transposed copy of W, dY or X is written."""
 
     @staticmethod
     def forward(ctx, x, W, b):
@@ -343,30 +378,45 @@ class LinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, Kx)
         if x2.stride(1) != 1 or x2.stride(0) % 8 != 0:
             x2 = x2.contiguous()
-        Np = pad64(Nn)
+        direct = Nn % 8 == 0 and _LINEAR_XT            # (row strides of dY must be whole 16-byte chunks for the K-major reads)
         Wd = W.detach().contiguous().float()
         wb = torch.empty((Nn, Kx), dtype=BF16, device=x.device)
-        wt = torch.zeros((Kx, Np), dtype=BF16, device=x.device) if (Kx > Kin) else torch.empty((Kx, Np), dtype=BF16, device=x.device)
-        cast_pad(Wd, dst=wb, dst_t=wt)
+        wt = None
+        if direct:
+            cast_pad(Wd, dst=wb)
+        else:
+            Np = pad64(Nn)
+            wt = torch.zeros((Kx, Np), dtype=BF16, device=x.device) if (Kx > Kin) else torch.empty((Kx, Np), dtype=BF16, device=x.device)
+            cast_pad(Wd, dst=wb, dst_t=wt)
         y = gemm_nt(x2, wb, bias=None if b is None else b.detach().float().contiguous())
-        ctx.save_for_backward(x2, wt)
-        ctx.meta = (tuple(x.shape), Nn, Kin, b is not None)
+        ctx.save_for_backward(x2, wb if direct else wt)
+        ctx.meta = (tuple(x.shape), Nn, Kin, b is not None, direct)
         return y.reshape(*x.shape[:-1], Nn)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, wt = ctx.saved_tensors
-        xshape, Nn, Kin, has_b = ctx.meta
+        x2, w = ctx.saved_tensors
+        xshape, Nn, Kin, has_b, direct = ctx.meta
         M, Kx = x2.shape
-        Np = wt.shape[1]
         dy2 = dy.reshape(M, Nn)
         if dy2.dtype != BF16:
             dy2 = dy2.to(BF16)
         dy2 = dy2.contiguous()
-        dyp = dy2 if Np == Nn else torch.nn.functional.pad(dy2, (0, Np - Nn))
-        dx = gemm_nt(dyp, wt).reshape(xshape) if ctx.needs_input_grad[0] else None
-        dW = db = None
+        dx = dW = db = None
         want_b = has_b and ctx.needs_input_grad[2]
+        if direct:
+            if ctx.needs_input_grad[0]:
+                dx = gemm_xt(dy2, w, b_trans=True).reshape(xshape)                     # [M, Kx] = dY [M, N] . W [N, Kx]
+            if ctx.needs_input_grad[1]:
+                xk = x2[:, :Kin] if Kin != Kx else x2
+                res = gemm_xt(dy2, xk, a_trans=True, b_trans=True, out_dtype=F32, want_colsum=want_b)   # [N, Kin] = dY^T . X
+                dW, db = res if want_b else (res, None)
+            elif want_b:
+                db = colsum(dy2)
+            return dx, dW, db
+        Np = w.shape[1]
+        dyp = dy2 if Np == Nn else torch.nn.functional.pad(dy2, (0, Np - Nn))
+        dx = gemm_nt(dyp, w).reshape(xshape) if ctx.needs_input_grad[0] else None
         if ctx.needs_input_grad[1]:
             Mp = pad64(M)
             if want_b:

@@ -267,6 +267,51 @@ def test_attention_online_softmax_rescale(ops):
     assert rel_err(o.float(), ref) < TOL_ATTN_FWD
 
 
+# ------------------------------------------------------------------------------------------------ transposed-operand GEMM
+@pytest.mark.parametrize("M,Nn,K,split", [(1024, 384, 4096, 0), (136, 264, 515, 1), (768, 1024, 4099, 4), (1152, 16384, 32, 0), (8, 8, 40, 1)])
+def test_gemm_xt_weight_gradient_form(ops, M, Nn, K, split):
+    """dW = dY^T . X with BOTH operands K-major (the contraction runs over their rows), fp32 output + the column sums of dY (bias
+    gradient); ragged M / N / K, one-pass and split contraction"""
+    dy = torch.randn(K, M, generator=g(1)).to(BF16).cuda()
+    x = torch.randn(K, Nn, generator=g(2)).to(BF16).cuda()
+    out, cs = ops.gemm_xt(dy, x, a_trans=True, b_trans=True, out_dtype=F32, want_colsum=True, split_k=split)
+    ref = dy.double().t() @ x.double()
+    assert rel_err(out.double(), ref) < TOL_F32
+    assert rel_err(cs.double(), dy.double().sum(0)) < TOL_F32
+    out_b = ops.gemm_xt(dy, x, a_trans=True, b_trans=True, out_dtype=BF16, alpha=0.5, split_k=split)
+    assert rel_err(out_b.double(), 0.5 * ref) < TOL_BF16
+
+
+@pytest.mark.parametrize("M,Nn,K,split", [(4096, 768, 1024, 0), (300, 136, 264, 1), (32, 16384, 1152, 0), (515, 72, 2048, 4)])
+def test_gemm_xt_input_gradient_form(ops, M, Nn, K, split):
+    """dX = dY . W with W K-major ([K = out features, N = in features], as the forward holds it); and the mirrored a_trans form"""
+    dy = torch.randn(M, K, generator=g(3)).to(BF16).cuda()
+    w = torch.randn(K, Nn, generator=g(4)).to(BF16).cuda()
+    ref = dy.double() @ w.double()
+    out = ops.gemm_xt(dy, w, b_trans=True, out_dtype=BF16, split_k=split)
+    assert rel_err(out.double(), ref) < TOL_BF16
+    out32 = ops.gemm_xt(dy, w, b_trans=True, out_dtype=F32, split_k=split)
+    assert rel_err(out32.double(), ref) < TOL_F32
+    wn = w.t().contiguous()                                                     # [Nn, K] K-contiguous
+    dyk = dy.t().contiguous() if M % 8 == 0 else None                           # [K, M] K-major A
+    if dyk is not None:
+        out_t = ops.gemm_xt(dyk, wn, a_trans=True, out_dtype=F32, split_k=split)
+        assert rel_err(out_t.double(), ref) < TOL_F32
+
+
+def test_gemm_xt_strided_views_and_errors(ops):
+    """column-sliced K-major B (x2[:, :Kin] of a K-padded activation) and the argument checks"""
+    x = torch.randn(512, 448, generator=g(5)).to(BF16).cuda()
+    dy = torch.randn(512, 128, generator=g(6)).to(BF16).cuda()
+    out = ops.gemm_xt(dy, x[:, :384], a_trans=True, b_trans=True, out_dtype=F32)
+    assert rel_err(out.double(), dy.double().t() @ x[:, :384].double()) < TOL_F32
+    with pytest.raises(Exception):
+        ops.gemm_xt(dy, x)                                                      # no K-major operand
+    with pytest.raises(Exception):
+        ops.gemm_xt(dy[:, :100], x, a_trans=True, b_trans=True)                 # fine: row stride 128 — but K mismatch below
+        ops.gemm_xt(dy, x[:100], a_trans=True, b_trans=True)
+
+
 # ------------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("M,d", [(7, 64), (300, 768), (64, 4096), (10, 1000)])
 def test_layernorm(ops, M, d):
