@@ -371,7 +371,9 @@ class LinearFn(torch.autograd.Function):
     the bias gradient as the column sums of the dY tiles that GEMM loads — no transposed copy of W, dY or X is written."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, W, b, shadow=None):
+        """shadow: hip.optim.Bf16Shadow of W with Kx columns (zero beyond Kin) that HipAdam keeps current — the per-call weight cast
+        then only runs when the master changed behind the optimiser's back"""
         Kx = x.shape[-1]
         Nn, Kin = W.shape
         _req(x.dtype == BF16 and Kx % 64 == 0 and Kx >= Kin, "LinearFn: x must be bf16 with K padded to 64")
@@ -379,10 +381,15 @@ class LinearFn(torch.autograd.Function):
         if x2.stride(1) != 1 or x2.stride(0) % 8 != 0:
             x2 = x2.contiguous()
         direct = Nn % 8 == 0 and _LINEAR_XT            # (row strides of dY must be whole 16-byte chunks for the K-major reads)
+        use_sh = direct and shadow is not None and shadow.param is W and tuple(shadow.tensor.shape) == (Nn, Kx) and shadow.tensor.device == x.device
         Wd = W.detach().contiguous().float()
-        wb = torch.empty((Nn, Kx), dtype=BF16, device=x.device)
+        wb = shadow.tensor if use_sh else torch.empty((Nn, Kx), dtype=BF16, device=x.device)
         wt = None
-        if direct:
+        if use_sh:
+            if not shadow.fresh():
+                cast_pad(Wd, dst=wb)
+                shadow.version = W._version
+        elif direct:
             cast_pad(Wd, dst=wb)
         else:
             Np = pad64(Nn)
@@ -413,7 +420,7 @@ class LinearFn(torch.autograd.Function):
                 dW, db = res if want_b else (res, None)
             elif want_b:
                 db = colsum(dy2)
-            return dx, dW, db
+            return dx, dW, db, None
         Np = w.shape[1]
         dyp = dy2 if Np == Nn else torch.nn.functional.pad(dy2, (0, Np - Nn))
         dx = gemm_nt(dyp, w).reshape(xshape) if ctx.needs_input_grad[0] else None
@@ -427,7 +434,7 @@ class LinearFn(torch.autograd.Function):
             dW = gemm_nt(dyT, xT, out_dtype=F32)     # [N, Kin] fp32
         elif want_b:
             db = colsum(dy2)
-        return dx, dW, db
+        return dx, dW, db, None
 
 
 class MappingFn(torch.autograd.Function):

@@ -348,11 +348,35 @@ class MedTsLLM(nn.Module):
             self._map_shadow = sh
         return sh
 
+    def _linear_shadow(self, lin):
+        """Persistent bf16 copy [N, pad64(K)] (zero K padding) of a trainable Linear's weight: the operand of its forward GEMM and,
+        read K-major, of its input-gradient GEMM. Same contract as _mapping_shadow."""
+        W = lin.weight
+        if not W.is_cuda:
+            return None
+        table = self.__dict__.setdefault("_lin_shadows", {})
+        sh = table.get(id(lin))
+        if sh is None or sh.param is not W or sh.tensor.device != W.device:
+            from ..hip.optim import Bf16Shadow
+            sh = Bf16Shadow(W, torch.zeros((W.shape[0], pad64(W.shape[1])), dtype=torch.bfloat16, device=W.device))
+            table[id(lin)] = sh
+        return sh
+
+    def _shadowed_linears(self):
+        rl = self.reprogramming_layer
+        lins = [rl.query_projection, rl.key_projection, rl.value_projection, rl.out_projection, self.output_projection.linear]
+        if isinstance(getattr(self, "embedding_downsample_layer", None), nn.Linear):
+            lins.append(self.embedding_downsample_layer)
+        return lins
+
     def bf16_shadows(self):
         """Shadows an optimiser may keep current (HipAdam.register_shadow)."""
-        if self.word_embeddings.requires_grad or not self.mapping_layer.weight.is_cuda:
+        if not self.mapping_layer.weight.is_cuda:
             return []
-        return [self._mapping_shadow()]
+        out = [sh for sh in (self._linear_shadow(m) for m in self._shadowed_linears()) if sh is not None]
+        if not self.word_embeddings.requires_grad:
+            out.append(self._mapping_shadow())
+        return out
 
     def encode_ts(self, x_enc):
         """R:models/medtsllm.py:263-297 -> (x_tok bf16 [B', P', d_llm], mean [B,C], stdev [B,C])."""
@@ -380,14 +404,14 @@ class MedTsLLM(nn.Module):
                 rank, world, _, _, group = self._map_shard
                 source = AllGatherRows.apply(source, rank, world, group)
         self._tap("source", source)
-        q = self._tap("q", LinearFn.apply(tokens, rl.query_projection.weight, rl.query_projection.bias))
-        k = self._tap("k", LinearFn.apply(source, rl.key_projection.weight, rl.key_projection.bias))
-        v = self._tap("v", LinearFn.apply(source, rl.value_projection.weight, rl.value_projection.bias))
+        q = self._tap("q", LinearFn.apply(tokens, rl.query_projection.weight, rl.query_projection.bias, self._linear_shadow(rl.query_projection)))
+        k = self._tap("k", LinearFn.apply(source, rl.key_projection.weight, rl.key_projection.bias, self._linear_shadow(rl.key_projection)))
+        v = self._tap("v", LinearFn.apply(source, rl.value_projection.weight, rl.value_projection.bias, self._linear_shadow(rl.value_projection)))
         if drop_on:   # A = dropout(softmax(.)), R:models/medtsllm.py:588
             a = CrossAttnFn.apply(q, k, v, self.n_attention_heads, self.d_ff, float(self.dropout), seed)
         else:
             a = CrossAttnFn.apply(q, k, v, self.n_attention_heads, self.d_ff)
-        enc = self._tap("reprog", LinearFn.apply(a, rl.out_projection.weight, rl.out_projection.bias))     # [B', P, d_llm]
+        enc = self._tap("reprog", LinearFn.apply(a, rl.out_projection.weight, rl.out_projection.bias, self._linear_shadow(rl.out_projection)))     # [B', P, d_llm]
         n_patches, d_llm = enc.shape[1], self.d_llm
         cm = self.covariate_mode
         if cm == "add":
@@ -438,14 +462,14 @@ class MedTsLLM(nn.Module):
         if mode == "truncate":
             dec = dec[:, :, :self.d_ff]
         elif mode == "linear":
-            dec = self._tap("down", LinearFn.apply(dec, self.embedding_downsample_layer.weight, self.embedding_downsample_layer.bias))
+            dec = self._tap("down", LinearFn.apply(dec, self.embedding_downsample_layer.weight, self.embedding_downsample_layer.bias, self._linear_shadow(self.embedding_downsample_layer)))
         else:
             dec = dec.reshape(dec.shape[0], self.n_patches, self.d_ff, -1).float().mean(dim=-1).to(BF16)
         head_in = dec.permute(0, 2, 1).reshape(dec.shape[0], -1)       # feature index = f * P + p (R:models/medtsllm.py:366,549)
         kp = pad64(head_in.shape[1])
         if kp != head_in.shape[1]:
             head_in = F.pad(head_in, (0, kp - head_in.shape[1]))
-        out = self._tap("head", LinearFn.apply(head_in.contiguous(), self.output_projection.linear.weight, self.output_projection.linear.bias))
+        out = self._tap("head", LinearFn.apply(head_in.contiguous(), self.output_projection.linear.weight, self.output_projection.linear.bias, self._linear_shadow(self.output_projection.linear)))
         if cm == "independent":
             out = out.float().view(bs, C, self.pred_len, self.n_outputs_per_step).mean(dim=1)
         elif cm == "merge-end":
