@@ -271,6 +271,44 @@ def test_trainer_end_to_end_on_gpu(tmp_path, kind, task):
     assert preds.shape[0] == len(trainer.test_dataset) and torch.isfinite(preds).all()
 
 
+def test_linear_weight_shadows_track_the_masters(tmp_path):
+    """the bf16 operand copies of the trainable Linear weights (written by HipAdam next to the fp32 masters, re-cast by the forward
+    when a master changed behind the optimiser's back) always equal bf16(master) with zero K padding — after training steps, after
+    load_state_dict, after an in-place edit — and predictions do not depend on who refreshed them"""
+    from med_ts_llm_amd.tasks import get_trainer
+    from med_ts_llm_amd.utils import dict_to_object
+    _write_hf_dir(tmp_path, "gpt2")
+    trainer = get_trainer("DEBUG-test", dict_to_object(_trainer_config("forecasting", str(tmp_path), epochs=1)))
+    trainer.train()
+    m = trainer.model
+
+    def check():
+        shadows = m.bf16_shadows()
+        assert len(shadows) >= 6
+        for sh in shadows:
+            W = sh.param.detach()
+            assert sh.fresh(), tuple(W.shape)
+            assert torch.equal(sh.tensor[:, :W.shape[1]], W.to(torch.bfloat16))
+            if sh.tensor.shape[1] > W.shape[1] + 1:              # (the mapping shadow keeps its bias in column V)
+                assert not sh.tensor[:, W.shape[1] + 1:].any()
+    check()                                                        # written by the optimiser
+    batch = next(iter(trainer.test_dataloader))
+    batch = {k: v.cuda() for k, v in batch.items() if torch.is_tensor(v)}
+    m.eval()
+    with torch.no_grad():
+        p0 = m(batch).float()
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        with torch.no_grad():
+            m.output_projection.linear.weight.mul_(0.5)            # a master edited in place: stale shadow
+        assert not m._linear_shadow(m.output_projection.linear).fresh()
+        p1 = m(batch).float()
+        assert float((p1 - p0).abs().max()) > 0
+        m.load_state_dict(sd, strict=False)                        # and restored: stale again, re-cast by the next forward
+        p2 = m(batch).float()
+    assert torch.equal(p2, p0)
+    check()
+
+
 @pytest.mark.parametrize("task", ["forecasting", "anomaly_detection"])
 def test_stitched_eval_on_gpu(tmp_path, task):
     """§8f-1 on the device: train one epoch on a sliding-window series dataset, then val()/test() through the HIP model
