@@ -75,26 +75,32 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__
     }
 }
 
-template <int NV, bool RMS>
+// WPR waves share a row (wide rows: d >= 2048): the row's NV float4 per lane would otherwise pin ~190 registers (two waves per SIMD, 3.3 TB/s
+// at d = 4096); with four waves per row a lane keeps NV / 4 of them and the two row sums cross the waves through LDS.
+template <int NV, bool RMS, int WPR = 1>
 __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict__ dy, int64_t ld_dy, const float* __restrict__ x,
                                                        const float* __restrict__ gamma, const float* __restrict__ stats,
                                                        const float* dres_in, float* dres_out, bf16_t* dres_out_bf16,
                                                        int64_t M, int d, int64_t group_rows, int64_t group_stride,
                                                        int64_t row_offset, int stats_physical, float drop_p, uint32_t drop_seed) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    static_assert(NV % WPR == 0 && 4 % WPR == 0, "waves per row");
+    constexpr int NVW = NV / WPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = wave % WPR;
+    const int64_t row_raw = (int64_t)blockIdx.x * (4 / WPR) + wave / WPR;
+    const bool row_ok = row_raw < M;
+    if (WPR == 1 && !row_ok) return;
+    const int64_t row = row_ok ? row_raw : M - 1;       // (WPR > 1: every wave reaches the barrier; stores are predicated)
     const int64_t prow = remap_row(row, group_rows, group_stride, row_offset);
     const float* xr = x + prow * (int64_t)d;
     const bf16_t* dyr = dy + row * ld_dy;
     const int64_t srow = stats_physical ? prow : row;
     const float mean = RMS ? 0.f : stats[srow * 2];
     const float rstd = stats[srow * 2 + 1];
-    float4 g[NV], xh[NV];
+    float4 g[NVW], xh[NVW];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (lane + 64 * i) * 4;
+    for (int i = 0; i < NVW; ++i) {
+        const int c = (lane + 64 * (sub + WPR * i)) * 4;
         if (c < d) {
             const u32x2 dk = *reinterpret_cast<const u32x2*>(dyr + c);
             const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
@@ -111,11 +117,22 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict_
         }
     }
     const float inv_d = 1.0f / (float)d;
-    const float c1 = RMS ? 0.f : wave_sum(s1) * inv_d;
-    const float c2 = wave_sum(s2) * inv_d;
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if constexpr (WPR > 1) {
+        __shared__ float red[4][2];
+        if (lane == 0) { red[wave][0] = s1; red[wave][1] = s2; }
+        __syncthreads();
+        s1 = 0.f; s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (lane + 64 * i) * 4;
+        for (int w = 0; w < WPR; ++w) { s1 += red[(wave / WPR) * WPR + w][0]; s2 += red[(wave / WPR) * WPR + w][1]; }
+        if (!row_ok) return;
+    }
+    const float c1 = RMS ? 0.f : s1 * inv_d;
+    const float c2 = s2 * inv_d;
+#pragma unroll
+    for (int i = 0; i < NVW; ++i) {
+        const int c = (lane + 64 * (sub + WPR * i)) * 4;
         if (c < d) {
             float4 o;
             o.x = rstd * (g[i].x - c1 - xh[i].x * c2); o.y = rstd * (g[i].y - c1 - xh[i].y * c2);
@@ -187,18 +204,20 @@ extern "C" int mtl_norm_bwd(const void* dy, int64_t ld_dy, const float* x, const
     if (!dy || !x || !gamma || !stats || !dres_out || M <= 0 || d <= 0 || bf16_drop_p < 0.f || bf16_drop_p >= 1.f) return MTL_ERR_ARG;
     if (d % 4 != 0 || ld_dy % 4 != 0) return MTL_ERR_ALIGN;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)((M + 3) / 4)), block(256);
+    const dim3 block(256);
     auto go = [&](auto nv) -> int {
         constexpr int NV = decltype(nv)::value;
+        constexpr int WPR = NV >= 8 ? 4 : 1;
+        const dim3 grid((unsigned)((M + 4 / WPR - 1) / (4 / WPR)));
         char kname[64];
         snprintf(kname, sizeof kname, "norm_bwd_kernel<%d, %s>", NV, rms ? "true" : "false");
         // bf16 dy + fp32 x in (+ fp32 incoming residual gradient), fp32 residual gradient out (+ its bf16 copy)
         const double bytes = (double)M * d * (2 + 4 + (dres_in ? 4 : 0) + 4 + (dres_out_bf16 ? 2 : 0)) + (double)M * 8;
         if (rms)
-            MTL_LAUNCH(kname, bytes, 1, (norm_bwd_kernel<NV, true>), grid, block, 0, st, (const bf16_t*)dy, ld_dy, x, gamma, stats, dres_in,
+            MTL_LAUNCH(kname, bytes, 1, (norm_bwd_kernel<NV, true, WPR>), grid, block, 0, st, (const bf16_t*)dy, ld_dy, x, gamma, stats, dres_in,
                        dres_out, (bf16_t*)dres_out_bf16, M, (int)d, group_rows, group_stride, row_offset, stats_physical, bf16_drop_p, bf16_drop_seed);
         else
-            MTL_LAUNCH(kname, bytes, 1, (norm_bwd_kernel<NV, false>), grid, block, 0, st, (const bf16_t*)dy, ld_dy, x, gamma, stats, dres_in,
+            MTL_LAUNCH(kname, bytes, 1, (norm_bwd_kernel<NV, false, WPR>), grid, block, 0, st, (const bf16_t*)dy, ld_dy, x, gamma, stats, dres_in,
                        dres_out, (bf16_t*)dres_out_bf16, M, (int)d, group_rows, group_stride, row_offset, stats_physical, bf16_drop_p, bf16_drop_seed);
         MTL_CHECK_LAUNCH();
         return MTL_OK;
