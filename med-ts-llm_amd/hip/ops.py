@@ -254,13 +254,19 @@ def attention_fwd(q, k, v, Hq, Hkv, D, scale, causal, shared_kv=False, dropout=(
     return o, lse
 
 
-def attention_bwd(q, k, v, o, lse, dout, Hq, Hkv, D, scale, causal, shared_kv=False, dropout=(0.0, 0)):
+def attention_bwd(q, k, v, o, lse, dout, Hq, Hkv, D, scale, causal, shared_kv=False, dropout=(0.0, 0), dkv_out=None):
+    """dkv_out = (dk, dv): write the key / value gradients there (row-strided views of one buffer are fine: the paired K/V
+    projection backward then reads both as ONE operand)"""
     B, Tq = q.shape[0], q.shape[1]
     Tk = k.shape[-2]
     dout = dout.contiguous()
     dq = torch.empty((B, Tq, Hq * D), dtype=BF16, device=q.device)
-    dk = torch.empty(k.shape, dtype=BF16, device=q.device)
-    dv = torch.empty(v.shape, dtype=BF16, device=q.device)
+    if dkv_out is not None:
+        dk, dv = dkv_out
+        _req(dk.shape == k.shape and dv.shape == v.shape and dk.stride(-1) == 1 and dv.stride(-1) == 1 and dk.stride(-2) == dv.stride(-2), "attention_bwd: dkv_out layout")
+    else:
+        dk = torch.empty(k.shape, dtype=BF16, device=q.device)
+        dv = torch.empty(v.shape, dtype=BF16, device=q.device)
     delta = torch.empty((B, Hq, Tq), dtype=F32, device=q.device)
     ks = (0, k.stride(-2), D) if shared_kv else (k.stride(0), k.stride(1), D)
     vs = (0, v.stride(-2), D) if shared_kv else (v.stride(0), v.stride(1), D)
@@ -437,6 +443,55 @@ class LinearFn(torch.autograd.Function):
         return dx, dW, db, None
 
 
+class LinearPairFn(torch.autograd.Function):
+    """(y1, y2) = (x W1^T + b1, x W2^T + b2): the key and value projections of the reprogramming layer (R:models/medtsllm.py:572-573),
+    which share their input. Forward = two GEMMs; the BACKWARD treats [W1; W2] as one weight — dX = [dY1 | dY2] . [W1; W2] and
+    d[W1; W2] = [dY1 | dY2]^T . X are one mtl_gemm_xt launch each (instead of two + an add) — when the two weight shadows are halves of
+    one buffer (`pair` = the [N1 + N2, Kx] base tensor) and the incoming gradients are halves of one buffer (CrossAttnFn's backward
+    makes them so); anything else falls back to LinearFn's arithmetic per projection."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, sh1, sh2, pair):
+        Kx = x.shape[-1]
+        x2 = x.reshape(-1, Kx)
+        if x2.stride(1) != 1 or x2.stride(0) % 8 != 0:
+            x2 = x2.contiguous()
+        N1, N2, Kin = W1.shape[0], W2.shape[0], W1.shape[1]
+        _req(W2.shape[1] == Kin and x.dtype == BF16 and Kx % 64 == 0 and Kx >= Kin and N1 % 8 == 0 and N2 % 8 == 0, "LinearPairFn: shapes")
+        _req(pair is not None and tuple(pair.shape) == (N1 + N2, Kx) and sh1.tensor.data_ptr() == pair.data_ptr()
+             and sh2.tensor.data_ptr() == pair[N1:].data_ptr(), "LinearPairFn: the shadows must be the halves of `pair`")
+        ys = []
+        for W, b, sh in ((W1, b1, sh1), (W2, b2, sh2)):
+            if not sh.fresh():
+                cast_pad(W.detach().contiguous().float(), dst=sh.tensor)
+                sh.version = W._version
+            ys.append(gemm_nt(x2, sh.tensor, bias=None if b is None else b.detach().float().contiguous()))
+        ctx.save_for_backward(x2, pair)
+        ctx.meta = (tuple(x.shape), N1, N2, Kin, b1 is not None, b2 is not None)
+        return ys[0].reshape(*x.shape[:-1], N1), ys[1].reshape(*x.shape[:-1], N2)
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        x2, pair = ctx.saved_tensors
+        xshape, N1, N2, Kin, has_b1, has_b2 = ctx.meta
+        M, Kx = x2.shape
+        dy1, dy2 = dy1.reshape(M, N1), dy2.reshape(M, N2)
+        adjacent = (dy1.dtype == BF16 and dy2.dtype == BF16 and dy1.stride(1) == 1 and dy2.stride(1) == 1 and dy1.stride(0) == dy2.stride(0) == N1 + N2
+                    and dy2.data_ptr() == dy1.data_ptr() + 2 * N1)
+        if adjacent:
+            dy = torch.as_strided(dy1, (M, N1 + N2), (N1 + N2, 1))
+        else:
+            dy = torch.cat([dy1.to(BF16), dy2.to(BF16)], dim=1)
+        dx = gemm_xt(dy, pair, b_trans=True).reshape(xshape) if ctx.needs_input_grad[0] else None
+        dW1 = dW2 = db1 = db2 = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[3]:
+            xk = x2[:, :Kin] if Kin != Kx else x2
+            dW, db = gemm_xt(dy, xk, a_trans=True, b_trans=True, out_dtype=F32, want_colsum=True)
+            dW1, dW2 = dW[:N1], dW[N1:]
+            db1, db2 = (db[:N1] if has_b1 else None), (db[N1:] if has_b2 else None)
+        return dx, dW1, db1, dW2, db2, None, None, None
+
+
 class MappingFn(torch.autograd.Function):
     """source[S, d] = Wmap[S, V] @ Wemb[V, d] + b[:, None]   (R:models/medtsllm.py:281), batch independent.
 
@@ -525,7 +580,10 @@ class CrossAttnFn(torch.autograd.Function):
     def backward(ctx, do):
         q, k, v, o, lse = ctx.saved_tensors
         H, E, scale, drop = ctx.meta
-        dq, dk, dv = attention_bwd(q, k, v, o, lse, do, H, H, E, scale, causal=False, shared_kv=True, dropout=drop)
+        # dK | dV side by side in one [S, 2 H E] buffer: LinearPairFn's backward reads them as one GEMM operand
+        dkv = torch.empty((k.shape[0], 2 * H * E), dtype=BF16, device=q.device)
+        dq, dk, dv = attention_bwd(q, k, v, o, lse, do, H, H, E, scale, causal=False, shared_kv=True, dropout=drop,
+                                   dkv_out=(dkv[:, :H * E], dkv[:, H * E:]))
         return dq, dk, dv, None, None, None, None
 
 

@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..hip import ops
-from ..hip.ops import (PatchTokenizeFn, LinearFn, MappingFn, MappingTrainableFn, CrossAttnFn, AssembleFn, BackboneFn, EmbdDropoutFn, RevinDenormFn, pad64, pad_vocab,
+from ..hip.ops import (PatchTokenizeFn, LinearFn, LinearPairFn, MappingFn, MappingTrainableFn, CrossAttnFn, AssembleFn, BackboneFn, EmbdDropoutFn, RevinDenormFn, pad64, pad_vocab,
                        mapping_split_k)
 from . import prompt as P
 from .backbone import FrozenBackbone, load_hf_dir, normalise_config
@@ -362,6 +362,23 @@ class MedTsLLM(nn.Module):
             table[id(lin)] = sh
         return sh
 
+    def _kv_shadow_pair(self):
+        """(key shadow, value shadow, base): the two projections' bf16 weight copies as the halves of ONE [2 H E, pad64(d_llm)] buffer, so
+        that their backward can treat [Wk; Wv] as one weight (LinearPairFn)."""
+        rl = self.reprogramming_layer
+        Wk, Wv = rl.key_projection.weight, rl.value_projection.weight
+        if not Wk.is_cuda or Wk.shape[1] != Wv.shape[1] or Wk.shape[0] % 8 or Wv.shape[0] % 8:
+            return self._linear_shadow(rl.key_projection), self._linear_shadow(rl.value_projection), None
+        table = self.__dict__.setdefault("_lin_shadows", {})
+        ent = table.get("kv_pair")
+        if ent is None or ent[0].param is not Wk or ent[1].param is not Wv or ent[2].device != Wk.device:
+            from ..hip.optim import Bf16Shadow
+            base = torch.zeros((Wk.shape[0] + Wv.shape[0], pad64(Wk.shape[1])), dtype=torch.bfloat16, device=Wk.device)
+            ent = (Bf16Shadow(Wk, base[:Wk.shape[0]]), Bf16Shadow(Wv, base[Wk.shape[0]:]), base)
+            table["kv_pair"] = ent
+            table[id(rl.key_projection)], table[id(rl.value_projection)] = ent[0], ent[1]
+        return ent
+
     def _shadowed_linears(self):
         rl = self.reprogramming_layer
         lins = [rl.query_projection, rl.key_projection, rl.value_projection, rl.out_projection, self.output_projection.linear]
@@ -373,6 +390,7 @@ class MedTsLLM(nn.Module):
         """Shadows an optimiser may keep current (HipAdam.register_shadow)."""
         if not self.mapping_layer.weight.is_cuda:
             return []
+        self._kv_shadow_pair()                 # (key / value shadows are halves of one buffer)
         out = [sh for sh in (self._linear_shadow(m) for m in self._shadowed_linears()) if sh is not None]
         if not self.word_embeddings.requires_grad:
             out.append(self._mapping_shadow())
@@ -405,8 +423,13 @@ class MedTsLLM(nn.Module):
                 source = AllGatherRows.apply(source, rank, world, group)
         self._tap("source", source)
         q = self._tap("q", LinearFn.apply(tokens, rl.query_projection.weight, rl.query_projection.bias, self._linear_shadow(rl.query_projection)))
-        k = self._tap("k", LinearFn.apply(source, rl.key_projection.weight, rl.key_projection.bias, self._linear_shadow(rl.key_projection)))
-        v = self._tap("v", LinearFn.apply(source, rl.value_projection.weight, rl.value_projection.bias, self._linear_shadow(rl.value_projection)))
+        shk, shv, pair = self._kv_shadow_pair()
+        if pair is not None and ops._LINEAR_XT:
+            k, v = LinearPairFn.apply(source, rl.key_projection.weight, rl.key_projection.bias, rl.value_projection.weight, rl.value_projection.bias, shk, shv, pair)
+            k, v = self._tap("k", k), self._tap("v", v)
+        else:
+            k = self._tap("k", LinearFn.apply(source, rl.key_projection.weight, rl.key_projection.bias, shk))
+            v = self._tap("v", LinearFn.apply(source, rl.value_projection.weight, rl.value_projection.bias, shv))
         if drop_on:   # A = dropout(softmax(.)), R:models/medtsllm.py:588
             a = CrossAttnFn.apply(q, k, v, self.n_attention_heads, self.d_ff, float(self.dropout), seed)
         else:

@@ -312,6 +312,38 @@ def test_gemm_xt_strided_views_and_errors(ops):
         ops.gemm_xt(dy, x[:100], a_trans=True, b_trans=True)
 
 
+def test_linear_pair_backward_equals_two_linears(ops):
+    """the key / value projections share their input: [Wk; Wv] treated as ONE weight in the backward (one dX GEMM over K = 2 N, one
+    d[Wk; Wv] GEMM) == the two projections differentiated separately, for adjacent incoming gradients (what the reprogramming
+    attention's backward hands over) and for unrelated ones (concatenated)"""
+    from med_ts_llm_amd.hip.optim import Bf16Shadow
+    M, K, N1 = 1024, 768, 256
+    x = torch.randn(M, K, generator=g(1)).to(BF16).cuda()
+    W = [torch.nn.Parameter((torch.randn(N1, K, generator=g(2 + i)) * 0.05).cuda()) for i in range(2)]
+    b = [torch.nn.Parameter((torch.randn(N1, generator=g(4 + i)) * 0.05).cuda()) for i in range(2)]
+    base = torch.zeros(2 * N1, K, dtype=BF16, device="cuda")
+    sh = [Bf16Shadow(W[0], base[:N1]), Bf16Shadow(W[1], base[N1:])]
+    dyy = torch.randn(M, 2 * N1, generator=g(6)).to(BF16).cuda()
+    for adjacent in (True, False):
+        xs = [x.clone().requires_grad_(True) for _ in range(2)]
+        y1, y2 = ops.LinearPairFn.apply(xs[0], W[0], b[0], W[1], b[1], sh[0], sh[1], base)
+        d1, d2 = (dyy[:, :N1], dyy[:, N1:]) if adjacent else (dyy[:, :N1].contiguous(), dyy[:, N1:].contiguous())
+        torch.autograd.backward([y1, y2], [d1, d2])
+        got = [xs[0].grad.clone()] + [p.grad.clone() for p in W + b]
+        for p in W + b:
+            p.grad = None
+        r1 = ops.LinearFn.apply(xs[1], W[0], b[0])
+        r2 = ops.LinearFn.apply(xs[1], W[1], b[1])
+        assert torch.equal(r1, y1) and torch.equal(r2, y2)
+        torch.autograd.backward([r1, r2], [d1.contiguous(), d2.contiguous()])
+        want = [xs[1].grad.clone()] + [p.grad.clone() for p in W + b]
+        for p in W + b:
+            p.grad = None
+        assert rel_err(got[0].float(), want[0].float()) < 2 * TOL_BF16      # (one bf16 rounding of the sum here; two roundings + a rounded add there)
+        for a_, w_ in zip(got[1:], want[1:]):
+            assert rel_err(a_, w_) < TOL_F32
+
+
 # ------------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("M,d", [(7, 64), (300, 768), (64, 4096), (10, 1000)])
 def test_layernorm(ops, M, d):
