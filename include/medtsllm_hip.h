@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MTL_ABI_VERSION 7
+#define MTL_ABI_VERSION 8
 
 enum { MTL_OK = 0, MTL_ERR_ARG = -1, MTL_ERR_ALIGN = -2, MTL_ERR_UNSUPPORTED = -3, MTL_ERR_LAUNCH = -4,
        MTL_ERR_WORKSPACE = -5 };
@@ -189,6 +189,8 @@ int mtl_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int mtl_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 /* column sums of a bf16 [R, Cc] matrix into f32 [Cc] (bias gradients) */
 int mtl_colsum_bf16(const void* src, int64_t ld_src, float* dst, int64_t R, int64_t Cc, void* stream);
+/* dst[r] = sum_c src[r, c] (bf16 in, fp32 out): the mapping layer's bias gradient (row sums of d source, R:models/medtsllm.py:281) */
+int mtl_rowsum_bf16(const void* src, int64_t ld_src, float* dst, int64_t R, int64_t Cc, void* stream);
 
 /* ------------------------------------------------------------------ optimiser step
  * torch.optim.Adam / AdamW (R:tasks/base.py:97,99; stepped at R:tasks/forecasting.py:27 and the 4 other task loops)
@@ -296,9 +298,14 @@ int mtl_swiglu_bwd_rows(const void* gu, const void* dh, void* dgu, int64_t M, in
  * Replaces the embedding gather, left padding (ids are already left-padded with pad_token_id host-side,
  * identical to padding with the pad embedding, R:models/medtsllm.py:304-311) and torch.cat (:349), plus
  * GPT-2's position add (HF:models/gpt2/modeling_gpt2.py:576-577). ids int32 [ids_B, n_tok] with ids_B == B or 1
- * (1 = the same constant prompt for every sample). x_tok bf16 [B, P, d]. embed f32 [V, d]. */
+ * (1 = the same constant prompt for every sample). x_tok bf16 [B, P, d]. embed f32 [V, d].
+ * drop_p > 0: GPT-2's embd_pdrop (HF:models/gpt2/modeling_gpt2.py:579) applied to the assembled rows in the same pass, mask of
+ * (drop_seed, row b * T + t, column) — the one mtl_dropout_f32 applies to h0 viewed as [B * T, d].
+ * mtl_assemble_bwd: dx_tok bf16 [B, P, d] = mask * dh0[:, n_tok:, :] (the prompt rows have no trainable ancestor). */
 int mtl_assemble_llm_input(const int32_t* ids, int64_t ids_B, const float* embed, const void* x_tok, const float* wpe,
-                           float* h0, int64_t B, int64_t n_tok, int64_t P, int64_t d, void* stream);
+                           float* h0, int64_t B, int64_t n_tok, int64_t P, int64_t d, float drop_p, uint32_t drop_seed, void* stream);
+int mtl_assemble_bwd(const float* dh0, void* dx_tok, int64_t B, int64_t n_tok, int64_t P, int64_t d, float drop_p, uint32_t drop_seed,
+                     void* stream);
 
 /* ------------------------------------------------------------------ frozen backbone stack (a7)
  * Whole GPT-2 / Llama decoder stack forward and activation-gradient-only backward as ONE host call each

@@ -189,17 +189,29 @@ __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* _
 // ---------------------------------------------------------------- LLM input assembly: one block per (b, t) row
 __global__ __launch_bounds__(256) void assemble_kernel(const int32_t* __restrict__ ids, int64_t ids_B, const float* __restrict__ embed,
                                                        const bf16_t* __restrict__ x_tok, const float* __restrict__ wpe,
-                                                       float* __restrict__ h0, int64_t n_tok, int64_t P, int64_t d) {
+                                                       float* __restrict__ h0, int64_t n_tok, int64_t P, int64_t d, uint32_t drop_thr,
+                                                       uint32_t drop_seed) {
     const int64_t T = n_tok + P;
     const int64_t row = blockIdx.x, b = row / T, t = row % T;
     float* out = h0 + row * d;
     const float* pe = wpe ? wpe + t * d : nullptr;
+    // GPT-2 embd_pdrop on inputs_embeds + wpe (HF:models/gpt2/modeling_gpt2.py:579), mask of (seed, flattened row, column) = mtl_dropout_f32's
+    const uint32_t dbase = drop_base(drop_seed, 0u);
+    const float dscale = drop_scale_of(drop_thr);
+    auto drop4 = [&](float4& v, int64_t c) {
+        if (drop_thr) {
+            const uint2 w = drop_quad(dbase, (uint32_t)row, (uint32_t)c >> 2);
+            v.x = (w.x & 0xffffu) >= drop_thr ? v.x * dscale : 0.f; v.y = (w.x >> 16) >= drop_thr ? v.y * dscale : 0.f;
+            v.z = (w.y & 0xffffu) >= drop_thr ? v.z * dscale : 0.f; v.w = (w.y >> 16) >= drop_thr ? v.w * dscale : 0.f;
+        }
+    };
     if (t < n_tok) {
         const int64_t id = ids[(ids_B == 1 ? 0 : b) * n_tok + t];
         const float* e = embed + id * d;
         for (int64_t c = (int64_t)threadIdx.x * 4; c < d; c += 1024) {
             float4 v = *reinterpret_cast<const float4*>(e + c);
             if (pe) { const float4 p4 = *reinterpret_cast<const float4*>(pe + c); v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w; }
+            drop4(v, c);
             *reinterpret_cast<float4*>(out + c) = v;
         }
     } else {
@@ -209,8 +221,27 @@ __global__ __launch_bounds__(256) void assemble_kernel(const int32_t* __restrict
             float4 v = make_float4(__uint_as_float(k[0] << 16), __uint_as_float(k[0] & 0xffff0000u), __uint_as_float(k[1] << 16),
                                    __uint_as_float(k[1] & 0xffff0000u));
             if (pe) { const float4 p4 = *reinterpret_cast<const float4*>(pe + c); v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w; }
+            drop4(v, c);
             *reinterpret_cast<float4*>(out + c) = v;
         }
+    }
+}
+
+// backward of the assembly (+ embd dropout): dx_tok[b, p, :] = bf16(mask * dh0[b, n_tok + p, :]) — the token rows only, one pass
+__global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restrict__ dh0, bf16_t* __restrict__ dx, int64_t n_tok, int64_t P, int64_t d,
+                                                           uint32_t drop_thr, uint32_t drop_seed) {
+    const int64_t T = n_tok + P;
+    const int64_t r = blockIdx.x, b = r / P, pp = r % P, row = b * T + n_tok + pp;
+    const uint32_t dbase = drop_base(drop_seed, 0u);
+    const float dscale = drop_scale_of(drop_thr);
+    for (int64_t c = (int64_t)threadIdx.x * 4; c < d; c += 1024) {
+        float4 v = *reinterpret_cast<const float4*>(dh0 + row * d + c);
+        if (drop_thr) {
+            const uint2 w = drop_quad(dbase, (uint32_t)row, (uint32_t)c >> 2);
+            v.x = (w.x & 0xffffu) >= drop_thr ? v.x * dscale : 0.f; v.y = (w.x >> 16) >= drop_thr ? v.y * dscale : 0.f;
+            v.z = (w.y & 0xffffu) >= drop_thr ? v.z * dscale : 0.f; v.w = (w.y >> 16) >= drop_thr ? v.w * dscale : 0.f;
+        }
+        *reinterpret_cast<u32x2*>(dx + r * d + c) = (u32x2){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
     }
 }
 
@@ -283,6 +314,25 @@ extern "C" int mtl_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void
     return MTL_OK;
 }
 
+// row sums of a bf16 matrix in fp32: one wave per row (the mapping layer's bias gradient = row sums of d source)
+__global__ __launch_bounds__(256) void rowsum_kernel(const bf16_t* __restrict__ src, int64_t ld, float* __restrict__ dst, int64_t R, int64_t Cc) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const bf16_t* r = src + row * ld;
+    float s = 0.f;
+    for (int64_t c = lane; c < Cc; c += 64) s += bf16_to_f32(r[c]);
+    s = wave_sum(s);
+    if (lane == 0) dst[row] = s;
+}
+
+extern "C" int mtl_rowsum_bf16(const void* src, int64_t ld_src, float* dst, int64_t R, int64_t Cc, void* stream) {
+    if (!src || !dst || R <= 0 || Cc <= 0) return MTL_ERR_ARG;
+    hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld_src, dst, R, Cc);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
 extern "C" int mtl_colsum_bf16(const void* src, int64_t ld_src, float* dst, int64_t R, int64_t Cc, void* stream) {
     if (!src || !dst || R <= 0 || Cc <= 0) return MTL_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -336,13 +386,25 @@ extern "C" int mtl_swiglu_bwd(const void* gu, const void* dh, void* dgu, int64_t
     return mtl_swiglu_bwd_rows(gu, dh, dgu, M, F, 0, 0, 0, 0, stream);
 }
 
+extern "C" int mtl_assemble_bwd(const float* dh0, void* dx_tok, int64_t B, int64_t n_tok, int64_t P, int64_t d, float drop_p,
+                                uint32_t drop_seed, void* stream) {
+    if (!dh0 || !dx_tok || B <= 0 || P <= 0 || d <= 0 || n_tok < 0 || drop_p < 0.f || drop_p >= 1.f) return MTL_ERR_ARG;
+    if (d % 4 != 0) return MTL_ERR_ALIGN;
+    hipLaunchKernelGGL(assemble_bwd_kernel, dim3((unsigned)(B * P)), dim3(256), 0, (hipStream_t)stream, dh0, (bf16_t*)dx_tok, n_tok, P, d,
+                       drop_p > 0.f ? drop_threshold(drop_p) : 0u, drop_seed);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
 extern "C" int mtl_assemble_llm_input(const int32_t* ids, int64_t ids_B, const float* embed, const void* x_tok, const float* wpe,
-                                      float* h0, int64_t B, int64_t n_tok, int64_t P, int64_t d, void* stream) {
+                                      float* h0, int64_t B, int64_t n_tok, int64_t P, int64_t d, float drop_p, uint32_t drop_seed,
+                                      void* stream) {
+    if (drop_p < 0.f || drop_p >= 1.f) return MTL_ERR_ARG;
     if (!x_tok || !h0 || B <= 0 || P <= 0 || d <= 0 || n_tok < 0) return MTL_ERR_ARG;
     if (n_tok > 0 && (!ids || !embed || (ids_B != 1 && ids_B != B))) return MTL_ERR_ARG;
     if (d % 4 != 0) return MTL_ERR_ALIGN;
     hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)(B * (n_tok + P))), dim3(256), 0, (hipStream_t)stream, ids, ids_B, embed,
-                       (const bf16_t*)x_tok, wpe, h0, n_tok, P, d);
+                       (const bf16_t*)x_tok, wpe, h0, n_tok, P, d, drop_p > 0.f ? drop_threshold(drop_p) : 0u, drop_seed);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("MTL_LIB_PATH") or os.path.join(_HERE, "libmedtsllm_hi
 MTL_F32, MTL_BF16 = 0, 1
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM, EPI_SWIGLU, EPI_DSWIGLU = 0, 1, 2, 3, 4, 5, 6
 ARCH_GPT2, ARCH_LLAMA = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 i64, vp, f32, i32 = C.c_int64, C.c_void_p, C.c_float, C.c_int
 
@@ -111,6 +111,7 @@ SIGNATURES = {
     "mtl_cast_f32_to_bf16": (i32, [vp, vp, i64, vp]),
     "mtl_cast_bf16_to_f32": (i32, [vp, vp, i64, vp]),
     "mtl_colsum_bf16": (i32, [vp, i64, vp, i64, i64, vp]),
+    "mtl_rowsum_bf16": (i32, [vp, i64, vp, i64, i64, vp]),
     "mtl_adam_step": (i32, [C.POINTER(AdamTensor), i32, f32, f32, f32, f32, f32, i32, i64, vp]),
     "mtl_attention_fwd": (i32, [C.POINTER(AttnFwdArgs), vp]),
     "mtl_attention_tune": (i32, [i32]),
@@ -123,7 +124,8 @@ SIGNATURES = {
     "mtl_swiglu_bwd_rows": (i32, [vp, vp, vp, i64, i64, i64, i64, i64, i32, vp]),
     "mtl_swiglu_fwd": (i32, [vp, vp, i64, i64, vp]),
     "mtl_swiglu_bwd": (i32, [vp, vp, vp, i64, i64, vp]),
-    "mtl_assemble_llm_input": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, vp]),
+    "mtl_assemble_llm_input": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, f32, C.c_uint32, vp]),
+    "mtl_assemble_bwd": (i32, [vp, vp, i64, i64, i64, i64, f32, C.c_uint32, vp]),
     "mtl_input_stats_workspace_bytes": (C.c_size_t, [i64, i64, i64]),
     "mtl_input_stats": (i32, [vp, vp, vp, vp, C.c_size_t, i64, i64, i64, i64, i64, vp]),
     "mtl_backbone_saved_bytes": (C.c_size_t, [C.POINTER(BackboneWeights), i64, i64]),

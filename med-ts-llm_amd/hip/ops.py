@@ -171,6 +171,13 @@ def colsum(x):
     return out
 
 
+def rowsum(x):
+    _req(x.dtype == BF16 and x.dim() == 2 and x.stride(1) == 1, "rowsum: bf16 2-D")
+    out = torch.empty(x.shape[0], dtype=F32, device=x.device)
+    check(lib().mtl_rowsum_bf16(ptr(x), x.stride(0), ptr(out), x.shape[0], x.shape[1], stream()), "mtl_rowsum_bf16")
+    return out
+
+
 def patch_index_map(L, patch_len, stride, device):
     P = (L + stride - patch_len) // stride + 1
     idx = torch.empty((P, patch_len), dtype=torch.int32, device=device)
@@ -335,13 +342,22 @@ def swiglu_bwd(gu, dh, interleaved=False):
     return dgu
 
 
-def assemble_llm_input(ids, embed, x_tok, wpe):
+def assemble_llm_input(ids, embed, x_tok, wpe, drop=(0.0, 0)):
     B, P, d = x_tok.shape
     n_tok = 0 if ids is None else ids.shape[1]
     h0 = torch.empty((B, n_tok + P, d), dtype=F32, device=x_tok.device)
     check(lib().mtl_assemble_llm_input(ptr(ids), 0 if ids is None else ids.shape[0], ptr(embed), ptr(x_tok), ptr(wpe), ptr(h0),
-                                       B, n_tok, P, d, stream()), "mtl_assemble_llm_input")
+                                       B, n_tok, P, d, float(drop[0]), int(drop[1]) & 0xFFFFFFFF, stream()), "mtl_assemble_llm_input")
     return h0
+
+
+def assemble_bwd(dh0, n_tok, drop=(0.0, 0)):
+    """bf16 [B, P, d] = mask * dh0[:, n_tok:, :]"""
+    dh0 = dh0.contiguous()
+    B, T, d = dh0.shape
+    out = torch.empty((B, T - n_tok, d), dtype=BF16, device=dh0.device)
+    check(lib().mtl_assemble_bwd(ptr(dh0), ptr(out), B, n_tok, T - n_tok, d, float(drop[0]), int(drop[1]) & 0xFFFFFFFF, stream()), "mtl_assemble_bwd")
+    return out
 
 
 # =============================================================================================== autograd ops
@@ -522,7 +538,7 @@ class MappingFn(torch.autograd.Function):
         S, V = ctx.meta
         dsrc = dsrc.contiguous()
         dW = gemm_nt(dsrc, w, out_dtype=F32) if ctx.needs_input_grad[0] else None   # [S, V] = dsrc[S,d] @ Wemb[V,d]^T
-        db = colsum(transpose_bf16(dsrc)) if ctx.needs_input_grad[1] else None       # row sums of dsrc
+        db = rowsum(dsrc) if ctx.needs_input_grad[1] else None       # row sums of dsrc
         return dW, db, None, None, None, None
 
 
@@ -557,7 +573,7 @@ class MappingTrainableFn(torch.autograd.Function):
         dsrc = dsrc.contiguous()
         dW = gemm_nt(dsrc, we, out_dtype=F32) if ctx.needs_input_grad[0] else None          # [S, V]
         dsT = transpose_bf16(dsrc, wmT.shape[1])                                               # [d, Sp]
-        db = colsum(transpose_bf16(dsrc)) if ctx.needs_input_grad[1] else None              # row sums of dsrc
+        db = rowsum(dsrc) if ctx.needs_input_grad[1] else None              # row sums of dsrc
         dE = gemm_nt(wmT, dsT, out_dtype=F32) if ctx.needs_input_grad[2] else None            # [V, d]
         return dW, db, dE, None
 
@@ -591,14 +607,16 @@ class AssembleFn(torch.autograd.Function):
     """h0 = cat[embed[ids], x_tok] (+ wpe) in fp32 (R:models/medtsllm.py:331-337,349; HF gpt2 :576-577)."""
 
     @staticmethod
-    def forward(ctx, x_tok, ids, embed, wpe):
-        h0 = assemble_llm_input(ids, embed, x_tok.contiguous(), wpe)
+    def forward(ctx, x_tok, ids, embed, wpe, drop_p=0.0, drop_seed=0):
+        """drop_p > 0: GPT-2's embd_pdrop fused into the assembly (same mask as EmbdDropoutFn on the assembled tensor)"""
+        ctx.drop = (float(drop_p), int(drop_seed))
+        h0 = assemble_llm_input(ids, embed, x_tok.contiguous(), wpe, ctx.drop)
         ctx.n_tok = 0 if ids is None else ids.shape[1]
         return h0
 
     @staticmethod
     def backward(ctx, dh0):
-        return to_bf16(dh0[:, ctx.n_tok:, :]), None, None, None
+        return assemble_bwd(dh0, ctx.n_tok, ctx.drop), None, None, None, None, None
 
 
 def dropout_f32(x, p, seed, out=None):

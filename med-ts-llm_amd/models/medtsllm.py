@@ -457,7 +457,13 @@ class MedTsLLM(nn.Module):
         cm = self.covariate_mode
         if ids is not None and cm in ("independent", "merge-end") and ids.shape[0] != 1:
             ids = ids.repeat_interleave(C, dim=0)        # R:models/medtsllm.py:343-344
-        h0 = AssembleFn.apply(x_tok, ids, bb.embed_f32, bb.wpe)
+        # GPT-2's own dropouts are live whenever the module is in train mode (the reference calls model.train() on the whole
+        # model, frozen LLM included): embd_pdrop on inputs_embeds + wpe, attn_pdrop / resid_pdrop inside the stack
+        llm_drop = self.training and bb.arch == "gpt2" and self.llm_dropout
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if llm_drop else 0          # host RNG: no device sync
+        embd_p = bb.cfg["embd_pdrop"] if llm_drop else 0.0
+        fuse_embd = embd_p > 0 and splice is None           # (spliced examples are added before the dropout: separate pass there)
+        h0 = AssembleFn.apply(x_tok, ids, bb.embed_f32, bb.wpe, embd_p if fuse_embd else 0.0, seed ^ 0x5bd1e995)
         # only the x_tok rows of h0 have a trainable ancestor: prompt-row gradients are dead
         n_grad = x_tok.shape[1] if self.prune_dead_prompt_grads else None
         if splice is not None:
@@ -469,14 +475,11 @@ class MedTsLLM(nn.Module):
             h0 = h0.index_put((bidx, rows), delta, accumulate=True)
             if n_grad is not None:                       # gradients are alive from the first example row on
                 n_grad = h0.shape[1] - splice["first"]
-        # GPT-2's own dropouts are live whenever the module is in train mode (the reference calls model.train() on the whole
-        # model, frozen LLM included): embd_pdrop on inputs_embeds + wpe, attn_pdrop / resid_pdrop inside the stack
         drop = None
-        if self.training and bb.arch == "gpt2" and self.llm_dropout:
+        if llm_drop:
             c = bb.cfg
-            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())          # host RNG: no device sync
-            if c["embd_pdrop"] > 0:
-                h0 = EmbdDropoutFn.apply(h0, c["embd_pdrop"], seed ^ 0x5bd1e995)
+            if embd_p > 0 and not fuse_embd:
+                h0 = EmbdDropoutFn.apply(h0, embd_p, seed ^ 0x5bd1e995)
             if c["attn_pdrop"] > 0 or c["resid_pdrop"] > 0:
                 drop = (c["attn_pdrop"], c["resid_pdrop"], seed)
         self._tap("h0", h0)

@@ -535,6 +535,19 @@ def test_assemble_and_denorm(ops):
     ref1 = torch.cat([emb[ids[:1].long()].expand(B, -1, -1), xt.float()], dim=1)
     assert rel_err(ops.assemble_llm_input(dev(ids[:1]), dev(emb), dev(xt), None), ref1) < 1e-7
     assert rel_err(ops.assemble_llm_input(None, None, dev(xt), None), xt.float()) < 1e-7
+    # embd dropout fused into the assembly == assembly, then mtl_dropout_f32 (bit-identical); its backward = masked token rows in bf16
+    from helpers import drop_mult_matrix
+    p_, seed = 0.1, 4242
+    h_plain = ops.assemble_llm_input(dev(ids), dev(emb), dev(xt), dev(wpe))
+    h_drop = ops.assemble_llm_input(dev(ids), dev(emb), dev(xt), dev(wpe), drop=(p_, seed))
+    assert torch.equal(h_drop, ops.dropout_f32(h_plain, p_, seed))
+    mult = drop_mult_matrix(seed, p_, B * (n_tok + Pn), d).view(B, n_tok + Pn, d)
+    assert torch.equal(h_drop.cpu(), h_plain.cpu() * mult)
+    dh = torch.randn(B, n_tok + Pn, d, generator=g(8))
+    assert torch.equal(ops.assemble_bwd(dev(dh), n_tok, drop=(p_, seed)).cpu(), (dh * mult)[:, n_tok:].to(BF16))
+    assert torch.equal(ops.assemble_bwd(dev(dh), n_tok).cpu(), dh[:, n_tok:].to(BF16))
+    m = torch.randn(300, 770, generator=g(9)).to(BF16)
+    assert rel_err(ops.rowsum(dev(m)), m.double().sum(1)) < 1e-6
     y = torch.randn(B, 7, 3, generator=g(5))
     mean, sd = torch.randn(B, 3, generator=g(6)), torch.rand(B, 3, generator=g(7)) + 0.1
     assert rel_err(ops.revin_denorm(dev(y), dev(mean), dev(sd)), y * sd[:, None] + mean[:, None]) < 1e-6
