@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MTL_ABI_VERSION 8
+#define MTL_ABI_VERSION 9
 
 enum { MTL_OK = 0, MTL_ERR_ARG = -1, MTL_ERR_ALIGN = -2, MTL_ERR_UNSUPPORTED = -3, MTL_ERR_LAUNCH = -4,
        MTL_ERR_WORKSPACE = -5 };
@@ -233,6 +233,11 @@ typedef struct {
     /* attention dropout A = dropout(softmax(.)) of the reprogramming layer (R:models/medtsllm.py:588, p = training.dropout);
      * non-causal only. keep(b*Hq+h, q, key) is a counter-based hash of dropout_seed, regenerated identically in the backward. */
     float dropout_p; uint32_t dropout_seed;
+    /* optional fp32 copy of the output (same element strides as o), non-causal kernels only. The backward then takes
+     * delta_q = dO_q . O_q from it: with the bf16-rounded O the error of delta is coherent over the keys when the probabilities
+     * are near-uniform (reprogramming attention); with the fp32 O it is the rounding of the individual P V products,
+     * sqrt(Tk) times smaller, and the extra pass over K / V that the bf16 route needs to rebuild delta is not run. */
+    float* o_f32;
 } mtl_attn_fwd_args;
 int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream);
 typedef struct {

@@ -225,6 +225,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a
         u32x2 pk = {pack_bf16x2(o[dt][0] * inv_l, o[dt][1] * inv_l), pack_bf16x2(o[dt][2] * inv_l, o[dt][3] * inv_l)};
         *reinterpret_cast<u32x2*>(O + dt * 16 + g * 4) = pk;
     }
+    if (a.o_f32) {       // fp32 copy for the backward's delta (see the header)
+        float* O32 = a.o_f32 + b * a.o_bs + h * a.o_hs + qrow * a.o_ts;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) *reinterpret_cast<f32x4*>(O32 + dt * 16 + g * 4) = o[dt] * inv_l;
+    }
     // natural-log sum-exp of the scaled scores
     if (g == 0 && a.lse) a.lse[(b * a.Hq + h) * (a.stat_stride ? a.stat_stride : a.Tq) + qrow] = (m_run + __builtin_amdgcn_logf(l_run)) * LN2;
 }
@@ -285,7 +290,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
     }
     const int64_t wave_qmax = ((q0 + 15 < f.Tq - 1) ? q0 + 15 : f.Tq - 1) + coff;
 
-    if (!CAUSAL || MTL_CONSISTENT_DELTA) {
+    if (!CAUSAL && f.o_f32) {
+        // delta from the fp32 forward output: no extra pass
+        const float* O32 = f.o_f32 + b * f.o_bs + h * f.o_hs + qrow * f.o_ts;
+        float acc = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            frag8 d8;
+            d8.v = dof[ks];
+            const f32x4 oa = *reinterpret_cast<const f32x4*>(O32 + ks * 32 + g * 8), ob = *reinterpret_cast<const f32x4*>(O32 + ks * 32 + g * 8 + 4);
+            acc += __uint_as_float(d8.u[0] << 16) * oa[0] + __uint_as_float(d8.u[0] & 0xffff0000u) * oa[1];
+            acc += __uint_as_float(d8.u[1] << 16) * oa[2] + __uint_as_float(d8.u[1] & 0xffff0000u) * oa[3];
+            acc += __uint_as_float(d8.u[2] << 16) * ob[0] + __uint_as_float(d8.u[2] & 0xffff0000u) * ob[1];
+            acc += __uint_as_float(d8.u[3] << 16) * ob[2] + __uint_as_float(d8.u[3] & 0xffff0000u) * ob[3];
+        }
+        dl = rows_sum(acc);
+    } else if (!CAUSAL || MTL_CONSISTENT_DELTA) {
         // CONSISTENT delta for the (unmasked) reprogramming attention: delta_q = sum_s p_qs * dP_qs from the very p and dP the main loop
         // uses, so that sum_s dS_qs = 0 holds to fp32 round-off, as it does in an unfused softmax backward. dO . O with the bf16-rounded
         // O is the same number only to ~2^-9, and with near-uniform probabilities over the vocabulary prototypes (keys that share a

@@ -212,9 +212,12 @@ extern "C" int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, 
     const int64_t r0 = D.T - n_grad;
     const int64_t Mg = D.B * n_grad;
     const RowMap rm = (n_grad == D.T) ? kIdentity : RowMap{n_grad, D.T, r0};
-    if (n_last < T) {   // rows without incoming gradient start at zero
+    if (n_last < T) {   // rows without incoming gradient start at zero (dh0: all of them, it is the returned gradient; the bf16 scratch copy:
+                        // only rows [r0, T - n_last) — the kernels never read it below r0)
         if (hipMemsetAsync(dh0, 0, (size_t)D.M * D.d * 4, st) != hipSuccess) return MTL_ERR_LAUNCH;
-        if (hipMemsetAsync(wk + W.dres_b, 0, (size_t)D.M * D.d * 2, st) != hipSuccess) return MTL_ERR_LAUNCH;
+        if (n_last < n_grad &&
+            hipMemset2DAsync(wk + W.dres_b + (size_t)r0 * D.d * 2, (size_t)D.T * D.d * 2, 0, (size_t)(n_grad - n_last) * D.d * 2, (size_t)D.B, st) != hipSuccess)
+            return MTL_ERR_LAUNCH;
     }
     const float* stf = reinterpret_cast<const float*>(sv + S.stats_f);
     // the bf16 copy of the residual gradient is the A operand of the next branch's first GEMM: it carries that branch's

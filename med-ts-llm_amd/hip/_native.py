@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("MTL_LIB_PATH") or os.path.join(_HERE, "libmedtsllm_hi
 MTL_F32, MTL_BF16 = 0, 1
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM, EPI_SWIGLU, EPI_DSWIGLU = 0, 1, 2, 3, 4, 5, 6
 ARCH_GPT2, ARCH_LLAMA = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 i64, vp, f32, i32 = C.c_int64, C.c_void_p, C.c_float, C.c_int
 
@@ -61,7 +61,7 @@ class AttnFwdArgs(C.Structure):
                 ("o", vp), ("o_bs", i64), ("o_ts", i64), ("o_hs", i64),
                 ("lse", vp), ("B", i64), ("Hq", i64), ("Hkv", i64), ("Tq", i64), ("Tk", i64), ("D", i64),
                 ("scale", f32), ("causal", i32), ("causal_off", i64), ("stat_stride", i64),
-                ("dropout_p", f32), ("dropout_seed", C.c_uint32)]
+                ("dropout_p", f32), ("dropout_seed", C.c_uint32), ("o_f32", vp)]
 
 
 class AttnBwdArgs(C.Structure):

@@ -247,21 +247,24 @@ def _attn_fwd_args(q, k, v, o, lse, B, Hq, Hkv, Tq, Tk, D, scale, causal, qs, ks
     return a
 
 
-def attention_fwd(q, k, v, Hq, Hkv, D, scale, causal, shared_kv=False, dropout=(0.0, 0)):
-    """q [B,Tq,Hq*D] bf16; k, v [B,Tk,Hkv*D] (or [Tk,Hkv*D] when shared_kv). Views with unit inner stride allowed."""
+def attention_fwd(q, k, v, Hq, Hkv, D, scale, causal, shared_kv=False, dropout=(0.0, 0), want_o32=False):
+    """q [B,Tq,Hq*D] bf16; k, v [B,Tk,Hkv*D] (or [Tk,Hkv*D] when shared_kv). Views with unit inner stride allowed.
+    want_o32 (non-causal): also returns the fp32 output, from which the backward takes delta (pass it as attention_bwd's o32)."""
     B, Tq = q.shape[0], q.shape[1]
     Tk = k.shape[-2]
     o = torch.empty((B, Tq, Hq * D), dtype=BF16, device=q.device)
+    o32 = torch.empty((B, Tq, Hq * D), dtype=F32, device=q.device) if (want_o32 and not causal) else None
     lse = torch.empty((B, Hq, Tq), dtype=F32, device=q.device)
     ks = (0, k.stride(-2), D) if shared_kv else (k.stride(0), k.stride(1), D)
     vs = (0, v.stride(-2), D) if shared_kv else (v.stride(0), v.stride(1), D)
     a = _attn_fwd_args(q, k, v, o, lse, B, Hq, Hkv, Tq, Tk, D, scale, causal, (q.stride(0), q.stride(1), D), ks, vs,
                        (o.stride(0), o.stride(1), D), dropout)
+    a.o_f32 = o32.data_ptr() if o32 is not None else None
     check(lib().mtl_attention_fwd(C.byref(a), stream()), "mtl_attention_fwd")
-    return o, lse
+    return (o, lse, o32) if want_o32 else (o, lse)
 
 
-def attention_bwd(q, k, v, o, lse, dout, Hq, Hkv, D, scale, causal, shared_kv=False, dropout=(0.0, 0), dkv_out=None):
+def attention_bwd(q, k, v, o, lse, dout, Hq, Hkv, D, scale, causal, shared_kv=False, dropout=(0.0, 0), dkv_out=None, o32=None):
     """dkv_out = (dk, dv): write the key / value gradients there (row-strided views of one buffer are fine: the paired K/V
     projection backward then reads both as ONE operand)"""
     B, Tq = q.shape[0], q.shape[1]
@@ -280,6 +283,9 @@ def attention_bwd(q, k, v, o, lse, dout, Hq, Hkv, D, scale, causal, shared_kv=Fa
     b = N.AttnBwdArgs()
     b.f = _attn_fwd_args(q, k, v, o, lse, B, Hq, Hkv, Tq, Tk, D, scale, causal, (q.stride(0), q.stride(1), D), ks, vs,
                          (o.stride(0), o.stride(1), D), dropout)
+    if o32 is not None:
+        _req(o32.dtype == F32 and o32.shape == o.shape and o32.stride() == o.stride(), "attention_bwd: o32 layout")
+        b.f.o_f32 = o32.data_ptr()
     b.dout, (b.do_bs, b.do_ts, b.do_hs) = dout.data_ptr(), (dout.stride(0), dout.stride(1), D)
     b.dq, (b.dq_bs, b.dq_ts, b.dq_hs) = dq.data_ptr(), (dq.stride(0), dq.stride(1), D)
     dks = (0, dk.stride(-2), D) if shared_kv else (dk.stride(0), dk.stride(1), D)
@@ -373,10 +379,13 @@ class PatchTokenizeFn(torch.autograd.Function):
         ctx.save_for_backward(x, mean, stdev)
         ctx.meta = (tuple(conv_w.shape), patch_len, stride, concat, (drop_p, drop_seed))
         ctx.mark_non_differentiable(mean, stdev)
+        ctx.set_materialize_grads(False)         # (no zero-filled gradients for the two statistics outputs: two fill launches per step)
         return out, mean, stdev
 
     @staticmethod
     def backward(ctx, dout, _dm, _ds):
+        if dout is None:
+            return None, None, None, None, None, None, None
         x, mean, stdev = ctx.saved_tensors
         shape, patch_len, stride, concat, drop = ctx.meta
         dw = patch_tokenize_bwd(x, mean, stdev, dout.contiguous(), shape, patch_len, stride, concat, drop=drop)
@@ -587,19 +596,19 @@ class CrossAttnFn(torch.autograd.Function):
         scale = 1.0 / math.sqrt(E)
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         drop = (float(dropout_p), int(dropout_seed))
-        o, lse = attention_fwd(q, k, v, H, H, E, scale, causal=False, shared_kv=True, dropout=drop)
-        ctx.save_for_backward(q, k, v, o, lse)
+        o, lse, o32 = attention_fwd(q, k, v, H, H, E, scale, causal=False, shared_kv=True, dropout=drop, want_o32=True)
+        ctx.save_for_backward(q, k, v, o, lse, o32)
         ctx.meta = (H, E, scale, drop)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, o, lse = ctx.saved_tensors
+        q, k, v, o, lse, o32 = ctx.saved_tensors
         H, E, scale, drop = ctx.meta
         # dK | dV side by side in one [S, 2 H E] buffer: LinearPairFn's backward reads them as one GEMM operand
         dkv = torch.empty((k.shape[0], 2 * H * E), dtype=BF16, device=q.device)
         dq, dk, dv = attention_bwd(q, k, v, o, lse, do, H, H, E, scale, causal=False, shared_kv=True, dropout=drop,
-                                   dkv_out=(dkv[:, :H * E], dkv[:, H * E:]))
+                                   dkv_out=(dkv[:, :H * E], dkv[:, H * E:]), o32=o32)
         return dq, dk, dv, None, None, None, None
 
 

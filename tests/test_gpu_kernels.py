@@ -227,6 +227,14 @@ def test_attention_cross_shared_kv(ops, B, L, S, H, E):
     assert rel_err(dq.float(), qf.grad) < TOL_ATTN_BWD
     assert rel_err(dk.float(), kf.grad) < TOL_ATTN_BWD
     assert rel_err(dv.float(), vf.grad) < TOL_ATTN_BWD
+    # delta from the fp32 forward output (the route the model takes: no second pass over K / V in the dQ kernel)
+    o2, lse2, o32 = ops.attention_fwd(dev(q), dev(k), dev(v), H, H, E, scale, False, shared_kv=True, want_o32=True)
+    assert torch.equal(o2, o) and torch.equal(o32.to(BF16), o)
+    dq2, dk2, dv2 = ops.attention_bwd(dev(q), dev(k), dev(v), o2, lse2, dev(do), H, H, E, scale, False, shared_kv=True, o32=o32)
+    assert rel_err(dq2.float(), qf.grad) < TOL_ATTN_BWD
+    assert rel_err(dk2.float(), kf.grad) < TOL_ATTN_BWD and rel_err(dv2.float(), vf.grad) < TOL_ATTN_BWD
+    # sum_s dS_qs = 0: the violation (per query, relative to sum_s |dS_qs| ~ |dQ| scale) must not be worse than the two-pass route's
+    assert rel_err(dq2.float(), qf.grad) < 1.5 * rel_err(dq.float(), qf.grad) + 5e-4
 
 
 @pytest.mark.parametrize("pdrop", [0.1, 0.5])
