@@ -735,11 +735,14 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn
     const float c = f.scale * LOG2E;
     const int64_t coff = f.causal_off;
     const int nt = (int)((f.Tq + 15) / 16), npairs = (nt + 1) / 2;
+    // few query tiles (the pruned backward: Tq = n_grad, e.g. 8 tiles for 8 waves): ONE tile per wave instead of a pair per wave on half
+    // of the waves — the launch then lasts as long as its heaviest tile (Tk keys) instead of a pair (~1.6 Tk)
+    const bool single = nt <= NW && gridDim.x == 1;
     const int pi = blockIdx.x * NW + wave;
-    if (pi >= npairs) return;
+    if (pi >= (single ? nt : npairs)) return;
     for (int half = 0; half < 2; ++half) {
-        const int tile = half == 0 ? pi : nt - 1 - pi;
-        if (half == 1 && tile == pi) break;
+        const int tile = single ? pi : (half == 0 ? pi : nt - 1 - pi);
+        if (half == 1 && (single || tile == pi)) break;
         const int64_t q0 = (int64_t)tile * 16;
         int64_t qrow = q0 + l15;
         const bool q_valid = qrow < f.Tq;
@@ -843,7 +846,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn
 // dK/dV with every query row (Q, dO, lse, delta) of the head resident in LDS; waves take pairs of 16-key tiles.
 // dynamic LDS: Q tile [Tq][D+8] | dO tile [Tq][D+8] | lse2[Tq] | delta[Tq]
 template <int D, int NW, bool DROP = false>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(const mtl_attn_bwd_args a) {
+__global__ __launch_bounds__(NW * 64, (D >= 128 && !DROP) ? 2 : 1) void attn_bwd_dkv_res_kernel(const mtl_attn_bwd_args a) {
     constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const mtl_attn_fwd_args& f = a.f;
