@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a
     constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
     __shared__ __attribute__((aligned(16))) bf16_t ktile[KC * LDT];
     __shared__ __attribute__((aligned(16))) bf16_t vtile[KC * LDT];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, g = lane >> 4;   // (wave index in an SGPR: tile offsets, loop bounds and the mask test become scalar)
     const int64_t b = blockIdx.z, h = blockIdx.y, hk = h / (a.Hq / a.Hkv);
     const int64_t qblk0 = (int64_t)blockIdx.x * 64;
     const int64_t q0 = qblk0 + wave * 16;
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
     __shared__ __attribute__((aligned(16))) bf16_t ktile[KC * LDT];
     __shared__ __attribute__((aligned(16))) bf16_t vtile[KC * LDT];
     const mtl_attn_fwd_args& f = a.f;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, g = lane >> 4;   // (wave index in an SGPR: tile offsets, loop bounds and the mask test become scalar)
     const int64_t b = blockIdx.z, h = blockIdx.y, hk = h / (f.Hq / f.Hkv);
     const int64_t qblk0 = (int64_t)blockIdx.x * 64;
     const int64_t q0 = qblk0 + wave * 16;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256, D >= 128 ? 2 : 1) void attn_bwd_dkv_kernel(con
     __shared__ __attribute__((aligned(16))) bf16_t dotile[KC * LDT];
     __shared__ float lse_s[KC], delta_s[KC];
     const mtl_attn_fwd_args& f = a.f;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, g = lane >> 4;   // (wave index in an SGPR: tile offsets, loop bounds and the mask test become scalar)
     const int64_t hk = blockIdx.y;
     const int group = (int)(f.Hq / f.Hkv);
     const bool shared_kv = (f.k_bs == 0);
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fw
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* ktile = reinterpret_cast<bf16_t*>(smem_raw);
     bf16_t* vtile = ktile + ceil32(a.Tk) * LDT;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, g = lane >> 4;   // (wave index in an SGPR: tile offsets, loop bounds and the mask test become scalar)
     const int64_t b = blockIdx.z, h = blockIdx.y, hk = h / (a.Hq / a.Hkv);
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * a.q_hs;
     load_rows_pair<D, NW * 64, 4>(ktile, reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + hk * a.k_hs, a.k_ts,
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn
     const mtl_attn_fwd_args& f = a.f;
     bf16_t* ktile = reinterpret_cast<bf16_t*>(smem_raw);
     bf16_t* vtile = ktile + ceil32(f.Tk) * LDT;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, g = lane >> 4;   // (wave index in an SGPR: tile offsets, loop bounds and the mask test become scalar)
     const int64_t b = blockIdx.z, h = blockIdx.y, hk = h / (f.Hq / f.Hkv);
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(f.q) + b * f.q_bs + h * f.q_hs;
     const bf16_t* O = reinterpret_cast<const bf16_t*>(f.o) + b * f.o_bs + h * f.o_hs;
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 && !DROP) ? 2 : 1) void attn_bwd
     bf16_t* dotile = qtile + ceil32(f.Tq) * LDT;
     float* lse_s = reinterpret_cast<float*>(dotile + ceil32(f.Tq) * LDT);
     float* delta_s = lse_s + ceil32(f.Tq);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, g = lane >> 4;   // (wave index in an SGPR: tile offsets, loop bounds and the mask test become scalar)
     const int64_t b = blockIdx.z, hk = blockIdx.y;
     const uint32_t drop_thr = DROP ? drop_threshold(f.dropout_p) : 0u;
     const float drop_scale = DROP ? drop_scale_of(drop_thr) : 1.0f;
