@@ -75,10 +75,17 @@ __global__ __launch_bounds__(THREADS) void adam_multi_kernel(const AdamTable tab
         if (sh) {   // bf16 shadow [rows, ld_shadow] of the fp32 [rows, cols] weight (n < 2^32 checked on the host)
             const uint32_t cols = (uint32_t)t.cols;
             uint32_t row = (uint32_t)e0 / cols, col = (uint32_t)e0 - row * cols;
+            if (nv == 4 && col + 4 <= cols) {
+                // the four elements sit in one row: ONE 8-byte store (2-byte aligned when cols is odd, as for the [1024, 50257] mapping
+                // weight: legal in the unaligned access mode compute queues run in) instead of four 2-byte ones
+                typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(2)));
+                *reinterpret_cast<u32x2_u*>(sh + (int64_t)row * t.ld_shadow + col) = (u32x2_u){pack_bf16x2(pp[0], pp[1]), pack_bf16x2(pp[2], pp[3])};
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (e < nv) sh[(int64_t)row * t.ld_shadow + col] = f32_to_bf16(pp[e]);
-                if (++col == cols) { col = 0; ++row; }
+                for (int e = 0; e < 4; ++e) {
+                    if (e < nv) sh[(int64_t)row * t.ld_shadow + col] = f32_to_bf16(pp[e]);
+                    if (++col == cols) { col = 0; ++row; }
+                }
             }
         }
     }
