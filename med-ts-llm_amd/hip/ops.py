@@ -517,6 +517,19 @@ class LinearPairFn(torch.autograd.Function):
         return dx, dW1, db1, dW2, db2, None, None, None
 
 
+def _whole_rounds_columns(S, V, device):
+    """columns of an [S, V] output (256 x 256 tiles, one per CU at a time) that make up whole rounds of the device's CUs, when the tail
+    round would be less than 35 % full; 0 = do not split"""
+    ncu = torch.cuda.get_device_properties(device).multi_processor_count
+    tiles_m, tiles_n = (S + 255) // 256, (V + 255) // 256
+    rounds = tiles_m * tiles_n / ncu
+    whole = int(rounds)
+    if whole < 1 or not (0.0 < rounds - whole < 0.35):
+        return 0
+    n_main = (whole * ncu // tiles_m) * 256
+    return n_main if 0 < n_main < V else 0
+
+
 class MappingFn(torch.autograd.Function):
     """source[S, d] = Wmap[S, V] @ Wemb[V, d] + b[:, None]   (R:models/medtsllm.py:281), batch independent.
 
@@ -546,7 +559,17 @@ class MappingFn(torch.autograd.Function):
         (w,) = ctx.saved_tensors
         S, V = ctx.meta
         dsrc = dsrc.contiguous()
-        dW = gemm_nt(dsrc, w, out_dtype=F32) if ctx.needs_input_grad[0] else None   # [S, V] = dsrc[S,d] @ Wemb[V,d]^T
+        dW = None
+        if ctx.needs_input_grad[0]:                                                   # [S, V] = dsrc[S,d] @ Wemb[V,d]^T
+            dW = torch.empty((S, V), dtype=F32, device=dsrc.device)
+            n_main = _whole_rounds_columns(S, V, dsrc.device)
+            if n_main:
+                # 788 tiles of 256 x 256 on 256 CUs are 3.08 rounds = the time of 4: the columns that fill whole rounds go in one launch,
+                # the remainder in a second, short one with small tiles
+                gemm_nt(dsrc, w[:n_main], out=dW[:, :n_main])
+                gemm_nt(dsrc, w[n_main:], out=dW[:, n_main:])
+            else:
+                gemm_nt(dsrc, w, out=dW)
         db = rowsum(dsrc) if ctx.needs_input_grad[1] else None       # row sums of dsrc
         return dW, db, None, None, None, None
 
