@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a
                 m_run = m_new;
             }
             l_run += psum;
-            if (DROP) {   // a lane's keys kb + t*16 + g*4 + {0,1,2,3} are two whole pairs: one mask word per pair
+            if (DROP) {   // a lane's keys kb + t*16 + g*4 + {0,1,2,3} are one mask quad: one hash per tile
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
                 {

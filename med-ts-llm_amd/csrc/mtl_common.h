@@ -62,12 +62,12 @@ __device__ __forceinline__ float dgelu_new_f(float x) {
 // dropout: counter-based keep mask, a pure function of (seed, stream, a, b) so that a backward kernel regenerates exactly the
 // forward's mask; tests replicate it on the host (tests/helpers.py). Attention: stream = batch*head, (a, b) = (query, key);
 // matrices: stream = 0, (a, b) = (row, column).
-// Cost matters: the mask is evaluated for every attention probability in four kernels per layer. One WORD carries the decisions of
-// the element PAIR (a, 2*pair) / (a, 2*pair + 1) as two uniform 16-bit fields, and the per-element mixing uses only full-rate
-// 24-bit multiply-adds (v_mad_u32_u24) — 32-bit integer multiplies are quarter rate on CDNA: 13 VALU issue slots per pair instead
-// of ~30 per element for the murmur-style hash this replaces (attention forward 23.8 -> see profiles/r02_dropout_hash_ab.txt).
+// Cost matters: the mask is evaluated for every attention probability in four kernels per layer. One hash (drop_quad) yields TWO words =
+// the decisions of the FOUR elements (a, 4*quad .. 4*quad + 3) as uniform 16-bit fields, and the mixing uses only full-rate 24-bit
+// multiply-adds (v_mad_u32_u24) — 32-bit integer multiplies are quarter rate on CDNA: 12 VALU operations per four elements instead of
+// ~30 per element for the murmur-style hash of round 1 (attention forward 23.8 -> 20.5 us per layer).
 // A keep threshold is a 16-bit number: the effective rate is thr / 65536 (p = 0.1 -> 0.09999), and the kept values are scaled by
-// the EXACT 1 / (1 - thr / 65536), so the mask is unbiased. a, pair < 2^24 (beyond that the pattern repeats).
+// the EXACT 1 / (1 - thr / 65536), so the mask is unbiased. a, quad < 2^24 (beyond that the pattern repeats).
 __host__ __device__ __forceinline__ uint32_t drop_base(uint32_t seed, uint32_t stream) {   // wave-uniform: scalar unit, once per kernel
     uint32_t a = seed ^ (stream * 0x9E3779B1u);
     a ^= a >> 16; a *= 0x85EBCA6Bu; a ^= a >> 13; a *= 0xC2B2AE35u; a ^= a >> 16;

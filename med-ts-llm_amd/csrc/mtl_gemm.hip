@@ -244,7 +244,7 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
                 float v[4] = {__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u), __uint_as_float(pk[1] << 16),
                               __uint_as_float(pk[1] & 0xffff0000u)};
                 if (p.drop_p > 0.f) {                                                      // resid_pdrop (uniform branch)
-                    // the lane's 4 columns n .. n+3 (n % 4 == 0) are two whole pairs: one mask word each
+                    // the lane's 4 columns n .. n+3 (n % 4 == 0) are one mask quad: one hash
                     const uint32_t thr = drop_threshold(p.drop_p), dbase = drop_base(p.drop_seed, 0u);
                     const float sc = drop_scale_of(thr);
                     const uint2 wq = drop_quad(dbase, (uint32_t)crow[mi], (uint32_t)n >> 2);
