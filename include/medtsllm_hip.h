@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MTL_ABI_VERSION 9
+#define MTL_ABI_VERSION 10
 
 enum { MTL_OK = 0, MTL_ERR_ARG = -1, MTL_ERR_ALIGN = -2, MTL_ERR_UNSUPPORTED = -3, MTL_ERR_LAUNCH = -4,
        MTL_ERR_WORKSPACE = -5 };
@@ -250,6 +250,10 @@ typedef struct {
     int64_t kv_row0;                /* dK/dV are produced only for keys >= kv_row0 (keys whose gradient is dead are skipped) */
     float* dkv_ws; int64_t kv_splits; /* batch-shared K/V only: fp32 [kv_splits, 2, Tk, Hkv, D] partial slabs; the batch is
                                        split into kv_splits chunks summed by a second kernel (NULL / <=1: one pass)  */
+    /* optional INVERSE rotary embedding of the query / key gradients (the backward of the forward's RoPE on q and k,
+     * HF:models/llama/modeling_llama.py:151-153) in the store epilogues: dq row r is position r + f.causal_off, dk row k position k;
+     * rope_cos / rope_sin f32 [positions, D]. = mtl_rope_inplace(inverse) on dq and dk, bit for bit. Not with batch-shared K/V. */
+    const float* rope_cos; const float* rope_sin;
 } mtl_attn_bwd_args;
 int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream);
 /* A/B knob: 1 (default) lets causal self-attention use the resident-K/V kernels (whole head in LDS, no barrier in the

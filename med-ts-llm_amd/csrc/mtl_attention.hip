@@ -59,6 +59,28 @@ __device__ __forceinline__ bf16x8 pack8(const float* a, const float* b) {
     return f.v;
 }
 
+// store epilogue of a gradient row held as NDT column tiles (lane: columns dt*16 + g*4 .. +3): scale, round to bf16 and — cos given — apply the
+// INVERSE rotary embedding (partner column + D/2 = tile dt + NDT/2 of the same lane) on the rounded values before the final rounding
+template <int NDT>
+__device__ __forceinline__ void store_grad_row(bf16_t* dst, const f32x4 (&v)[NDT], float scale, int g, const float* cos_row, const float* sin_row) {
+    if (cos_row) {
+#pragma unroll
+        for (int dt = 0; dt < NDT / 2; ++dt) {
+            const f32x4 c4 = *reinterpret_cast<const f32x4*>(cos_row + dt * 16 + g * 4), s4 = *reinterpret_cast<const f32x4*>(sin_row + dt * 16 + g * 4);
+            float y1[4], y2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                rope_pair(bf16_to_f32(f32_to_bf16(v[dt][e] * scale)), bf16_to_f32(f32_to_bf16(v[dt + NDT / 2][e] * scale)), c4[e], -s4[e], y1[e], y2[e]);
+            *reinterpret_cast<u32x2*>(dst + dt * 16 + g * 4) = (u32x2){pack_bf16x2(y1[0], y1[1]), pack_bf16x2(y1[2], y1[3])};
+            *reinterpret_cast<u32x2*>(dst + (dt + NDT / 2) * 16 + g * 4) = (u32x2){pack_bf16x2(y2[0], y2[1]), pack_bf16x2(y2[2], y2[3])};
+        }
+        return;
+    }
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+        *reinterpret_cast<u32x2*>(dst + dt * 16 + g * 4) = (u32x2){pack_bf16x2(v[dt][0] * scale, v[dt][1] * scale), pack_bf16x2(v[dt][2] * scale, v[dt][3] * scale)};
+}
+
 // TRANSPOSED operand from a row-major LDS tile via the gfx950 hardware transpose read (ds_read_b64_tr_b16):
 // the lane with l15 = lane & 15 receives, for output column c0 + l15, the 8 contraction rows
 //     j < 4: ra + j      j >= 4: rb + (j - 4)
@@ -390,11 +412,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
     }
     if (!q_valid) return;
     bf16_t* DQ = reinterpret_cast<bf16_t*>(a.dq) + b * a.dq_bs + h * a.dq_hs + qrow * a.dq_ts;
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) {
-        u32x2 pk = {pack_bf16x2(dq[dt][0] * f.scale, dq[dt][1] * f.scale), pack_bf16x2(dq[dt][2] * f.scale, dq[dt][3] * f.scale)};
-        *reinterpret_cast<u32x2*>(DQ + dt * 16 + g * 4) = pk;
-    }
+    store_grad_row<NDT>(DQ, dq, f.scale, g, a.rope_cos ? a.rope_cos + (qrow + coff) * D : nullptr, a.rope_cos ? a.rope_sin + (qrow + coff) * D : nullptr);
 }
 
 // =============================================================================================== backward: dK, dV
@@ -529,13 +547,8 @@ __global__ __launch_bounds__(256, D >= 128 ? 2 : 1) void attn_bwd_dkv_kernel(con
     const int64_t bo = shared_kv ? 0 : (int64_t)blockIdx.z;
     bf16_t* DK = reinterpret_cast<bf16_t*>(a.dk) + bo * a.dk_bs + hk * a.dk_hs + krow * a.dk_ts;
     bf16_t* DV = reinterpret_cast<bf16_t*>(a.dv) + bo * a.dv_bs + hk * a.dv_hs + krow * a.dv_ts;
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) {
-        u32x2 pk = {pack_bf16x2(dk[dt][0] * f.scale, dk[dt][1] * f.scale), pack_bf16x2(dk[dt][2] * f.scale, dk[dt][3] * f.scale)};
-        *reinterpret_cast<u32x2*>(DK + dt * 16 + g * 4) = pk;
-        u32x2 pv = {pack_bf16x2(dv[dt][0], dv[dt][1]), pack_bf16x2(dv[dt][2], dv[dt][3])};
-        *reinterpret_cast<u32x2*>(DV + dt * 16 + g * 4) = pv;
-    }
+    store_grad_row<NDT>(DK, dk, f.scale, g, a.rope_cos ? a.rope_cos + krow * D : nullptr, a.rope_cos ? a.rope_sin + krow * D : nullptr);
+    store_grad_row<NDT>(DV, dv, 1.0f, g, nullptr, nullptr);
 }
 
 // =============================================================================================== resident variants
@@ -834,11 +847,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn
         }
         if (q_valid) {
             bf16_t* DQ = reinterpret_cast<bf16_t*>(a.dq) + b * a.dq_bs + h * a.dq_hs + qrow * a.dq_ts;
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                u32x2 pk = {pack_bf16x2(dq[dt][0] * f.scale, dq[dt][1] * f.scale), pack_bf16x2(dq[dt][2] * f.scale, dq[dt][3] * f.scale)};
-                *reinterpret_cast<u32x2*>(DQ + dt * 16 + g * 4) = pk;
-            }
+            store_grad_row<NDT>(DQ, dq, f.scale, g, a.rope_cos ? a.rope_cos + (qrow + coff) * D : nullptr, a.rope_cos ? a.rope_sin + (qrow + coff) * D : nullptr);
         }
     }
 }
@@ -954,13 +963,8 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 && !DROP) ? 2 : 1) void attn_bwd
         if (!tile_on || krow >= f.Tk) continue;
         bf16_t* DK = reinterpret_cast<bf16_t*>(a.dk) + b * a.dk_bs + hk * a.dk_hs + krow * a.dk_ts;
         bf16_t* DV = reinterpret_cast<bf16_t*>(a.dv) + b * a.dv_bs + hk * a.dv_hs + krow * a.dv_ts;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            u32x2 pk = {pack_bf16x2(dk[dt][0] * f.scale, dk[dt][1] * f.scale), pack_bf16x2(dk[dt][2] * f.scale, dk[dt][3] * f.scale)};
-            *reinterpret_cast<u32x2*>(DK + dt * 16 + g * 4) = pk;
-            u32x2 pv2 = {pack_bf16x2(dv[dt][0], dv[dt][1]), pack_bf16x2(dv[dt][2], dv[dt][3])};
-            *reinterpret_cast<u32x2*>(DV + dt * 16 + g * 4) = pv2;
-        }
+        store_grad_row<NDT>(DK, dk, f.scale, g, a.rope_cos ? a.rope_cos + krow * D : nullptr, a.rope_cos ? a.rope_sin + krow * D : nullptr);
+        store_grad_row<NDT>(DV, dv, 1.0f, g, nullptr, nullptr);
     }
 }
 
@@ -1063,6 +1067,7 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
     if (rc != MTL_OK) return rc;
     if (!a->dout || !a->dq || !a->dk || !a->dv || !a->delta || !f.lse) return MTL_ERR_ARG;
     if ((f.k_bs == 0) != (f.v_bs == 0)) return MTL_ERR_ARG;
+    if ((a->rope_cos != nullptr) != (a->rope_sin != nullptr) || (a->rope_cos && f.k_bs == 0)) return MTL_ERR_ARG;
     const int64_t sts[] = {a->do_bs, a->do_ts, a->do_hs, a->dq_bs, a->dq_ts, a->dq_hs, a->dk_bs, a->dk_ts, a->dk_hs, a->dv_bs, a->dv_ts, a->dv_hs};
     for (int64_t s : sts) if (s % 4 != 0) return MTL_ERR_ALIGN;
     if (a->do_ts % 8 != 0 || a->do_hs % 8 != 0 || a->do_bs % 8 != 0 || ((uintptr_t)a->dout % 16)) return MTL_ERR_ALIGN;

@@ -8,6 +8,8 @@
 //   MLP pre-activation (GPT-2) / gate|up (Llama).
 #include "mtl_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -262,8 +264,12 @@ extern "C" int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, 
         ba.dk = dq + D.Hq * D.hd; ba.dk_bs = D.T * D.Nqkv; ba.dk_ts = D.Nqkv; ba.dk_hs = D.hd;
         ba.dv = dq + (D.Hq + D.Hkv) * D.hd; ba.dv_bs = D.T * D.Nqkv; ba.dv_ts = D.Nqkv; ba.dv_hs = D.hd;
         ba.delta = reinterpret_cast<float*>(wk + W.delta) + r0;
+        // Llama: the inverse rotary embedding of dq / dk rides in the attention kernels' store epilogues (MTL_ROPE_FUSE=0: a pass over dqkv)
+        static const bool rope_fuse = !(getenv("MTL_ROPE_FUSE") && atoi(getenv("MTL_ROPE_FUSE")) == 0);
+        if (D.llama && rope_fuse) { ba.rope_cos = w->rope_cos; ba.rope_sin = w->rope_sin; }
         MTL_TRY(mtl_attention_bwd(&ba, stream));
-        if (D.llama) MTL_TRY(mtl_rope_inplace_rows(wk + W.dqkv, D.Nqkv, w->rope_cos, w->rope_sin, Mg, D.T, D.Hq + D.Hkv, D.hd, 1, rm.rows, rm.stride, rm.offset, stream));
+        if (D.llama && !rope_fuse)
+            MTL_TRY(mtl_rope_inplace_rows(wk + W.dqkv, D.Nqkv, w->rope_cos, w->rope_sin, Mg, D.T, D.Hq + D.Hkv, D.hd, 1, rm.rows, rm.stride, rm.offset, stream));
         MTL_TRY(gemm(wk + W.dqkv, D.Nqkv, w->w_qkv_t[i], D.Nqkv, wk + W.dx, D.d, MTL_BF16, Mg, D.d, D.Nqkv, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream, rm));
         MTL_TRY(mtl_norm_bwd(wk + W.dx, D.d, H(2 * i), w->ln1_w[i], st1, dh0, dh0, wk + W.dres_b, Mg, D.d, rms, rm.rows, rm.stride, rm.offset, 1,
                              i > 0 ? resid_p : 0.f, drop_site_seed(dseed, i - 1, 2), stream));

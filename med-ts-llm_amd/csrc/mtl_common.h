@@ -124,6 +124,13 @@ __host__ __device__ __forceinline__ uint32_t drop_site_seed(uint32_t seed, int l
     return seed ^ (0x9E3779B9u * (uint32_t)(3 * layer + k + 1));
 }
 
+// rotary embedding of one (x1, x2) = (x[j], x[j + D/2]) pair: y1 = x1 c - x2 s, y2 = x2 c + x1 s (HF rotate_half). ONE operation order for the
+// stand-alone kernel and the fused epilogues, so that they agree bit for bit.
+__device__ __forceinline__ void rope_pair(float x1, float x2, float c, float s, float& y1, float& y2) {
+    y1 = __fmaf_rn(x1, c, -__fmul_rn(x2, s));
+    y2 = __fmaf_rn(x2, c, __fmul_rn(x1, s));
+}
+
 #define MTL_CHECK_LAUNCH()                                   \
     do {                                                     \
         hipError_t e__ = hipGetLastError();                  \

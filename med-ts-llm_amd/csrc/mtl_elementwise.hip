@@ -127,8 +127,11 @@ __global__ void rope_kernel(bf16_t* __restrict__ qkv, int64_t ld, const float* _
         float sa = sin_t[pos * D + i], sb = sin_t[pos * D + i + 1];
         if (inverse) { sa = -sa; sb = -sb; }
         // y1 = x1*c - x2*s ; y2 = x2*c + x1*s   (q*cos + rotate_half(q)*sin, rotate_half = cat(-x2, x1))
-        *reinterpret_cast<uint32_t*>(base + i) = pack_bf16x2(x1a * ca - x2a * sa, x1b * cb - x2b * sb);
-        *reinterpret_cast<uint32_t*>(base + half + i) = pack_bf16x2(x2a * ca + x1a * sa, x2b * cb + x1b * sb);
+        float y1a, y2a, y1b, y2b;
+        rope_pair(x1a, x2a, ca, sa, y1a, y2a);
+        rope_pair(x1b, x2b, cb, sb, y1b, y2b);
+        *reinterpret_cast<uint32_t*>(base + i) = pack_bf16x2(y1a, y1b);
+        *reinterpret_cast<uint32_t*>(base + half + i) = pack_bf16x2(y2a, y2b);
     }
 }
 

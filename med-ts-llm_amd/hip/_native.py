@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("MTL_LIB_PATH") or os.path.join(_HERE, "libmedtsllm_hi
 MTL_F32, MTL_BF16 = 0, 1
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM, EPI_SWIGLU, EPI_DSWIGLU = 0, 1, 2, 3, 4, 5, 6
 ARCH_GPT2, ARCH_LLAMA = 0, 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 i64, vp, f32, i32 = C.c_int64, C.c_void_p, C.c_float, C.c_int
 
@@ -70,7 +70,7 @@ class AttnBwdArgs(C.Structure):
                 ("dq", vp), ("dq_bs", i64), ("dq_ts", i64), ("dq_hs", i64),
                 ("dk", vp), ("dk_bs", i64), ("dk_ts", i64), ("dk_hs", i64),
                 ("dv", vp), ("dv_bs", i64), ("dv_ts", i64), ("dv_hs", i64),
-                ("delta", vp), ("kv_row0", i64), ("dkv_ws", vp), ("kv_splits", i64)]
+                ("delta", vp), ("kv_row0", i64), ("dkv_ws", vp), ("kv_splits", i64), ("rope_cos", vp), ("rope_sin", vp)]
 
 
 PP = C.POINTER(vp)

@@ -264,7 +264,7 @@ def attention_fwd(q, k, v, Hq, Hkv, D, scale, causal, shared_kv=False, dropout=(
     return (o, lse, o32) if want_o32 else (o, lse)
 
 
-def attention_bwd(q, k, v, o, lse, dout, Hq, Hkv, D, scale, causal, shared_kv=False, dropout=(0.0, 0), dkv_out=None, o32=None):
+def attention_bwd(q, k, v, o, lse, dout, Hq, Hkv, D, scale, causal, shared_kv=False, dropout=(0.0, 0), dkv_out=None, o32=None, rope=None):
     """dkv_out = (dk, dv): write the key / value gradients there (row-strided views of one buffer are fine: the paired K/V
     projection backward then reads both as ONE operand)"""
     B, Tq = q.shape[0], q.shape[1]
@@ -292,6 +292,8 @@ def attention_bwd(q, k, v, o, lse, dout, Hq, Hkv, D, scale, causal, shared_kv=Fa
     b.dk, (b.dk_bs, b.dk_ts, b.dk_hs) = dk.data_ptr(), dks
     b.dv, (b.dv_bs, b.dv_ts, b.dv_hs) = dv.data_ptr(), dks
     b.delta = delta.data_ptr()
+    if rope is not None:           # (cos, sin) f32 [positions, D]: inverse rotary embedding of dq / dk in the store epilogues
+        b.rope_cos, b.rope_sin = rope[0].data_ptr(), rope[1].data_ptr()
     ws = None
     if shared_kv and B > 1:
         splits = max(1, min(B, 1024 // max(1, ((Tk + 63) // 64) * Hkv)))

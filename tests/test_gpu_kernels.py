@@ -195,6 +195,30 @@ def test_attention_chunked_equals_resident(ops, B, T, Hq, Hkv, D):
     assert rel_err(res[0][0].float(), ref) < TOL_ATTN_FWD and rel_err(res[1][0].float(), ref) < TOL_ATTN_FWD
 
 
+@pytest.mark.parametrize("B,T,H,Hkv,D,resident", [(2, 96, 2, 2, 64, 1), (2, 200, 4, 2, 128, 1), (2, 96, 2, 1, 64, 0), (1, 256, 2, 2, 128, 0)])
+def test_attention_backward_fused_inverse_rope(ops, B, T, H, Hkv, D, resident):
+    """the inverse rotary embedding of dq / dk in the attention backward's store epilogues == mtl_rope_inplace(inverse) on the stored
+    gradients, bit for bit (resident and chunked kernels, GQA, hd 64 / 128); dv is untouched"""
+    q, k, v = (torch.randn(B, T, h_ * D, generator=g(i)).to(BF16).cuda() for i, h_ in ((1, H), (2, Hkv), (3, Hkv)))
+    do = torch.randn(B, T, H * D, generator=g(4)).to(BF16).cuda()
+    pos = torch.arange(T).float()[:, None]
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+    ang = torch.cat([pos * inv, pos * inv], dim=1)
+    cos, sin = ang.cos().contiguous().cuda(), ang.sin().contiguous().cuda()
+    scale = 1.0 / math.sqrt(D)
+    ops.lib().mtl_attention_tune(resident)
+    try:
+        o, lse = ops.attention_fwd(q, k, v, H, Hkv, D, scale, True)
+        dq0, dk0, dv0 = ops.attention_bwd(q, k, v, o, lse, do, H, Hkv, D, scale, True)
+        dq1, dk1, dv1 = ops.attention_bwd(q, k, v, o, lse, do, H, Hkv, D, scale, True, rope=(cos, sin))
+    finally:
+        ops.lib().mtl_attention_tune(1)
+    want_q = ops.rope_inplace(dq0.reshape(B * T, H * D).clone(), cos, sin, T, H, D, inverse=True).view_as(dq0)
+    want_k = ops.rope_inplace(dk0.reshape(B * T, Hkv * D).clone(), cos, sin, T, Hkv, D, inverse=True).view_as(dk0)
+    assert torch.equal(dq1, want_q) and torch.equal(dk1, want_k) and torch.equal(dv1, dv0)
+    assert not torch.equal(dq1, dq0)
+
+
 def test_attention_fused_qkv_views(ops):
     """strided q/k/v views into one fused [B,T,(Hq+2Hkv)*D] buffer, as the backbone uses them"""
     B, T, Hq, Hkv, D = 2, 80, 4, 2, 64
