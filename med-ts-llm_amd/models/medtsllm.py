@@ -390,8 +390,10 @@ class MedTsLLM(nn.Module):
         """Shadows an optimiser may keep current (HipAdam.register_shadow)."""
         if not self.mapping_layer.weight.is_cuda:
             return []
-        self._kv_shadow_pair()                 # (key / value shadows are halves of one buffer)
-        out = [sh for sh in (self._linear_shadow(m) for m in self._shadowed_linears()) if sh is not None]
+        out = []
+        if ops._LINEAR_XT:                     # (the fallback Linear path casts its weights per call and would never read them)
+            self._kv_shadow_pair()             # (key / value shadows are halves of one buffer)
+            out = [sh for sh in (self._linear_shadow(m) for m in self._shadowed_linears()) if sh is not None and sh.param.shape[0] % 8 == 0]
         if not self.word_embeddings.requires_grad:
             out.append(self._mapping_shadow())
         return out
