@@ -58,6 +58,8 @@ CASES = [
     ("llama", "forecasting", 2, 64, 3, 16, "weighted-average", "linear", False),
     ("llama", "forecasting", 2, 64, 3, 16, "merge-end", "linear", True),
     ("gpt2", "segmentation", 2, 64, 1, 64, "univariate", "linear", True),
+    # head width 7 * 3 = 21, not a multiple of 8: the Linear backward takes the transposed-copy route instead of the K-major GEMMs
+    ("gpt2", "forecasting", 2, 64, 3, 7, "concat", "linear", False),
     # vocabulary > 100 000: the sub-sampled word-embedding table is a trainable parameter (Llama-3 quirk, R:models/medtsllm.py:220-222)
     ("llama_gqa_bigvocab", "reconstruction", 2, 64, 2, 64, "concat", "linear", False),
     # "examples" prompting: a tensor part inside the prompt goes through encode_ts (R:models/medtsllm.py:313-319)
