@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MTL_ABI_VERSION 10
+#define MTL_ABI_VERSION 11
 
 enum { MTL_OK = 0, MTL_ERR_ARG = -1, MTL_ERR_ALIGN = -2, MTL_ERR_UNSUPPORTED = -3, MTL_ERR_LAUNCH = -4,
        MTL_ERR_WORKSPACE = -5 };
@@ -189,6 +189,16 @@ int mtl_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int mtl_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 /* column sums of a bf16 [R, Cc] matrix into f32 [Cc] (bias gradients) */
 int mtl_colsum_bf16(const void* src, int64_t ld_src, float* dst, int64_t R, int64_t Cc, void* stream);
+/* Channel mixing of the non-concat covariate modes: y[b, r, o] = bias[o] + sum_{j, c} W[o, j*C + c] * x[b, c, r, j], x bf16 [B, C, R, J],
+ * y bf16 or f32 [B, R, O]; W == NULL: the plain mean over the channels (J = O = 1). Replaces float().mean(dim = 1) of "add" /
+ * "independent" (R:models/medtsllm.py:286,371) and the feature_weighting Linear on the channel-last view of "weighted-average" /
+ * "merge-end" (:288-291,373-375). fp32 arithmetic, one rounding at the output. Backward: dx bf16 (NULL: skip), dW f32 [O, J*C], dbias
+ * f32 [O] (NULL: skip) through `workspace` (mtl_channel_mix_workspace_bytes), summed in a fixed order. */
+int mtl_channel_mix_fwd(const void* x, const float* W, const float* bias, void* y, int y_dtype, int64_t B, int64_t C, int64_t R, int64_t J,
+                        int64_t O, void* stream);
+size_t mtl_channel_mix_workspace_bytes(int64_t C, int64_t J, int64_t O);
+int mtl_channel_mix_bwd(const void* x, const float* W, const void* dy, int dy_dtype, void* dx, float* dW, float* dbias, void* workspace,
+                        int64_t B, int64_t C, int64_t R, int64_t J, int64_t O, void* stream);
 /* dst[r] = sum_c src[r, c] (bf16 in, fp32 out): the mapping layer's bias gradient (row sums of d source, R:models/medtsllm.py:281) */
 int mtl_rowsum_bf16(const void* src, int64_t ld_src, float* dst, int64_t R, int64_t Cc, void* stream);
 

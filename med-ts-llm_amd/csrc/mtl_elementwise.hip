@@ -317,6 +317,123 @@ extern "C" int mtl_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void
     return MTL_OK;
 }
 
+// ---------------------------------------------------------------- channel mixing of the non-concat covariate modes
+// y[b, r, o] = bias[o] + sum_{j, c} W[o, j*C + c] * x[b, c, r, j]        x bf16 [B, C, R, J], y bf16 or f32 [B, R, O]
+//   "add" (R:models/medtsllm.py:286: mean over the channels)       J = O = 1, W = NULL (every weight 1 / C), no bias
+//   "weighted-average" (:288-291, feature_weighting = Linear(C, 1)) J = O = 1
+//   "independent" (:371: mean of the per-channel predictions)        J = O = 1, W = NULL, fp32 output
+//   "merge-end" (:373-375, Linear(C * n_out, n_out) on the channel-last view)   J = O = n_out
+// fp32 arithmetic on the bf16 inputs, one rounding at the output — the same numbers the ATen route (float().mean() / F.linear on the
+// permuted fp32 view) produced, without the fp32 copies and permutes. Streaming kernels; the weight gradient is a fixed-order two-stage sum.
+template <bool YBF>
+__global__ __launch_bounds__(256) void channel_mix_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                                                              void* __restrict__ y, int64_t B, int C, int64_t R, int J, int O) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // (b, r)
+    if (idx >= B * R) return;
+    const int64_t b = idx / R, r = idx - b * R;
+    const float inv_c = 1.0f / (float)C;
+    for (int o = 0; o < O; ++o) {
+        float acc = 0.f;
+        for (int j = 0; j < J; ++j)
+            for (int c = 0; c < C; ++c) {
+                const float xv = bf16_to_f32(x[((b * C + c) * R + r) * J + j]);
+                acc += W ? W[o * J * C + j * C + c] * xv : xv;
+            }
+        if (!W) acc *= inv_c;
+        if (bias) acc += bias[o];
+        if (YBF) reinterpret_cast<bf16_t*>(y)[idx * O + o] = f32_to_bf16(acc);
+        else reinterpret_cast<float*>(y)[idx * O + o] = acc;
+    }
+}
+
+// dx[b, c, r, j] = sum_o W[o, j*C + c] * dy[b, r, o]   (bf16, the dtype of x)
+template <bool YBF>
+__global__ __launch_bounds__(256) void channel_mix_dx_kernel(const void* __restrict__ dy, const float* __restrict__ W, bf16_t* __restrict__ dx, int64_t B,
+                                                             int C, int64_t R, int J, int O) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // (b, c, r)
+    if (idx >= B * C * R) return;
+    const int64_t r = idx % R, bc = idx / R, c = bc % C, b = bc / C;
+    const float inv_c = 1.0f / (float)C;
+    for (int j = 0; j < J; ++j) {
+        float acc = 0.f;
+        for (int o = 0; o < O; ++o) {
+            const float g = YBF ? bf16_to_f32(reinterpret_cast<const bf16_t*>(dy)[(b * R + r) * O + o]) : reinterpret_cast<const float*>(dy)[(b * R + r) * O + o];
+            acc += (W ? W[o * J * C + j * C + c] : inv_c) * g;
+        }
+        dx[idx * J + j] = f32_to_bf16(acc);
+    }
+}
+
+// partial[s][o*J*C + j*C + c] = sum over the s-th slice of (b, r) of dy[b, r, o] * x[b, c, r, j]; partial[s][O*J*C + o] = the slice's sum of dy[., ., o]
+template <bool YBF>
+__global__ __launch_bounds__(256) void channel_mix_dw_kernel(const bf16_t* __restrict__ x, const void* __restrict__ dy, float* __restrict__ partial, int64_t B,
+                                                             int C, int64_t R, int J, int O, int S) {
+    __shared__ float red[4];
+    const int K = J * C, nw = O * K + O;
+    const int e = blockIdx.x, s = blockIdx.y;                 // e < O*K: a weight; e >= O*K: bias o = e - O*K
+    const bool is_b = e >= O * K;
+    const int o = is_b ? e - O * K : e / K, k = is_b ? 0 : e % K, j = k / C, c = k % C;
+    const int64_t n = B * R, per = (n + S - 1) / S, i0 = (int64_t)s * per, i1 = i0 + per < n ? i0 + per : n;
+    float acc = 0.f;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float g = YBF ? bf16_to_f32(reinterpret_cast<const bf16_t*>(dy)[i * O + o]) : reinterpret_cast<const float*>(dy)[i * O + o];
+        if (is_b) acc += g;
+        else {
+            const int64_t b = i / R, r = i - b * R;
+            acc += g * bf16_to_f32(x[((b * C + c) * R + r) * J + j]);
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)s * nw + e] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void channel_mix_dw_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, float* __restrict__ dbias, int nw_w, int O, int S) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nw_w + O) return;
+    float t = 0.f;
+    for (int s = 0; s < S; ++s) t += partial[(int64_t)s * (nw_w + O) + e];
+    if (e < nw_w) { if (dW) dW[e] = t; }
+    else if (dbias) dbias[e - nw_w] = t;
+}
+
+extern "C" int mtl_channel_mix_fwd(const void* x, const float* W, const float* bias, void* y, int y_dtype, int64_t B, int64_t C, int64_t R, int64_t J,
+                                   int64_t O, void* stream) {
+    if (!x || !y || B <= 0 || C <= 0 || R <= 0 || J <= 0 || O <= 0 || (y_dtype != MTL_BF16 && y_dtype != MTL_F32)) return MTL_ERR_ARG;
+    if (!W && (J != 1 || O != 1 || bias)) return MTL_ERR_ARG;              // the plain mean has one output and no bias
+    const dim3 grid((unsigned)((B * R + 255) / 256));
+    if (y_dtype == MTL_BF16) hipLaunchKernelGGL(channel_mix_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, W, bias, y, B, (int)C, R, (int)J, (int)O);
+    else hipLaunchKernelGGL(channel_mix_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, W, bias, y, B, (int)C, R, (int)J, (int)O);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
+extern "C" size_t mtl_channel_mix_workspace_bytes(int64_t C, int64_t J, int64_t O) { return (size_t)64 * (size_t)(O * J * C + O) * sizeof(float); }
+
+extern "C" int mtl_channel_mix_bwd(const void* x, const float* W, const void* dy, int dy_dtype, void* dx, float* dW, float* dbias, void* workspace,
+                                   int64_t B, int64_t C, int64_t R, int64_t J, int64_t O, void* stream) {
+    if (!x || !dy || B <= 0 || C <= 0 || R <= 0 || J <= 0 || O <= 0 || (dy_dtype != MTL_BF16 && dy_dtype != MTL_F32)) return MTL_ERR_ARG;
+    if (!W && (J != 1 || O != 1)) return MTL_ERR_ARG;
+    if ((dW || dbias) && !workspace) return MTL_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const bool ybf = dy_dtype == MTL_BF16;
+    if (dx) {
+        const dim3 grid((unsigned)((B * C * R + 255) / 256));
+        if (ybf) hipLaunchKernelGGL(channel_mix_dx_kernel<true>, grid, dim3(256), 0, st, dy, W, (bf16_t*)dx, B, (int)C, R, (int)J, (int)O);
+        else hipLaunchKernelGGL(channel_mix_dx_kernel<false>, grid, dim3(256), 0, st, dy, W, (bf16_t*)dx, B, (int)C, R, (int)J, (int)O);
+    }
+    if (dW || dbias) {
+        const int S = 64, nw_w = (int)(O * J * C);
+        const dim3 grid((unsigned)(nw_w + O), (unsigned)S);
+        if (ybf) hipLaunchKernelGGL(channel_mix_dw_kernel<true>, grid, dim3(256), 0, st, (const bf16_t*)x, dy, (float*)workspace, B, (int)C, R, (int)J, (int)O, S);
+        else hipLaunchKernelGGL(channel_mix_dw_kernel<false>, grid, dim3(256), 0, st, (const bf16_t*)x, dy, (float*)workspace, B, (int)C, R, (int)J, (int)O, S);
+        hipLaunchKernelGGL(channel_mix_dw_reduce_kernel, dim3((unsigned)((nw_w + O + 255) / 256)), dim3(256), 0, st, (const float*)workspace, dW, dbias, nw_w, (int)O, S);
+    }
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
 // row sums of a bf16 matrix in fp32: one wave per row (the mapping layer's bias gradient = row sums of d source)
 __global__ __launch_bounds__(256) void rowsum_kernel(const bf16_t* __restrict__ src, int64_t ld, float* __restrict__ dst, int64_t R, int64_t Cc) {
     const int lane = threadIdx.x & 63;

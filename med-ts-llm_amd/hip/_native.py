@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("MTL_LIB_PATH") or os.path.join(_HERE, "libmedtsllm_hi
 MTL_F32, MTL_BF16 = 0, 1
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM, EPI_SWIGLU, EPI_DSWIGLU = 0, 1, 2, 3, 4, 5, 6
 ARCH_GPT2, ARCH_LLAMA = 0, 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 i64, vp, f32, i32 = C.c_int64, C.c_void_p, C.c_float, C.c_int
 
@@ -112,6 +112,9 @@ SIGNATURES = {
     "mtl_cast_bf16_to_f32": (i32, [vp, vp, i64, vp]),
     "mtl_colsum_bf16": (i32, [vp, i64, vp, i64, i64, vp]),
     "mtl_rowsum_bf16": (i32, [vp, i64, vp, i64, i64, vp]),
+    "mtl_channel_mix_fwd": (i32, [vp, vp, vp, vp, i32, i64, i64, i64, i64, i64, vp]),
+    "mtl_channel_mix_workspace_bytes": (C.c_size_t, [i64, i64, i64]),
+    "mtl_channel_mix_bwd": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp]),
     "mtl_adam_step": (i32, [C.POINTER(AdamTensor), i32, f32, f32, f32, f32, f32, i32, i64, vp]),
     "mtl_attention_fwd": (i32, [C.POINTER(AttnFwdArgs), vp]),
     "mtl_attention_tune": (i32, [i32]),

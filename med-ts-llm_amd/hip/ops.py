@@ -637,6 +637,43 @@ class CrossAttnFn(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None
 
 
+class ChannelMixFn(torch.autograd.Function):
+    """y[b, r, o] = bias[o] + sum_{j, c} W[o, j*C + c] x[b, c, r, j] for x bf16 [B, C, R, J] -> y [B, R, O] (bf16 or f32): the channel
+    mean of the "add" / "independent" covariate modes (W None) and the feature_weighting Linear of "weighted-average" / "merge-end"
+    on the channel-last view (R:models/medtsllm.py:286-291,371-375), without the fp32 copies and permutes."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, out_dtype):
+        _req(x.dtype == BF16 and x.dim() == 4, "ChannelMixFn: x bf16 [B, C, R, J]")
+        x = x.contiguous()
+        B, Cc, R, J = x.shape
+        O = 1 if W is None else W.shape[0]
+        _req(W is None or (W.shape[1] == J * Cc), "ChannelMixFn: W [O, J*C]")
+        Wf = None if W is None else W.detach().float().contiguous()
+        bf = None if bias is None else bias.detach().float().contiguous()
+        y = torch.empty((B, R, O), dtype=out_dtype, device=x.device)
+        check(lib().mtl_channel_mix_fwd(ptr(x), ptr(Wf), ptr(bf), ptr(y), _dt(y), B, Cc, R, J, O, stream()), "mtl_channel_mix_fwd")
+        ctx.save_for_backward(x, Wf)
+        ctx.meta = (W is not None, bias is not None, O)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, Wf = ctx.saved_tensors
+        has_w, has_b, O = ctx.meta
+        B, Cc, R, J = x.shape
+        if dy.dtype not in (BF16, F32):
+            dy = dy.float()
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        want_w, want_b = has_w and ctx.needs_input_grad[1], has_b and ctx.needs_input_grad[2]
+        dW = torch.empty((O, J * Cc), dtype=F32, device=x.device) if want_w else None
+        db = torch.empty((O,), dtype=F32, device=x.device) if want_b else None
+        ws = torch.empty(lib().mtl_channel_mix_workspace_bytes(Cc, J, O), dtype=torch.uint8, device=x.device) if (want_w or want_b) else None
+        check(lib().mtl_channel_mix_bwd(ptr(x), ptr(Wf), ptr(dy), _dt(dy), ptr(dx), ptr(dW), ptr(db), ptr(ws), B, Cc, R, J, O, stream()), "mtl_channel_mix_bwd")
+        return dx, dW, db, None
+
+
 class AssembleFn(torch.autograd.Function):
     """h0 = cat[embed[ids], x_tok] (+ wpe) in fp32 (R:models/medtsllm.py:331-337,349; HF gpt2 :576-577)."""
 

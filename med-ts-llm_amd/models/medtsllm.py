@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..hip import ops
-from ..hip.ops import (PatchTokenizeFn, LinearFn, LinearPairFn, MappingFn, MappingTrainableFn, CrossAttnFn, AssembleFn, BackboneFn, EmbdDropoutFn, RevinDenormFn, pad64, pad_vocab,
+from ..hip.ops import (PatchTokenizeFn, LinearFn, LinearPairFn, ChannelMixFn, MappingFn, MappingTrainableFn, CrossAttnFn, AssembleFn, BackboneFn, EmbdDropoutFn, RevinDenormFn, pad64, pad_vocab,
                        mapping_split_k)
 from . import prompt as P
 from .backbone import FrozenBackbone, load_hf_dir, normalise_config
@@ -439,11 +439,13 @@ class MedTsLLM(nn.Module):
         enc = self._tap("reprog", LinearFn.apply(a, rl.out_projection.weight, rl.out_projection.bias, self._linear_shadow(rl.out_projection)))     # [B', P, d_llm]
         n_patches, d_llm = enc.shape[1], self.d_llm
         cm = self.covariate_mode
-        if cm == "add":
-            enc = enc.reshape(bs, C, n_patches, d_llm).float().mean(dim=1).to(BF16)
-        elif cm == "weighted-average":
-            enc = self._tap("fw_in", enc.reshape(bs, C, n_patches, d_llm).permute(0, 2, 3, 1).float())
-            enc = self._tap("fw_out", F.linear(enc, self.feature_weighting.weight, self.feature_weighting.bias)).squeeze(-1).to(BF16)
+        if cm == "add":              # mean over the channels (R:models/medtsllm.py:286)
+            enc = ChannelMixFn.apply(enc.reshape(bs, C, n_patches * d_llm, 1), None, None, BF16).view(bs, n_patches, d_llm)
+        elif cm == "weighted-average":   # feature_weighting = Linear(C, 1) on the channel-last view (:288-291)
+            if self.debug_tap is not None:     # (parity tests: the Linear's input as the reference sees it)
+                self._tap("fw_in", enc.detach().reshape(bs, C, n_patches, d_llm).permute(0, 2, 3, 1).float())
+            enc = self._tap("fw_out", ChannelMixFn.apply(enc.reshape(bs, C, n_patches * d_llm, 1), self.feature_weighting.weight,
+                                                         self.feature_weighting.bias, BF16).view(bs, n_patches, d_llm, 1)).squeeze(-1)
         elif cm == "interleave":
             enc = enc.reshape(bs, C, -1, d_llm).permute(0, 2, 1, 3).reshape(bs, -1, d_llm)
         return enc, mean, stdev
@@ -498,11 +500,14 @@ class MedTsLLM(nn.Module):
         if kp != head_in.shape[1]:
             head_in = F.pad(head_in, (0, kp - head_in.shape[1]))
         out = self._tap("head", LinearFn.apply(head_in.contiguous(), self.output_projection.linear.weight, self.output_projection.linear.bias, self._linear_shadow(self.output_projection.linear)))
-        if cm == "independent":
-            out = out.float().view(bs, C, self.pred_len, self.n_outputs_per_step).mean(dim=1)
-        elif cm == "merge-end":
-            out = self._tap("fw_in", out.float().view(bs, C, self.pred_len, self.n_outputs_per_step).permute(0, 2, 3, 1).reshape(bs, self.pred_len, -1))
-            out = self._tap("fw_out", F.linear(out, self.feature_weighting.weight, self.feature_weighting.bias))
+        if cm == "independent":      # mean of the per-channel predictions (R:models/medtsllm.py:371)
+            out = ChannelMixFn.apply(out.reshape(bs, C, self.pred_len * self.n_outputs_per_step, 1), None, None, torch.float32)
+            out = out.view(bs, self.pred_len, self.n_outputs_per_step)
+        elif cm == "merge-end":      # feature_weighting = Linear(C * n_out, n_out) on the [bs, pred, n_out * C] view (:373-375)
+            if self.debug_tap is not None:
+                self._tap("fw_in", out.detach().float().view(bs, C, self.pred_len, self.n_outputs_per_step).permute(0, 2, 3, 1).reshape(bs, self.pred_len, -1))
+            out = self._tap("fw_out", ChannelMixFn.apply(out.reshape(bs, C, self.pred_len, self.n_outputs_per_step), self.feature_weighting.weight,
+                                                         self.feature_weighting.bias, torch.float32))
         else:
             out = out.view(bs, self.pred_len, self.n_outputs_per_step)
         if self.task in FORECAST_LIKE:

@@ -376,6 +376,33 @@ def test_linear_pair_backward_equals_two_linears(ops):
             assert rel_err(a_, w_) < TOL_F32
 
 
+@pytest.mark.parametrize("B,C,R,J,O,mean,out_dtype", [(3, 5, 700, 1, 1, True, BF16), (2, 12, 1000, 1, 1, False, BF16), (4, 3, 96, 1, 1, True, F32),
+                                                      (2, 7, 33, 4, 4, False, F32)])
+def test_channel_mix_vs_reference(ops, B, C, R, J, O, mean, out_dtype):
+    """channel mean ("add" / "independent") and the feature_weighting Linear on the channel-last view ("weighted-average" / "merge-end"):
+    forward and all three gradients vs the ATen formulation in fp64"""
+    x = torch.randn(B, C, R, J, generator=g(1)).to(BF16)
+    W = None if mean else torch.randn(O, J * C, generator=g(2)) * 0.3
+    b = None if mean else torch.randn(O, generator=g(3)) * 0.1
+    dy = torch.randn(B, R, O, generator=g(4)).to(out_dtype)
+    xf = x.double().requires_grad_(True)
+    if mean:
+        ref = xf.mean(dim=1).reshape(B, R, 1)
+    else:
+        Wd, bd = W.double().requires_grad_(True), b.double().requires_grad_(True)
+        ref = F.linear(xf.permute(0, 2, 3, 1).reshape(B, R, J * C), Wd, bd)          # k = j * C + c
+    ref.backward(dy.double())
+    xd = x.cuda().requires_grad_(True)
+    Wg = None if mean else W.cuda().requires_grad_(True)
+    bg = None if mean else b.cuda().requires_grad_(True)
+    y = ops.ChannelMixFn.apply(xd, Wg, bg, out_dtype)
+    assert y.dtype == out_dtype and rel_err(y.double(), ref) < (TOL_BF16 if out_dtype == BF16 else TOL_F32)
+    y.backward(dy.cuda())
+    assert rel_err(xd.grad.double(), xf.grad) < TOL_BF16
+    if not mean:
+        assert rel_err(Wg.grad.double(), Wd.grad) < TOL_F32 and rel_err(bg.grad.double(), bd.grad) < TOL_F32
+
+
 # ------------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("M,d", [(7, 64), (300, 768), (64, 4096), (10, 1000)])
 def test_layernorm(ops, M, d):
