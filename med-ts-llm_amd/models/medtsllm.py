@@ -494,7 +494,11 @@ class MedTsLLM(nn.Module):
         elif mode == "linear":
             dec = self._tap("down", LinearFn.apply(dec, self.embedding_downsample_layer.weight, self.embedding_downsample_layer.bias, self._linear_shadow(self.embedding_downsample_layer)))
         else:
-            dec = dec.reshape(dec.shape[0], self.n_patches, self.d_ff, -1).float().mean(dim=-1).to(BF16)
+            # "average" down-sampling: mean over groups of d_llm / d_ff neighbouring features (R:models/medtsllm.py:360-362) = the channel-mix
+            # kernel with the group as its inner axis and constant weights
+            grp = dec.shape[-1] // self.d_ff
+            wavg = torch.full((1, grp), 1.0 / grp, dtype=torch.float32, device=dec.device)
+            dec = ChannelMixFn.apply(dec.reshape(dec.shape[0], 1, self.n_patches * self.d_ff, grp), wavg, None, BF16).view(dec.shape[0], self.n_patches, self.d_ff)
         head_in = dec.permute(0, 2, 1).reshape(dec.shape[0], -1)       # feature index = f * P + p (R:models/medtsllm.py:366,549)
         kp = pad64(head_in.shape[1])
         if kp != head_in.shape[1]:
