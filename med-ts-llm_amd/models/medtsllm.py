@@ -8,7 +8,6 @@ libmedtsllm_hip.so (see hip/ops.py); there is no CPU fallback — forward on a n
 Numerics follow the reference's default `setup.dtype = "mixed"`: fp32 master weights and fp32 residual stream,
 bf16 GEMM/attention operands with fp32 accumulation, fp32 norm/softmax statistics.
 """
-import math
 import os
 
 import torch
