@@ -58,8 +58,8 @@ int mtl_patch_tokenize_bwd(const float* x, const float* mean, const float* stdev
 int mtl_patch_index_map(int32_t* idx, int64_t L, int64_t patch_len, int64_t stride, void* stream);
 /* RevIN "denorm" (R:models/layers/RevIN.py:58-69): out[b,t,c] = y[b,t,c]*stdev[b,c] + mean[b,c]; y/out f32 [B,T,C].
  * mean == NULL multiplies by stdev only (its backward: statistics are detached constants). */
-int mtl_revin_denorm(const float* y, const float* mean, const float* stdev, float* out, int64_t B, int64_t T,
-                     int64_t C, void* stream);
+int mtl_revin_denorm(const void* y, int y_dtype, const float* mean, const float* stdev, void* out, int out_dtype, int64_t B, int64_t T,
+                     int64_t C, void* stream);   /* y, out: MTL_F32 or MTL_BF16 (the model's bf16 head output in, the bf16 gradient out: no cast passes) */
 
 /* ------------------------------------------------------------------ bf16 MFMA GEMM (NT)
  * C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T + bias[N]),  fp32 accumulation on v_mfma_f32_16x16x32_bf16.

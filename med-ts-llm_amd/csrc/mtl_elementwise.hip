@@ -248,12 +248,16 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restri
     }
 }
 
-__global__ void revin_denorm_kernel(const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ stdev,
-                                    float* __restrict__ out, int64_t B, int64_t T, int64_t C) {
+template <bool IN_BF, bool OUT_BF>
+__global__ void revin_denorm_kernel(const void* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ stdev,
+                                    void* __restrict__ out, int64_t B, int64_t T, int64_t C) {
     const int64_t total = B * T * C;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t c = i % C, b = i / (T * C);
-        out[i] = y[i] * stdev[b * C + c] + (mean ? mean[b * C + c] : 0.f);
+        const float yv = IN_BF ? bf16_to_f32(reinterpret_cast<const bf16_t*>(y)[i]) : reinterpret_cast<const float*>(y)[i];
+        const float v = yv * stdev[b * C + c] + (mean ? mean[b * C + c] : 0.f);
+        if (OUT_BF) reinterpret_cast<bf16_t*>(out)[i] = f32_to_bf16(v);
+        else reinterpret_cast<float*>(out)[i] = v;
     }
 }
 
@@ -529,10 +533,16 @@ extern "C" int mtl_assemble_llm_input(const int32_t* ids, int64_t ids_B, const f
     return MTL_OK;
 }
 
-extern "C" int mtl_revin_denorm(const float* y, const float* mean, const float* stdev, float* out, int64_t B, int64_t T, int64_t C,
-                                void* stream) {
+extern "C" int mtl_revin_denorm(const void* y, int y_dtype, const float* mean, const float* stdev, void* out, int out_dtype, int64_t B, int64_t T,
+                                int64_t C, void* stream) {
     if (!y || !stdev || !out || B <= 0 || T <= 0 || C <= 0) return MTL_ERR_ARG;
-    hipLaunchKernelGGL(revin_denorm_kernel, dim3(grid_for(B * T * C, 256)), dim3(256), 0, (hipStream_t)stream, y, mean, stdev, out, B, T, C);
+    if ((y_dtype != MTL_F32 && y_dtype != MTL_BF16) || (out_dtype != MTL_F32 && out_dtype != MTL_BF16)) return MTL_ERR_ARG;
+    const dim3 grid(grid_for(B * T * C, 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (y_dtype == MTL_BF16 && out_dtype == MTL_BF16) hipLaunchKernelGGL((revin_denorm_kernel<true, true>), grid, block, 0, st, y, mean, stdev, out, B, T, C);
+    else if (y_dtype == MTL_BF16) hipLaunchKernelGGL((revin_denorm_kernel<true, false>), grid, block, 0, st, y, mean, stdev, out, B, T, C);
+    else if (out_dtype == MTL_BF16) hipLaunchKernelGGL((revin_denorm_kernel<false, true>), grid, block, 0, st, y, mean, stdev, out, B, T, C);
+    else hipLaunchKernelGGL((revin_denorm_kernel<false, false>), grid, block, 0, st, y, mean, stdev, out, B, T, C);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }

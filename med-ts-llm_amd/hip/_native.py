@@ -94,7 +94,7 @@ SIGNATURES = {
     "mtl_patch_tokenize_fwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, f32, f32, C.c_uint32, vp]),
     "mtl_patch_tokenize_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, f32, C.c_uint32, vp]),
     "mtl_patch_index_map": (i32, [vp, i64, i64, i64, vp]),
-    "mtl_revin_denorm": (i32, [vp, vp, vp, vp, i64, i64, i64, vp]),
+    "mtl_revin_denorm": (i32, [vp, i32, vp, vp, vp, i32, i64, i64, i64, vp]),
     "mtl_gemm_workspace_bytes": (C.c_size_t, [i64, i64, i32]),
     "mtl_gemm_auto_split_k": (i32, [i64, i64, i64, i32]),
     "mtl_gemm_xt_workspace_bytes": (C.c_size_t, [i64, i64, i32]),

@@ -211,12 +211,13 @@ def patch_tokenize_bwd(x, mean, stdev, dout, conv_w_shape, patch_len, stride, co
     return dw
 
 
-def revin_denorm(y, mean, stdev):
-    """y f32 [B,T,C]; mean None -> multiply by stdev only (the backward)."""
+def revin_denorm(y, mean, stdev, out_dtype=F32):
+    """y f32 or bf16 [B,T,C] -> y * stdev (+ mean) as f32 or bf16; mean None -> multiply by stdev only (the backward)."""
+    _req(y.dtype in (F32, BF16) and out_dtype in (F32, BF16), "revin_denorm: f32 / bf16")
     y = y.contiguous()
     B, T, Cc = y.shape
-    out = torch.empty_like(y)
-    check(lib().mtl_revin_denorm(ptr(y), ptr(mean), ptr(stdev), ptr(out), B, T, Cc, stream()), "mtl_revin_denorm")
+    out = torch.empty(y.shape, dtype=out_dtype, device=y.device)
+    check(lib().mtl_revin_denorm(ptr(y), _dt(y), ptr(mean), ptr(stdev), ptr(out), _dt(out), B, T, Cc, stream()), "mtl_revin_denorm")
     return out
 
 
@@ -743,9 +744,11 @@ class RevinDenormFn(torch.autograd.Function):
     def forward(ctx, y, mean, stdev):
         ctx.save_for_backward(stdev)
         ctx.in_dtype = y.dtype
-        return revin_denorm(y.float(), mean, stdev)
+        return revin_denorm(y if y.dtype in (F32, BF16) else y.float(), mean, stdev)
 
     @staticmethod
     def backward(ctx, dout):
         (stdev,) = ctx.saved_tensors
-        return revin_denorm(dout.float(), None, stdev).to(ctx.in_dtype), None, None
+        od = ctx.in_dtype if ctx.in_dtype in (F32, BF16) else F32
+        g = revin_denorm(dout if dout.dtype in (F32, BF16) else dout.float(), None, stdev, out_dtype=od)
+        return (g if od == ctx.in_dtype else g.to(ctx.in_dtype)), None, None

@@ -611,6 +611,9 @@ def test_assemble_and_denorm(ops):
     mean, sd = torch.randn(B, 3, generator=g(6)), torch.rand(B, 3, generator=g(7)) + 0.1
     assert rel_err(ops.revin_denorm(dev(y), dev(mean), dev(sd)), y * sd[:, None] + mean[:, None]) < 1e-6
     assert rel_err(ops.revin_denorm(dev(y), None, dev(sd)), y * sd[:, None]) < 1e-6
+    yb = y.to(BF16)                                  # bf16 in (the model's head output), bf16 out (the gradient handed back to it)
+    assert rel_err(ops.revin_denorm(dev(yb), dev(mean), dev(sd)), yb.float() * sd[:, None] + mean[:, None]) < 1e-6
+    assert torch.equal(ops.revin_denorm(dev(y), None, dev(sd), out_dtype=BF16).cpu(), (y * sd[:, None]).to(BF16))
 
 
 @pytest.mark.gpu
