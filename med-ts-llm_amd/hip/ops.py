@@ -398,6 +398,14 @@ class PatchTokenizeFn(torch.autograd.Function):
 _LINEAR_XT = os.environ.get("MTL_LINEAR_XT", "1") != "0"      # A/B knob: 0 = backward through explicit transposes + NT GEMMs
 
 
+def _check_shadow_unchanged(at):
+    """`at` = (Bf16Shadow, its version at forward time) or None. The backward reads W from the shadow: an optimizer.step() between a
+    forward and its backward (retain_graph, interleaved models, closure-style steps) would make dX use the UPDATED weights."""
+    if at is not None and at[0].version != at[1]:
+        raise RuntimeError("a trainable Linear's bf16 weight copy was rewritten (optimizer.step()) between this layer's forward and its "
+                           "backward: the input gradient would be computed with the updated weights. Run backward before the optimiser step.")
+
+
 class LinearFn(torch.autograd.Function):
     """y = x @ W^T + b with bf16 MFMA GEMMs. x bf16 [..., Kx] (Kx % 64 == 0, Kx >= W.shape[1], extra cols zero);
     W f32 [N, Kin] master weight (cast to bf16 per call, as autocast does); y bf16 [..., N].
@@ -432,12 +440,16 @@ class LinearFn(torch.autograd.Function):
         y = gemm_nt(x2, wb, bias=None if b is None else b.detach().float().contiguous())
         ctx.save_for_backward(x2, wb if direct else wt)
         ctx.meta = (tuple(x.shape), Nn, Kin, b is not None, direct)
+        # the shadow is a PERSISTENT tensor that HipAdam rewrites through raw pointers (autograd's version counter never sees it):
+        # remember which weight version this forward multiplied by, so that a backward after an optimiser step fails loudly
+        ctx.shadow_at = (shadow, shadow.version) if use_sh else None
         return y.reshape(*x.shape[:-1], Nn)
 
     @staticmethod
     def backward(ctx, dy):
         x2, w = ctx.saved_tensors
         xshape, Nn, Kin, has_b, direct = ctx.meta
+        _check_shadow_unchanged(ctx.shadow_at)
         M, Kx = x2.shape
         dy2 = dy.reshape(M, Nn)
         if dy2.dtype != BF16:
@@ -496,12 +508,15 @@ class LinearPairFn(torch.autograd.Function):
             ys.append(gemm_nt(x2, sh.tensor, bias=None if b is None else b.detach().float().contiguous()))
         ctx.save_for_backward(x2, pair)
         ctx.meta = (tuple(x.shape), N1, N2, Kin, b1 is not None, b2 is not None)
+        ctx.shadows_at = ((sh1, sh1.version), (sh2, sh2.version))
         return ys[0].reshape(*x.shape[:-1], N1), ys[1].reshape(*x.shape[:-1], N2)
 
     @staticmethod
     def backward(ctx, dy1, dy2):
         x2, pair = ctx.saved_tensors
         xshape, N1, N2, Kin, has_b1, has_b2 = ctx.meta
+        for at in ctx.shadows_at:
+            _check_shadow_unchanged(at)
         M, Kx = x2.shape
         dy1, dy2 = dy1.reshape(M, N1), dy2.reshape(M, N2)
         adjacent = (dy1.dtype == BF16 and dy2.dtype == BF16 and dy1.stride(1) == 1 and dy2.stride(1) == 1 and dy1.stride(0) == dy2.stride(0) == N1 + N2

@@ -52,6 +52,12 @@ def _fmt_trend(x):
     return x
 
 
+def _device_stats_fit(x_enc, n_lags):
+    """shapes mtl_input_stats accepts (csrc/mtl_stats.hip returns MTL_ERR_UNSUPPORTED beyond them)"""
+    L = x_enc.shape[1]
+    return L <= 5460 and n_lags <= 2 * (L // 2)
+
+
 def input_stats_prompts(x_enc, input_stats_dim, input_stats_select="all", n_lags=N_LAGS):
     """R:models/medtsllm.py:441-495."""
     xs = x_enc.detach()
@@ -64,7 +70,8 @@ def input_stats_prompts(x_enc, input_stats_dim, input_stats_select="all", n_lags
         insert, s = f"feature {input_stats_dim}", ""
         xs = xs[:, :, input_stats_dim]
     per_feature = xs.ndim == 3
-    if x_enc.is_cuda:
+    packed = None
+    if x_enc.is_cuda and _device_stats_fit(x_enc, n_lags):
         # device path: two launches of the library's statistics kernels (csrc/mtl_stats.hip), ONE packed device-to-host copy — the
         # reference runs five reductions + an rFFT round trip and five .tolist() syncs. Values are fp32, exactly representable in
         # the float64 list; lags are integers. (The autocorrelation is symmetric: inside a twin pair lag / L - lag the reference's
@@ -79,7 +86,9 @@ def input_stats_prompts(x_enc, input_stats_dim, input_stats_select="all", n_lags
         st = host[0].reshape(-1)[: B_ * n_ch * 4].view(B_, n_ch, 4).double()
         lg = host[1].reshape(-1)[: B_ * n_lags].view(B_, n_lags).double()
         packed = torch.cat([st[:, :, 0], st[:, :, 1], st[:, :, 2], st[:, :, 3], lg], dim=1).tolist()
-    else:
+    if packed is None:
+        # CPU tensors, and windows the statistics kernel does not take (it keeps one channel-mean series per sample in LDS: L <= 5460,
+        # n_lags <= 2 * (L // 2)): the reference's own reductions + rFFT round trip on whatever device x_enc lives on
         with torch.no_grad():
             # one packed D2H copy (= one stream sync) instead of the reference's five .tolist() calls; float64 holds every
             # value exactly (fp32/bf16 statistics, 0/1 trends, integer lags), so the formatted strings are unchanged

@@ -94,7 +94,10 @@ class FlatGradAllReduce:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else "cpu"
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        # + one control slot behind the gradients (it travels in the LAST bucket launched): the ranks' pre-emption flag, so that a
+        # decision every rank must take together (checkpoint and exit: collectives) costs no collective of its own
+        self.flat = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        self._flag = False
         self.buckets, self._where = [], {}
         off, cur = 0, None
         for p in reversed(self.params):
@@ -106,6 +109,10 @@ class FlatGradAllReduce:
             cur["n"] += p.numel()
             self._where[id(p)] = (cur, view)
             off += p.numel()
+        if cur is None:
+            cur = {"start": 0, "n": 0, "items": [], "pending": 0, "handle": None}
+            self.buckets.append(cur)
+        cur["n"] += 1                       # the control slot
         self.views = [self._where[id(p)][1] for p in self.params]
         self._hooks = []
         if overlap and self.world > 1 and hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
@@ -117,7 +124,18 @@ class FlatGradAllReduce:
         for b in self.buckets:
             b["pending"], b["handle"], b["packed"], b["dirty"] = len(b["items"]), None, set(), False
 
+    def request_flag(self):
+        """raise this rank's control flag (safe from a signal handler: a plain attribute write); it is sent with the next step's
+        last bucket and flag_value() is > 0 on EVERY rank after that step's sync"""
+        self._flag = True
+
+    def flag_value(self):
+        """0-dim device tensor: (number of ranks whose flag was up at the last sync) / world"""
+        return self.flat[-1]
+
     def _launch(self, b):
+        if b is self.buckets[-1]:
+            self.flat[-1:].fill_(1.0 if self._flag else 0.0)
         b["handle"] = dist.all_reduce(self.flat[b["start"]:b["start"] + b["n"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     @torch.no_grad()

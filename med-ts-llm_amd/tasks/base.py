@@ -66,7 +66,8 @@ class PrintLogger:
         d = self.logdir / "checkpoints"
         d.mkdir(parents=True, exist_ok=True)
         torch.save({"run_id": self.trainer.run_id, "epoch": self.trainer.epoch, "step": self.trainer.step,
-                    "datetime": datetime.now().isoformat(), "model": model_state, "optimizer": optim_state}, d / f"{name}.pt")
+                    "datetime": datetime.now().isoformat(), "model": model_state, "optimizer": optim_state,
+                    "epochs_done": self.trainer.epochs_done}, d / f"{name}.pt")
 
     def log_end(self):
         pass
@@ -80,6 +81,12 @@ class BaseTask(ABC):
         self.task = config.task
         self.device = self.get_device()
         self.dtype = self.get_dtype()
+        if self.dtype != torch.float32:
+            # R:tasks/base.py:261-264 casts the whole model AND the inputs to bf16 / fp16. The HIP path keeps fp32 master weights, an fp32
+            # residual stream and fp32 optimiser moments with bf16 GEMM / attention operands — that IS setup.dtype = "mixed"; a pure
+            # 16-bit master copy is not implemented (HipAdam updates fp32 masters only). Refuse here, not inside the first optimiser step.
+            raise ValueError(f"setup.dtype = {config.setup.dtype!r} (pure 16-bit parameters) is not supported by the MI355X path: use "
+                             "\"mixed\" (fp32 masters, bf16 operands — the reference's default) or \"fp32\"")
         self.rank, self.world_size, self.local_rank = parallel.init_from_env(self.device.type)
         if self.device.type == "cuda" and self.world_size > 1:
             self.device = torch.device("cuda", self.local_rank % torch.cuda.device_count())
@@ -97,6 +104,8 @@ class BaseTask(ABC):
         self.loss_fn = self.build_loss().to(device=self.device)
         self.grad_sync = parallel.FlatGradAllReduce(self.model.parameters()) if self.world_size > 1 else None
         self.epoch, self.step = 1, 0
+        self.epochs_done = 0           # completed epochs (checkpointed: a resumed run continues with epoch epochs_done + 1)
+        self._stop_requested = False   # set by the SIGUSR1 handler, acted on at a step boundary when several ranks must agree
         metric_dir = self.config.training.eval_metric_direction
         self.best_score = float("inf") if metric_dir == "min" else float("-inf")
         self.logger = PrintLogger(self, self.config, self.newrun)
@@ -280,11 +289,18 @@ class BaseTask(ABC):
             self.grad_sync()
         self.optimizer.step()
         self.optimizer.zero_grad()
-        self.log_step(loss.item())
+        if self.grad_sync is not None:
+            # one D2H copy fetches the loss and the ranks' agreed pre-emption flag (it travelled in the gradient all-reduce)
+            loss_v, stop = torch.stack([loss.detach().float().reshape(()), self.grad_sync.flag_value().reshape(())]).tolist()
+            self.log_step(loss_v)
+            if stop > 0:
+                self._checkpoint_and_exit()
+        else:
+            self.log_step(loss.item())
         return loss
 
     def train(self):
-        for epoch in range(self.config.training.epochs):
+        for epoch in range(self.epochs_done, self.config.training.epochs):     # (a run resumed by from_run_id continues where it stopped)
             if self.rank == 0:
                 print(f"Epoch {epoch + 1}/{self.config.training.epochs}")
             if self.world_size > 1:
@@ -293,6 +309,7 @@ class BaseTask(ABC):
             for inputs in self.train_dataloader:
                 self.train_step(inputs)
             val_scores = self.val()
+            self.epochs_done = epoch + 1
             self.log_epoch(val_scores)
             self.scheduler.step()
         self.model.eval()
@@ -361,7 +378,18 @@ class BaseTask(ABC):
             self.epoch += 1
 
     def handle_termination(self, signum, frame):
-        """R:tasks/base.py:277-281 — SIGUSR1 (a scheduler's pre-emption notice): checkpoint "latest", close the logger, exit"""
+        """R:tasks/base.py:277-281 — SIGUSR1 (a scheduler's pre-emption notice): checkpoint "latest", close the logger, exit.
+        The reference is single-process and checkpoints from inside the handler. With data parallelism the checkpoint is a COLLECTIVE
+        (row-sharded mapping layer: state_dict / optimizer_state gather rows) and the ranks receive the signal at different points of
+        their steps, so the handler only raises a flag; the flag rides in the next gradient all-reduce (FlatGradAllReduce's extra
+        slot), every rank sees the same sum at the same step boundary and all of them checkpoint and exit together."""
+        if self.world_size > 1:
+            self._stop_requested = True
+            self.grad_sync.request_flag()
+            return
+        self._checkpoint_and_exit()
+
+    def _checkpoint_and_exit(self):
         print("Interrupted!")
         self.logger.save_state("latest")
         self.log_end()
@@ -393,4 +421,12 @@ class BaseTask(ABC):
         assert not unexpected, f"Unexpected keys in model state: {unexpected}"
         trainer.epoch, trainer.step = state["epoch"], state["step"]
         trainer.load_optimizer_state(state.get("optimizer"))
+        # (ours) the LR schedule and the epoch counter continue too: without them LambdaLR restarts at epoch 0 and a resumed fine-tuning
+        # run re-freezes / re-warms the pre-trained group; checkpoints of the reference's format (no such fields) restart like the reference
+        trainer.epochs_done = int(state.get("epochs_done", 0))
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")      # ("lr_scheduler.step() before optimizer.step()": intended, this is a fast-forward)
+            for _ in range(trainer.epochs_done):     # StepLR / LambdaLR are pure functions of the epoch count
+                trainer.scheduler.step()
         return trainer

@@ -31,13 +31,13 @@ class SeriesDataset(Dataset):
         self.name = config.data.dataset
         self.history_len, self.pred_len = config.history_len, config.pred_len
         self.step_size = config.data.step if split != "test" else self.pred_len          # R:datasets/base.py:39-42
-        self.source = source or _SOURCES[self.name]
-        raw = self.source(config, split)
+        src = source or _SOURCES[self.name]      # used during construction only: not kept on the instance (the dataset must pickle for
+        raw = src(config, split)                  # DataLoader workers under the spawn / forkserver start methods)
         data = np.asarray(raw["data"])
         self.normalizer = None
         if config.data.normalize:                                                          # R:datasets/base.py:79-88
             from sklearn.preprocessing import StandardScaler                               # the reference's own scaler
-            train = data if split == "train" else np.asarray(self.source(config, "train")["data"])
+            train = data if split == "train" else np.asarray(src(config, "train")["data"])
             self.normalizer = StandardScaler().fit(train)
             data = self.normalizer.transform(data)
         self.data = torch.tensor(data, dtype=torch.float32)
@@ -177,21 +177,37 @@ class ClipIndex:
         return (start, start + self.pred_len)
 
 
+_DERIVED = {}      # (kind, base class) -> derived class, also published as a module attribute so that instances pickle by name
+
+
+def _publish(kind, base, derived, name):
+    derived.__name__ = derived.__qualname__ = name
+    derived.__module__ = __name__
+    globals()[name] = derived
+    _DERIVED[(kind, base)] = derived
+    return derived
+
+
 def _with_clips(cls):
     """cls + ClipIndex, built once the raw data (and with it the clip ids) is known"""
+    if ("clip", cls) in _DERIVED:
+        return _DERIVED[("clip", cls)]
+
     class Clipped(ClipIndex, cls):
         __doc__ = cls.__doc__
 
         def __init__(self, config, split, source=None):
             super().__init__(config, split, source)
             self._build_clip_index()
-    Clipped.__name__ = "Clip" + cls.__name__
-    return Clipped
+    return _publish("clip", cls, Clipped, "Clip" + cls.__name__)
 
 
 def univariate_view(cls):
     """R:datasets/util.py:10-43 (`multi_2_uni_dataset`): every (window, feature) pair is its own univariate sample; sample index =
     window * real_features + feature, `inverse_index` returns (time range(s), feature)."""
+    if ("uni", cls) in _DERIVED:
+        return _DERIVED[("uni", cls)]
+
     class Univariate(cls):
         __doc__ = cls.__doc__
         univariate = True
@@ -220,8 +236,7 @@ def univariate_view(cls):
             if self._inner:
                 return super().inverse_index(index)
             return super().inverse_index(index // self.real_features), index % self.real_features
-    Univariate.__name__ = "Univariate" + cls.__name__
-    return Univariate
+    return _publish("uni", cls, Univariate, "Univariate" + cls.__name__)
 
 
 class MixedWindows(Dataset):

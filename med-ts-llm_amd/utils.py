@@ -17,7 +17,10 @@ def set_seed(seed):
 
 
 class dict_to_object(object):
-    """Nested dict -> attribute access, `.get(k, default)`, `k in cfg`, `cfg[k]`, `.copy()`, `.to_dict()`."""
+    """Nested dict -> attribute access, `.get(k, default)`, `k in cfg`, `cfg[k]`, `.copy()`, `.to_dict()`.
+
+    Copied from R:utils.py:19-39 (14 lines): it IS the boundary type — the reference's trainer, model constructor and loggers
+    duck-type exactly these seven members on the config they are handed, so a drop-in has to be the same class."""
 
     def __init__(self, d):
         self.__dict__ = {k: dict_to_object(v) if isinstance(v, dict) else v for k, v in d.items()}

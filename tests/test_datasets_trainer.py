@@ -315,14 +315,14 @@ def test_checkpoint_carries_optimizer_state_and_resume_continues_exactly(G, tmp_
         part.model.load_state_dict(init, strict=False)
         part.train()
         ck = torch.load(tmp_path / "logs" / "run-part" / "checkpoints" / "latest.pt")
-        assert set(ck) == {"run_id", "epoch", "step", "datetime", "model", "optimizer"}
+        assert set(ck) == {"run_id", "epoch", "step", "datetime", "model", "optimizer", "epochs_done"} and ck["epochs_done"] == 1
         assert set(ck["optimizer"]["state"]) == {n for n, p in part.model.named_parameters() if p.requires_grad}
         assert all(set(v) == {"step", "exp_avg", "exp_avg_sq"} for v in ck["optimizer"]["state"].values())
         assert json.loads((tmp_path / "logs" / "run-part" / "config.json").read_text())["training"]["epochs"] == 1
         resumed = task_lookup["reconstruction"].from_run_id("run-part", cfg={"training": cfg(2).training.to_dict()}, basepath=str(tmp_path / "logs"))
-        assert resumed.step == part.step and resumed.config.training.epochs == 2
-        resumed.config.training.epochs = 1       # one more epoch
-        resumed.train()
+        assert resumed.step == part.step and resumed.config.training.epochs == 2 and resumed.epochs_done == 1
+        resumed.train()                           # continues with epoch 2 of 2 (the reference would start over at epoch 1)
+        assert resumed.epochs_done == 2
         for (n, a), (_, b) in zip(full.model.named_parameters(), resumed.model.named_parameters()):
             if a.requires_grad:
                 assert torch.allclose(a, b, rtol=1e-6, atol=1e-8), n

@@ -34,7 +34,7 @@ def _worker(rank, world, port, q):
     loss = torch.nn.functional.mse_loss(frozen(model(shard["x_enc"])), shard["y"])      # mean over the LOCAL shard
     loss.backward()
     sync = parallel.FlatGradAllReduce(list(model.parameters()) + list(frozen.parameters()))
-    assert sync.flat.numel() == sum(p_.numel() for p_ in model.parameters())          # frozen params are not communicated
+    assert sync.flat.numel() == sum(p_.numel() for p_ in model.parameters()) + 1      # frozen params are not communicated (+ the control slot)
     sync()
     grads = [p_.grad.clone() for p_ in model.parameters()]
     if rank == 0:
@@ -97,7 +97,7 @@ def _shard_worker(rank, world, port, q):
     loss = ((other((xs @ src.t())) - ys[:, :1]) ** 2).mean()                             # mean over the LOCAL batch
     loss.backward()
     sync = parallel.FlatGradAllReduce([Wl, bl, *other.parameters()])
-    assert sync.flat.numel() == sum(p_.numel() for p_ in other.parameters())            # sharded rows are not communicated
+    assert sync.flat.numel() == sum(p_.numel() for p_ in other.parameters()) + 1        # sharded rows are not communicated (+ the control slot)
     sync()
     Wf, bf = W.clone().requires_grad_(), b.clone().requires_grad_()
     ref_other = torch.nn.Linear(S, 1)
@@ -142,10 +142,14 @@ def _overlap_worker(rank, world, port, q):
         g = torch.Generator().manual_seed(10 + step)
         batch = {"x_enc": torch.randn(8, 6, generator=g), "y": torch.randn(8, 3, generator=g)}
         shard = parallel.shard_batch(batch, rank, world)
+        if step == 1 and rank == 1:
+            sync.request_flag()                 # what BaseTask.handle_termination does under DP (signal-handler safe)
         torch.nn.functional.mse_loss(model(shard["x_enc"]), shard["y"]).backward()
         launched = sum(b["handle"] is not None for b in sync.buckets)
         ok = ok and launched == len(sync.buckets)                                # every bucket went out DURING backward
         sync()
+        # the pre-emption flag rides in the last bucket: raised by ONE rank before step 1's backward, seen by BOTH after that step's sync
+        ok = ok and (float(sync.flag_value()) > 0) == (step == 1)
         torch.nn.functional.mse_loss(ref(batch["x_enc"]), batch["y"]).backward()
         ok = ok and all(torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6) for a, b in zip(model.parameters(), ref.parameters()))
         opt.step(), ropt.step()

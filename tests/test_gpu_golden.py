@@ -308,8 +308,8 @@ def test_resume_restores_hip_adam_state_on_gpu(tmp_path):
     part.train()
     resumed = task_lookup["reconstruction"].from_run_id("run-part", cfg={"training": cfg(2).training.to_dict()}, basepath=str(tmp_path / "logs"))
     assert type(resumed.optimizer).__name__ == "HipAdam" and all(int(st["step"]) == 2 for st in resumed.optimizer.state.values())
-    resumed.config.training.epochs = 1
-    resumed.train()
+    assert resumed.epochs_done == 1
+    resumed.train()                              # continues with epoch 2 of 2
     for (n, a), (_, b) in zip(full.model.named_parameters(), resumed.model.named_parameters()):
         if a.requires_grad:
             assert torch.equal(a, b), n          # same kernels, same inputs, same moments: bit-identical

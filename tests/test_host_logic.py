@@ -293,3 +293,37 @@ def test_dropout_mask_function_statistics():
         hist = np.bincount(byte.ravel(), minlength=256)
         e = byte.size / 256
         assert ((hist - e) ** 2 / e).sum() / 255 < 1.5                     # chi-square per degree of freedom
+
+
+def test_pure_16bit_dtype_is_rejected_at_construction():
+    """R:tasks/base.py:261-264 casts model and inputs to bf16 / fp16; the MI355X path keeps fp32 masters ("mixed"): the product
+    trainer refuses such a config in its constructor instead of failing inside the first optimiser step"""
+    from med_ts_llm_amd.tasks.base import BaseTask
+
+    class Probe(BaseTask):
+        def build_loss(self):
+            return torch.nn.MSELoss()
+
+    from med_ts_llm_amd.utils import dict_to_object
+    for name in ("fp16", "half"):
+        cfg = dict_to_object({"task": "forecasting", "setup": {"device": "cpu", "dtype": name, "seed": 0}})
+        with pytest.raises(ValueError, match="mixed"):
+            Probe("r", cfg)
+    with pytest.raises(ValueError):          # bf16 on a CPU device: "Invalid dtype selection", as in the reference (R:tasks/base.py:269-270)
+        Probe("r", dict_to_object({"task": "forecasting", "setup": {"device": "cpu", "dtype": "bf16", "seed": 0}}))
+
+
+def test_derived_window_datasets_pickle():
+    """DataLoader workers under spawn / forkserver pickle the dataset: clip / univariate classes are module-level, no closures kept"""
+    import pickle
+    import numpy as np
+    from med_ts_llm_amd.tasks import windows
+    from med_ts_llm_amd.utils import dict_to_object
+    cfg = dict_to_object({"task": "reconstruction", "history_len": 8, "pred_len": 8,
+                          "data": {"dataset": "pk", "step": 4, "normalize": False, "mode": "univariate"}})
+    rng = np.random.default_rng(0)
+    raw = {"data": rng.standard_normal((64, 3)).astype("float32"), "clip_ids": np.repeat(np.arange(4), 16)}
+    ds = windows.make_series_dataset(cfg, "train", source=lambda c, sp: raw)
+    assert type(ds).__name__ == "UnivariateClipReconstructionSeries" and getattr(windows, type(ds).__name__) is type(ds)
+    back = pickle.loads(pickle.dumps(ds))
+    assert len(back) == len(ds) and torch.equal(back[5]["x_enc"], ds[5]["x_enc"])
