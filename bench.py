@@ -51,17 +51,26 @@ WORKLOADS = {
     "llama3_8b_recon_B32_L1024_C12": (LLAMA3_8B, 32, 1024, 12, 1024, 128, "reconstruction"),
     # BASELINE.json configs[3] shape: PSM anomaly detection = reconstruction of 25-channel L=2048 windows (P=256, T=384; head 32768 -> 51200)
     "llama2_7b_psm_B32_L2048_C25": (LLAMA2_7B, 32, 2048, 25, 2048, 128, "anomaly_detection"),
+    # covariate_mode = "interleave" (R:models/medtsllm.py:73-74,292-295) — every channel's patches are their own LLM
+    # tokens: T = 128 + 128 * 12 = 1664 per sample. K/V no longer fit the LDS: the chunked (flash) causal attention carries the stack.
+    "llama2_7b_semseg_interleave_B16_L1024_C12": (LLAMA2_7B, 16, 1024, 12, 1024, 128, "semantic_segmentation", "interleave"),
 }
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0            # HBM3E spec (6.29 TB/s is the measured achievable, same guide)
 
 
-def model_cfg(L, pred, task="forecasting"):
+def workload(name):
+    """(hf cfg, B per GPU, L, C, pred_len, n_tok, task, covariate mode)"""
+    w = WORKLOADS[name]
+    return w if len(w) == 8 else w + ("concat",)
+
+
+def model_cfg(L, pred, task="forecasting", cov="concat"):
     return {
         "DEBUG": True, "task": task, "model": "medtsllm", "history_len": L, "pred_len": pred,
         "training": {"dropout": 0.1}, "setup": {"dtype": "mixed"},     # every shipped reference config trains at 0.1 (configs/datasets/*.toml)
         "models": {"timellm": {
-            "d_model": 32, "d_ff": 128, "n_heads": 8, "num_tokens": 1024, "covariate_mode": "concat",
+            "d_model": 32, "d_ff": 128, "n_heads": 8, "num_tokens": 1024, "covariate_mode": cov,
             "embedding_downsample_mode": "linear", "patching": {"patch_len": 16, "stride": 8},
             "prompting": {"dataset": False, "task": False, "clip": False, "input_stats": False, "examples": False,
                           "input_stats_dim": 0, "input_stats_select": "all"},
@@ -82,8 +91,10 @@ def make_batch(B, L, C_, pred, seed, device, task="forecasting"):
     return {"x_enc": x.to(device), "y": y.to(device)}
 
 
-def flops_per_step(cfg, B, T, P, C_, n_out, V, S=1024, d_model=32, d_ff=128, H=8):
-    """Algorithmic fwd+bwd FLOPs: frozen GEMMs 2x fwd, attention 3x fwd, trainables 3x fwd, mapping 2x."""
+def flops_per_step(cfg, B, T, P, C_, n_out, V, S=1024, d_model=32, d_ff=128, H=8, cov="concat", n_cached=0):
+    """Algorithmic fwd+bwd FLOPs: frozen GEMMs 2x fwd, attention 3x fwd, trainables 3x fwd, mapping 2x.
+    P = patch rows per sample in the LLM sequence (interleave: C_ times the per-channel count). n_cached: leading prompt rows whose
+    forward is served from the prompt-row cache (executed FLOPs only; the algorithmic count never takes a discount)."""
     if cfg["model_type"] == "llama":
         d, L_, ffn = cfg["hidden_size"], cfg["num_hidden_layers"], cfg["intermediate_size"]
         M = B * T
@@ -95,13 +106,16 @@ def flops_per_step(cfg, B, T, P, C_, n_out, V, S=1024, d_model=32, d_ff=128, H=8
         gemm_fwd = L_ * 2 * M * (d * 3 * d + d * d + 2 * d * ffn)
     attn_fwd = L_ * 4 * B * T * T * d
     HE = H * d_ff
-    front = 2 * B * P * (C_ * d_model) * HE + 2 * 2 * S * d * HE + 4 * B * P * S * HE + 2 * B * P * HE * d
+    q_width = C_ * d_model if cov == "concat" else d_model          # (interleave: P already counts every channel's patches)
+    front = 2 * B * P * q_width * HE + 2 * 2 * S * d * HE + 4 * B * P * S * HE + 2 * B * P * HE * d
     tail = 2 * B * P * d * d_ff + 2 * B * d_ff * P * n_out
     mapping = 2 * S * V * d
     algorithmic = 2 * gemm_fwd + 3 * attn_fwd + 3 * (front + tail) + 2 * mapping
     # executed with the exact dead-gradient elimination: backward GEMMs on the P patch rows only; attention backward keeps
     # dQ of the patch queries (3/4 of the causal area) and dK/dV of the patch keys (1/4) -> about half of its FLOPs
-    executed = gemm_fwd * (1 + P / T) + attn_fwd * (1 + 2 * 0.5) + 3 * (front + tail) + 2 * mapping
+    Tq = T - n_cached
+    # forward attention of the computed rows only: queries Tq x keys T, minus nothing else (causal counted as the full rectangle)
+    executed = gemm_fwd * (Tq / T + P / T) + attn_fwd * (Tq / T + 2 * 0.5) + 3 * (front + tail) + 2 * mapping
     return algorithmic, executed
 
 
@@ -241,11 +255,11 @@ def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline):
     from med_ts_llm_amd.models.backbone import random_state_dict
     from med_ts_llm_amd.utils import dict_to_object
     rank, world, device = ctx
-    hf_cfg, B, L, C_, pred, n_tok, task = WORKLOADS[name]
+    hf_cfg, B, L, C_, pred, n_tok, task, cov = workload(name)
     big = hf_cfg["model_type"] == "llama"
     sd = random_state_dict(hf_cfg, seed=0, std=0.02, device=device if big else "cpu", dtype=torch.bfloat16 if big else torch.float32)
     torch.manual_seed(0)
-    model = model_lookup["medtsllm"](dict_to_object(model_cfg(L, pred, task)), DS(C_, 4 if task == "semantic_segmentation" else 0),
+    model = model_lookup["medtsllm"](dict_to_object(model_cfg(L, pred, task, cov)), DS(C_, 4 if task == "semantic_segmentation" else 0),
                                      backbone_state=(hf_cfg, sd)).to(device)
     prompt_ids = torch.randint(0, hf_cfg["vocab_size"], (1, n_tok), generator=torch.Generator().manual_seed(1), dtype=torch.int32)
     model.fixed_prompt_ids = prompt_ids

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MTL_ABI_VERSION 11
+#define MTL_ABI_VERSION 12
 
 enum { MTL_OK = 0, MTL_ERR_ARG = -1, MTL_ERR_ALIGN = -2, MTL_ERR_UNSUPPORTED = -3, MTL_ERR_LAUNCH = -4,
        MTL_ERR_WORKSPACE = -5 };
@@ -274,10 +274,11 @@ int mtl_attention_tune(int resident);
  * LayerNorm eps 1e-5 (HF:models/gpt2/modeling_gpt2.py:252,254,497) and LlamaRMSNorm
  * (HF:models/llama/modeling_llama.py:62-67). x f32 [M, d] (the fp32 residual stream of dtype="mixed"),
  * y bf16 [M, d] (ld_y). rms != 0 -> RMSNorm (beta ignored). stats f32 [M, 2] = (mean, rstd).
- * Row gather like the GEMM: logical row m -> (m / group_rows)*group_stride + row_offset + m % group_rows. */
+ * Row gather like the GEMM: logical row m -> (m / group_rows)*group_stride + row_offset + m % group_rows.
+ * y rows are compact (logical); stats rows are physical (gathered) when stats_physical != 0, logical otherwise. */
 int mtl_norm_fwd(const float* x, const float* gamma, const float* beta, void* y, int64_t ld_y, float* stats,
                  int64_t M, int64_t d, float eps, int rms, int64_t group_rows, int64_t group_stride,
-                 int64_t row_offset, void* stream);
+                 int64_t row_offset, int stats_physical, void* stream);
 /* dX only (gamma/beta are frozen). dres_out[m] = (dres_in ? dres_in[m] : 0) + LN'(dy[m]); optionally also
  * a bf16 copy of dres_out (A operand of the next dX GEMM). dres_in may alias dres_out. dy rows are compact (logical);
  * x / dres rows are physical (gathered); stats rows are physical when stats_physical != 0 (statistics saved by a
@@ -358,8 +359,22 @@ size_t mtl_backbone_work_bytes(const mtl_backbone_weights* w, int64_t B, int64_t
  * to the last n_last tokens of every sample (only those are consumed downstream, R:models/medtsllm.py:353). */
 /* n_save (0 <= n_save <= T): the MLP pre-activations that only the backward reads are stored for the last n_save tokens of every
  * sample: pass the n_grad the matching mtl_backbone_bwd will use (T when unknown), 0 for inference. */
+/* Prompt-row forward cache (prefix_kv != NULL, 0 < n_prefix <= T - n_last; SURVEY.md 7 "legal shortcut i"): the first n_prefix tokens of
+ * EVERY sample are the same constant text prompt (R:models/medtsllm.py:328-339 with a dataset / task prompt only) and the stack is
+ * deterministic (no dropout struct): attention is causal, so every hidden state of those rows is the same in every sample and every
+ * step. The forward then runs norms / GEMMs / MLP / attention queries on the last T - n_prefix tokens of every sample only and takes the
+ * per-layer keys and values of the prompt rows from `prefix_kv` (mtl_backbone_prefix_build). h0's first n_prefix rows are not read.
+ * Results for the computed rows equal the full forward's up to the summation order of differently tiled GEMMs; the matching
+ * mtl_backbone_bwd needs n_grad <= T - n_prefix. Reported as executed work only: no roofline denominator takes the discount. */
 int mtl_backbone_fwd(const mtl_backbone_weights* w, const float* h0, void* out, void* saved, void* work,
-                     int64_t B, int64_t T, int64_t n_last, int64_t n_save, const mtl_backbone_dropout* drop /* NULL: off */, void* stream);
+                     int64_t B, int64_t T, int64_t n_last, int64_t n_save, const mtl_backbone_dropout* drop /* NULL: off */,
+                     const void* prefix_kv, int64_t n_prefix, void* stream);
+/* bytes of the prompt-row cache: bf16 [n_layers, n_prefix, 2 * n_kv_heads * head_dim] (keys after RoPE | values) */
+size_t mtl_backbone_prefix_bytes(const mtl_backbone_weights* w, int64_t n_prefix);
+/* fills `prefix_kv` from the prompt rows h0_prefix f32 [1, n_prefix, d] (wpe already added for GPT-2): one forward of that single
+ * sequence; `saved` / `work` sized by mtl_backbone_saved_bytes / _work_bytes(w, 1, n_prefix). w->rope_cos / rope_sin need >= n_prefix rows. */
+int mtl_backbone_prefix_build(const mtl_backbone_weights* w, const float* h0_prefix, void* prefix_kv, void* saved, void* work,
+                              int64_t n_prefix, void* stream);
 /* dout bf16 [B, n_last, d] -> dh0 f32 [B, T, d]. `saved` from the matching forward.
  * n_grad (n_last <= n_grad <= the forward's n_save): only the LAST n_grad tokens of every sample receive a gradient; rows before that are
  * left zero. The leading tokens are the text prompt: causal attention never lets them see a patch token, so they are

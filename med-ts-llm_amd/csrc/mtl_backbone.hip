@@ -134,8 +134,23 @@ extern "C" size_t mtl_backbone_work_bytes(const mtl_backbone_weights* w, int64_t
     return work_layout(dims_of(w, B, T)).total;
 }
 
-extern "C" int mtl_backbone_fwd(const mtl_backbone_weights* w, const float* h0, void* out, void* saved, void* work, int64_t B,
-                                int64_t T, int64_t n_last, int64_t n_save, const mtl_backbone_dropout* drop, void* stream) {
+// prompt-row cache: K (after RoPE) | V of the first n_prefix tokens, per layer, the same for every sample
+__global__ void prefix_kv_fill_kernel(const bf16_t* __restrict__ cache, bf16_t* __restrict__ qkv, int64_t n_prefix, int64_t T, int64_t ldq,
+                                      int64_t kv_off, int64_t kv_cols, int64_t B) {
+    // one 16-byte chunk of one cache row per thread, written to that row of every sample (the cache row stays in L2 / registers)
+    const int64_t cpr = kv_cols / 8, total = n_prefix * cpr;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / cpr, c = (idx % cpr) * 8;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(cache + r * kv_cols + c);
+        for (int64_t b = blockIdx.y; b < B; b += gridDim.y) *reinterpret_cast<u32x4*>(qkv + (b * T + r) * ldq + kv_off + c) = v;
+    }
+}
+
+namespace {
+
+// the forward over the last n_fwd = T - n_prefix tokens of every sample (n_prefix == 0: all of them, identity row maps)
+int backbone_fwd_impl(const mtl_backbone_weights* w, const float* h0, void* out, void* saved, void* work, int64_t B, int64_t T, int64_t n_last,
+                      int64_t n_save, const mtl_backbone_dropout* drop, const void* prefix_kv, int64_t n_prefix, void* stream) {
     MTL_TRY(check_weights(w));
     if (n_save < 0 || n_save > T) return MTL_ERR_ARG;
     // GPT-2 train-mode dropouts (HF:models/gpt2/modeling_gpt2.py:65,243,397): attention probabilities + both residual branches
@@ -143,15 +158,24 @@ extern "C" int mtl_backbone_fwd(const mtl_backbone_weights* w, const float* h0, 
     const uint32_t dseed = drop ? drop->seed : 0u;
     if (attn_p < 0.f || attn_p >= 1.f || resid_p < 0.f || resid_p >= 1.f) return MTL_ERR_ARG;
     if (!h0 || !out || !saved || !work || B <= 0 || T <= 0 || n_last <= 0 || n_last > T) return MTL_ERR_ARG;
+    if (n_prefix < 0 || (n_prefix > 0 && (!prefix_kv || n_prefix > T - n_last || attn_p > 0.f || resid_p > 0.f))) return MTL_ERR_ARG;
     const Dims D = dims_of(w, B, T);
     const SavedLayout S = saved_layout(D, T);
     const WorkLayout W = work_layout(D);
     char* sv = reinterpret_cast<char*>(saved);
     char* wk = reinterpret_cast<char*>(work);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int rms = D.llama ? 1 : 0;
     auto H = [&](int idx) -> float* {  // residual stream H[0] = h0, H[1..2L] in saved
         return idx == 0 ? const_cast<float*>(h0) : reinterpret_cast<float*>(sv + S.h + S.h_stride * (size_t)(idx - 1));
     };
+    // computed rows: the last n_fwd tokens of every sample. Buffers addressed by (b, t) keep their full-size physical layout (the
+    // backward reads them there) and are touched through the row map; the norm output xln is compact.
+    const int64_t r0 = n_prefix, n_fwd = D.T - n_prefix, Mf = D.B * n_fwd;
+    const RowMap rm = (n_prefix == 0) ? kIdentity : RowMap{n_fwd, D.T, r0};
+    if (n_save > n_fwd) n_save = n_fwd;
+    const int64_t save_group = n_save < n_fwd ? n_fwd : 0, save_first = n_fwd - n_save;
+    const int64_t kv_cols = 2 * D.Hkv * D.hd;
     for (int i = 0; i < D.L; ++i) {
         float* st1 = reinterpret_cast<float*>(sv + S.stats + S.stats_stride * (size_t)(2 * i));
         float* st2 = reinterpret_cast<float*>(sv + S.stats + S.stats_stride * (size_t)(2 * i + 1));
@@ -164,31 +188,80 @@ extern "C" int mtl_backbone_fwd(const mtl_backbone_weights* w, const float* h0, 
         const float* bf = w->b_fc ? w->b_fc[i] : nullptr;
         const float* bp = w->b_proj ? w->b_proj[i] : nullptr;
         // --- attention block
-        MTL_TRY(mtl_norm_fwd(H(2 * i), w->ln1_w[i], w->ln1_b ? w->ln1_b[i] : nullptr, wk + W.xln, D.d, st1, D.M, D.d, w->eps, rms, 0, 0, 0, stream));
-        MTL_TRY(gemm(wk + W.xln, D.d, w->w_qkv[i], D.d, qkv, D.Nqkv, MTL_BF16, D.M, D.Nqkv, D.d, bq, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream));
-        if (D.llama) MTL_TRY(mtl_rope_inplace(qkv, D.Nqkv, w->rope_cos, w->rope_sin, D.M, D.T, D.Hq + D.Hkv, D.hd, 0, stream));
+        MTL_TRY(mtl_norm_fwd(H(2 * i), w->ln1_w[i], w->ln1_b ? w->ln1_b[i] : nullptr, wk + W.xln, D.d, st1, Mf, D.d, w->eps, rms, rm.rows, rm.stride,
+                             rm.offset, 1, stream));
+        MTL_TRY(gemm(wk + W.xln, D.d, w->w_qkv[i], D.d, qkv, D.Nqkv, MTL_BF16, Mf, D.Nqkv, D.d, bq, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream,
+                     kIdentity, rm));
+        if (D.llama) MTL_TRY(mtl_rope_inplace_rows(qkv, D.Nqkv, w->rope_cos, w->rope_sin, Mf, D.T, D.Hq + D.Hkv, D.hd, 0, rm.rows, rm.stride, rm.offset, stream));
+        if (n_prefix > 0) {      // keys / values of the prompt rows: from the cache into every sample's rows [0, n_prefix)
+            const bf16_t* cache = reinterpret_cast<const bf16_t*>(prefix_kv) + (size_t)i * n_prefix * kv_cols;
+            const int64_t chunks = n_prefix * (kv_cols / 8);
+            const unsigned gx = (unsigned)((chunks + 255) / 256), gy = (unsigned)(D.B < 8 ? D.B : 8);
+            hipLaunchKernelGGL(prefix_kv_fill_kernel, dim3(gx, gy), dim3(256), 0, st, cache, reinterpret_cast<bf16_t*>(qkv), n_prefix, D.T, D.Nqkv,
+                               D.Hq * D.hd, kv_cols, D.B);
+            MTL_CHECK_LAUNCH();
+        }
         mtl_attn_fwd_args fa = {};
         attn_args(D, qkv, attn, lse, &fa);
         fa.dropout_p = attn_p; fa.dropout_seed = drop_site_seed(dseed, i, 0);
+        if (n_prefix > 0) {      // queries = the computed rows, keys = all rows
+            fa.q = reinterpret_cast<const bf16_t*>(fa.q) + r0 * fa.q_ts;
+            fa.o = reinterpret_cast<bf16_t*>(fa.o) + r0 * fa.o_ts;
+            fa.lse = lse + r0;
+            fa.Tq = n_fwd; fa.causal_off = r0; fa.stat_stride = D.T;
+        }
         MTL_TRY(mtl_attention_fwd(&fa, stream));
-        MTL_TRY(gemm(attn, D.No, w->w_o[i], D.No, H(2 * i + 1), D.d, MTL_F32, D.M, D.d, D.No, bo, MTL_EPI_RESID, H(2 * i), D.d, nullptr, 0, stream,
-                     kIdentity, kIdentity, resid_p, drop_site_seed(dseed, i, 1)));
+        MTL_TRY(gemm(attn, D.No, w->w_o[i], D.No, H(2 * i + 1), D.d, MTL_F32, Mf, D.d, D.No, bo, MTL_EPI_RESID, H(2 * i), D.d, nullptr, 0, stream,
+                     rm, rm, resid_p, drop_site_seed(dseed, i, 1)));
         // --- MLP block
-        MTL_TRY(mtl_norm_fwd(H(2 * i + 1), w->ln2_w[i], w->ln2_b ? w->ln2_b[i] : nullptr, wk + W.xln, D.d, st2, D.M, D.d, w->eps, rms, 0, 0, 0, stream));
+        MTL_TRY(mtl_norm_fwd(H(2 * i + 1), w->ln2_w[i], w->ln2_b ? w->ln2_b[i] : nullptr, wk + W.xln, D.d, st2, Mf, D.d, w->eps, rms, rm.rows, rm.stride,
+                             rm.offset, 1, stream));
         if (D.llama) {
             // gate|up GEMM with the SwiGLU fused into its epilogue (weights row-interleaved: columns 2j / 2j+1 = gate_j / up_j)
             // (the saved pre-activations are only read by the backward: stored for the last n_save tokens of every sample)
-            MTL_TRY(gemm(wk + W.xln, D.d, w->w_fc[i], D.d, fc, D.Nfc, MTL_BF16, D.M, D.Nfc, D.d, bf, MTL_EPI_SWIGLU, nullptr, 0, wk + W.act, D.ffn, stream,
-                         kIdentity, kIdentity, 0.f, 0u, n_save < D.T ? D.T : 0, D.T - n_save));
+            MTL_TRY(gemm(wk + W.xln, D.d, w->w_fc[i], D.d, fc, D.Nfc, MTL_BF16, Mf, D.Nfc, D.d, bf, MTL_EPI_SWIGLU, nullptr, 0, wk + W.act, D.ffn, stream,
+                         kIdentity, rm, 0.f, 0u, save_group, save_first));
         } else {
-            MTL_TRY(gemm(wk + W.xln, D.d, w->w_fc[i], D.d, wk + W.act, D.ffn, MTL_BF16, D.M, D.ffn, D.d, bf, MTL_EPI_GELU, nullptr, 0, fc, D.ffn, stream,
-                         kIdentity, kIdentity, 0.f, 0u, n_save < D.T ? D.T : 0, D.T - n_save));
+            MTL_TRY(gemm(wk + W.xln, D.d, w->w_fc[i], D.d, wk + W.act, D.ffn, MTL_BF16, Mf, D.ffn, D.d, bf, MTL_EPI_GELU, nullptr, 0, fc, D.ffn, stream,
+                         kIdentity, rm, 0.f, 0u, save_group, save_first));
         }
-        MTL_TRY(gemm(wk + W.act, D.ffn, w->w_proj[i], D.ffn, H(2 * i + 2), D.d, MTL_F32, D.M, D.d, D.ffn, bp, MTL_EPI_RESID, H(2 * i + 1), D.d, nullptr, 0, stream,
-                     kIdentity, kIdentity, resid_p, drop_site_seed(dseed, i, 2)));
+        MTL_TRY(gemm(wk + W.act, D.ffn, w->w_proj[i], D.ffn, H(2 * i + 2), D.d, MTL_F32, Mf, D.d, D.ffn, bp, MTL_EPI_RESID, H(2 * i + 1), D.d, nullptr, 0, stream,
+                     rm, rm, resid_p, drop_site_seed(dseed, i, 2)));
     }
     float* stf = reinterpret_cast<float*>(sv + S.stats_f);
-    return mtl_norm_fwd(H(2 * D.L), w->lnf_w, w->lnf_b, out, D.d, stf, D.B * n_last, D.d, w->eps, rms, n_last, D.T, D.T - n_last, stream);
+    return mtl_norm_fwd(H(2 * D.L), w->lnf_w, w->lnf_b, out, D.d, stf, D.B * n_last, D.d, w->eps, rms, n_last, D.T, D.T - n_last, 0, stream);
+}
+
+}  // namespace
+
+extern "C" int mtl_backbone_fwd(const mtl_backbone_weights* w, const float* h0, void* out, void* saved, void* work, int64_t B,
+                                int64_t T, int64_t n_last, int64_t n_save, const mtl_backbone_dropout* drop, const void* prefix_kv,
+                                int64_t n_prefix, void* stream) {
+    return backbone_fwd_impl(w, h0, out, saved, work, B, T, n_last, n_save, drop, prefix_kv, prefix_kv ? n_prefix : 0, stream);
+}
+
+extern "C" size_t mtl_backbone_prefix_bytes(const mtl_backbone_weights* w, int64_t n_prefix) {
+    if (check_weights(w) != MTL_OK || n_prefix <= 0) return 0;
+    return (size_t)w->n_layers * (size_t)n_prefix * (size_t)(2 * w->n_kv_heads * w->head_dim) * 2;
+}
+
+extern "C" int mtl_backbone_prefix_build(const mtl_backbone_weights* w, const float* h0_prefix, void* prefix_kv, void* saved, void* work,
+                                         int64_t n_prefix, void* stream) {
+    MTL_TRY(check_weights(w));
+    if (!h0_prefix || !prefix_kv || !saved || !work || n_prefix <= 0) return MTL_ERR_ARG;
+    const Dims D = dims_of(w, 1, n_prefix);
+    const SavedLayout S = saved_layout(D, n_prefix);
+    // one ordinary forward of the single prompt sequence; its final-norm output (1 row) lands in the work buffer's dx scratch
+    const WorkLayout W = work_layout(D);
+    MTL_TRY(backbone_fwd_impl(w, h0_prefix, reinterpret_cast<char*>(work) + W.dx, saved, work, 1, n_prefix, 1, 0, nullptr, nullptr, 0, stream));
+    const size_t kv_bytes = (size_t)(2 * D.Hkv * D.hd) * 2;
+    for (int i = 0; i < D.L; ++i) {
+        const char* qkv = reinterpret_cast<const char*>(saved) + S.qkv + S.qkv_stride * (size_t)i + (size_t)D.Hq * D.hd * 2;
+        char* dst = reinterpret_cast<char*>(prefix_kv) + (size_t)i * n_prefix * kv_bytes;
+        if (hipMemcpy2DAsync(dst, kv_bytes, qkv, (size_t)D.Nqkv * 2, kv_bytes, (size_t)n_prefix, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream)) != hipSuccess)
+            return MTL_ERR_LAUNCH;
+    }
+    return MTL_OK;
 }
 
 extern "C" int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, const void* dout, float* dh0, void* saved, void* work,

@@ -19,11 +19,12 @@ template <int NV, bool RMS>
 __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                        int64_t ld_y, float* __restrict__ stats, int64_t M, int d, float eps,
-                                                       int64_t group_rows, int64_t group_stride, int64_t row_offset) {
+                                                       int64_t group_rows, int64_t group_stride, int64_t row_offset, int stats_physical) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const float* xr = x + remap_row(row, group_rows, group_stride, row_offset) * (int64_t)d;
+    const int64_t prow = remap_row(row, group_rows, group_stride, row_offset);
+    const float* xr = x + prow * (int64_t)d;
     float4 v[NV];
     float s = 0.f;
 #pragma unroll
@@ -70,8 +71,9 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__
         }
     }
     if (lane == 0 && stats) {
-        stats[row * 2] = mean;
-        stats[row * 2 + 1] = rstd;
+        const int64_t srow = stats_physical ? prow : row;
+        stats[srow * 2] = mean;
+        stats[srow * 2 + 1] = rstd;
     }
 }
 
@@ -175,7 +177,7 @@ int dispatch_nv(int64_t d, F&& f) {
 
 extern "C" int mtl_norm_fwd(const float* x, const float* gamma, const float* beta, void* y, int64_t ld_y, float* stats,
                             int64_t M, int64_t d, float eps, int rms, int64_t group_rows, int64_t group_stride,
-                            int64_t row_offset, void* stream) {
+                            int64_t row_offset, int stats_physical, void* stream) {
     if (!x || !gamma || !y || M <= 0 || d <= 0 || (!rms && !beta)) return MTL_ERR_ARG;
     if (d % 4 != 0 || ld_y % 4 != 0) return MTL_ERR_ALIGN;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -187,10 +189,10 @@ extern "C" int mtl_norm_fwd(const float* x, const float* gamma, const float* bet
         const double bytes = (double)M * d * (4 + 2) + (stats ? (double)M * 8 : 0.0);      // fp32 row in, bf16 row out, 2 statistics
         if (rms)
             MTL_LAUNCH(kname, bytes, 1, (norm_fwd_kernel<NV, true>), grid, block, 0, st, x, gamma, beta, (bf16_t*)y, ld_y, stats, M, (int)d,
-                       eps, group_rows, group_stride, row_offset);
+                       eps, group_rows, group_stride, row_offset, stats_physical);
         else
             MTL_LAUNCH(kname, bytes, 1, (norm_fwd_kernel<NV, false>), grid, block, 0, st, x, gamma, beta, (bf16_t*)y, ld_y, stats, M, (int)d,
-                       eps, group_rows, group_stride, row_offset);
+                       eps, group_rows, group_stride, row_offset, stats_physical);
         MTL_CHECK_LAUNCH();
         return MTL_OK;
     };

@@ -321,7 +321,6 @@ extern "C" int mtl_patch_tokenize_bwd(const float* x, const float* mean, const f
     const uint32_t drop_thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
     const int P = (int)((L + stride - patch_len) / stride + 1);
     const size_t lds_bytes = (size_t)(L + P * d_patch) * sizeof(float);
-    if (lds_bytes > 64 * 1024) return MTL_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int nw = (int)(d_patch * patch_len * 3);
     const size_t fast_tile = (size_t)P * d_patch > (size_t)nw * (256 / (d_patch > 0 && d_patch <= 256 ? d_patch : 256)) ? (size_t)P * d_patch : (size_t)nw * (256 / (d_patch <= 256 ? d_patch : 256));
@@ -332,6 +331,7 @@ extern "C" int mtl_patch_tokenize_bwd(const float* x, const float* mean, const f
         hipLaunchKernelGGL(tokenize_bwd_fast_kernel, dim3((unsigned)(B * C)), dim3(256), fast_bytes, st, x, mean, stdev, (const bf16_t*)dout, partial,
                            (int)L, (int)C, (int)stride, (int)d_patch, P, ld_out, concat, drop_thr, drop_seed);
     } else {
+        if (lds_bytes > 64 * 1024) return MTL_ERR_UNSUPPORTED;      // (the generic kernel's static budget; long windows take the fast kernel above)
         hipLaunchKernelGGL(tokenize_bwd_kernel, dim3((unsigned)(B * C)), dim3(256), lds_bytes, st, x, mean, stdev, (const bf16_t*)dout, partial,
                            (int)L, (int)C, (int)patch_len, (int)stride, (int)d_patch, P, ld_out, concat, drop_thr, drop_seed);
     }

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("MTL_LIB_PATH") or os.path.join(_HERE, "libmedtsllm_hi
 MTL_F32, MTL_BF16 = 0, 1
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM, EPI_SWIGLU, EPI_DSWIGLU = 0, 1, 2, 3, 4, 5, 6
 ARCH_GPT2, ARCH_LLAMA = 0, 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 i64, vp, f32, i32 = C.c_int64, C.c_void_p, C.c_float, C.c_int
 
@@ -119,7 +119,7 @@ SIGNATURES = {
     "mtl_attention_fwd": (i32, [C.POINTER(AttnFwdArgs), vp]),
     "mtl_attention_tune": (i32, [i32]),
     "mtl_attention_bwd": (i32, [C.POINTER(AttnBwdArgs), vp]),
-    "mtl_norm_fwd": (i32, [vp, vp, vp, vp, i64, vp, i64, i64, f32, i32, i64, i64, i64, vp]),
+    "mtl_norm_fwd": (i32, [vp, vp, vp, vp, i64, vp, i64, i64, f32, i32, i64, i64, i64, i32, vp]),
     "mtl_norm_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, i64, i64, i32, i64, i64, i64, i32, f32, C.c_uint32, vp]),
     "mtl_dropout_f32": (i32, [vp, vp, i64, i64, f32, C.c_uint32, vp]),
     "mtl_rope_inplace": (i32, [vp, i64, vp, vp, i64, i64, i64, i64, i32, vp]),
@@ -133,7 +133,9 @@ SIGNATURES = {
     "mtl_input_stats": (i32, [vp, vp, vp, vp, C.c_size_t, i64, i64, i64, i64, i64, vp]),
     "mtl_backbone_saved_bytes": (C.c_size_t, [C.POINTER(BackboneWeights), i64, i64]),
     "mtl_backbone_work_bytes": (C.c_size_t, [C.POINTER(BackboneWeights), i64, i64]),
-    "mtl_backbone_fwd": (i32, [C.POINTER(BackboneWeights), vp, vp, vp, vp, i64, i64, i64, i64, C.POINTER(BackboneDropout), vp]),
+    "mtl_backbone_fwd": (i32, [C.POINTER(BackboneWeights), vp, vp, vp, vp, i64, i64, i64, i64, C.POINTER(BackboneDropout), vp, i64, vp]),
+    "mtl_backbone_prefix_bytes": (C.c_size_t, [C.POINTER(BackboneWeights), i64]),
+    "mtl_backbone_prefix_build": (i32, [C.POINTER(BackboneWeights), vp, vp, vp, vp, i64, vp]),
     "mtl_backbone_bwd": (i32, [C.POINTER(BackboneWeights), vp, vp, vp, vp, vp, i64, i64, i64, i64, C.POINTER(BackboneDropout), vp]),
 }
 

@@ -311,7 +311,7 @@ def norm_fwd(x, gamma, beta, eps, rms=False, rows=None, M=None):
     y = torch.empty((M, d), dtype=BF16, device=x.device)
     stats = torch.empty((M, 2), dtype=F32, device=x.device)
     gr, gs, ro = rows if rows is not None else (0, 0, 0)
-    check(lib().mtl_norm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), d, ptr(stats), M, d, eps, 1 if rms else 0, gr, gs, ro,
+    check(lib().mtl_norm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), d, ptr(stats), M, d, eps, 1 if rms else 0, gr, gs, ro, 0,
                              stream()), "mtl_norm_fwd")
     return y, stats
 
@@ -732,14 +732,18 @@ class BackboneFn(torch.autograd.Function):
     """Frozen decoder stack (R:models/medtsllm.py:350) fwd + activation-gradient-only bwd, one C call each."""
 
     @staticmethod
-    def forward(ctx, h0, backbone, n_last, n_grad=None, drop=None):
+    def forward(ctx, h0, backbone, n_last, n_grad=None, drop=None, prefix=None):
         """n_grad: number of trailing tokens per sample whose input gradient is consumed (the patch tokens). The text
         prompt rows before them never depend on a trainable parameter (causal attention), so their gradient is dead and
-        the backward runs on B*n_grad rows only; dh0 is zero there. None -> full backward."""
+        the backward runs on B*n_grad rows only; dh0 is zero there. None -> full backward.
+        prefix = (cache, n_prefix) from FrozenBackbone.prefix_cache: the first n_prefix rows are a constant prompt whose per-layer keys /
+        values are cached; the forward runs on the remaining rows only (mtl_backbone_fwd)."""
         h0 = h0.contiguous()
         T = h0.shape[1]
         n_save = (T if n_grad is None else max(int(n_grad), n_last)) if ctx.needs_input_grad[0] else 0
-        out, saved = backbone.run_forward(h0, n_last, keep=ctx.needs_input_grad[0], drop=drop, n_save=n_save)
+        if prefix is not None and ctx.needs_input_grad[0] and (n_grad is None or n_save > T - prefix[1]):
+            prefix = None                      # a backward over rows the cached forward would not compute: run the full forward
+        out, saved = backbone.run_forward(h0, n_last, keep=ctx.needs_input_grad[0], drop=drop, n_save=n_save, prefix=prefix)
         ctx.backbone, ctx.n_last, ctx.saved, ctx.n_grad, ctx.drop = backbone, n_last, saved, n_grad, drop
         ctx.save_for_backward(h0)
         return out
@@ -749,7 +753,7 @@ class BackboneFn(torch.autograd.Function):
         (h0,) = ctx.saved_tensors
         dh0 = ctx.backbone.run_backward(h0, dout.contiguous(), ctx.saved, ctx.n_last, ctx.n_grad, drop=ctx.drop)
         ctx.saved = None
-        return dh0, None, None, None, None
+        return dh0, None, None, None, None, None
 
 
 class RevinDenormFn(torch.autograd.Function):

@@ -189,8 +189,31 @@ class FrozenBackbone:
             return None
         return C.byref(N.BackboneDropout(float(drop[0]), float(drop[1]), int(drop[2]) & 0xFFFFFFFF))
 
-    def run_forward(self, h0, n_last, keep=True, drop=None, n_save=None):
+    def prefix_cache(self, h0_prefix, key, T):
+        """Prompt-row forward cache (SURVEY.md 7 "legal shortcut i"): per-layer keys / values of a CONSTANT prompt, bf16
+        [L, n_prefix, 2 Hkv hd], built by one forward of the single prompt sequence h0_prefix f32 [1, n_prefix, d] and kept until `key`
+        (the caller's identity of the prompt: its token ids) changes. The frozen weights never change (a new FrozenBackbone is built when
+        they do). Returns (cache, n_prefix) for run_forward / BackboneFn."""
+        n_prefix = h0_prefix.shape[1]
+        ent = getattr(self, "_prefix", None)
+        if ent is not None and ent[0] == key and ent[1].device == h0_prefix.device:
+            return ent[1], n_prefix
+        w = self._struct(T)                      # (RoPE table of the full sequence: rows [0, n_prefix) are the prompt's positions)
+        lib = N.lib()
+        dev = h0_prefix.device
+        cache = torch.empty(lib.mtl_backbone_prefix_bytes(C.byref(w), n_prefix), dtype=torch.uint8, device=dev)
+        saved = torch.empty(lib.mtl_backbone_saved_bytes(C.byref(w), 1, n_prefix), dtype=torch.uint8, device=dev)
+        work = torch.empty(lib.mtl_backbone_work_bytes(C.byref(w), 1, n_prefix), dtype=torch.uint8, device=dev)
+        h = h0_prefix.detach().contiguous()
+        N.check(lib.mtl_backbone_prefix_build(C.byref(w), N.ptr(h), N.ptr(cache), N.ptr(saved), N.ptr(work), n_prefix, N.stream()),
+                "mtl_backbone_prefix_build")
+        self._prefix = (key, cache)
+        self.prefix_builds = getattr(self, "prefix_builds", 0) + 1
+        return cache, n_prefix
+
+    def run_forward(self, h0, n_last, keep=True, drop=None, n_save=None, prefix=None):
         """h0 f32 [B,T,d] (wpe already added for GPT-2) -> (out bf16 [B,n_last,d], saved buffer).
+        prefix = (cache, n_prefix) from prefix_cache(): forward on the last T - n_prefix rows of every sample only.
         drop = (attn_p, resid_p, seed): GPT-2's train-mode dropouts inside the stack (the backward needs the same tuple).
         n_save: trailing tokens per sample whose backward-only state (MLP pre-activations) is stored — the n_grad the backward
         will use; default all T when the buffer is kept, 0 otherwise."""
@@ -205,9 +228,15 @@ class FrozenBackbone:
         out = torch.empty((B, n_last, d), dtype=BF16, device=h0.device)
         if drop and self.arch != "gpt2" and (drop[0] > 0 or drop[1] > 0):
             raise ValueError("dropout inside the frozen stack exists for GPT-2 only (Llama has none)")
+        dstruct = self._drop_struct(drop)
+        if prefix is not None and (dstruct is not None or prefix[1] > T - n_last):
+            prefix = None                         # dropout makes the prompt rows step-dependent: full forward
+        pk, n_prefix = (N.ptr(prefix[0]), int(prefix[1])) if prefix is not None else (None, 0)
         N.check(lib.mtl_backbone_fwd(C.byref(w), N.ptr(h0), N.ptr(out), N.ptr(saved), N.ptr(work), B, T, n_last, n_save,
-                                     self._drop_struct(drop), N.stream()), "mtl_backbone_fwd")
+                                     dstruct, pk, n_prefix, N.stream()), "mtl_backbone_fwd")
+        n_save = min(n_save, T - n_prefix)
         saved._n_save = n_save
+        self.last_n_prefix = n_prefix
         return out, (saved if keep else None)
 
     def run_backward(self, h0, dout, saved, n_last, n_grad=None, drop=None):

@@ -129,6 +129,7 @@ class MedTsLLM(nn.Module):
         self.lora_enabled = False
         self._id_cache = {}
         self.prune_dead_prompt_grads = True   # exact: skips gradients nobody consumes (set False for the full dh0)
+        self.prompt_row_cache = True          # constant prompt + deterministic stack: per-layer prompt K/V cached, forward on the patch rows only
         self.fixed_prompt_ids = None   # int32 [1 or B, n_tok]: synthetic-benchmark prompt (no tokenizer files needed)
         self.debug_tap = None          # dict -> stage tensors (and, after backward, their gradients as "grad:<name>") for parity tests
 
@@ -315,7 +316,14 @@ class MedTsLLM(nn.Module):
             if all(r == rows[0] for r in rows):
                 rows = rows[:1]                       # one shared prompt: the kernel broadcasts it
         self._check_ids(rows)
+        self._last_prompt_rows = ("ids", tuple(rows[0])) if len(rows) == 1 else None
         return torch.tensor(rows, dtype=torch.int32, device=device), splice
+
+    def _prompt_key(self, ids):
+        """host-side identity of a shared prompt (no device sync: the ids came from host lists / a host tensor checked once)"""
+        if self.fixed_prompt_ids is not None:
+            return ("fixed", id(self.fixed_prompt_ids), tuple(self.fixed_prompt_ids.shape))
+        return self._last_prompt_rows
 
     def _check_ids(self, rows):
         """prompt token ids index the frozen embedding table inside a kernel that cannot raise: range-check them on the host (the
@@ -486,7 +494,15 @@ class MedTsLLM(nn.Module):
             if c["attn_pdrop"] > 0 or c["resid_pdrop"] > 0:
                 drop = (c["attn_pdrop"], c["resid_pdrop"], seed)
         self._tap("h0", h0)
-        dec = self._tap("dec", BackboneFn.apply(h0, bb, self.n_patches, n_grad, drop))   # [B', n_patches, d_llm] (final norm on the consumed rows only)
+        # prompt-row forward cache: ONE prompt shared by every sample (ids [1, n_tok]: dataset / task text, R:configs/datasets/ludb.toml:49-52)
+        # and a deterministic stack (Llama always; GPT-2 outside train mode) -> the prompt rows' keys / values per layer are the same in
+        # every sample and every step. Keyed by the token ids; per-sample prompts (statistics, clip descriptions, examples) never cache.
+        prefix = None
+        if (self.prompt_row_cache and ids is not None and ids.shape[0] == 1 and splice is None and not llm_drop
+                and ids.shape[1] <= h0.shape[1] - self.n_patches):
+            key = self._prompt_key(ids)
+            prefix = bb.prefix_cache(h0[:1, :ids.shape[1]], key, h0.shape[1])
+        dec = self._tap("dec", BackboneFn.apply(h0, bb, self.n_patches, n_grad, drop, prefix))   # [B', n_patches, d_llm] (final norm on the consumed rows only)
         mode = self.embedding_downsample_mode
         if mode == "truncate":
             dec = dec[:, :, :self.d_ff]

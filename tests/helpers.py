@@ -110,6 +110,12 @@ def hf_cfg(kind, vocab=512):
     if kind == "llama_gqa":
         return {"model_type": "llama", "vocab_size": vocab, "hidden_size": 256, "intermediate_size": 384, "num_hidden_layers": 2,
                 "num_attention_heads": 4, "num_key_value_heads": 2, "head_dim": 64, "rms_norm_eps": 1e-5, "rope_theta": 500000.0}
+    if kind == "llama_hd128":        # Llama-2-7B's head geometry (hd 128, MHA) on a small stack
+        return {"model_type": "llama", "vocab_size": vocab, "hidden_size": 256, "intermediate_size": 384, "num_hidden_layers": 2,
+                "num_attention_heads": 2, "num_key_value_heads": 2, "head_dim": 128, "rms_norm_eps": 1e-5, "rope_theta": 10000.0}
+    if kind == "llama_gqa_hd128":    # Llama-3-8B's (hd 128, 4 query heads per KV head); n_heads * head_dim = 512 != hidden_size
+        return {"model_type": "llama", "vocab_size": vocab, "hidden_size": 256, "intermediate_size": 384, "num_hidden_layers": 2,
+                "num_attention_heads": 4, "num_key_value_heads": 1, "head_dim": 128, "rms_norm_eps": 1e-5, "rope_theta": 500000.0}
     raise ValueError(kind)
 
 

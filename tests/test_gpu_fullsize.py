@@ -133,3 +133,23 @@ def test_full_size_pruned_backward_equals_full_backward(model):
         # comes out at 1e-8, pure round-off): compare it — like every analytically-small gradient — on an absolute scale
         scale = max(float(gf[n].norm()), 1e-3 * float(params[n].detach().norm()) + 1e-6)
         assert float((gp[n] - gf[n]).norm()) / scale < 2.5e-2, n
+
+
+def test_full_size_prompt_row_cache_equals_full_forward(model):
+    """the prompt-row forward cache (mtl_backbone_fwd's prefix_kv) at size: same prediction and gradients as the full forward, to the floor
+    between two tile configurations of the same arithmetic (the computed rows run M = B * n_patches GEMMs instead of M = B * T)"""
+    x, y = _x(6), _target(model, 7)
+    assert model.prompt_row_cache
+    oc, gc = _grads(model, x, y)
+    assert model.backbone.last_n_prefix == NTOK
+    model.prompt_row_cache = False
+    try:
+        of, gf = _grads(model, x, y)
+        assert model.backbone.last_n_prefix == 0
+    finally:
+        model.prompt_row_cache = True
+    assert rel_err(oc, of) < 1.2e-2
+    params = dict(model.named_parameters())
+    for n in gc:
+        scale = max(float(gf[n].norm()), 1e-3 * float(params[n].detach().norm()) + 1e-6)
+        assert float((gc[n] - gf[n]).norm()) / scale < 2.5e-2, n

@@ -1,0 +1,56 @@
+"""SURVEY.md 8f-4, second half: the covariate modes that make LONG LLM sequences on a Llama backbone (GPT-2 stops at its 1024 learned
+positions) — `interleave` (R:models/medtsllm.py:73-74,292-295: n_patches *= n_features, T = n_tok + P*C: 1 664 at the metric shape,
+6 528 for PSM's 25 channels) and `independent` (LLM batch B*C, T = n_tok + P, long for long windows). There K/V no longer fit the LDS:
+the chunked causal attention kernels carry the stack (MHA and GQA, head dims 64 and 128), forward, pruned backward and every trainable
+gradient against the fp32 oracle, same bars as tests/test_gpu_model.py."""
+import pytest
+import torch
+
+from helpers import hf_cfg, rel_err
+from test_gpu_model import _check_full_model, L3
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+
+LONG_CASES = [
+    # kind, task, B, L, C, pred, covariate mode, prompt  ->  T
+    ("llama", "forecasting", 2, 1024, 14, 16, "interleave", True),             # 128 * 14 = 1792 patch rows + prompt (MHA, hd 64)
+    ("llama_gqa_hd128", "reconstruction", 1, 1024, 14, 1024, "interleave", False),     # T = 1792, GQA 4/1 at hd 128
+    ("llama_hd128", "forecasting", 1, 13904, 2, 16, "independent", True),      # P = 1738 per channel, LLM batch B*C = 2 (MHA, hd 128); L > 5460:
+                                                                               # the prompt statistics take the torch route (models/prompt.py)
+    ("llama_gqa", "anomaly_detection", 1, 13904, 2, 13904, "independent", False),      # GQA 4/2 at hd 64
+]
+
+
+@pytest.mark.parametrize("kind,task,B,L,C,pred,cov,prompt_on", LONG_CASES)
+def test_long_sequence_modes_vs_oracle(kind, task, B, L, C, pred, cov, prompt_on):
+    _check_full_model(kind, task, B, L, C, pred, cov, "linear", prompt_on)
+
+
+@pytest.mark.parametrize("kind,T", [("llama_hd128", 3328), ("llama_gqa", 3328), ("llama_gqa_hd128", 1664), ("llama", 1664)])
+def test_llama_stack_long_T(kind, T):
+    """the frozen stack alone at T = 1 664 (metric shape, interleave) and 3 328 (the row's "T ~ 3.3 k"): forward on the consumed rows, full and
+    pruned backward vs the oracle; the prompt rows of the pruned input gradient are exactly zero"""
+    from med_ts_llm_amd.models.backbone import FrozenBackbone, random_state_dict
+    from oracle import medtsllm_oracle as O
+    cfg = hf_cfg(kind)
+    sd = random_state_dict(cfg, seed=5, std=0.06)
+    bb = FrozenBackbone(cfg, sd, "cuda")
+    B, d = 2, cfg["hidden_size"]
+    n_tok = 128
+    n_last = T - n_tok
+    g = torch.Generator().manual_seed(9)
+    h0 = torch.randn(B, T, d, generator=g)
+    dout = torch.randn(B, n_last, d, generator=g).to(BF16)
+    h0r = h0.clone().requires_grad_(True)
+    ref = O.backbone_forward(h0r, sd, cfg)[:, -n_last:, :]
+    (ref * dout.float()).sum().backward()
+    out, saved = bb.run_forward(h0.cuda(), n_last)
+    assert rel_err(out.float(), ref) < L3
+    dh0 = bb.run_backward(h0.cuda(), dout.cuda(), saved, n_last).cpu()
+    assert rel_err(dh0, h0r.grad) < 2 * L3
+    out2, saved2 = bb.run_forward(h0.cuda(), n_last, n_save=n_last)
+    assert torch.equal(out2, out)
+    dh0p = bb.run_backward(h0.cuda(), dout.cuda(), saved2, n_last, n_last).cpu()
+    assert rel_err(dh0p[:, n_tok:], h0r.grad[:, n_tok:]) < 2 * L3
+    assert rel_err(dh0p[:, n_tok:], dh0[:, n_tok:]) < 2e-3 and torch.all(dh0p[:, :n_tok] == 0)
