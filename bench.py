@@ -119,17 +119,17 @@ def flops_per_step(cfg, B, T, P, C_, n_out, V, S=1024, d_model=32, d_ff=128, H=8
     return algorithmic, executed
 
 
-def cpu_baseline(hf_cfg, sd, L, C_, pred, n_tok, prompt_ids, max_seconds=30.0):
+def cpu_baseline(hf_cfg, sd, L, C_, pred, n_tok, prompt_ids, max_seconds=30.0, task="forecasting", Bs=4, cov="concat"):
     """Oracle fwd+bwd on the host cores on a bounded sample of the same workload (same shapes, smaller batch)."""
     from oracle import medtsllm_oracle as O
-    Bs = 4
     g = torch.Generator().manual_seed(123)
-    d = hf_cfg["n_embd"]   # CPU baseline is only run for the GPT-2 workloads
+    d = hf_cfg["n_embd"] if hf_cfg["model_type"] == "gpt2" else hf_cfg["hidden_size"]
+    n_out = pred * C_ if task != "semantic_segmentation" else pred * 4
     p = {
         "patch_embedding.value_embedding.tokenConv.weight": torch.randn(32, 16, 3, generator=g) * 0.2,
         "mapping_layer.weight": torch.randn(1024, hf_cfg["vocab_size"], generator=g) * 0.01,
         "mapping_layer.bias": torch.zeros(1024),
-        "reprogramming_layer.query_projection.weight": torch.randn(1024, C_ * 32, generator=g) * 0.05,
+        "reprogramming_layer.query_projection.weight": torch.randn(1024, (C_ if cov == "concat" else 1) * 32, generator=g) * 0.05,
         "reprogramming_layer.query_projection.bias": torch.zeros(1024),
         "reprogramming_layer.key_projection.weight": torch.randn(1024, d, generator=g) * 0.03,
         "reprogramming_layer.key_projection.bias": torch.zeros(1024),
@@ -140,19 +140,23 @@ def cpu_baseline(hf_cfg, sd, L, C_, pred, n_tok, prompt_ids, max_seconds=30.0):
         "embedding_downsample_layer.weight": torch.randn(128, d, generator=g) * 0.03,
         "embedding_downsample_layer.bias": torch.zeros(128),
     }
-    P = (L + 8 - 16) // 8 + 1
-    p["output_projection.linear.weight"] = torch.randn(pred * C_, 128 * P, generator=g) * 0.01
-    p["output_projection.linear.bias"] = torch.zeros(pred * C_)
+    P = ((L + 8 - 16) // 8 + 1) * (C_ if cov == "interleave" else 1)
+    p["output_projection.linear.weight"] = torch.randn(n_out, 128 * P, generator=g) * 0.01
+    p["output_projection.linear.bias"] = torch.zeros(n_out)
     for t in p.values():
         t.requires_grad_(True)
-    m = dict(task="forecasting", pred_len=pred, patch_len=16, stride=8, n_heads=8, d_ff=128, covariate_mode="concat",
-             embedding_downsample_mode="linear", n_outputs_per_step=C_, n_classes=0)
-    b = make_batch(Bs, L, C_, pred, 7, "cpu")
+    semseg = task == "semantic_segmentation"
+    m = dict(task=task, pred_len=pred, patch_len=16, stride=8, n_heads=8, d_ff=128, covariate_mode=cov,
+             embedding_downsample_mode="linear", n_outputs_per_step=4 if semseg else C_, n_classes=4 if semseg else 0)
+    b = make_batch(Bs, L, C_, pred, 7, "cpu", task)
     tok = [[prompt_ids] for _ in range(Bs)]
 
     def step():
         out = O.medtsllm_forward(b["x_enc"], p, sd, hf_cfg, m, token_ids=tok, pad_token_id=0, training=True)
-        torch.nn.functional.mse_loss(out, b["y"]).backward()
+        if semseg:
+            torch.nn.functional.cross_entropy(out.permute(0, 2, 1), b["y"]).backward()
+        else:
+            torch.nn.functional.mse_loss(out, b["y"]).backward()
         for t in p.values():
             t.grad = None
 
@@ -183,6 +187,31 @@ def cpu_baseline(hf_cfg, sd, L, C_, pred, n_tok, prompt_ids, max_seconds=30.0):
             # measured once in the build container (8 cores, the only machine where both run): the real
             # reference does the same B=4 step 1.54x faster than this port (HF's fused attention/MLP paths vs plain restatement)
             "reference_speed_over_port": 1.54}
+
+
+def cpu_baseline_llama(hf_cfg, L, C_, pred, n_tok, prompt_ids, task, cov="concat"):
+    """the Llama configs' CPU figure, EXTRAPOLATED — a 32-layer 7B/8B stack in fp32 does not fit a bounded
+    sample, so the same oracle step is timed with the stack cut to 2 layers and to 1 layer (llm_layers, R:models/medtsllm.py:145-146; same
+    front end, mapping GEMM and head); a layer costs t2 - t1, the full depth t1 + (n_layers - 1) (t2 - t1). Also reported: the cruder
+    "2 layers x n_layers / 2" figure of BASELINE.md (it scales the front end and the head along with the stack, i.e. favours the GPU)."""
+    from med_ts_llm_amd.models.backbone import random_state_dict
+    n_layers = hf_cfg["num_hidden_layers"]
+    out = {}
+    times = {}
+    for k in (1, 2):
+        cfg_k = dict(hf_cfg, num_hidden_layers=k)
+        sd = random_state_dict(cfg_k, seed=0, std=0.02)
+        r = cpu_baseline(cfg_k, sd, L, C_, pred, n_tok, prompt_ids, max_seconds=12.0, task=task, Bs=2, cov=cov)
+        times[k] = 2.0 / r["value"]
+        out = r
+        del sd
+    per_layer = max(times[2] - times[1], 1e-9)
+    full = times[1] + (n_layers - 1) * per_layer
+    out.update({"value": round(2.0 / full, 4), "kind": "port", "extrapolated": True,
+                "sample": f"B=2 windows [L={L}, C={C_}], fp32 plain-torch oracle, stack cut to 1 and 2 layers: {times[1]:.2f} s and {times[2]:.2f} s per "
+                          f"fwd+bwd step -> {per_layer:.2f} s per layer, {full:.1f} s per step at {n_layers} layers (EXTRAPOLATED, not run)",
+                "two_layers_times_half_depth_value": round(2.0 / (times[2] * n_layers / 2), 4)})
+    return out
 
 
 def csrc_sha16():
@@ -229,6 +258,58 @@ def roofline_objects(rows, workload):
     return roof, roof_hbm, inst
 
 
+def trainer_loop_rate(model, opt, sync, su, task, device, world, rank, dev_batches, steps, B):
+    """samples/s of BaseTask.train_step driven the way get_trainer(...).train() drives it: batches start in (pinned) HOST memory, every step
+    logs its loss. Two figures: the product default (the loss is copied out asynchronously and logged one step later: no queue drain) and the
+    reference's blocking `loss.item()` per step (setup.deferred_loss_log = false)."""
+    from med_ts_llm_amd.tasks import task_lookup
+    from med_ts_llm_amd.utils import dict_to_object
+    cls = task_lookup[task if task != "anomaly_detection" else "reconstruction"]
+    host_batches = [{k: v.cpu().pin_memory() for k, v in b.items()} for b in dev_batches]
+
+    class Quiet:
+        history = []
+
+        def log_scores(self, scores):
+            self.history.append(scores["train/loss"])
+
+    out = {}
+    for label, deferred in (("samples_per_s", True), ("samples_per_s_blocking_loss_item", False)):
+        tr = cls.__new__(cls)
+        tr.device, tr.dtype, tr.mixed, tr.model, tr.optimizer, tr.grad_sync = device, torch.float32, True, model, opt, sync
+        tr.config = dict_to_object({"training": {"batch_size": B * world}, "setup": {"deferred_loss_log": deferred}})
+        tr.logger, tr.step, tr.rank, tr.world_size, tr.opt_shards = Quiet(), 0, rank, world, su
+        if task == "semantic_segmentation":
+            tr.loss_fn = torch.nn.CrossEntropyLoss()
+            tr.compute_loss = lambda inputs, tr=tr: tr.loss_fn(tr.model(inputs).permute(0, 2, 1), inputs["y"])
+        else:
+            tr.loss_fn = torch.nn.MSELoss()
+            if task == "forecasting":
+                tr.compute_loss = lambda inputs, tr=tr: tr.loss_fn(tr.model(inputs), inputs["y"])
+        for i in range(2):
+            tr.train_step(host_batches[i % len(host_batches)])
+        tr._flush_losses()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            tr.train_step(host_batches[i % len(host_batches)])
+        tr._flush_losses()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        out[label] = round(B * world * steps / dt, 2)
+        assert len(tr.logger.history) >= steps
+    out["steps"] = steps
+    out["what"] = ("BaseTask.train_step (tasks/base.py): prepare_batch from pinned host memory + autocast + forward + loss + backward + optimizer + "
+                   "zero_grad + per-step loss logging; default = loss logged one step late from an async copy, blocking = loss.item() every step")
+    return out
+
+
 def self_spawn(args):
     """`python bench.py --gpus N` without a launcher: re-run under torch.distributed.run, one rank per GPU. With fewer GPUs than
     ranks (a 1-GPU test box) the ranks share devices over gloo, since RCCL refuses two ranks per GPU."""
@@ -269,13 +350,20 @@ def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline):
     sharded = world > 1 and not args.replicate_mapping and model.shard_mapping_layer(rank, world)
     torch.manual_seed(1234 + 7919 * rank)      # rank-specific dropout streams (weights above were built from one seed)
     params = [p for p in model.parameters() if p.requires_grad]
+    # DP: row-sharded optimiser step for the big replicated tensors (wide flatten heads, Llama-3's trainable vocabulary): reduce-scatter,
+    # Adam on the owned rows, all-gather of the bf16 copy the forward reads
+    su = parallel.ShardedUpdate(list(model.named_parameters()), rank, world) if (world > 1 and not args.replicate_optimizer) else None
+    opt_params = su.optimizer_params(params) if su is not None else params
     if args.torch_adam:
-        opt = torch.optim.Adam(params, lr=1e-4, fused=True)
+        opt = torch.optim.Adam(opt_params, lr=1e-4, fused=True)
     else:
-        from med_ts_llm_amd.hip.optim import HipAdam
-        opt = HipAdam(params, lr=1e-4)
+        from med_ts_llm_amd.hip.optim import HipAdam, Bf16Shadow
+        opt = HipAdam(opt_params, lr=1e-4)
         for sh in model.bf16_shadows():
-            opt.register_shadow(sh)
+            if su is not None and id(sh.param) in su._by_param:
+                opt.register_shadow(Bf16Shadow(su._by_param[id(sh.param)]["shard"], su.attach_shadow(sh.param, sh.tensor)))
+            else:
+                opt.register_shadow(sh)
     sync = parallel.FlatGradAllReduce(params) if world > 1 else None
     loss_fn = torch.nn.MSELoss() if task != "semantic_segmentation" else torch.nn.CrossEntropyLoss()
     batches = [make_batch(B, L, C_, pred, 1000 + rank * 97 + i, device, task) for i in range(4)]
@@ -288,7 +376,11 @@ def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline):
         loss.backward()
         if sync is not None:
             sync()
+        if su is not None:
+            su.sync()
         opt.step()
+        if su is not None:
+            su.publish()
         opt.zero_grad()
         return loss
 
@@ -331,19 +423,30 @@ def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline):
             adam = [r for r in rows if r["kernel"].startswith("adam")]
             optimizer_ms = sum(r["total_ms"] for r in adam) / n_replay if adam else None
 
+    # the product trainer's own loop body (tasks/base.py::train_step = R:tasks/forecasting.py:19-30): prepare_batch from HOST memory
+    # (H2D + cast), autocast, forward, loss, backward, [all-reduce], optimizer, zero_grad, per-step loss logging. `value` above is the same
+    # step without the host batch and the logging; this is what a user of get_trainer(...).train() gets.
+    loop = None
+    if want_roofline:
+        loop = trainer_loop_rate(model, opt, sync, su, task, device, world, rank, batches, min(steps, 10), B)
+
     cpu = None
+    if rank == 0 and world == 1 and want_cpu and big:
+        cpu = cpu_baseline_llama(hf_cfg, L, C_, pred, n_tok, prompt_ids[0].tolist(), task, cov)
     if rank == 0 and world == 1 and want_cpu and not big:
         cpu = cpu_baseline(hf_cfg, sd, L, C_, pred, n_tok, prompt_ids[0].tolist())
         if name == "gpt2s_B32_L1024_C12":     # BASELINE.json configs[0]: the reference's CPU-runnable case, timed beside the metric workload
-            _, _, L1, C1, pred1, n_tok1, _ = WORKLOADS["gpt2s_etth1_B32_L512_C7"]
+            _, _, L1, C1, pred1, n_tok1, _, _ = workload("gpt2s_etth1_B32_L512_C7")
             cpu["configs"] = [dict(cpu_baseline(hf_cfg, sd, L1, C1, pred1, n_tok1, prompt_ids[0].tolist(), max_seconds=20.0),
                                    workload="gpt2s_etth1_B32_L512_C7 (BASELINE.json configs[0]: ETTh1-shaped [B, 512, 7] forecasting, GPT-2-small, CPU fp32)")]
 
     out = None
     if rank == 0:
-        P = (L + 8 - 16) // 8 + 1
+        P = ((L + 8 - 16) // 8 + 1) * (C_ if cov == "interleave" else 1)
         T = n_tok + P
-        fl, fl_exec = flops_per_step(hf_cfg, B, T, P, C_, pred * (C_ if task != "semantic_segmentation" else 4), min(hf_cfg["vocab_size"], 100_000))
+        n_cached = int(getattr(model.backbone, "last_n_prefix", 0))
+        fl, fl_exec = flops_per_step(hf_cfg, B, T, P, C_, pred * (C_ if task != "semantic_segmentation" else 4), min(hf_cfg["vocab_size"], 100_000),
+                                     cov=cov, n_cached=n_cached)
         if args.full_backward:
             fl_exec = fl
         value = B * world * steps / elapsed
@@ -352,7 +455,7 @@ def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline):
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{name}: [B={B}/GPU, L={L}, C={C_}] windows, P={P}, prompt {n_tok} tok -> T={T}, "
-                                   f"frozen {name.split('_')[0] + '-' + name.split('_')[1] if big else 'GPT-2-small'} (random init) backbone, concat covariates, "
+                                   f"frozen {name.split('_')[0] + '-' + name.split('_')[1] if big else 'GPT-2-small'} (random init) backbone, {cov} covariates, "
                                    f"{task} pred_len={pred}, training.dropout=0.1 (patch-embedding + reprogramming-attention dropout live"
                                    f"{', GPT-2 embd/attn/resid dropouts live' if (not big and not args.no_llm_dropout) else ''}), "
                                    f"step = fwd+loss+bwd+{'allreduce+' if world > 1 else ''}Adam", "global_batch": B * world,
@@ -362,13 +465,17 @@ def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline):
             "final_loss": final_loss,
             "backward": "full (incl. unused prompt-row input gradients)" if args.full_backward else
                         "exact dead-gradient elimination: prompt rows never depend on a trainable parameter, their input gradient is not computed",
+            "forward": (f"prompt-row cache: the {n_cached} prompt rows are one constant prompt shared by every sample and the stack is deterministic, so their "
+                        "per-layer keys / values are cached and the forward runs on the patch rows only (executed FLOPs drop; the algorithmic count and every "
+                        "roofline denominator keep the full sequence)") if n_cached else "full sequence",
+            "trainer_loop": loop,
             "algorithmic_tflop_per_step_per_gpu": round(fl / 1e12, 3), "executed_tflop_per_step_per_gpu": round(fl_exec / 1e12, 3),
             "step_mfma_frac": round(fl_exec / (elapsed / steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
             "step_mfma_frac_algorithmic": round(fl / (elapsed / steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
             "optimizer_ms_per_step": optimizer_ms, "roofline": roofline, "roofline_hbm": roofline_hbm, "kernel_instances": instances,
             "cpu_baseline": cpu,
         }
-    del model, opt, sync, batches, sd, params
+    del model, opt, sync, batches, sd, params, su, opt_params
     torch.cuda.empty_cache()
     return out
 
@@ -384,6 +491,7 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the Llama-2-7B line that the default run attaches as configs[]")
     ap.add_argument("--full-backward", action="store_true", help="also compute the (unused) prompt-row input gradients")
     ap.add_argument("--replicate-mapping", action="store_true", help="DP: keep the mapping layer replicated (all-reduce its gradient)")
+    ap.add_argument("--replicate-optimizer", action="store_true", help="DP: no row-sharded optimiser step for the big tensors (all-reduce + replicated Adam)")
     ap.add_argument("--no-llm-dropout", action="store_true", help="GPT-2: switch the frozen LLM's train-mode dropouts (0.1) off")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the HIP multi-tensor Adam")
     args = ap.parse_args()
@@ -405,10 +513,15 @@ def main():
     if args.workload == "gpt2s_B32_L1024_C12" and not args.no_extra_configs:
         # BASELINE.json configs[2] (LUDB-shaped semantic segmentation on a frozen Llama-2-7B) on the same GPUs, right after the headline
         # workload's timed region: the configuration where the backbone GEMMs are large enough for the >= 40 % MFMA target
-        extra = run_workload("llama2_7b_semseg_B32_L1024_C12", args, ctx, steps=5, warmup=2, want_cpu=False, want_roofline=not args.no_roofline)
+        extra = run_workload("llama2_7b_semseg_B32_L1024_C12", args, ctx, steps=5, warmup=2, want_cpu=not args.no_cpu_baseline, want_roofline=not args.no_roofline)
         if rank == 0:
             extra["metric"] = "samples/sec ([B, 1024, 12] windows, Llama-2-7B frozen backbone) through MedTsLLM fwd+bwd"
             out["configs"] = [extra]
+        # the same backbone with interleave covariates -> T = 1664 per sample (flash attention regime)
+        extra2 = run_workload("llama2_7b_semseg_interleave_B16_L1024_C12", args, ctx, steps=3, warmup=2, want_cpu=not args.no_cpu_baseline, want_roofline=not args.no_roofline)
+        if rank == 0:
+            extra2["metric"] = "samples/sec ([B, 1024, 12] windows, interleave covariates: T = 1664, Llama-2-7B frozen backbone) through MedTsLLM fwd+bwd"
+            out["configs"].append(extra2)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

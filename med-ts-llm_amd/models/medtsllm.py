@@ -224,6 +224,15 @@ class MedTsLLM(nn.Module):
             _, world, _, _, group = self._map_shard
             for k in [k for k in sd if k.endswith("mapping_layer.weight") or k.endswith("mapping_layer.bias")]:
                 sd[k] = parallel.gather_rows(sd[k], world, group)
+        su = getattr(self, "_opt_shards", None)
+        if su is not None and su.world > 1:
+            # row-sharded optimiser step that publishes bf16 rows only (parallel.ShardedUpdate): a rank's fp32 master is current for the
+            # rows it owns; the checkpoint gathers every owner's rows (a collective, like the mapping rows above)
+            from .. import parallel
+            for it in su.items:
+                for k in [k for k in sd if k == it["name"] or k.endswith("." + it["name"])]:
+                    if it["shadow"] is not None:
+                        sd[k] = parallel.gather_rows(sd[k][it["r0"]:it["r1"]].contiguous(), su.world, su.group)
         return sd
 
     def load_state_dict(self, state_dict, *args, **kwargs):
@@ -498,7 +507,7 @@ class MedTsLLM(nn.Module):
         # and a deterministic stack (Llama always; GPT-2 outside train mode) -> the prompt rows' keys / values per layer are the same in
         # every sample and every step. Keyed by the token ids; per-sample prompts (statistics, clip descriptions, examples) never cache.
         prefix = None
-        if (self.prompt_row_cache and ids is not None and ids.shape[0] == 1 and splice is None and not llm_drop
+        if (self.prompt_row_cache and ids is not None and ids.shape[0] == 1 and splice is None and drop is None and embd_p == 0
                 and ids.shape[1] <= h0.shape[1] - self.n_patches):
             key = self._prompt_key(ids)
             prefix = bb.prefix_cache(h0[:1, :ids.shape[1]], key, h0.shape[1])

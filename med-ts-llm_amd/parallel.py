@@ -89,7 +89,7 @@ class FlatGradAllReduce:
     def __init__(self, params, group=None, bucket_elems=32 * 1024 * 1024, overlap=True):
         # row-sharded parameters (p._dp_sharded, see AllGatherRows) already hold globally averaged gradients of rows no
         # other rank owns: they are neither communicated nor averaged again
-        self.params = [p for p in params if p.requires_grad and not getattr(p, "_dp_sharded", False)]
+        self.params = [p for p in params if p.requires_grad and not getattr(p, "_dp_sharded", False) and not getattr(p, "_dp_opt_sharded", False)]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         n = sum(p.numel() for p in self.params)
@@ -175,6 +175,122 @@ class FlatGradAllReduce:
         for p, view in zip(self.params, self.views):
             p.grad = view                # the optimiser reads the averaged gradient straight from the flat buffer
         self._arm()
+
+
+class ShardedUpdate:
+    """Row-sharded optimiser step for the BIG replicated tensors (ZeRO-1 restricted to tensors of >= min_numel elements whose rows
+    divide by the world size): the PSM flatten head (51 200 x 32 768 = 1.68 G elements), Llama-3's trainable sub-sampled word
+    embeddings (100 000 x 4096) and its mapping weight. Per step and tensor:
+
+      backward        every rank forms the full local gradient (the forward needs the full weight anyway)
+      reduce-scatter  rank r receives the sum of rows [r R/N, (r+1) R/N) — launched from a post-accumulate-grad hook, so the head's
+                      payload travels under the frozen backbone's backward (gloo has no reduce-scatter: all-reduce + slice, same sums)
+      optimiser       on the owned rows only: `shard` is an nn.Parameter VIEW of those rows of p, so any optimiser updates p's storage
+                      in place; its moments exist for 1/N of the tensor (the 8.2 ms replicated Adam of the PSM head becomes ~1 ms at N = 8)
+      all-gather      of what the forward READS: the bf16 shadow rows (2 B per element on the wire) when the optimiser maintains one
+                      (HipAdam + Bf16Shadow), else the fp32 rows themselves
+
+    Wire bytes per element: 4 (reduce-scatter) + 2 (bf16 all-gather) instead of the all-reduce's 4 + 4. With bf16 publishing the fp32
+    master rows of OTHER ranks go stale locally; `owned_rows(name)` tells a checkpoint writer what to gather (MedTsLLM.state_dict does).
+    Results equal the replicated path's up to the summation order of the collective."""
+
+    def __init__(self, named_params, rank, world, group=None, min_numel=1 << 24):
+        self.rank, self.world, self.group = rank, world, group
+        self.items, self._by_param = [], {}
+        self._rs = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        for name, p in named_params:
+            if (not p.requires_grad or getattr(p, "_dp_sharded", False) or p.dim() < 2 or p.numel() < min_numel or p.shape[0] % world
+                    or not p.is_contiguous()):
+                continue
+            r0, r1 = shard_range(p.shape[0], rank, world)
+            shard = torch.nn.Parameter(p.data[r0:r1])
+            p._dp_opt_sharded = True                       # FlatGradAllReduce leaves it alone
+            it = {"name": name, "p": p, "shard": shard, "r0": r0, "r1": r1, "handle": None, "dirty": False, "shadow": None,
+                  "gshard": torch.empty_like(p.data[r0:r1])}
+            self.items.append(it)
+            self._by_param[id(p)] = it
+            if world > 1 and hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
+                p.register_post_accumulate_grad_hook(lambda q, it=it: self._on_grad(it))
+
+    def optimizer_params(self, params):
+        """`params` (list of tensors or of param-group dicts) with every sharded tensor replaced by its owned-rows parameter"""
+        def swap(ps):
+            return [self._by_param[id(q)]["shard"] if id(q) in self._by_param else q for q in ps]
+        if params and isinstance(params[0], dict):
+            return [{**g, "params": swap(g["params"])} for g in params]
+        return swap(list(params))
+
+    def owned_rows(self, name):
+        for it in self.items:
+            if it["name"] == name:
+                return it["r0"], it["r1"]
+        return None
+
+    def attach_shadow(self, param, shadow_tensor):
+        """the optimiser keeps shadow_tensor[r0:r1] (bf16) = bf16(updated owned rows): publish() then gathers the shadow instead of the
+        master. Returns the owned-rows slice (what the optimiser's shadow hook must write)."""
+        it = self._by_param[id(param)]
+        it["shadow"] = shadow_tensor
+        return shadow_tensor[it["r0"]:it["r1"]]
+
+    @torch.no_grad()
+    def _reduce(self, it):
+        g = it["p"].grad
+        if self._rs:
+            it["handle"] = dist.reduce_scatter_tensor(it["gshard"], g.contiguous(), op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            it["handle"] = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    @torch.no_grad()
+    def _on_grad(self, it):
+        if it["handle"] is not None:
+            it["dirty"] = True                         # a second backward before sync(): reduce again from the accumulated gradient
+            return
+        self._reduce(it)
+
+    @torch.no_grad()
+    def sync(self):
+        """after backward: every owned-rows parameter gets the global-mean gradient of its rows; the full local gradient is released"""
+        for it in self.items:
+            p = it["p"]
+            if p.grad is None:
+                it["shard"].grad = None
+                continue
+            if self.world > 1:
+                if it["dirty"] and it["handle"] is not None:
+                    it["handle"].wait()
+                    if not self._rs:
+                        raise RuntimeError("gradient accumulation with an all-reduce fallback would sum the first micro-batch twice: "
+                                           "call sync() after every backward on this backend")
+                    it["handle"] = None
+                if it["handle"] is None:
+                    self._reduce(it)
+                it["handle"].wait()
+                if not self._rs:
+                    it["gshard"].copy_(p.grad[it["r0"]:it["r1"]])
+                it["gshard"].div_(self.world)
+            else:
+                it["gshard"].copy_(p.grad[it["r0"]:it["r1"]])
+            it["shard"].grad = it["gshard"]
+            p.grad = None
+            it["handle"], it["dirty"] = None, False
+
+    @torch.no_grad()
+    def publish(self):
+        """after optimizer.step(): every rank's updated rows reach every rank — as bf16 shadow rows when there is one, else as fp32"""
+        if self.world <= 1:
+            return
+        for it in self.items:
+            full = it["shadow"] if it["shadow"] is not None else it["p"].data
+            per = it["r1"] - it["r0"]
+            if self._rs and full.is_contiguous():
+                dist.all_gather_into_tensor(full.view(-1), full[it["r0"]:it["r1"]].reshape(-1), group=self.group)
+            else:
+                parts = [torch.empty_like(full[:per]) for _ in range(self.world)]
+                dist.all_gather(parts, full[it["r0"]:it["r1"]].contiguous(), group=self.group)
+                for i, t in enumerate(parts):
+                    if i != self.rank:
+                        full[i * per:(i + 1) * per].copy_(t)
 
 
 def shard_batch(batch, rank, world):

@@ -99,6 +99,14 @@ class BaseTask(ABC):
             torch.manual_seed(self.config.setup.seed + 7919 * (self.rank + 1))
         if self.world_size > 1 and self.config.setup.get("shard_mapping", True) and hasattr(self.model, "shard_mapping_layer"):
             self.model.shard_mapping_layer(self.rank, self.world_size)      # DP: rows of the mapping layer live on one rank each
+        # DP: the big replicated tensors (flatten head of the wide configs, Llama-3's trainable vocabulary) get a row-sharded optimiser
+        # step — reduce-scatter of their gradient, Adam on the owned rows, all-gather of the bf16 copy the forward reads (parallel.ShardedUpdate)
+        self.opt_shards = None
+        if self.world_size > 1 and self.config.setup.get("shard_optimizer", True):
+            su = parallel.ShardedUpdate(list(self.model.named_parameters()), self.rank, self.world_size,
+                                        min_numel=int(self.config.setup.get("shard_optimizer_min_numel", 1 << 24)))
+            if su.items:
+                self.opt_shards = self.model._opt_shards = su
         self.optimizer = self.build_optimizer()
         self.scheduler = self.build_scheduler()
         self.loss_fn = self.build_loss().to(device=self.device)
@@ -138,6 +146,9 @@ class BaseTask(ABC):
                       {"params": [p for n, p in named if n in self.loaded_params]}]
         else:
             params = [p for p in self.model.parameters() if p.requires_grad]
+        su = getattr(self, "opt_shards", None)
+        if su is not None:
+            params = su.optimizer_params(params)          # owned-rows views instead of the full tensors
         lr = self.config.training.learning_rate
         opt = self.config.training.optimizer
         if self.device.type == "cuda" and opt in ("adam", "adamw"):
@@ -145,8 +156,14 @@ class BaseTask(ABC):
             # copy of the big mapping weight is written by the same kernel (hip/optim.py)
             from ..hip.optim import HipAdam
             o = HipAdam(params, lr=lr, weight_decay=0.01 if opt == "adamw" else 0.0, decoupled_weight_decay=opt == "adamw")
+            from ..hip.optim import Bf16Shadow
             for sh in getattr(self.model, "bf16_shadows", lambda: [])():
-                o.register_shadow(sh)
+                if su is not None and id(sh.param) in su._by_param:
+                    # the optimiser writes the bf16 copy of the rows it owns; ShardedUpdate.publish() gathers the others' (2 B / element)
+                    it = su._by_param[id(sh.param)]
+                    o.register_shadow(Bf16Shadow(it["shard"], su.attach_shadow(sh.param, sh.tensor)))
+                else:
+                    o.register_shadow(sh)
             return o
         if opt == "adam":
             return optim.Adam(params, lr=lr)
@@ -179,6 +196,9 @@ class BaseTask(ABC):
     # ---- optimiser state in checkpoints, keyed by parameter NAME so that it survives a changed parameter order
     def optimizer_state(self):
         named = {id(p): n for n, p in self.model.named_parameters()}
+        su = getattr(self, "opt_shards", None)
+        owned = {id(it["shard"]): it for it in su.items} if su is not None else {}
+        named.update({k: it["name"] for k, it in owned.items()})
         shard = getattr(self.model, "_map_shard", None)
         out = {"type": type(self.optimizer).__name__, "state": {}, "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.optimizer.param_groups],
                "group_of": {}}
@@ -190,6 +210,8 @@ class BaseTask(ABC):
             for k, v in st.items():
                 if torch.is_tensor(v) and v.dim() > 0 and shard is not None and getattr(p, "_dp_sharded", False):
                     v = parallel.gather_rows(v, shard[1], shard[4])              # row-sharded mapping layer: full moments, like the weights
+                elif torch.is_tensor(v) and v.dim() > 0 and id(p) in owned:
+                    v = parallel.gather_rows(v, su.world, su.group)              # row-sharded optimiser step: the moments of every rank's rows
                 rec[k] = v.detach().cpu() if torch.is_tensor(v) else v
             out["state"][named[id(p)]] = rec
         return out
@@ -198,6 +220,12 @@ class BaseTask(ABC):
         if not saved or saved.get("type") != type(self.optimizer).__name__:
             return False
         by_name = dict(self.model.named_parameters())
+        su = getattr(self, "opt_shards", None)
+        owned_rows = {}
+        if su is not None:
+            for it in su.items:
+                by_name[it["name"]] = it["shard"]
+                owned_rows[id(it["shard"])] = (it["r0"], it["r1"])
         shard = getattr(self.model, "_map_shard", None)
         for g, sg in zip(self.optimizer.param_groups, saved["param_groups"]):
             g.update({k: v for k, v in sg.items() if k in g and k != "params"})
@@ -210,6 +238,8 @@ class BaseTask(ABC):
                 if torch.is_tensor(v) and v.dim() > 0:
                     if shard is not None and getattr(p, "_dp_sharded", False) and v.shape[0] != p.shape[0]:
                         v = v[shard[2]:shard[3]]
+                    elif id(p) in owned_rows and v.shape[0] != p.shape[0]:
+                        v = v[owned_rows[id(p)][0]:owned_rows[id(p)][1]]
                     v = v.to(device=p.device, dtype=p.dtype if v.is_floating_point() else v.dtype).contiguous().clone()
                 st[k] = v
             self.optimizer.state[p] = st
@@ -251,7 +281,9 @@ class BaseTask(ABC):
         if isinstance(batch, (list, tuple)):
             return [self.prepare_batch(x) for x in batch]
         if isinstance(batch, torch.Tensor):
-            batch = batch.to(self.device)
+            # pinned source (the loaders pin): an asynchronous copy ordered on the current stream; a blocking one would wait for the GPU
+            # queue to drain before every step (the host allocator keeps a pinned block alive until the copies that read it have run)
+            batch = batch.to(self.device, non_blocking=batch.is_pinned())
             if batch.dtype.is_floating_point:
                 batch = batch.to(self.dtype)
             return batch
@@ -287,17 +319,50 @@ class BaseTask(ABC):
         loss.backward()
         if self.grad_sync is not None:
             self.grad_sync()
+        if self.opt_shards is not None:
+            self.opt_shards.sync()
         self.optimizer.step()
+        if self.opt_shards is not None:
+            self.opt_shards.publish()
         self.optimizer.zero_grad()
-        if self.grad_sync is not None:
-            # one D2H copy fetches the loss and the ranks' agreed pre-emption flag (it travelled in the gradient all-reduce)
-            loss_v, stop = torch.stack([loss.detach().float().reshape(()), self.grad_sync.flag_value().reshape(())]).tolist()
-            self.log_step(loss_v)
-            if stop > 0:
-                self._checkpoint_and_exit()
-        else:
-            self.log_step(loss.item())
+        self._log_loss(loss)
         return loss
+
+    # ---- per-step loss logging without draining the GPU queue
+    # R:tasks/forecasting.py:30 logs `loss.item()` after every step: a blocking D2H copy that waits for the whole step, after which the host
+    # starts enqueueing the next step's ~230 launches into an EMPTY queue (the GPU idles for the host's enqueue latency every step). On a
+    # GPU the loss (and, under DP, the ranks' agreed pre-emption flag that travelled in the gradient all-reduce) is instead copied to a pinned
+    # host slot asynchronously, and each step logs the PREVIOUS step's value once its copy event has fired — the same numbers in the same
+    # order, one step later; the epoch's last loss is flushed before validation. setup.deferred_loss_log = false restores the blocking read.
+    def _log_loss(self, loss):
+        vals = [loss.detach().float().reshape(())]
+        if self.grad_sync is not None:
+            vals.append(self.grad_sync.flag_value().reshape(()))
+        if self.device.type != "cuda" or not self.config.setup.get("deferred_loss_log", True):
+            host = torch.stack(vals).tolist()
+            self._loss_arrived(host)
+            return
+        if not hasattr(self, "_loss_ring"):
+            self._loss_ring = [(torch.empty(2, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+            self._loss_pending, self._loss_i = [], 0
+        slot, ev = self._loss_ring[self._loss_i]
+        self._loss_i ^= 1
+        slot[:len(vals)].copy_(torch.stack(vals), non_blocking=True)
+        ev.record()
+        self._loss_pending.append((slot, ev, len(vals)))
+        self._flush_losses(keep=1)
+
+    def _flush_losses(self, keep=0):
+        pend = getattr(self, "_loss_pending", None)
+        while pend and len(pend) > keep:
+            slot, ev, n = pend.pop(0)
+            ev.synchronize()
+            self._loss_arrived(slot[:n].tolist())
+
+    def _loss_arrived(self, host):
+        self.log_step(host[0])
+        if len(host) > 1 and host[1] > 0:          # some rank was told to stop: every rank sees the same sum at the same step
+            self._checkpoint_and_exit()
 
     def train(self):
         for epoch in range(self.epochs_done, self.config.training.epochs):     # (a run resumed by from_run_id continues where it stopped)
@@ -308,6 +373,7 @@ class BaseTask(ABC):
             self.model.train()
             for inputs in self.train_dataloader:
                 self.train_step(inputs)
+            self._flush_losses()
             val_scores = self.val()
             self.epochs_done = epoch + 1
             self.log_epoch(val_scores)
@@ -316,15 +382,15 @@ class BaseTask(ABC):
 
     def _eval_loss(self, loader, prefix):
         self.model.eval()
-        tot, n = 0.0, 0
+        tot, n = 0.0, 0          # (the running sum stays on the device: ONE D2H read per split instead of one queue drain per batch)
         with torch.no_grad():
             for inputs in loader:
                 inputs = self.prepare_batch(inputs)
                 with torch.autocast(self.device.type, dtype=torch.bfloat16, enabled=self.mixed):
                     loss = self.compute_loss(inputs)
                 bs = inputs["x_enc"].shape[0]
-                tot, n = tot + loss.item() * bs, n + bs
-        scores = {f"{prefix}/{self.config.training.eval_metric}": tot / max(n, 1)}
+                tot, n = tot + loss.detach().double() * bs, n + bs
+        scores = {f"{prefix}/{self.config.training.eval_metric}": float(tot) / max(n, 1)}
         self.log_scores(scores)
         return scores
 
@@ -391,6 +457,7 @@ class BaseTask(ABC):
 
     def _checkpoint_and_exit(self):
         print("Interrupted!")
+        self._flush_losses()
         self.logger.save_state("latest")
         self.log_end()
         raise SystemExit(0)

@@ -86,8 +86,10 @@ def test_model_cached_equals_uncached(kind, task, cov):
     # GPT-2's own dropouts are off in this fixture config (pdrop = 0): its stack is deterministic in train mode too
     assert npre == 24
     assert rel_err(o_c, o_ref) < 3e-3
+    params = dict(model.named_parameters())
     for n in g_ref:
-        scale = max(float(g_ref[n].norm()), 1e-6)
+        # analytically-zero gradients (the key bias: softmax shift invariance) are pure round-off: compared on an absolute scale
+        scale = max(float(g_ref[n].norm()), 1e-3 * float(params[n].detach().norm()) + 1e-6)
         assert float((g_c[n] - g_ref[n]).norm()) / scale < 1.5e-2, n
     e_ref, _, _ = run(False, False)
     e_c, _, npre = run(True, False)
