@@ -23,8 +23,21 @@ GPT2_SMALL = {"model_type": "gpt2", "vocab_size": 50257, "n_positions": 1024, "n
 # SwiGLU / dSwiGLU epilogues at ffn = 11008, hd = 128 resident attention, RoPE, the 16384 -> 4096 head — at 1/16 of the run time
 LLAMA2_7B = {"model_type": "llama", "vocab_size": 32000, "hidden_size": 4096, "intermediate_size": 11008, "num_hidden_layers": 32,
              "num_attention_heads": 32, "num_key_value_heads": 32, "rms_norm_eps": 1e-5, "rope_theta": 10000.0}
-B, L, C, NTOK = 32, 1024, 12, 128
-GEOMETRIES = {"gpt2s": (GPT2_SMALL, "forecasting", 96, -1), "llama2_7b_2layers": (LLAMA2_7B, "semantic_segmentation", 1024, 2)}
+LLAMA3_8B = {"model_type": "llama", "vocab_size": 128256, "hidden_size": 4096, "intermediate_size": 14336, "num_hidden_layers": 32,
+             "num_attention_heads": 32, "num_key_value_heads": 8, "rms_norm_eps": 1e-5, "rope_theta": 500000.0}
+NTOK = 128
+# name: (hf config, task, pred_len, llm_layers, B, L, C)
+GEOMETRIES = {
+    "gpt2s": (GPT2_SMALL, "forecasting", 96, -1, 32, 1024, 12),                                   # the metric workload
+    "llama2_7b_2layers": (LLAMA2_7B, "semantic_segmentation", 1024, 2, 32, 1024, 12),           # BASELINE.json configs[2]
+    # configs[1]: ETTh1-shaped [32, 512, 7] forecasting — concat width 7 * 32 = 224 (padded to 256), P = 64, T = 192
+    "gpt2s_etth1": (GPT2_SMALL, "forecasting", 96, -1, 32, 512, 7),
+    # configs[3] geometry: PSM anomaly detection, C = 25 -> concat width 800 (padded to 832), P = 256, T = 384, flatten head
+    # 32768 -> 51200 = 1.68 G parameters: every fp32 tensor of it is > 2^31 BYTES (index widths), HipAdam walks 6.7 GB per moment
+    "llama2_7b_psm_2layers": (LLAMA2_7B, "anomaly_detection", 2048, 2, 32, 2048, 25),
+    # configs[4] geometry: Llama-3-8B — GQA 32 / 8 at hd 128, ffn 14336, vocabulary 128 256 -> 100 000 TRAINABLE sub-sampled rows
+    "llama3_8b_2layers": (LLAMA3_8B, "reconstruction", 1024, 2, 32, 1024, 12),
+}
 
 
 @pytest.fixture(scope="module", params=list(GEOMETRIES))
@@ -32,7 +45,7 @@ def model(request):
     from med_ts_llm_amd.models import model_lookup
     from med_ts_llm_amd.models.backbone import random_state_dict
     from med_ts_llm_amd.utils import dict_to_object
-    hf, task, pred, layers = GEOMETRIES[request.param]
+    hf, task, pred, layers, B, L, C = GEOMETRIES[request.param]
     cfg = {"DEBUG": True, "task": task, "model": "medtsllm", "history_len": L, "pred_len": pred,
            "training": {"dropout": 0.0}, "setup": {"dtype": "mixed"}, "tasks": {"segmentation": {"mode": "boundary-prediction"}},
            "models": {"timellm": {"d_model": 32, "d_ff": 128, "n_heads": 8, "num_tokens": 1024, "covariate_mode": "concat",
@@ -46,17 +59,20 @@ def model(request):
     m = model_lookup["medtsllm"](dict_to_object(cfg), FakeDataset(C, 4 if task == "semantic_segmentation" else 0), backbone_state=(hf_small, sd)).to("cuda")
     m.fixed_prompt_ids = torch.randint(0, hf["vocab_size"], (1, NTOK), generator=torch.Generator().manual_seed(1), dtype=torch.int32)
     m.train()
+    m.geo = (B, L, C)
     yield m
     del m
     torch.cuda.empty_cache()
 
 
-def _x(seed=0):
+def _x(model, seed=0):
+    B, L, C = model.geo
     g = torch.Generator().manual_seed(seed)
     return (torch.randn(B, L, C, generator=g) * (0.5 + torch.rand(1, 1, C, generator=g)) + 4 * torch.rand(1, 1, C, generator=g) - 2).cuda()
 
 
 def _target(model, seed):
+    B, L, C = model.geo
     g = torch.Generator().manual_seed(seed)
     if model.task == "semantic_segmentation":
         return torch.randint(0, 4, (B, model.pred_len), generator=g).cuda()
@@ -75,10 +91,11 @@ def _grads(model, x, y):
 
 
 def test_full_size_step_is_deterministic(model):
-    x, y = _x(), _target(model, 3)
+    x, y = _x(model), _target(model, 3)
     o1, g1 = _grads(model, x, y)
     o2, g2 = _grads(model, x, y)
-    assert o1.shape == (B, model.pred_len, C if model.task == "forecasting" else 4) and torch.isfinite(o1).all()
+    B, L, C = model.geo
+    assert o1.shape == (B, model.pred_len, 4 if model.task == "semantic_segmentation" else C) and torch.isfinite(o1).all()
     assert torch.equal(o1, o2)
     for n in g1:
         if n.endswith(".bias") or n.endswith("tokenConv.weight"):     # column sums / partial reductions accumulate with fp32 atomics: order varies
@@ -88,24 +105,26 @@ def test_full_size_step_is_deterministic(model):
 
 
 def test_full_size_samples_are_independent(model):
-    x = _x(1)
+    x = _x(model, 1)
+    B = model.geo[0]
     with torch.no_grad():
         full = model({"x_enc": x})
-        for i in (0, 17, 31):
+        for i in (0, 17, B - 1):
             one = model({"x_enc": x[i:i + 1]})
             assert rel_err(one, full[i:i + 1]) < 2e-2, i        # same arithmetic, different GEMM tile / split order
 
 
 def test_full_size_revin_equivariance(model):
-    x = _x(2)
-    a = torch.tensor([0.5, 3.0, 1.0, 7.5, 0.1, 2.0, 1.5, 0.25, 4.0, 1.0, 9.0, 0.7]).view(1, 1, C).cuda()
+    x = _x(model, 2)
+    C = model.geo[2]
+    a = torch.tensor(([0.5, 3.0, 1.0, 7.5, 0.1, 2.0, 1.5, 0.25, 4.0, 1.0, 9.0, 0.7] * 3)[:C]).view(1, 1, C).cuda()
     b = torch.linspace(-5, 5, C).view(1, 1, C).cuda()
     with torch.no_grad():
         y0 = model({"x_enc": x})
         y1 = model({"x_enc": a * x + b})
     # RevIN's eps (1e-5 under the sqrt) breaks exactness only at the 1e-5 level for unit-scale channels
-    if model.task == "forecasting":
-        assert rel_err(y1, a * y0 + b) < 2e-3
+    if model.task != "semantic_segmentation":
+        assert rel_err(y1, a * y0 + b) < (2e-3 if model.task == "forecasting" else 1.5e-2)
     else:
         # no de-normalisation on the classification head: the logits are INVARIANT under a per-channel affine map — up to the
         # 1e-5 perturbation of the normalised series by RevIN's eps, which flips bf16 roundings of the tokens and reaches the
@@ -114,7 +133,7 @@ def test_full_size_revin_equivariance(model):
 
 
 def test_full_size_pruned_backward_equals_full_backward(model):
-    x, y = _x(4), _target(model, 5)
+    x, y = _x(model, 4), _target(model, 5)
     model.prune_dead_prompt_grads = True
     _, gp = _grads(model, x, y)
     model.prune_dead_prompt_grads = False
@@ -132,13 +151,15 @@ def test_full_size_pruned_backward_equals_full_backward(model):
         # the key bias' exact gradient is zero (softmax shift invariance; with the consistent delta of the attention backward it
         # comes out at 1e-8, pure round-off): compare it — like every analytically-small gradient — on an absolute scale
         scale = max(float(gf[n].norm()), 1e-3 * float(params[n].detach().norm()) + 1e-6)
-        assert float((gp[n] - gf[n]).norm()) / scale < 2.5e-2, n
+        # (vectors of < 4096 elements — biases: sums with cancellation over an upstream gradient, e.g. the mapping bias = row sums of d source over
+        # d_llm columns — move coherently under a bf16-level perturbation of their summands: 3 x, the small-tensor rule of tests/test_gpu_model.py)
+        assert float((gp[n] - gf[n]).norm()) / scale < 2.5e-2 * (3.0 if gp[n].numel() < 4096 else 1.0), n
 
 
 def test_full_size_prompt_row_cache_equals_full_forward(model):
     """the prompt-row forward cache (mtl_backbone_fwd's prefix_kv) at size: same prediction and gradients as the full forward, to the floor
     between two tile configurations of the same arithmetic (the computed rows run M = B * n_patches GEMMs instead of M = B * T)"""
-    x, y = _x(6), _target(model, 7)
+    x, y = _x(model, 6), _target(model, 7)
     assert model.prompt_row_cache
     oc, gc = _grads(model, x, y)
     assert model.backbone.last_n_prefix == NTOK
@@ -156,3 +177,35 @@ def test_full_size_prompt_row_cache_equals_full_forward(model):
         # bf16-level perturbation of the summands moves them coherently — 3 x for tensors of < 4096 elements, as in tests/test_gpu_model.py
         bar = 2.5e-2 * (3.0 if gc[n].numel() < 4096 else 1.0)
         assert float((gc[n] - gf[n]).norm()) / scale < bar, n
+
+
+def test_full_size_hip_adam_step(model):
+    """one optimiser step at size (the PSM head: 1.68 G elements, every fp32 tensor of it > 2^31 bytes): HipAdam == the Adam formulas evaluated
+    by torch on strided samples of every tensor, the bf16 shadows of the trainable Linear weights == bf16(updated master) exactly"""
+    from med_ts_llm_amd.hip.optim import HipAdam
+    x, y = _x(model, 8), _target(model, 9)
+    params = [p for p in model.parameters() if p.requires_grad]
+    before = {id(p): p.detach().flatten()[:: max(1, p.numel() // 65536)].clone() for p in params}
+    _, _ = _grads(model, x, y)
+    grads = {id(p): p.grad.detach().flatten()[:: max(1, p.numel() // 65536)].clone() for p in params}
+    tail = {id(p): (p.detach().flatten()[-1].clone(), p.grad.detach().flatten()[-1].clone()) for p in params}
+    opt = HipAdam(params, lr=1e-3)
+    shadows = model.bf16_shadows()
+    for sh in shadows:
+        opt.register_shadow(sh)
+    opt.step()
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-8
+    for p in params:
+        g = grads[id(p)].double()
+        m, v = (1 - b1) * g, (1 - b2) * g * g
+        want = before[id(p)].double() - lr * (m / (1 - b1)) / ((v / (1 - b2)).sqrt() + eps)
+        got = p.detach().flatten()[:: max(1, p.numel() // 65536)].double()
+        assert float((got - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())), "strided sample"
+        p0, g0 = tail[id(p)]                                      # the LAST element: offsets beyond 2^31 bytes in the big tensors
+        w_last = p0.double() - lr * torch.sign(g0.double()) * (g0.double().abs() / (g0.double().abs() + eps))
+        assert abs(float(p.detach().flatten()[-1]) - float(w_last)) <= 2e-6 * max(1.0, abs(float(w_last)))
+    for sh in shadows:
+        W = sh.param.detach()
+        assert torch.equal(sh.tensor[:, :W.shape[1]][-2:], W[-2:].to(torch.bfloat16)) and torch.equal(sh.tensor[:2, :W.shape[1]], W[:2].to(torch.bfloat16))
+    opt.zero_grad()
+    del opt
