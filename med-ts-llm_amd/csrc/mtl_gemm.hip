@@ -151,94 +151,114 @@ __device__ __forceinline__ void epilogue4(const mtl_gemm_args& p, int64_t m, int
 // PAIR: the B fragments of column tiles 2t / 2t+1 were read from LDS rows permuted so that a lane's 4 + 4 columns are the 8
 // CONSECUTIVE columns n_base + 32t + 8g .. +7: tile ni < NPT covers n_base + (ni/2)*32 + 8g + (ni%2)*4 + 0..3; an odd last tile
 // (ni >= NPT) keeps the plain layout n_base + 16 ni + 4g + 0..3. `g` = lane >> 4.
-template <int EPI, int CDT, int NI, bool FULL, bool PAIR = false>
-__device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m_first, int64_t n_base, const int g, f32x4 (*acc)[4],
-                                               const bool dword_stores) {
-    constexpr int NPT = PAIR ? (NI & ~1) : 0;      // column tiles that come in pairs
-    // lane owns rows m_first + mi*16 (mi = 0..3) and columns n_first + ni*16 .. +3.  Edge tiles (!FULL) LOAD from
-    // clamped (always valid) addresses and predicate only the stores: no load result is ever consumed inside a branch.
-    int64_t crow[4];
-    bool mok[4];
+// The epilogue of a wave's 64 x (NI*16) sub-tile runs as a SOFTWARE PIPELINE over column chunks (<= 4 column tiles each, so that the prefetched
+// auxiliary operands — residual: 4 float4 per column tile — fit the register budget of the wide wave tiles): chunk c + 1's auxiliary loads
+// (bias, residual, saved pre-activations) are issued BEFORE chunk c's stores. gfx950 retires loads and stores through ONE in-order counter
+// (vmcnt): with load -> wait -> store per chunk, every chunk's wait for its loads also waited for the previous chunk's stores to be
+// acknowledged — one full store round trip per chunk, 3 per tile on the 256 x 256 Llama tiles (NI = 8). Issued in this order the loads
+// a chunk waits for are OLDER than the previous chunk's stores, and hipcc's own counted s_waitcnt leaves those stores in flight.
+struct EpiRows { int64_t crow[4]; bool mok[4]; bool bwd_ok[4]; };
+
+template <int EPI, bool FULL>
+__device__ __forceinline__ EpiRows epi_rows(const mtl_gemm_args& p, int64_t m_first) {
+    // lane owns rows m_first + mi*16 (mi = 0..3). Edge tiles (!FULL) LOAD from clamped (always valid) addresses and predicate only the
+    // stores: no load result is ever consumed inside a branch.
+    EpiRows r;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int64_t m = m_first + mi * 16;
-        mok[mi] = FULL || m < p.M;
-        crow[mi] = remap_row(mok[mi] ? m : p.M - 1, p.c_group_rows, p.c_group_stride, p.c_row_offset);
+        r.mok[mi] = FULL || m < p.M;
+        r.crow[mi] = remap_row(r.mok[mi] ? m : p.M - 1, p.c_group_rows, p.c_group_stride, p.c_row_offset);
+        r.bwd_ok[mi] = true;          // rows whose backward-only output is stored (GELU: aux_out, SWIGLU: C)
     }
-    bool bwd_ok[4] = {true, true, true, true};   // rows whose backward-only output is stored (GELU: aux_out, SWIGLU: C)
     if constexpr (EPI == MTL_EPI_GELU || EPI == MTL_EPI_SWIGLU) {
         if (p.bwd_group_rows > 0) {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
-                bwd_ok[mi] = (uint32_t)(m_first + mi * 16) % (uint32_t)p.bwd_group_rows >= (uint32_t)p.bwd_first_row;
+                r.bwd_ok[mi] = (uint32_t)(m_first + mi * 16) % (uint32_t)p.bwd_group_rows >= (uint32_t)p.bwd_first_row;
         }
     }
-    bool nok[NI];
-    int64_t ncol[NI];
+    return r;
+}
+
+// auxiliary operands of one chunk of NI column tiles
+template <int EPI, int NI>
+struct EpiAux {
     float4 b4[NI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int64_t n = n_base + (ni < NPT ? (ni >> 1) * 32 + g * 8 + (ni & 1) * 4 : ni * 16 + g * 4);
-        nok[ni] = FULL || n < p.N;  // vector path: N % 4 == 0, so the 4 columns are valid together
-        ncol[ni] = nok[ni] ? n : p.N - 4;
-        b4[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (p.bias) {                   // uniform branch around ALL bias loads
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b4[ni] = *reinterpret_cast<const float4*>(p.bias + ncol[ni]);
-    }
-    // bf16 outputs of a column-tile pair leave as ONE 16-byte store per lane (8 consecutive columns) when the rows are 16-B aligned
-    const bool wide_c = PAIR && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (p.ldc & 7) == 0;
-    const bool wide_a = PAIR && (reinterpret_cast<uintptr_t>(p.aux_out) & 15) == 0 && (p.ld_aux_out & 7) == 0;
-    auto put_bf16 = [&](bf16_t* base, int64_t ld, int mi, int ni, const u32x2& pk, bool ok, u32x2& hold, bool& hold_ok, bool wide) {
-        bf16_t* dst = base + crow[mi] * ld + ncol[ni];
-        if (!PAIR || ni >= NPT) {
-            if (ok) *reinterpret_cast<u32x2*>(dst) = pk;
-        } else if ((ni & 1) == 0) {
-            hold = pk; hold_ok = ok;
-        } else {
-            bf16_t* d0 = base + crow[mi] * ld + ncol[ni - 1];
-            if (wide && hold_ok && ok) {
-                *reinterpret_cast<u32x4*>(d0) = (u32x4){hold[0], hold[1], pk[0], pk[1]};
-            } else {
-                if (hold_ok) *reinterpret_cast<u32x2*>(d0) = hold;
-                if (ok) *reinterpret_cast<u32x2*>(dst) = pk;
-            }
-        }
-    };
     float4 res[EPI == MTL_EPI_RESID || EPI == MTL_EPI_ACCUM ? NI : 1][4];
     u32x2 hk[EPI == MTL_EPI_DGELU ? NI : 1][4];
     u32x4 gq[EPI == MTL_EPI_DSWIGLU ? NI : 1][4];        // saved (gate, up) pairs of the lane's 4 activation columns
+};
+
+// PAIR: the B fragments of column tiles 2t / 2t+1 were read from LDS rows permuted so that a lane's 4 + 4 columns are the 8
+// CONSECUTIVE columns n_base + 32t + 8g .. +7: tile ni < NPT covers n_base + (ni/2)*32 + 8g + (ni%2)*4 + 0..3; an odd last tile
+// (ni >= NPT) keeps the plain layout n_base + 16 ni + 4g + 0..3. `g` = lane >> 4.
+// columns of the chunk's NI column tiles; T0 = index of its first tile inside the wave's sub-tile, NPTW = how many of the wave's tiles are paired
+template <int NI, bool FULL, int NPTW, int T0>
+__device__ __forceinline__ void epi_cols(const mtl_gemm_args& p, int64_t n_wave, const int g, int64_t (&ncol)[NI], bool (&nok)[NI]) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int t = T0 + ni;
+        const int64_t n = n_wave + (t < NPTW ? (t >> 1) * 32 + g * 8 + (t & 1) * 4 : t * 16 + g * 4);
+        nok[ni] = FULL || n < p.N;  // vector path: N % 4 == 0, so the 4 columns are valid together
+        ncol[ni] = nok[ni] ? n : p.N - 4;
+    }
+}
+
+template <int EPI, int CDT, int NI, bool FULL, int NPTW, int T0>
+__device__ __forceinline__ void epi_load(const mtl_gemm_args& p, const EpiRows& r, int64_t n_base, const int g, EpiAux<EPI, NI>& a) {
+    int64_t ncol[NI];
+    bool nok[NI];
+    epi_cols<NI, FULL, NPTW, T0>(p, n_base, g, ncol, nok);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) a.b4[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) {                   // uniform branch around ALL bias loads
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) a.b4[ni] = *reinterpret_cast<const float4*>(p.bias + ncol[ni]);
+    }
     if constexpr (EPI == MTL_EPI_RESID || EPI == MTL_EPI_ACCUM || EPI == MTL_EPI_DGELU || EPI == MTL_EPI_DSWIGLU) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                if constexpr (EPI == MTL_EPI_RESID) res[ni][mi] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.aux_in) + crow[mi] * p.ld_aux_in + ncol[ni]);
-                if constexpr (EPI == MTL_EPI_ACCUM) res[ni][mi] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.C) + crow[mi] * p.ldc + ncol[ni]);
-                if constexpr (EPI == MTL_EPI_DGELU) hk[ni][mi] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.aux_in) + crow[mi] * p.ld_aux_in + ncol[ni]);
-                if constexpr (EPI == MTL_EPI_DSWIGLU) gq[ni][mi] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.aux_in) + crow[mi] * p.ld_aux_in + 2 * ncol[ni]);
+                if constexpr (EPI == MTL_EPI_RESID) a.res[ni][mi] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.aux_in) + r.crow[mi] * p.ld_aux_in + ncol[ni]);
+                if constexpr (EPI == MTL_EPI_ACCUM) a.res[ni][mi] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.C) + r.crow[mi] * p.ldc + ncol[ni]);
+                if constexpr (EPI == MTL_EPI_DGELU) a.hk[ni][mi] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.aux_in) + r.crow[mi] * p.ld_aux_in + ncol[ni]);
+                if constexpr (EPI == MTL_EPI_DSWIGLU) a.gq[ni][mi] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.aux_in) + r.crow[mi] * p.ld_aux_in + 2 * ncol[ni]);
             }
     }
-    // edge tiles: hipcc sinks the bias/residual math into the predicated store blocks, which leaves the load results
-    // "pending" at the merge and costs a vmcnt(0) before every later ds_read; a compiler-visible wait here settles it.
-    if constexpr (!FULL) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0) only (gfx9 encoding)
+}
+
+// output stores of the wave-level epilogue: plain stores. (Write-through `sc1` stores — the line is then not retained in the XCD's L2, so a
+// 100-360 MB output would not evict the operand panels the main loop re-reads — were measured and are WORSE everywhere: Llama residual GEMM
+// +7 %, SwiGLU +4.5 %, dSwiGLU +14 %, GPT-2 residual GEMM +18 %; profiles/r03_gemm_experiments.txt.)
+template <typename V>
+__device__ __forceinline__ void epi_st(void* ptr, const V v) { *reinterpret_cast<V*>(ptr) = v; }
+
+// math of one chunk, IN PLACE: the lane's results replace its accumulators as raw bits —
+//   fp32 outputs (STORE / RESID / ACCUM, CDT f32): acc[ni][mi] = the 4 output values
+//   bf16 outputs: [0..1] = the 4 packed C values; GELU: [0..1] = saved pre-activation, [2..3] = activation; SWIGLU: [2] = the 2 packed
+//   activation columns; DSWIGLU: [0..3] = the 8 packed d(gate | up) values
+// so that the auxiliary registers are dead when the NEXT chunk's loads are issued into them, before this chunk's stores (epilogue_wave).
+template <int EPI, int CDT, int NI, bool FULL, int NPTW, int T0>
+__device__ __forceinline__ void epi_math(const mtl_gemm_args& p, const EpiRows& r, int64_t n_base, const int g, f32x4 (*acc)[4], const EpiAux<EPI, NI>& a,
+                                         const int mi0 = 0, const int mi1 = 4) {
+    int64_t ncol[NI];
+    bool nok[NI];
+    epi_cols<NI, FULL, NPTW, T0>(p, n_base, g, ncol, nok);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        u32x2 hold_c = {0u, 0u}, hold_a = {0u, 0u};
-        uint32_t hold_s = 0u;
-        bool hold_c_ok = false, hold_a_ok = false, hold_s_ok = false;
+    for (int mi = mi0; mi < mi1; ++mi) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-            const bool ok = mok[mi] && nok[ni];
-            const int64_t n = ncol[ni];
-            float o[4] = {acc[ni][mi][0] * p.alpha + b4[ni].x, acc[ni][mi][1] * p.alpha + b4[ni].y, acc[ni][mi][2] * p.alpha + b4[ni].z,
-                          acc[ni][mi][3] * p.alpha + b4[ni].w};
+            float o[4] = {acc[ni][mi][0] * p.alpha + a.b4[ni].x, acc[ni][mi][1] * p.alpha + a.b4[ni].y, acc[ni][mi][2] * p.alpha + a.b4[ni].z,
+                          acc[ni][mi][3] * p.alpha + a.b4[ni].w};
+            u32x4 out = {0u, 0u, 0u, 0u};
             if constexpr (EPI == MTL_EPI_GELU) {
                 const u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-                put_bf16(reinterpret_cast<bf16_t*>(p.aux_out), p.ld_aux_out, mi, ni, pk, ok && bwd_ok[mi], hold_a, hold_a_ok, wide_a);
-                o[0] = gelu_new_f(__uint_as_float(pk[0] << 16)); o[1] = gelu_new_f(__uint_as_float(pk[0] & 0xffff0000u));
-                o[2] = gelu_new_f(__uint_as_float(pk[1] << 16)); o[3] = gelu_new_f(__uint_as_float(pk[1] & 0xffff0000u));
+                // the activation sees the bf16-rounded pre-activation, exactly like a bf16 Linear followed by gelu_new
+                out = (u32x4){pk[0], pk[1],
+                              pack_bf16x2(gelu_new_f(__uint_as_float(pk[0] << 16)), gelu_new_f(__uint_as_float(pk[0] & 0xffff0000u))),
+                              pack_bf16x2(gelu_new_f(__uint_as_float(pk[1] << 16)), gelu_new_f(__uint_as_float(pk[1] & 0xffff0000u)))};
             } else if constexpr (EPI == MTL_EPI_RESID) {
                 const u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};   // bf16 Linear output, then fp32 add
                 float v[4] = {__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u), __uint_as_float(pk[1] << 16),
@@ -247,59 +267,118 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
                     // the lane's 4 columns n .. n+3 (n % 4 == 0) are one mask quad: one hash
                     const uint32_t thr = drop_threshold(p.drop_p), dbase = drop_base(p.drop_seed, 0u);
                     const float sc = drop_scale_of(thr);
-                    const uint2 wq = drop_quad(dbase, (uint32_t)crow[mi], (uint32_t)n >> 2);
-                        const uint32_t w0 = wq.x, w1 = wq.y;
+                    const uint2 wq = drop_quad(dbase, (uint32_t)r.crow[mi], (uint32_t)ncol[ni] >> 2);
+                    const uint32_t w0 = wq.x, w1 = wq.y;
                     v[0] = (w0 & 0xffffu) >= thr ? v[0] * sc : 0.f; v[1] = (w0 >> 16) >= thr ? v[1] * sc : 0.f;
                     v[2] = (w1 & 0xffffu) >= thr ? v[2] * sc : 0.f; v[3] = (w1 >> 16) >= thr ? v[3] * sc : 0.f;
                 }
-                o[0] = res[ni][mi].x + v[0]; o[1] = res[ni][mi].y + v[1]; o[2] = res[ni][mi].z + v[2]; o[3] = res[ni][mi].w + v[3];
+                out = (u32x4){__float_as_uint(a.res[ni][mi].x + v[0]), __float_as_uint(a.res[ni][mi].y + v[1]), __float_as_uint(a.res[ni][mi].z + v[2]),
+                              __float_as_uint(a.res[ni][mi].w + v[3])};
             } else if constexpr (EPI == MTL_EPI_DGELU) {
-                o[0] *= dgelu_new_f(__uint_as_float(hk[ni][mi][0] << 16)); o[1] *= dgelu_new_f(__uint_as_float(hk[ni][mi][0] & 0xffff0000u));
-                o[2] *= dgelu_new_f(__uint_as_float(hk[ni][mi][1] << 16)); o[3] *= dgelu_new_f(__uint_as_float(hk[ni][mi][1] & 0xffff0000u));
+                o[0] *= dgelu_new_f(__uint_as_float(a.hk[ni][mi][0] << 16)); o[1] *= dgelu_new_f(__uint_as_float(a.hk[ni][mi][0] & 0xffff0000u));
+                o[2] *= dgelu_new_f(__uint_as_float(a.hk[ni][mi][1] << 16)); o[3] *= dgelu_new_f(__uint_as_float(a.hk[ni][mi][1] & 0xffff0000u));
+                out = (u32x4){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), 0u, 0u};
             } else if constexpr (EPI == MTL_EPI_ACCUM) {
-                o[0] += res[ni][mi].x; o[1] += res[ni][mi].y; o[2] += res[ni][mi].z; o[3] += res[ni][mi].w;
-            }
-            if constexpr (EPI == MTL_EPI_DSWIGLU) {
+                out = (u32x4){__float_as_uint(o[0] + a.res[ni][mi].x), __float_as_uint(o[1] + a.res[ni][mi].y), __float_as_uint(o[2] + a.res[ni][mi].z),
+                              __float_as_uint(o[3] + a.res[ni][mi].w)};
+            } else if constexpr (EPI == MTL_EPI_DSWIGLU) {
                 // d(act) is a bf16 tensor in the unfused chain: round first. d gate = dh*up*sig*(1 + g*(1 - sig)), d up = dh*g*sig
                 const u32x2 dk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
                 const float dh[4] = {__uint_as_float(dk[0] << 16), __uint_as_float(dk[0] & 0xffff0000u), __uint_as_float(dk[1] << 16),
                                      __uint_as_float(dk[1] & 0xffff0000u)};
-                u32x4 outq;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float gv = __uint_as_float(gq[ni][mi][e] << 16), uv = __uint_as_float(gq[ni][mi][e] & 0xffff0000u);
+                    const float gv = __uint_as_float(a.gq[ni][mi][e] << 16), uv = __uint_as_float(a.gq[ni][mi][e] & 0xffff0000u);
                     const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-gv));
-                    outq[e] = pack_bf16x2(dh[e] * uv * sg * (1.0f + gv * (1.0f - sg)), dh[e] * gv * sg);
+                    out[e] = pack_bf16x2(dh[e] * uv * sg * (1.0f + gv * (1.0f - sg)), dh[e] * gv * sg);
                 }
-                if (ok) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + crow[mi] * p.ldc + 2 * n) = outq;
-            } else if constexpr (CDT == MTL_BF16) {
+            } else if constexpr (EPI == MTL_EPI_SWIGLU) {
                 const u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-                put_bf16(reinterpret_cast<bf16_t*>(p.C), p.ldc, mi, ni, pk, ok && (EPI != MTL_EPI_SWIGLU || bwd_ok[mi]), hold_c, hold_c_ok, wide_c);
+                // columns (n .. n+3) = (gate_j, up_j, gate_j+1, up_j+1), j = n/2; the activation sees the bf16-rounded Linear
+                // outputs and silu's own output is a bf16 tensor before the product (HF:modeling_llama.py:176)
+                const float g0 = __uint_as_float(pk[0] << 16), u0 = __uint_as_float(pk[0] & 0xffff0000u);
+                const float g1 = __uint_as_float(pk[1] << 16), u1 = __uint_as_float(pk[1] & 0xffff0000u);
+                const float s0 = bf16_to_f32(f32_to_bf16(g0 * __builtin_amdgcn_rcpf(1.0f + __expf(-g0))));
+                const float s1 = bf16_to_f32(f32_to_bf16(g1 * __builtin_amdgcn_rcpf(1.0f + __expf(-g1))));
+                out = (u32x4){pk[0], pk[1], pack_bf16x2(s0 * u0, s1 * u1), 0u};     // 2 activation columns
+            } else if constexpr (CDT == MTL_BF16) {
+                out = (u32x4){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), 0u, 0u};
+            } else {
+                out = (u32x4){__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
+            }
+            acc[ni][mi] = __builtin_bit_cast(f32x4, out);
+        }
+    }
+}
+
+// stores of one chunk whose results epi_math left in the accumulators
+template <int EPI, int CDT, int NI, bool FULL, int NPTW, int T0>
+__device__ __forceinline__ void epi_store(const mtl_gemm_args& p, const EpiRows& r, int64_t n_base, const int g, f32x4 (*acc)[4], const bool dword_stores,
+                                          const int mi0 = 0, const int mi1 = 4) {
+    constexpr bool PAIR = NPTW > 0;
+    constexpr int NPT = NPTW > T0 ? (NPTW - T0 < NI ? NPTW - T0 : NI) : 0;       // paired tiles of THIS chunk (they lead it)
+    // outputs whose stores join a column-tile pair need both tiles of a pair in one chunk; fp32 / DSWIGLU outputs store per tile
+    static_assert(NPT == 0 || EPI == MTL_EPI_DSWIGLU || (CDT == MTL_F32) || (T0 % 2 == 0 && NPT % 2 == 0), "a pair of column tiles stays inside one chunk");
+    int64_t ncol[NI];
+    bool nok[NI];
+    epi_cols<NI, FULL, NPTW, T0>(p, n_base, g, ncol, nok);
+    const int64_t (&crow)[4] = r.crow;
+    // bf16 outputs of a column-tile pair leave as ONE 16-byte store per lane (8 consecutive columns) when the rows are 16-B aligned
+    const bool wide_c = PAIR && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (p.ldc & 7) == 0;
+    const bool wide_a = PAIR && (reinterpret_cast<uintptr_t>(p.aux_out) & 15) == 0 && (p.ld_aux_out & 7) == 0;
+    auto put_bf16 = [&](bf16_t* base, int64_t ld, int mi, int ni, const u32x2& pk, bool ok, u32x2& hold, bool& hold_ok, bool wide) {
+        bf16_t* dst = base + crow[mi] * ld + ncol[ni];
+        if (!PAIR || ni >= NPT) {
+            if (ok) epi_st<u32x2>(dst, pk);
+        } else if ((ni & 1) == 0) {
+            hold = pk; hold_ok = ok;
+        } else {
+            bf16_t* d0 = base + crow[mi] * ld + ncol[ni - 1];
+            if (wide && hold_ok && ok) {
+                epi_st<u32x4>(d0, (u32x4){hold[0], hold[1], pk[0], pk[1]});
+            } else {
+                if (hold_ok) epi_st<u32x2>(d0, hold);
+                if (ok) epi_st<u32x2>(dst, pk);
+            }
+        }
+    };
+#pragma unroll
+    for (int mi = mi0; mi < mi1; ++mi) {
+        u32x2 hold_c = {0u, 0u}, hold_a = {0u, 0u};
+        uint32_t hold_s = 0u;
+        bool hold_c_ok = false, hold_a_ok = false, hold_s_ok = false;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const bool ok = r.mok[mi] && nok[ni];
+            const int64_t n = ncol[ni];
+            const u32x4 v = __builtin_bit_cast(u32x4, acc[ni][mi]);
+            if constexpr (EPI == MTL_EPI_DSWIGLU) {
+                if (ok) epi_st<u32x4>(reinterpret_cast<bf16_t*>(p.C) + crow[mi] * p.ldc + 2 * n, v);
+            } else if constexpr (EPI == MTL_EPI_GELU) {
+                put_bf16(reinterpret_cast<bf16_t*>(p.aux_out), p.ld_aux_out, mi, ni, (u32x2){v[0], v[1]}, ok && r.bwd_ok[mi], hold_a, hold_a_ok, wide_a);
+                put_bf16(reinterpret_cast<bf16_t*>(p.C), p.ldc, mi, ni, (u32x2){v[2], v[3]}, ok, hold_c, hold_c_ok, wide_c);
+            } else if constexpr (CDT == MTL_BF16) {
+                put_bf16(reinterpret_cast<bf16_t*>(p.C), p.ldc, mi, ni, (u32x2){v[0], v[1]}, ok && (EPI != MTL_EPI_SWIGLU || r.bwd_ok[mi]), hold_c, hold_c_ok, wide_c);
                 if constexpr (EPI == MTL_EPI_SWIGLU) {
-                    // columns (n .. n+3) = (gate_j, up_j, gate_j+1, up_j+1), j = n/2; the activation sees the bf16-rounded Linear
-                    // outputs and silu's own output is a bf16 tensor before the product (HF:modeling_llama.py:176)
-                    const float g0 = __uint_as_float(pk[0] << 16), u0 = __uint_as_float(pk[0] & 0xffff0000u);
-                    const float g1 = __uint_as_float(pk[1] << 16), u1 = __uint_as_float(pk[1] & 0xffff0000u);
-                    const float s0 = bf16_to_f32(f32_to_bf16(g0 * __builtin_amdgcn_rcpf(1.0f + __expf(-g0))));
-                    const float s1 = bf16_to_f32(f32_to_bf16(g1 * __builtin_amdgcn_rcpf(1.0f + __expf(-g1))));
-                    const uint32_t av = pack_bf16x2(s0 * u0, s1 * u1);      // 2 activation columns; a tile pair's 4 leave in one 8-byte store
+                    const uint32_t av = v[2];      // a tile pair's 4 activation columns leave in one 8-byte store
                     bf16_t* ad = reinterpret_cast<bf16_t*>(p.aux_out) + crow[mi] * p.ld_aux_out + (n >> 1);
                     if (!PAIR || ni >= NPT) {
-                        if (ok) *reinterpret_cast<uint32_t*>(ad) = av;
+                        if (ok) epi_st<uint32_t>(ad, av);
                     } else if ((ni & 1) == 0) {
                         hold_s = av; hold_s_ok = ok;
                     } else {
                         bf16_t* a0 = reinterpret_cast<bf16_t*>(p.aux_out) + crow[mi] * p.ld_aux_out + (ncol[ni - 1] >> 1);
                         if (hold_s_ok && ok && (reinterpret_cast<uintptr_t>(p.aux_out) & 7) == 0 && (p.ld_aux_out & 3) == 0) {
-                            *reinterpret_cast<u32x2*>(a0) = (u32x2){hold_s, av};
+                            epi_st<u32x2>(a0, (u32x2){hold_s, av});
                         } else {
-                            if (hold_s_ok) *reinterpret_cast<uint32_t*>(a0) = hold_s;
-                            if (ok) *reinterpret_cast<uint32_t*>(ad) = av;
+                            if (hold_s_ok) epi_st<uint32_t>(a0, hold_s);
+                            if (ok) epi_st<uint32_t>(ad, av);
                         }
                     }
                 }
             } else {
                 float* cp = reinterpret_cast<float*>(p.C) + crow[mi] * p.ldc + n;
+                const float o[4] = {__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
                 if (EPI == MTL_EPI_STORE && dword_stores) {
                     // rows that are only 4-B aligned (N % 4 != 0, e.g. the [num_tokens, 50257] mapping weight gradient):
                     // four dword stores, still straight-line on interior tiles
@@ -314,24 +393,71 @@ __device__ __forceinline__ void epilogue_chunk(const mtl_gemm_args& p, int64_t m
                             if (ok && n + e < p.N) cp[e] = o[e];
                     }
                 } else {
-                    if (ok) *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
+                    if (ok) epi_st<f32x4>(cp, (f32x4){o[0], o[1], o[2], o[3]});
                 }
             }
         }
     }
 }
 
-// column tiles are processed NCH at a time so that the prefetched auxiliary operands (residual: 4 float4 per column tile)
-// stay within the register budget of the wide wave tiles (64x96, 64x128 per wave); <= 4 column tiles go in one piece
+// Wave-level epilogue of a 64 x (NI*16) sub-tile, vector path. FULL = the whole tile lies inside C: no per-lane predicate at all, so the loads,
+// the waits and the stores come out as straight-line code. (With predicates every use sits in its own branch and hipcc waits vmcnt(0) in
+// each, i.e. every store waits for the previous store to complete, and the still-"pending" bias registers force a vmcnt(0) in front of
+// the next k-step's first ds_read, draining the LDS-DMA pipeline.)
+// Column tiles go NCH at a time (<= 4 in one piece; wider wave tiles 2 at a time: 64x96 .. 64x144 per wave); an odd count (NI = 9) ends with ONE
+// unpaired column tile. Per chunk: wait for its auxiliary operands, math in place, ISSUE THE NEXT CHUNK'S LOADS (into the same registers), stores.
 template <int EPI, int CDT, int NI, bool FULL, bool PAIR = false>
 __device__ __forceinline__ void epilogue_wave(const mtl_gemm_args& p, int64_t m_first, int64_t n_base, const int g, f32x4 (&acc)[NI][4],
                                               const bool dword_stores = false) {
+    // PIPE (bias-only epilogues: plain store, GELU, SwiGLU): chunk c + 1's bias loads go out between chunk c's math and its stores, so the wait
+    // for them does not drain chunk c's stores (in-step A/B inside one process: GELU GEMM 256x192 54.4 -> 50.7 us, plain 256x256 340.9 -> 337.5 us).
+    // Residual-type epilogues (16 B of auxiliary operand per output quad) keep load -> math -> store per chunk: what they wait for is the
+    // auxiliary loads' own round trip, and more chunks in flight do not fit the 256-register wide-tile kernels (measured, same A/B: two chunks
+    // of prefetch spilled into the main loop, 222 -> 495 us; one-tile chunks exposed 8 load round trips per tile, dSwiGLU 376 -> 402 us).
+    constexpr bool PIPE = (EPI == MTL_EPI_STORE || EPI == MTL_EPI_GELU || EPI == MTL_EPI_SWIGLU);
     constexpr int NCH = NI > 4 ? 2 : NI;
-    constexpr int NEVEN = NI - NI % NCH;       // an odd count (NI = 9: 64 x 144 per wave) ends with ONE unpaired column tile
-    static_assert(!PAIR || NCH == NI || NCH % 2 == 0, "paired column tiles stay inside one chunk");
+    constexpr int NFULL = NI / NCH;            // whole chunks
+    constexpr int NTAIL = NI - NFULL * NCH;    // 0 or 1 column tile left over
+    constexpr int NPTW = PAIR ? (NI & ~1) : 0; // paired column tiles of the wave's sub-tile
+    static_assert(NFULL >= 1 && NFULL <= 4 && NTAIL <= 1, "chunk schedule");
+    const EpiRows r = epi_rows<EPI, FULL>(p, m_first);
+    EpiAux<EPI, NCH> a;
+    EpiAux<EPI, NTAIL ? NTAIL : 1> at;
+    epi_load<EPI, CDT, NCH, FULL, NPTW, 0>(p, r, n_base, g, a);
+    // edge tiles: hipcc sinks the bias/residual math into the predicated store blocks, which leaves the load results "pending" at the
+    // merge and costs a vmcnt(0) before every later ds_read; a compiler-visible wait per chunk settles it (edge tiles only).
+#define MTL_EPI_NEXT(C)                                                                                                                  \
+    if constexpr ((C) + 1 < NFULL) epi_load<EPI, CDT, NCH, FULL, NPTW, ((C) + 1) * NCH>(p, r, n_base, g, a);                              \
+    else if constexpr (NTAIL > 0) epi_load<EPI, CDT, NTAIL, FULL, NPTW, NFULL * NCH>(p, r, n_base, g, at);
+#define MTL_EPI_STEP(C)                                                                                                                  \
+    if constexpr ((C) < NFULL) {                                                                                                          \
+        if constexpr (!FULL) __builtin_amdgcn_s_waitcnt(0x0f70);   /* vmcnt(0) only (gfx9 encoding) */                                    \
+        if constexpr (PIPE && ((C) + 1 < NFULL || NTAIL > 0)) {                                                                           \
+            epi_math<EPI, CDT, NCH, FULL, NPTW, (C) * NCH>(p, r, n_base, g, &acc[(C) * NCH], a);                                          \
+            MTL_EPI_NEXT(C)                                                                                                               \
+            epi_store<EPI, CDT, NCH, FULL, NPTW, (C) * NCH>(p, r, n_base, g, &acc[(C) * NCH], dword_stores);                              \
+        } else {                                                                                                                          \
+            _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {          /* row by row: the first stores leave while the rest computes */  \
+                epi_math<EPI, CDT, NCH, FULL, NPTW, (C) * NCH>(p, r, n_base, g, &acc[(C) * NCH], a, mi, mi + 1);                          \
+                epi_store<EPI, CDT, NCH, FULL, NPTW, (C) * NCH>(p, r, n_base, g, &acc[(C) * NCH], dword_stores, mi, mi + 1);              \
+            }                                                                                                                             \
+            MTL_EPI_NEXT(C)                                                                                                               \
+        }                                                                                                                                 \
+    }
+    MTL_EPI_STEP(0)
+    MTL_EPI_STEP(1)
+    MTL_EPI_STEP(2)
+    MTL_EPI_STEP(3)
+#undef MTL_EPI_STEP
+#undef MTL_EPI_NEXT
+    if constexpr (NTAIL > 0) {
+        if constexpr (!FULL) __builtin_amdgcn_s_waitcnt(0x0f70);
 #pragma unroll
-    for (int c0 = 0; c0 < NEVEN; c0 += NCH) epilogue_chunk<EPI, CDT, NCH, FULL, PAIR>(p, m_first, n_base + c0 * 16, g, &acc[c0], dword_stores);
-    if constexpr (NEVEN < NI) epilogue_chunk<EPI, CDT, NI - NEVEN, FULL, false>(p, m_first, n_base + NEVEN * 16, g, &acc[NEVEN], dword_stores);
+        for (int mi = 0; mi < 4; ++mi) {
+            epi_math<EPI, CDT, NTAIL, FULL, NPTW, NFULL * NCH>(p, r, n_base, g, &acc[NFULL * NCH], at, mi, mi + 1);
+            epi_store<EPI, CDT, NTAIL, FULL, NPTW, NFULL * NCH>(p, r, n_base, g, &acc[NFULL * NCH], dword_stores, mi, mi + 1);
+        }
+    }
 }
 
 // SPLIT: raw fp32 partial sums go to workspace slab [split][M][N]; epilogue runs in splitk_reduce_kernel.
@@ -557,6 +683,9 @@ __global__ __launch_bounds__(NW_ALL * 64, persist_waves_per_simd(BM_, BN_, STAGE
 
     const bf16_t* asrc[NA];
     const bf16_t* bsrc[NB];
+    // (Measured and dropped, profiles/r03_gemm_experiments.txt: an L2 warm-up load per lane and k-step, three k-steps ahead of the LDS-DMA that
+    //  stages its line — the loads retire in order with the DMA (one vmcnt), so the miss it takes off the DMA's path lands in front of the NEXT
+    //  stage's wait instead: 6-10 % slower on every shape.)
     const int gm = gm_all & 0xff;
     const int col_rot = (gm_all & (1 << 9)) ? (xcd * tiles_n) >> 3 : 0;   // per-XCD column rotation (host: chunks of whole tile rows only)
     // k-tile rotation per XCD (a tile's k-steps commute): the eight XCDs walk the SAME B panels; started at the same k they ask the
