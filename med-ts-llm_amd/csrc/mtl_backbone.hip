@@ -174,8 +174,12 @@ int backbone_fwd_impl(const mtl_backbone_weights* w, const float* h0, void* out,
     const int64_t r0 = n_prefix, n_fwd = D.T - n_prefix, Mf = D.B * n_fwd;
     const RowMap rm = (n_prefix == 0) ? kIdentity : RowMap{n_fwd, D.T, r0};
     if (n_save > n_fwd) n_save = n_fwd;
-    const int64_t save_group = n_save < n_fwd ? n_fwd : 0, save_first = n_fwd - n_save;
+    const int64_t save_group = 0, save_first = 0;     // (per layer below: the last layer may compute fewer rows)
     const int64_t kv_cols = 2 * D.Hkv * D.hd;
+    // LAST layer, after its keys / values exist: nothing downstream reads the hidden states of the leading tokens — the final norm takes the
+    // last n_last tokens, the backward the last n_save — so its attention queries, output projection and whole MLP run on the last
+    // max(n_last, n_save) tokens of every sample only (exact: those rows' results do not change; the others are dead stores).
+    const int64_t n_tail = (n_last > n_save ? n_last : n_save) < n_fwd ? (n_last > n_save ? n_last : n_save) : n_fwd;
     for (int i = 0; i < D.L; ++i) {
         float* st1 = reinterpret_cast<float*>(sv + S.stats + S.stats_stride * (size_t)(2 * i));
         float* st2 = reinterpret_cast<float*>(sv + S.stats + S.stats_stride * (size_t)(2 * i + 1));
@@ -201,32 +205,38 @@ int backbone_fwd_impl(const mtl_backbone_weights* w, const float* h0, void* out,
                                D.Hq * D.hd, kv_cols, D.B);
             MTL_CHECK_LAUNCH();
         }
+        // rows of the rest of this layer: the computed rows, or (last layer) only the tail somebody still reads
+        const bool tail_only = (i == D.L - 1) && n_tail < n_fwd;
+        const int64_t n_rows = tail_only ? n_tail : n_fwd, q0 = D.T - n_rows, Mr = D.B * n_rows;
+        const RowMap rr = (n_rows == D.T) ? kIdentity : RowMap{n_rows, D.T, q0};
+        const int64_t sv_group = n_save < n_rows ? n_rows : 0, sv_first = n_rows - n_save;
+        (void)save_group; (void)save_first;
         mtl_attn_fwd_args fa = {};
         attn_args(D, qkv, attn, lse, &fa);
         fa.dropout_p = attn_p; fa.dropout_seed = drop_site_seed(dseed, i, 0);
-        if (n_prefix > 0) {      // queries = the computed rows, keys = all rows
-            fa.q = reinterpret_cast<const bf16_t*>(fa.q) + r0 * fa.q_ts;
-            fa.o = reinterpret_cast<bf16_t*>(fa.o) + r0 * fa.o_ts;
-            fa.lse = lse + r0;
-            fa.Tq = n_fwd; fa.causal_off = r0; fa.stat_stride = D.T;
+        if (n_rows < D.T) {      // queries = the rows computed from here on, keys = all rows
+            fa.q = reinterpret_cast<const bf16_t*>(fa.q) + q0 * fa.q_ts;
+            fa.o = reinterpret_cast<bf16_t*>(fa.o) + q0 * fa.o_ts;
+            fa.lse = lse + q0;
+            fa.Tq = n_rows; fa.causal_off = q0; fa.stat_stride = D.T;
         }
         MTL_TRY(mtl_attention_fwd(&fa, stream));
-        MTL_TRY(gemm(attn, D.No, w->w_o[i], D.No, H(2 * i + 1), D.d, MTL_F32, Mf, D.d, D.No, bo, MTL_EPI_RESID, H(2 * i), D.d, nullptr, 0, stream,
-                     rm, rm, resid_p, drop_site_seed(dseed, i, 1)));
+        MTL_TRY(gemm(attn, D.No, w->w_o[i], D.No, H(2 * i + 1), D.d, MTL_F32, Mr, D.d, D.No, bo, MTL_EPI_RESID, H(2 * i), D.d, nullptr, 0, stream,
+                     rr, rr, resid_p, drop_site_seed(dseed, i, 1)));
         // --- MLP block
-        MTL_TRY(mtl_norm_fwd(H(2 * i + 1), w->ln2_w[i], w->ln2_b ? w->ln2_b[i] : nullptr, wk + W.xln, D.d, st2, Mf, D.d, w->eps, rms, rm.rows, rm.stride,
-                             rm.offset, 1, stream));
+        MTL_TRY(mtl_norm_fwd(H(2 * i + 1), w->ln2_w[i], w->ln2_b ? w->ln2_b[i] : nullptr, wk + W.xln, D.d, st2, Mr, D.d, w->eps, rms, rr.rows, rr.stride,
+                             rr.offset, 1, stream));
         if (D.llama) {
             // gate|up GEMM with the SwiGLU fused into its epilogue (weights row-interleaved: columns 2j / 2j+1 = gate_j / up_j)
             // (the saved pre-activations are only read by the backward: stored for the last n_save tokens of every sample)
-            MTL_TRY(gemm(wk + W.xln, D.d, w->w_fc[i], D.d, fc, D.Nfc, MTL_BF16, Mf, D.Nfc, D.d, bf, MTL_EPI_SWIGLU, nullptr, 0, wk + W.act, D.ffn, stream,
-                         kIdentity, rm, 0.f, 0u, save_group, save_first));
+            MTL_TRY(gemm(wk + W.xln, D.d, w->w_fc[i], D.d, fc, D.Nfc, MTL_BF16, Mr, D.Nfc, D.d, bf, MTL_EPI_SWIGLU, nullptr, 0, wk + W.act, D.ffn, stream,
+                         kIdentity, rr, 0.f, 0u, sv_group, sv_first));
         } else {
-            MTL_TRY(gemm(wk + W.xln, D.d, w->w_fc[i], D.d, wk + W.act, D.ffn, MTL_BF16, Mf, D.ffn, D.d, bf, MTL_EPI_GELU, nullptr, 0, fc, D.ffn, stream,
-                         kIdentity, rm, 0.f, 0u, save_group, save_first));
+            MTL_TRY(gemm(wk + W.xln, D.d, w->w_fc[i], D.d, wk + W.act, D.ffn, MTL_BF16, Mr, D.ffn, D.d, bf, MTL_EPI_GELU, nullptr, 0, fc, D.ffn, stream,
+                         kIdentity, rr, 0.f, 0u, sv_group, sv_first));
         }
-        MTL_TRY(gemm(wk + W.act, D.ffn, w->w_proj[i], D.ffn, H(2 * i + 2), D.d, MTL_F32, Mf, D.d, D.ffn, bp, MTL_EPI_RESID, H(2 * i + 1), D.d, nullptr, 0, stream,
-                     rm, rm, resid_p, drop_site_seed(dseed, i, 2)));
+        MTL_TRY(gemm(wk + W.act, D.ffn, w->w_proj[i], D.ffn, H(2 * i + 2), D.d, MTL_F32, Mr, D.d, D.ffn, bp, MTL_EPI_RESID, H(2 * i + 1), D.d, nullptr, 0, stream,
+                     rr, rr, resid_p, drop_site_seed(dseed, i, 2)));
     }
     float* stf = reinterpret_cast<float*>(sv + S.stats_f);
     return mtl_norm_fwd(H(2 * D.L), w->lnf_w, w->lnf_b, out, D.d, stf, D.B * n_last, D.d, w->eps, rms, n_last, D.T, D.T - n_last, 0, stream);

@@ -1125,7 +1125,7 @@ __attribute__((format(printf, 4, 5))) void kname_shape(char* buf, size_t cap, co
 }
 
 template <int EPI, int CDT>
-int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
+int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st, int fbm = 0, int fbn = 0, int fstages = 0, int fnw = 0) {
     const int tiles_m = (int)((p.M + BM - 1) / BM), tiles_n = (int)((p.N + BN - 1) / BN);
     const int S = p.split_k > 1 ? p.split_k : 1;
     const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
@@ -1135,7 +1135,7 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
     if (S == 1 && tuning().mode == 1 && (vec_ok || dword_ok) && p.N >= 4) {
         const int ncu = num_cus();
         // tile choice, measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_ab*.txt)
-        int bm = tuning().bm, bn = tuning().bn, stages = tuning().stages, nw = tuning().waves;
+        int bm = fbm ? fbm : tuning().bm, bn = fbn ? fbn : tuning().bn, stages = fstages ? fstages : tuning().stages, nw = fnw ? fnw : tuning().waves;
         const int t128 = tiles_m * tiles_n;            // grid size in 128x128 tiles
         // Llama-class grids: 256x128 / 16 waves / 3 stages reaches 1.04-1.12 PF/s (also the M = B*n_grad backward GEMMs with long K)
         if (bm == 0) bm = (t128 >= 8 * ncu || (t128 >= 4 * ncu && p.K >= 4096)) ? 256 : 128;
@@ -1176,6 +1176,33 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st) {
             static int f[6] = {-1, 0, 0, 0, 0, 0};
             static const bool parsed = spec && sscanf(spec, "%d,%d,%d,%d,%d,%d", &f[0], &f[1], &f[2], &f[3], &f[4], &f[5]) == 6;
             if (parsed && f[0] == EPI && f[1] == p.N && tuning().bm == 0) { bm = f[2]; bn = f[3]; stages = f[4]; nw = f[5]; }
+        }
+        // 256 x 256 grids whose last round of tiles would leave most CUs idle: the columns that fill WHOLE rounds go in this launch, the
+        // remaining columns in a second one with half-width tiles (256 x 128 / 16 waves / 3 stages: twice the tiles for the same columns).
+        // Llama-2 gate|up with the prompt-row cache: [4096 x 22016 x 4096] = 16 x 86 tiles = 5.375 rounds of 256 -> 5 rounds + 96 half-width
+        // pairs on 192 of the 256 CUs (rule 128 of MTL_GEMM_RULES_OFF switches it off). Column-split only: the outputs are disjoint column
+        // ranges of the same buffers. Not for the residual epilogue (its dropout mask is indexed by the absolute column).
+        if (bm == 256 && bn == 256 && fbm == 0 && tuning().bm == 0 && !(rules_off() & 128) && p.N % 256 == 0 &&
+            (EPI == MTL_EPI_STORE || EPI == MTL_EPI_GELU || EPI == MTL_EPI_DGELU || EPI == MTL_EPI_SWIGLU || EPI == MTL_EPI_DSWIGLU)) {
+            const int tm256 = (int)((p.M + 255) / 256), tn256 = (int)(p.N / 256);
+            if (tm256 <= ncu && ncu % tm256 == 0) {
+                const int per_round = ncu / tm256, rem = tn256 % per_round;
+                if (tn256 > per_round && rem > 0 && 2 * rem <= per_round) {          // the tail round would be at most half full
+                    const int64_t n_main = (int64_t)(tn256 - rem) * 256;
+                    mtl_gemm_args a = p, b = p;
+                    a.N = n_main;
+                    b.N = p.N - n_main;
+                    b.B = reinterpret_cast<const bf16_t*>(p.B) + n_main * p.ldb;
+                    if (p.bias) b.bias = p.bias + n_main;
+                    const int64_t cmul = EPI == MTL_EPI_DSWIGLU ? 2 : 1;              // dSwiGLU writes (and reads) 2 columns per GEMM column
+                    b.C = reinterpret_cast<char*>(p.C) + n_main * cmul * (CDT == MTL_BF16 ? 2 : 4);
+                    if (p.aux_in) b.aux_in = reinterpret_cast<const char*>(p.aux_in) + n_main * cmul * 2;       // (bf16 for every epilogue listed)
+                    if (p.aux_out) b.aux_out = reinterpret_cast<char*>(p.aux_out) + (EPI == MTL_EPI_SWIGLU ? n_main / 2 : n_main) * 2;
+                    const int rc = launch<EPI, CDT>(a, vec_ok, st, 256, 256, 2, 8);
+                    if (rc != MTL_OK) return rc;
+                    return launch<EPI, CDT>(b, vec_ok, st, 256, 128, 3, 16);
+                }
+            }
         }
         const bool auto_cfg = nw == 0 && stages == 0;
         if (nw == 0) nw = bm == 256 ? 16 : (bn >= 128 ? 8 : 4);

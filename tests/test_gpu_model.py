@@ -81,7 +81,7 @@ def test_psm_shaped_anomaly_detection_vs_oracle():
     _check_full_model("llama", "anomaly_detection", 2, 512, 25, 512, "concat", "linear", True, d_model=32, d_ff=128, H=8, num_tokens=1024)
 
 
-def _check_full_model(kind, task, B, L, C, pred, cov, down, prompt_on, d_model=8, d_ff=64, H=2, num_tokens=64):
+def _check_full_model(kind, task, B, L, C, pred, cov, down, prompt_on, d_model=8, d_ff=64, H=2, num_tokens=64, grad_bar=1.5):
     from med_ts_llm_amd.models import model_lookup
     from med_ts_llm_amd.models.backbone import random_state_dict
     from med_ts_llm_amd.utils import dict_to_object
@@ -177,7 +177,7 @@ def _check_full_model(kind, task, B, L, C, pred, cov, down, prompt_on, d_model=8
         # and the ratio of two error samples scatters: 3 x, on the larger of the two scales. tests/test_gpu_golden.py bounds the
         # scatter the other way with an aggregate criterion over all gradients of a case.
         small = t.numel() < 4096
-        if e_hip > (3.0 if small else 1.5) * max(e_ref, 1e-2, cond.get(n, 0.0) / scale if small else 0.0):
+        if e_hip > (3.0 if small else grad_bar) * max(e_ref, 1e-2, cond.get(n, 0.0) / scale if small else 0.0):
             bad[n] = (e_hip, e_ref)
     assert not bad, bad
 
