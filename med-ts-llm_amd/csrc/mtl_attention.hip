@@ -16,6 +16,7 @@
 #include "mtl_common.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 
 namespace {
@@ -100,13 +101,14 @@ __device__ __forceinline__ bf16x8 gather_col(const bf16_t* tile, int ldt, int ra
 // cooperative load of KC rows x D bf16 (row stride src_ts elements) into a padded LDS tile; rows >= limit are clamped.
 // All global loads of a thread are issued BEFORE the first LDS store: a load->store->load loop costs one full memory
 // round trip per iteration (hipcc waits vmcnt(0) in front of every ds_write), which was most of these kernels' time.
-template <int D>
+template <int D, int NT = 256>
 __device__ __forceinline__ void load_tile(bf16_t* tile, const bf16_t* src, int64_t src_ts, int64_t row0, int64_t limit) {
-    constexpr int LDT = D + 8, CPR = D / 8, NIT = KC * CPR / 256;
+    constexpr int LDT = D + 8, CPR = D / 8, NIT = KC * CPR / NT;
+    static_assert(KC * CPR % NT == 0 && NIT >= 1, "whole 16-byte chunks per thread");
     u32x4 v[NIT];
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-        const int s = threadIdx.x + i * 256;
+        const int s = threadIdx.x + i * NT;
         const int r = s / CPR, c = s % CPR;
         int64_t gr = row0 + r;
         if (gr > limit - 1) gr = limit - 1;
@@ -114,8 +116,34 @@ __device__ __forceinline__ void load_tile(bf16_t* tile, const bf16_t* src, int64
     }
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-        const int s = threadIdx.x + i * 256;
+        const int s = threadIdx.x + i * NT;
         *reinterpret_cast<u32x4*>(tile + (s / CPR) * LDT + (s % CPR) * 8) = v[i];
+    }
+}
+
+// the two halves of load_tile for a software pipeline (GUIDE T14: issue early, write late): fetch_tile issues the NEXT chunk's global loads
+// right after the barrier that publishes the CURRENT chunk, so their latency runs under the current chunk's MFMAs; stash_tile writes them to
+// the LDS tile after the next barrier. Costs KC * D * 2 / NT bytes of registers per tile and thread (16 B .. 64 B).
+template <int D, int NT>
+struct TileRegs { u32x4 v[KC * (D / 8) / NT]; };
+template <int D, int NT>
+__device__ __forceinline__ void fetch_tile(TileRegs<D, NT>& t, const bf16_t* src, int64_t src_ts, int64_t row0, int64_t limit) {
+    constexpr int CPR = D / 8, NIT = KC * CPR / NT;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int s = threadIdx.x + i * NT;
+        int64_t gr = row0 + s / CPR;
+        if (gr > limit - 1) gr = limit - 1;
+        t.v[i] = *reinterpret_cast<const u32x4*>(src + gr * src_ts + (s % CPR) * 8);
+    }
+}
+template <int D, int NT>
+__device__ __forceinline__ void stash_tile(bf16_t* tile, const TileRegs<D, NT>& t) {
+    constexpr int LDT = D + 8, CPR = D / 8, NIT = KC * CPR / NT;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int s = threadIdx.x + i * NT;
+        *reinterpret_cast<u32x4*>(tile + (s / CPR) * LDT + (s % CPR) * 8) = t.v[i];
     }
 }
 
@@ -124,14 +152,17 @@ __device__ __forceinline__ void load_tile(bf16_t* tile, const bf16_t* src, int64
 #define LN2 0.6931471805599453f
 
 // =============================================================================================== forward
-template <int D, bool CAUSAL, bool DROP>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a) {
+// NW waves x 16 query rows per workgroup. NW = 8 for long causal sequences (T >= 512; interleave / independent covariates on a Llama backbone):
+// every K / V chunk a workgroup stages serves 128 instead of 64 queries — at T = 1664 the 64-row blocks re-read each head's K / V 13 times
+// through L2 (5.6 GB per layer), which is what the kernels spent most of their time on.
+template <int D, bool CAUSAL, bool DROP, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const mtl_attn_fwd_args a) {
     constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
     __shared__ __attribute__((aligned(16))) bf16_t ktile[KC * LDT];
     __shared__ __attribute__((aligned(16))) bf16_t vtile[KC * LDT];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, g = lane >> 4;   // (wave index in an SGPR: tile offsets, loop bounds and the mask test become scalar)
     const int64_t b = blockIdx.z, h = blockIdx.y, hk = h / (a.Hq / a.Hkv);
-    const int64_t qblk0 = (int64_t)blockIdx.x * 64;
+    const int64_t qblk0 = (int64_t)blockIdx.x * (NW * 16);
     const int64_t q0 = qblk0 + wave * 16;
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * a.q_hs;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + hk * a.k_hs;
@@ -159,17 +190,35 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a
     const int klim = (int)((CAUSAL && qrow + coff < a.Tk - 1) ? qrow + coff : a.Tk - 1);   // last visible key of the lane's query
     int64_t k_end = a.Tk;
     if (CAUSAL) {
-        const int64_t lim = (qblk0 + 64 < a.Tq ? qblk0 + 64 : a.Tq) + coff;  // keys <= last query of the block
+        const int64_t lim = (qblk0 + NW * 16 < a.Tq ? qblk0 + NW * 16 : a.Tq) + coff;  // keys <= last query of the block
         k_end = lim < a.Tk ? lim : a.Tk;
     }
     const int64_t wave_qmin = q0 + coff;
     const int64_t wave_qmax = ((q0 + 15 < a.Tq - 1) ? q0 + 15 : a.Tq - 1) + coff;
 
+    // NW = 8 (long causal sequences, 2 workgroups per CU): software pipeline over the key chunks — 880 -> 730 us from the wider workgroup, -> 678 us
+    // with the pipeline at T = 1664 (per layer, Llama-2-7B, B = 16). The 4-wave kernels keep the plain load: four workgroups per CU already hide
+    // the latency, and the pipeline's registers cost them occupancy (cross-attention forward at Tq = 128: 242 -> 280 us with it).
+    constexpr bool PIPE = NW == 8;
+    TileRegs<D, NW * 64> rk, rv;
+    if constexpr (PIPE) {
+        fetch_tile<D, NW * 64>(rk, K, a.k_ts, 0, a.Tk);
+        fetch_tile<D, NW * 64>(rv, V, a.v_ts, 0, a.Tk);
+    }
     for (int64_t kc0 = 0; kc0 < k_end; kc0 += KC) {
         __syncthreads();
-        load_tile<D>(ktile, K, a.k_ts, kc0, a.Tk);
-        load_tile<D>(vtile, V, a.v_ts, kc0, a.Tk);
+        if constexpr (PIPE) {
+            stash_tile<D, NW * 64>(ktile, rk);
+            stash_tile<D, NW * 64>(vtile, rv);
+        } else {
+            load_tile<D, NW * 64>(ktile, K, a.k_ts, kc0, a.Tk);
+            load_tile<D, NW * 64>(vtile, V, a.v_ts, kc0, a.Tk);
+        }
         __syncthreads();
+        if (PIPE && kc0 + KC < k_end) {      // the next chunk's loads fly under this chunk's MFMAs
+            fetch_tile<D, NW * 64>(rk, K, a.k_ts, kc0 + KC, a.Tk);
+            fetch_tile<D, NW * 64>(rv, V, a.v_ts, kc0 + KC, a.Tk);
+        }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int64_t kb = kc0 + sub * 32;
@@ -257,15 +306,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mtl_attn_fwd_args a
 }
 
 // =============================================================================================== backward: dQ (+ delta)
-template <int D, bool CAUSAL, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_args a) {
+template <int D, bool CAUSAL, bool DROP, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const mtl_attn_bwd_args a) {
     constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
     __shared__ __attribute__((aligned(16))) bf16_t ktile[KC * LDT];
     __shared__ __attribute__((aligned(16))) bf16_t vtile[KC * LDT];
     const mtl_attn_fwd_args& f = a.f;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, g = lane >> 4;   // (wave index in an SGPR: tile offsets, loop bounds and the mask test become scalar)
     const int64_t b = blockIdx.z, h = blockIdx.y, hk = h / (f.Hq / f.Hkv);
-    const int64_t qblk0 = (int64_t)blockIdx.x * 64;
+    const int64_t qblk0 = (int64_t)blockIdx.x * (NW * 16);
     const int64_t q0 = qblk0 + wave * 16;
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(f.q) + b * f.q_bs + h * f.q_hs;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(f.k) + b * f.k_bs + hk * f.k_hs;
@@ -307,7 +356,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
     const int klim = (int)((CAUSAL && qrow + coff < f.Tk - 1) ? qrow + coff : f.Tk - 1);   // last visible key of the lane's query
     int64_t k_end = f.Tk;
     if (CAUSAL) {
-        const int64_t lim = (qblk0 + 64 < f.Tq ? qblk0 + 64 : f.Tq) + coff;
+        const int64_t lim = (qblk0 + NW * 16 < f.Tq ? qblk0 + NW * 16 : f.Tq) + coff;
         k_end = lim < f.Tk ? lim : f.Tk;
     }
     const int64_t wave_qmax = ((q0 + 15 < f.Tq - 1) ? q0 + 15 : f.Tq - 1) + coff;
@@ -337,8 +386,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
         float acc = 0.f;
         for (int64_t kc0 = 0; kc0 < k_end; kc0 += KC) {
             __syncthreads();
-            load_tile<D>(ktile, K, f.k_ts, kc0, f.Tk);
-            load_tile<D>(vtile, V, f.v_ts, kc0, f.Tk);
+            load_tile<D, NW * 64>(ktile, K, f.k_ts, kc0, f.Tk);
+            load_tile<D, NW * 64>(vtile, V, f.v_ts, kc0, f.Tk);
             __syncthreads();
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
@@ -370,10 +419,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
     }
     if (g == 0 && q_valid) a.delta[stat_idx] = dl;
 
+    // (no software pipeline here: measured 989 -> 1106 us at T = 1664 with it, the extra registers cost a wave per SIMD)
     for (int64_t kc0 = 0; kc0 < k_end; kc0 += KC) {
         __syncthreads();
-        load_tile<D>(ktile, K, f.k_ts, kc0, f.Tk);
-        load_tile<D>(vtile, V, f.v_ts, kc0, f.Tk);
+        load_tile<D, NW * 64>(ktile, K, f.k_ts, kc0, f.Tk);
+        load_tile<D, NW * 64>(vtile, V, f.v_ts, kc0, f.Tk);
         __syncthreads();
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -418,8 +468,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const mtl_attn_bwd_arg
 // =============================================================================================== backward: dK, dV
 // One workgroup per (64-key tile, kv head, batch or ALL batches when K/V are batch-shared); loops over the query
 // heads of the GQA group and over 64-query chunks. Lane owns key = lane & 15 of its wave's 16 keys.
-template <int D, bool CAUSAL, bool DROP>
-__global__ __launch_bounds__(256, D >= 128 ? 2 : 1) void attn_bwd_dkv_kernel(const mtl_attn_bwd_args a) {
+template <int D, bool CAUSAL, bool DROP, int NW = 4>
+__global__ __launch_bounds__(NW * 64, (D >= 128 && NW == 4) ? 2 : 1) void attn_bwd_dkv_kernel(const mtl_attn_bwd_args a) {
     constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
     __shared__ __attribute__((aligned(16))) bf16_t qtile[KC * LDT];
     __shared__ __attribute__((aligned(16))) bf16_t dotile[KC * LDT];
@@ -435,7 +485,7 @@ __global__ __launch_bounds__(256, D >= 128 ? 2 : 1) void attn_bwd_dkv_kernel(con
     const int64_t b_begin = shared_kv ? (int64_t)blockIdx.z * chunk : blockIdx.z;
     const int64_t b_end = shared_kv ? ((b_begin + chunk < f.B) ? b_begin + chunk : f.B) : blockIdx.z + 1;
     const int64_t coff = f.causal_off;
-    const int64_t kblk0 = a.kv_row0 + (int64_t)blockIdx.x * 64;   // keys below kv_row0 need no gradient (pruned)
+    const int64_t kblk0 = a.kv_row0 + (int64_t)blockIdx.x * (NW * 16);   // keys below kv_row0 need no gradient (pruned)
     const int64_t k0 = kblk0 + wave * 16;
     int64_t krow = k0 + l15;
     const bool k_valid = krow < f.Tk;
@@ -471,17 +521,32 @@ __global__ __launch_bounds__(256, D >= 128 ? 2 : 1) void attn_bwd_dkv_kernel(con
             const int64_t stat0 = (b * f.Hq + h) * (f.stat_stride ? f.stat_stride : f.Tq);
             // queries q with q + coff < kblk0 never see this key tile
             const int64_t qc_begin = (CAUSAL && kblk0 > coff) ? ((kblk0 - coff) / KC) * KC : 0;
+            // software pipeline over the query chunks of this head: chunk c + 1's Q / dO rows and statistics are fetched while chunk c computes
+            // (this kernel runs at two waves per SIMD: nothing else hides the load round trip; 1621 -> 1523 us at T = 1664, 470 -> 455 us for the
+            //  batch-shared reprogramming keys)
+            TileRegs<D, NW * 64> rq, rdo;
+            float r_lse = 0.f, r_delta = 0.f;
+            auto fetch_chunk = [&](int64_t qc) __attribute__((always_inline)) {
+                fetch_tile<D, NW * 64>(rq, Q, f.q_ts, qc, f.Tq);
+                fetch_tile<D, NW * 64>(rdo, dO, a.do_ts, qc, f.Tq);
+                if (threadIdx.x < KC) {
+                    int64_t qq = qc + threadIdx.x;
+                    if (qq > f.Tq - 1) qq = f.Tq - 1;
+                    r_lse = f.lse[stat0 + qq] * LOG2E;
+                    r_delta = a.delta[stat0 + qq];
+                }
+            };
+            if (qc_begin < f.Tq) fetch_chunk(qc_begin);
             for (int64_t qc0 = qc_begin; qc0 < f.Tq; qc0 += KC) {
                 __syncthreads();
-                load_tile<D>(qtile, Q, f.q_ts, qc0, f.Tq);
-                load_tile<D>(dotile, dO, a.do_ts, qc0, f.Tq);
+                stash_tile<D, NW * 64>(qtile, rq);
+                stash_tile<D, NW * 64>(dotile, rdo);
                 if (threadIdx.x < KC) {
-                    int64_t qq = qc0 + threadIdx.x;
-                    if (qq > f.Tq - 1) qq = f.Tq - 1;
-                    lse_s[threadIdx.x] = f.lse[stat0 + qq] * LOG2E;
-                    delta_s[threadIdx.x] = a.delta[stat0 + qq];
+                    lse_s[threadIdx.x] = r_lse;
+                    delta_s[threadIdx.x] = r_delta;
                 }
                 __syncthreads();
+                if (qc0 + KC < f.Tq) fetch_chunk(qc0 + KC);
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub) {
                     const int64_t qb = qc0 + sub * 32;
@@ -1001,6 +1066,7 @@ namespace {
 // resident-K/V path: causal, per-sample K/V, >= 4 rows, and both tiles fit the 160 KiB LDS
 constexpr size_t kLdsBudget = 156 * 1024;
 int g_attn_mode = 1;   // 1 = use the resident kernels when they fit, 0 = always the chunked kernels (A/B knob)
+const int g_attn_wide = getenv("MTL_ATTN_WIDE") ? atoi(getenv("MTL_ATTN_WIDE")) : 1;   // A/B knob: 0 = 64-row workgroups for long sequences too
 
 template <typename KernelT>
 void set_lds(KernelT k, size_t bytes) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); }
@@ -1049,6 +1115,13 @@ extern "C" int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream) {
     const dim3 grid((unsigned)((a->Tq + 63) / 64), (unsigned)a->Hq, (unsigned)a->B), block(256);
     const bool drop = a->dropout_p > 0.f;
     if (drop && a->dropout_p >= 1.f) return MTL_ERR_UNSUPPORTED;
+    if (a->causal && !drop && a->Tq >= 512 && (a->D == 64 || a->D == 128) && g_attn_wide == 1) {      // long sequences: 128 queries per workgroup
+        const dim3 grid8((unsigned)((a->Tq + 127) / 128), (unsigned)a->Hq, (unsigned)a->B), block8(512);
+        if (a->D == 64) MTL_LAUNCH("attn_fwd_kernel<64, true, false, 8>", fl_fwd, 0, (attn_fwd_kernel<64, true, false, 8>), grid8, block8, 0, st, *a);
+        else MTL_LAUNCH("attn_fwd_kernel<128, true, false, 8>", fl_fwd, 0, (attn_fwd_kernel<128, true, false, 8>), grid8, block8, 0, st, *a);
+        MTL_CHECK_LAUNCH();
+        return MTL_OK;
+    }
 #define MTL_FWD(DD)                                                                                                                        \
     if (a->causal && drop) MTL_LAUNCH("attn_fwd_kernel<" #DD ", true, true>", fl_fwd, 0, (attn_fwd_kernel<DD, true, true>), grid, block, 0, st, *a);   \
     else if (a->causal) MTL_LAUNCH("attn_fwd_kernel<" #DD ", true, false>", fl_fwd, 0, (attn_fwd_kernel<DD, true, false>), grid, block, 0, st, *a);    \
@@ -1118,6 +1191,18 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
     const dim3 gk((unsigned)((f.Tk - a->kv_row0 + 63) / 64), (unsigned)f.Hkv, (unsigned)(f.k_bs == 0 ? splits : f.B));
     const bool drop = f.dropout_p > 0.f;
     if (drop && f.dropout_p >= 1.f) return MTL_ERR_UNSUPPORTED;
+    if (f.causal && !drop && f.k_bs != 0 && f.Tq >= 512 && (f.D == 64 || f.D == 128) && g_attn_wide == 1) {   // long sequences: 128 rows per workgroup
+        const dim3 gq8((unsigned)((f.Tq + 127) / 128), (unsigned)f.Hq, (unsigned)f.B), gk8((unsigned)((f.Tk - a->kv_row0 + 127) / 128), (unsigned)f.Hkv, (unsigned)f.B), block8(512);
+        if (f.D == 64) {
+            MTL_LAUNCH("attn_bwd_dq_kernel<64, true, false, 8>", fl_half, 0, (attn_bwd_dq_kernel<64, true, false, 8>), gq8, block8, 0, st, *a);
+            MTL_LAUNCH("attn_bwd_dkv_kernel<64, true, false, 8>", fl_half, 0, (attn_bwd_dkv_kernel<64, true, false, 8>), gk8, block8, 0, st, *a);
+        } else {
+            MTL_LAUNCH("attn_bwd_dq_kernel<128, true, false, 8>", fl_half, 0, (attn_bwd_dq_kernel<128, true, false, 8>), gq8, block8, 0, st, *a);
+            MTL_LAUNCH("attn_bwd_dkv_kernel<128, true, false, 8>", fl_half, 0, (attn_bwd_dkv_kernel<128, true, false, 8>), gk8, block8, 0, st, *a);
+        }
+        MTL_CHECK_LAUNCH();
+        return MTL_OK;
+    }
 #define MTL_BWD(DD)                                                                                        \
     if (f.causal && drop) {                                                                                \
         MTL_LAUNCH("attn_bwd_dq_kernel<" #DD ", true, true>", fl_half, 0, (attn_bwd_dq_kernel<DD, true, true>), gq, block, 0, st, *a);                    \
