@@ -695,11 +695,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fw
     const float c = a.scale * LOG2E;
     const int64_t coff = a.causal_off;
     const int nt = (int)((a.Tq + 15) / 16), npairs = (nt + 1) / 2;
+    // few query tiles (the prompt-row cache / last layer: Tq = the patch rows, e.g. 8 tiles for 8 waves): ONE tile per wave instead of a pair per
+    // wave on half of the waves, as in the dQ kernel below
+    const bool single = nt <= NW && gridDim.x == 1;
     const int pi = blockIdx.x * NW + wave;
-    if (pi >= npairs) return;
+    if (pi >= (single ? nt : npairs)) return;
     for (int half = 0; half < 2; ++half) {
-        const int tile = half == 0 ? pi : nt - 1 - pi;
-        if (half == 1 && tile == pi) break;
+        const int tile = single ? pi : (half == 0 ? pi : nt - 1 - pi);
+        if (half == 1 && (single || tile == pi)) break;
         const int64_t q0 = (int64_t)tile * 16;
         int64_t qrow = q0 + l15;
         const bool q_valid = qrow < a.Tq;
@@ -1067,6 +1070,9 @@ namespace {
 constexpr size_t kLdsBudget = 156 * 1024;
 int g_attn_mode = 1;   // 1 = use the resident kernels when they fit, 0 = always the chunked kernels (A/B knob)
 const int g_attn_wide = getenv("MTL_ATTN_WIDE") ? atoi(getenv("MTL_ATTN_WIDE")) : 1;   // A/B knob: 0 = 64-row workgroups for long sequences too
+// rows from which the 128-row workgroups are used. Forward / dQ from 256 (PSM shape, Tq = 256 of T = 384: 131 -> 97 us, 184 -> 150 us); the
+// dK/dV kernel gains nothing there (190 -> 194 us) and switches at 512.
+const int g_attn_wide_min = getenv("MTL_ATTN_WIDE_MIN") ? atoi(getenv("MTL_ATTN_WIDE_MIN")) : 256;
 
 template <typename KernelT>
 void set_lds(KernelT k, size_t bytes) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); }
@@ -1115,7 +1121,7 @@ extern "C" int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream) {
     const dim3 grid((unsigned)((a->Tq + 63) / 64), (unsigned)a->Hq, (unsigned)a->B), block(256);
     const bool drop = a->dropout_p > 0.f;
     if (drop && a->dropout_p >= 1.f) return MTL_ERR_UNSUPPORTED;
-    if (a->causal && !drop && a->Tq >= 512 && (a->D == 64 || a->D == 128) && g_attn_wide == 1) {      // long sequences: 128 queries per workgroup
+    if (a->causal && !drop && a->Tq >= g_attn_wide_min && (a->D == 64 || a->D == 128) && g_attn_wide == 1) {      // long sequences: 128 queries per workgroup
         const dim3 grid8((unsigned)((a->Tq + 127) / 128), (unsigned)a->Hq, (unsigned)a->B), block8(512);
         if (a->D == 64) MTL_LAUNCH("attn_fwd_kernel<64, true, false, 8>", fl_fwd, 0, (attn_fwd_kernel<64, true, false, 8>), grid8, block8, 0, st, *a);
         else MTL_LAUNCH("attn_fwd_kernel<128, true, false, 8>", fl_fwd, 0, (attn_fwd_kernel<128, true, false, 8>), grid8, block8, 0, st, *a);
@@ -1191,14 +1197,18 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
     const dim3 gk((unsigned)((f.Tk - a->kv_row0 + 63) / 64), (unsigned)f.Hkv, (unsigned)(f.k_bs == 0 ? splits : f.B));
     const bool drop = f.dropout_p > 0.f;
     if (drop && f.dropout_p >= 1.f) return MTL_ERR_UNSUPPORTED;
-    if (f.causal && !drop && f.k_bs != 0 && f.Tq >= 512 && (f.D == 64 || f.D == 128) && g_attn_wide == 1) {   // long sequences: 128 rows per workgroup
+    if (f.causal && !drop && f.k_bs != 0 && f.Tq >= g_attn_wide_min && (f.D == 64 || f.D == 128) && g_attn_wide == 1) {   // long sequences: 128 rows per workgroup
         const dim3 gq8((unsigned)((f.Tq + 127) / 128), (unsigned)f.Hq, (unsigned)f.B), gk8((unsigned)((f.Tk - a->kv_row0 + 127) / 128), (unsigned)f.Hkv, (unsigned)f.B), block8(512);
+        const bool wide_kv = f.Tk - a->kv_row0 >= 512;
+        const dim3 gk4((unsigned)((f.Tk - a->kv_row0 + 63) / 64), (unsigned)f.Hkv, (unsigned)f.B);
         if (f.D == 64) {
             MTL_LAUNCH("attn_bwd_dq_kernel<64, true, false, 8>", fl_half, 0, (attn_bwd_dq_kernel<64, true, false, 8>), gq8, block8, 0, st, *a);
-            MTL_LAUNCH("attn_bwd_dkv_kernel<64, true, false, 8>", fl_half, 0, (attn_bwd_dkv_kernel<64, true, false, 8>), gk8, block8, 0, st, *a);
+            if (wide_kv) MTL_LAUNCH("attn_bwd_dkv_kernel<64, true, false, 8>", fl_half, 0, (attn_bwd_dkv_kernel<64, true, false, 8>), gk8, block8, 0, st, *a);
+            else MTL_LAUNCH("attn_bwd_dkv_kernel<64, true, false>", fl_half, 0, (attn_bwd_dkv_kernel<64, true, false>), gk4, dim3(256), 0, st, *a);
         } else {
             MTL_LAUNCH("attn_bwd_dq_kernel<128, true, false, 8>", fl_half, 0, (attn_bwd_dq_kernel<128, true, false, 8>), gq8, block8, 0, st, *a);
-            MTL_LAUNCH("attn_bwd_dkv_kernel<128, true, false, 8>", fl_half, 0, (attn_bwd_dkv_kernel<128, true, false, 8>), gk8, block8, 0, st, *a);
+            if (wide_kv) MTL_LAUNCH("attn_bwd_dkv_kernel<128, true, false, 8>", fl_half, 0, (attn_bwd_dkv_kernel<128, true, false, 8>), gk8, block8, 0, st, *a);
+            else MTL_LAUNCH("attn_bwd_dkv_kernel<128, true, false>", fl_half, 0, (attn_bwd_dkv_kernel<128, true, false>), gk4, dim3(256), 0, st, *a);
         }
         MTL_CHECK_LAUNCH();
         return MTL_OK;
