@@ -353,6 +353,8 @@ def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline):
     # DP: row-sharded optimiser step for the big replicated tensors (wide flatten heads, Llama-3's trainable vocabulary): reduce-scatter,
     # Adam on the owned rows, all-gather of the bf16 copy the forward reads
     su = parallel.ShardedUpdate(list(model.named_parameters()), rank, world) if (world > 1 and not args.replicate_optimizer) else None
+    if su is not None:
+        model._opt_shards = su             # (the model waits for asynchronously published rows in front of the GEMM that reads them)
     opt_params = su.optimizer_params(params) if su is not None else params
     if args.torch_adam:
         opt = torch.optim.Adam(opt_params, lr=1e-4, fused=True)
@@ -380,7 +382,7 @@ def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline):
             su.sync()
         opt.step()
         if su is not None:
-            su.publish()
+            su.publish(async_op=True)      # the model waits for a tensor's rows in front of the first kernel that reads it
         opt.zero_grad()
         return loss
 
@@ -388,6 +390,8 @@ def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline):
         step(i)
 
     def fence():
+        if su is not None:
+            su.wait_published()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

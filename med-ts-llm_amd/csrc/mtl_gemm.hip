@@ -1085,6 +1085,12 @@ int tile_order(int tiles_m, int tiles_n, int bm, int bn, int per_cu, int64_t K, 
     if (nt > 8 * 2 * 32 * per_cu) return 8;
     const int rotate = (one_tile_per_wg && K / BK <= 48 && !(rules_off() & 8)) ? 1 << 8 : 0;
     if (rules_off() & 16) return 8 | rotate;
+    {   // diagnostic: MTL_GEMM_G="bm,g" forces the group height of the short-chunk grids of bm-row tiles (in-step A/B)
+        static const char* spec = getenv("MTL_GEMM_G");
+        static int fg[2] = {0, 0};
+        static const bool parsed = spec && sscanf(spec, "%d,%d", &fg[0], &fg[1]) == 2;
+        if (parsed && fg[0] == bm && fg[1] > 0) return (fg[1] > tiles_m ? tiles_m : fg[1]) | rotate;
+    }
     // whole tile rows per XCD (tiles_m % 8 == 0): g = tiles_m/8 makes every XCD's chunk one group (its own eighth of the rows, all
     // columns: fewest A bytes) and a per-XCD column rotation (bit 9) keeps the XCDs off the same B panels. Per-kernel A/B against
     // the sqrt rule: qkv 35.6 -> 34.2, two-k-group 21.1 -> 20.5, dGELU 33.1 -> 32.2, residual 36.0 -> 34.8, GELU 61.0 -> 59.9 us.

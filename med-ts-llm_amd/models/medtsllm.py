@@ -328,6 +328,14 @@ class MedTsLLM(nn.Module):
         self._last_prompt_rows = ("ids", tuple(rows[0])) if len(rows) == 1 else None
         return torch.tensor(rows, dtype=torch.int32, device=device), splice
 
+    def _await_rows(self, *params):
+        """DP with a row-sharded optimiser step (parallel.ShardedUpdate.publish(async_op=True)): the other ranks' updated rows of these
+        tensors must have arrived before a kernel reads them"""
+        su = getattr(self, "_opt_shards", None)
+        if su is not None:
+            for p in params:
+                su.wait_published(p)
+
     def _prompt_key(self, ids):
         """host-side identity of a shared prompt (no device sync: the ids came from host lists / a host tensor checked once)"""
         if self.fixed_prompt_ids is not None:
@@ -430,6 +438,7 @@ class MedTsLLM(nn.Module):
                                                     self.patch_len, self.stride, concat, float(self.dropout) if drop_on else 0.0, seed ^ 0x2545F491)
         self._tap("tokens", tokens)
         if self.word_embeddings.requires_grad:
+            self._await_rows(self.mapping_layer.weight, self.word_embeddings)
             source = MappingTrainableFn.apply(self.mapping_layer.weight, self.mapping_layer.bias, self.word_embeddings, self._map_split_k)
         else:
             W = self.mapping_layer.weight
@@ -527,6 +536,7 @@ class MedTsLLM(nn.Module):
         kp = pad64(head_in.shape[1])
         if kp != head_in.shape[1]:
             head_in = F.pad(head_in, (0, kp - head_in.shape[1]))
+        self._await_rows(self.output_projection.linear.weight)
         out = self._tap("head", LinearFn.apply(head_in.contiguous(), self.output_projection.linear.weight, self.output_projection.linear.bias, self._linear_shadow(self.output_projection.linear)))
         if cm == "independent":      # mean of the per-channel predictions (R:models/medtsllm.py:371)
             out = ChannelMixFn.apply(out.reshape(bs, C, self.pred_len * self.n_outputs_per_step, 1), None, None, torch.float32)

@@ -276,21 +276,33 @@ class ShardedUpdate:
             it["handle"], it["dirty"] = None, False
 
     @torch.no_grad()
-    def publish(self):
-        """after optimizer.step(): every rank's updated rows reach every rank — as bf16 shadow rows when there is one, else as fp32"""
+    def publish(self, async_op=False):
+        """after optimizer.step(): every rank's updated rows reach every rank — as bf16 shadow rows when there is one, else as fp32.
+        async_op: the all-gathers are only LAUNCHED (RCCL's stream); wait_published(name) must run before the tensor is read again — the model
+        calls it right in front of the first GEMM that reads it, so that e.g. the flatten head's 3.4 GB gather (PSM, bf16) travels under the NEXT
+        step's whole frozen-backbone forward instead of in front of it."""
         if self.world <= 1:
             return
         for it in self.items:
             full = it["shadow"] if it["shadow"] is not None else it["p"].data
             per = it["r1"] - it["r0"]
             if self._rs and full.is_contiguous():
-                dist.all_gather_into_tensor(full.view(-1), full[it["r0"]:it["r1"]].reshape(-1), group=self.group)
+                h = dist.all_gather_into_tensor(full.view(-1), full[it["r0"]:it["r1"]].reshape(-1), group=self.group, async_op=async_op)
+                it["pub"] = h if async_op else None
             else:
                 parts = [torch.empty_like(full[:per]) for _ in range(self.world)]
                 dist.all_gather(parts, full[it["r0"]:it["r1"]].contiguous(), group=self.group)
                 for i, t in enumerate(parts):
                     if i != self.rank:
                         full[i * per:(i + 1) * per].copy_(t)
+                it["pub"] = None
+
+    def wait_published(self, param=None):
+        """block (stream-ordered on a GPU) until the rows published asynchronously have arrived: for `param` (the full tensor) or for all"""
+        for it in self.items:
+            if (param is None or it["p"] is param) and it.get("pub") is not None:
+                it["pub"].wait()
+                it["pub"] = None
 
 
 def shard_batch(batch, rank, world):

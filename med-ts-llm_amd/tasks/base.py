@@ -323,7 +323,8 @@ class BaseTask(ABC):
             self.opt_shards.sync()
         self.optimizer.step()
         if self.opt_shards is not None:
-            self.opt_shards.publish()
+            # launched only: the model waits for a tensor's rows right before the first kernel that reads it (MedTsLLM._await_rows)
+            self.opt_shards.publish(async_op=self.device.type == "cuda")
         self.optimizer.zero_grad()
         self._log_loss(loss)
         return loss
@@ -374,6 +375,8 @@ class BaseTask(ABC):
             for inputs in self.train_dataloader:
                 self.train_step(inputs)
             self._flush_losses()
+            if self.opt_shards is not None:
+                self.opt_shards.wait_published()
             val_scores = self.val()
             self.epochs_done = epoch + 1
             self.log_epoch(val_scores)

@@ -130,7 +130,8 @@ def _bf16_worker(rank, world, port, q):
     with torch.no_grad():
         it["shard"].add_(it["shard"].grad, alpha=-0.1)             # "the optimiser": owned rows of the master + their bf16 copy
         mine.copy_(it["shard"].to(torch.bfloat16))
-    su.publish()
+    su.publish(async_op=True)
+    su.wait_published(W)                                                                   # (what the model does in front of the GEMM that reads it)
     full = parallel.gather_rows(W.detach()[it["r0"]:it["r1"]].contiguous(), world)        # what a checkpoint writer does
     ok = ok and torch.equal(shadow, full.to(torch.bfloat16))                               # every rank's shadow = bf16(every owner's rows)
     stale = torch.ones(16, dtype=torch.bool)
