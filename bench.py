@@ -361,6 +361,9 @@ def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline):
     else:
         from med_ts_llm_amd.hip.optim import HipAdam, Bf16Shadow
         opt = HipAdam(opt_params, lr=1e-4)
+        if args.optimizer_overlap and su is None:
+            opt.defer(model.late_parameters())          # the tail's parameters: updated on a side stream under the next step's front end + backbone
+            model.optimizer_wait = opt.wait_deferred
         for sh in model.bf16_shadows():
             if su is not None and id(sh.param) in su._by_param:
                 opt.register_shadow(Bf16Shadow(su._by_param[id(sh.param)]["shard"], su.attach_shadow(sh.param, sh.tensor)))
@@ -497,6 +500,7 @@ def main():
     ap.add_argument("--replicate-mapping", action="store_true", help="DP: keep the mapping layer replicated (all-reduce its gradient)")
     ap.add_argument("--replicate-optimizer", action="store_true", help="DP: no row-sharded optimiser step for the big tensors (all-reduce + replicated Adam)")
     ap.add_argument("--no-llm-dropout", action="store_true", help="GPT-2: switch the frozen LLM's train-mode dropouts (0.1) off")
+    ap.add_argument("--optimizer-overlap", action="store_true", help="update the tail's parameters on a side stream under the next step (measured flat; off by default)")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the HIP multi-tensor Adam")
     args = ap.parse_args()
 

@@ -27,9 +27,25 @@ class HipAdam(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled_weight_decay=decoupled_weight_decay)
         super().__init__(params, defaults)
         self._shadows = {}
+        self._late, self._side, self._late_done = set(), None, None
 
     def register_shadow(self, shadow):
         self._shadows[id(shadow.param)] = shadow
+
+    def defer(self, params):
+        """Parameters that the NEXT forward reads only after the frozen backbone (down-sample layer, flatten head): their update runs on a side
+        stream, ordered after everything the step has enqueued so far, and overlaps the next step's front end and backbone — HBM-bound Adam traffic
+        under MFMA-bound GEMMs (the PSM head: 8 ms of a 226 ms step). Whoever reads such a parameter next must call wait_deferred() first
+        (MedTsLLM.predict does, in front of the down-sample GEMM; the trainer before validation / checkpoints). Same arithmetic, same results."""
+        self._late = {id(p) for p in params}
+        if self._late and self._side is None:
+            self._side = torch.cuda.Stream()
+
+    def wait_deferred(self):
+        """make the current stream wait for the deferred updates launched by the last step() (no-op when there are none)"""
+        if self._late_done is not None:
+            torch.cuda.current_stream().wait_event(self._late_done)
+            self._late_done = None
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -51,29 +67,51 @@ class HipAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] = int(st["step"]) + 1
                 by_step.setdefault(st["step"], []).append(p)
+            batches = []
             for step, ps in by_step.items():
-                arr = (N.AdamTensor * len(ps))()
-                keep = []
-                for i, p in enumerate(ps):
-                    st = self.state[p]
-                    g = p.grad
-                    if g.dtype != torch.float32 or not g.is_contiguous():
-                        g = g.float().contiguous()
-                    keep.append(g)
-                    sh = self._shadows.get(id(p))
-                    arr[i].p, arr[i].g, arr[i].m, arr[i].v = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-                    arr[i].n = p.numel()
-                    if sh is not None:
-                        arr[i].shadow, arr[i].cols, arr[i].ld_shadow = sh.tensor.data_ptr(), p.shape[1], sh.tensor.stride(0)
-                    else:
-                        arr[i].shadow, arr[i].cols, arr[i].ld_shadow = None, 0, 0
-                b1, b2 = group["betas"]
-                N.check(N.lib().mtl_adam_step(arr, len(ps), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                              float(group["weight_decay"]), 1 if group["decoupled_weight_decay"] else 0,
-                                              int(step), N.stream()), "mtl_adam_step")
-                for p in ps:   # the kernel wrote through raw pointers: bump the autograd version like an in-place op
-                    torch.autograd.graph.increment_version(p)
-                    sh = self._shadows.get(id(p))
-                    if sh is not None:
-                        sh.version = p._version
+                late = [p for p in ps if id(p) in self._late]
+                batches.append((step, [p for p in ps if id(p) not in self._late], False))
+                if late:
+                    batches.append((step, late, True))
+            for step, ps, deferred in batches:
+                if not ps:
+                    continue
+                if deferred:
+                    self._side.wait_stream(torch.cuda.current_stream())       # after the backward / all-reduce that produced the gradients
+                    with torch.cuda.stream(self._side):
+                        self._launch(group, step, ps)
+                        self._late_done = torch.cuda.Event()
+                        self._late_done.record(self._side)
+                    for p in ps:
+                        if p.grad is not None:
+                            p.grad.record_stream(self._side)                      # zero_grad() may release it while the side stream still reads it
+                else:
+                    self._launch(group, step, ps)
         return loss
+
+    def _launch(self, group, step, ps):
+        """one mtl_adam_step launch (all tensors of `ps`, which share `step`) on the current stream"""
+        arr = (N.AdamTensor * len(ps))()
+        keep = []
+        for i, p in enumerate(ps):
+            st = self.state[p]
+            g = p.grad
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                g = g.float().contiguous()
+            keep.append(g)
+            sh = self._shadows.get(id(p))
+            arr[i].p, arr[i].g, arr[i].m, arr[i].v = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            arr[i].n = p.numel()
+            if sh is not None:
+                arr[i].shadow, arr[i].cols, arr[i].ld_shadow = sh.tensor.data_ptr(), p.shape[1], sh.tensor.stride(0)
+            else:
+                arr[i].shadow, arr[i].cols, arr[i].ld_shadow = None, 0, 0
+        b1, b2 = group["betas"]
+        N.check(N.lib().mtl_adam_step(arr, len(ps), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                      float(group["weight_decay"]), 1 if group["decoupled_weight_decay"] else 0,
+                                      int(step), N.stream()), "mtl_adam_step")
+        for p in ps:   # the kernel wrote through raw pointers: bump the autograd version like an in-place op
+            torch.autograd.graph.increment_version(p)
+            sh = self._shadows.get(id(p))
+            if sh is not None:
+                sh.version = p._version

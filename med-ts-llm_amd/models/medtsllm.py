@@ -328,6 +328,18 @@ class MedTsLLM(nn.Module):
         self._last_prompt_rows = ("ids", tuple(rows[0])) if len(rows) == 1 else None
         return torch.tensor(rows, dtype=torch.int32, device=device), splice
 
+    def late_parameters(self):
+        """parameters a forward reads only AFTER the frozen backbone: an optimiser may update them under the next step's front end and backbone
+        (HipAdam.defer) as long as `optimizer_wait` runs before they are read — predict() calls it in front of the down-sample GEMM"""
+        ps = list(self.output_projection.parameters())
+        if isinstance(getattr(self, "embedding_downsample_layer", None), nn.Linear):
+            ps += list(self.embedding_downsample_layer.parameters())
+        if self.covariate_mode == "merge-end":
+            ps += list(self.feature_weighting.parameters())
+        return ps
+
+    optimizer_wait = None      # callable set by whoever defers updates of late_parameters() (BaseTask.build_optimizer, bench.py)
+
     def _await_rows(self, *params):
         """DP with a row-sharded optimiser step (parallel.ShardedUpdate.publish(async_op=True)): the other ranks' updated rows of these
         tensors must have arrived before a kernel reads them"""
@@ -521,6 +533,8 @@ class MedTsLLM(nn.Module):
             key = self._prompt_key(ids)
             prefix = bb.prefix_cache(h0[:1, :ids.shape[1]], key, h0.shape[1])
         dec = self._tap("dec", BackboneFn.apply(h0, bb, self.n_patches, n_grad, drop, prefix))   # [B', n_patches, d_llm] (final norm on the consumed rows only)
+        if self.optimizer_wait is not None:
+            self.optimizer_wait()        # deferred updates of the tail's parameters (side stream) must have landed before the tail reads them
         mode = self.embedding_downsample_mode
         if mode == "truncate":
             dec = dec[:, :, :self.d_ff]

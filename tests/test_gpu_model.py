@@ -273,6 +273,27 @@ def test_trainer_end_to_end_on_gpu(tmp_path, kind, task):
     assert preds.shape[0] == len(trainer.test_dataset) and torch.isfinite(preds).all()
 
 
+def test_deferred_tail_optimizer_step_is_the_same_training_run(tmp_path):
+    """HipAdam.defer: the tail's parameters (down-sample layer, flatten head) are updated on a side stream under the next step's front end and
+    backbone; the model waits for it in front of the down-sample GEMM. Same kernels, same inputs: the run is bit-identical to one that updates
+    everything on the main stream (the default: the overlap measured flat and is opt-in, setup.overlap_optimizer = true), losses and final weights."""
+    from med_ts_llm_amd.tasks import get_trainer
+    from med_ts_llm_amd.utils import dict_to_object
+    _write_hf_dir(tmp_path, "gpt2")
+    runs = []
+    for overlap in (True, False):
+        cfg = _trainer_config("forecasting", str(tmp_path), epochs=2)
+        cfg["setup"]["overlap_optimizer"] = overlap
+        tr = get_trainer("DEBUG-test", dict_to_object(cfg))
+        assert (tr.model.optimizer_wait is not None) == overlap and bool(tr.optimizer._late) == overlap
+        tr.train()
+        runs.append(([h["train/loss"] for h in tr.logger.history if "train/loss" in h],
+                     {n: p.detach().clone() for n, p in tr.model.named_parameters() if p.requires_grad}))
+    assert runs[0][0] == runs[1][0]
+    for n in runs[0][1]:
+        assert torch.equal(runs[0][1][n], runs[1][1][n]), n
+
+
 def test_linear_weight_shadows_track_the_masters(tmp_path):
     """the bf16 operand copies of the trainable Linear weights (written by HipAdam next to the fp32 masters, re-cast by the forward
     when a master changed behind the optimiser's back) always equal bf16(master) with zero K padding — after training steps, after
