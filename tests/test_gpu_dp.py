@@ -122,3 +122,97 @@ def test_two_rank_dp_step_matches_single_process():
     assert set(sd1) == set(sd2)
     for k in sd1:
         assert tuple(sd1[k].shape) == sd2[k], k
+
+
+# ---- row-sharded optimiser step on the device: HipAdam on the owned rows, bf16 shadow rows published to the other rank
+def _train3(model, batches, world, rank, sharded):
+    from med_ts_llm_amd import parallel
+    from med_ts_llm_amd.hip.optim import HipAdam, Bf16Shadow
+    params = [p for p in model.parameters() if p.requires_grad]
+    su = None
+    if sharded:
+        su = parallel.ShardedUpdate(list(model.named_parameters()), rank, world, min_numel=4096)
+        assert {it["name"] for it in su.items} >= {"output_projection.linear.weight"}
+        model._opt_shards = su
+    opt = HipAdam(su.optimizer_params(params) if su else params, lr=1e-3)
+    for sh in model.bf16_shadows():
+        if su is not None and id(sh.param) in su._by_param:
+            opt.register_shadow(Bf16Shadow(su._by_param[id(sh.param)]["shard"], su.attach_shadow(sh.param, sh.tensor)))
+        else:
+            opt.register_shadow(sh)
+    sync = parallel.FlatGradAllReduce(params, bucket_elems=20000) if world > 1 else None
+    losses = []
+    for inputs in batches:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = torch.nn.functional.mse_loss(model(inputs), inputs["y"])
+        loss.backward()
+        if sync is not None:
+            sync()
+        if su is not None:
+            su.sync()
+        opt.step()
+        if su is not None:
+            su.publish(async_op=True)
+        opt.zero_grad()
+        losses.append(float(loss.detach()))
+    if su is not None:
+        su.wait_published()
+    return losses, su, opt
+
+
+def _sharded_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MTL_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from med_ts_llm_amd import parallel
+    parallel.init_from_env("cuda")
+    model = _build(shard=(rank, world))
+    full = [_batch()]
+    g = torch.Generator().manual_seed(6)
+    full.append({"x_enc": torch.randn(B, L, C, generator=g).cuda(), "y": torch.randn(B, PRED, C, generator=g).cuda()})
+    full.append(full[0])
+    losses, su, opt = _train3(model, [parallel.shard_batch(b, rank, world) for b in full], world, rank, sharded=True)
+    head = model.output_projection.linear
+    it = su._by_param[id(head.weight)]
+    assert opt.state[it["shard"]]["exp_avg"].shape[0] == head.weight.shape[0] // world         # moments for the owned rows only
+    sh = model._linear_shadow(head)
+    shadows = [torch.zeros_like(sh.tensor) for _ in range(world)]
+    dist.all_gather(shadows, sh.tensor)
+    assert torch.equal(shadows[0], shadows[1])                                                  # what the forward reads: identical on both ranks
+    sd = model.state_dict()                                                                     # collective: gathers every owner's master rows
+    assert torch.equal(sd["output_projection.linear.weight"].to(torch.bfloat16), sh.tensor[:, :head.weight.shape[1]])
+    mine = sd["output_projection.linear.weight"][it["r0"]:it["r1"]]
+    assert torch.equal(mine, head.weight.detach()[it["r0"]:it["r1"]])
+    ls = [torch.zeros(3, device="cuda") for _ in range(world)]
+    dist.all_gather(ls, torch.tensor(losses, device="cuda"))
+    if rank == 0:
+        q.put((torch.stack(ls).mean(0).cpu().numpy(), {k: v.float().cpu().numpy() for k, v in sd.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_optimizer_matches_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    losses2, sd2 = q.get(timeout=240)
+    for p_ in procs:
+        p_.join(120)
+        assert p_.exitcode == 0
+    model = _build()
+    full = [_batch()]
+    g = torch.Generator().manual_seed(6)
+    full.append({"x_enc": torch.randn(B, L, C, generator=g).cuda(), "y": torch.randn(B, PRED, C, generator=g).cuda()})
+    full.append(full[0])
+    losses1, _, _ = _train3(model, full, 1, 0, sharded=False)
+    for a, b in zip(losses1, losses2):
+        assert abs(a - float(b)) < 5e-3 * abs(a), (losses1, losses2)
+    assert losses1[2] < losses1[0]
+    sd1 = model.state_dict()
+    for k in ("output_projection.linear.weight", "mapping_layer.weight", "reprogramming_layer.out_projection.weight"):
+        w1, w2 = sd1[k].float().cpu(), torch.from_numpy(sd2[k])
+        moved = 3e-3 * (w1.numel() ** 0.5)       # three Adam steps of lr 1e-3 move every element by <= 3e-3
+        assert float((w1 - w2).norm()) < 0.1 * moved, k      # the two runs agree to a small fraction of the distance the weights moved
