@@ -437,6 +437,30 @@ def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline):
     if want_roofline:
         loop = trainer_loop_rate(model, opt, sync, su, task, device, world, rank, batches, min(steps, 10), B)
 
+    # forward-only (predict) rate in eval mode, with and without the prompt-row cache (outside the timed region; every rank runs it)
+    predict = None
+    if want_roofline:
+        model.eval()
+        predict = {}
+        with torch.no_grad():
+            for label, on in (("samples_per_s", True), ("samples_per_s_full_forward", False)):
+                model.prompt_row_cache = on
+                for i in range(2):
+                    model(batches[i % len(batches)])
+                torch.cuda.synchronize()
+                n_pred = max(3, min(steps, 10))
+                t0 = time.perf_counter()
+                for i in range(n_pred):
+                    with torch.autocast("cuda", dtype=torch.bfloat16):
+                        model(batches[i % len(batches)])
+                torch.cuda.synchronize()
+                predict[label] = round(B * n_pred / (time.perf_counter() - t0), 2)
+                if on:
+                    predict["cached_prompt_rows"] = int(getattr(model.backbone, "last_n_prefix", 0))
+        model.prompt_row_cache = True
+        predict["what"] = "model.eval() forward under no_grad (the predict() path), per GPU; second figure: prompt-row cache switched off"
+        model.train()
+
     cpu = None
     if rank == 0 and world == 1 and want_cpu and big:
         cpu = cpu_baseline_llama(hf_cfg, L, C_, pred, n_tok, prompt_ids[0].tolist(), task, cov)
@@ -475,7 +499,7 @@ def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline):
             "forward": (f"prompt-row cache: the {n_cached} prompt rows are one constant prompt shared by every sample and the stack is deterministic, so their "
                         "per-layer keys / values are cached and the forward runs on the patch rows only (executed FLOPs drop; the algorithmic count and every "
                         "roofline denominator keep the full sequence)") if n_cached else "full sequence",
-            "trainer_loop": loop,
+            "trainer_loop": loop, "predict": predict,
             "algorithmic_tflop_per_step_per_gpu": round(fl / 1e12, 3), "executed_tflop_per_step_per_gpu": round(fl_exec / 1e12, 3),
             "step_mfma_frac": round(fl_exec / (elapsed / steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
             "step_mfma_frac_algorithmic": round(fl / (elapsed / steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),

@@ -647,6 +647,11 @@ __device__ __forceinline__ void load_rows(bf16_t* tile, const bf16_t* src, int64
     }
 }
 
+// loads in flight per thread and matrix while a resident kernel fills its LDS tiles: the whole 256-row tile in ONE round trip where the registers
+// allow it (hd 128, 8 waves: 8 chunks per thread and matrix; with 4 the fill took two trips per workgroup, and a workgroup is alone on its CU)
+template <int D, int NW>
+struct RES_BATCH { static constexpr int value = (D >= 128 && NW >= 8) ? 8 : 4; };
+
 // two matrices (K and V, or Q and dO) in ONE round trip: every load of both is issued before the first LDS store
 template <int D, int NT, int BATCH>
 __device__ __forceinline__ void load_rows_pair(bf16_t* tile_a, const bf16_t* src_a, int64_t ts_a, bf16_t* tile_b, const bf16_t* src_b,
@@ -686,7 +691,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fw
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, g = lane >> 4;   // (wave index in an SGPR: tile offsets, loop bounds and the mask test become scalar)
     const int64_t b = blockIdx.z, h = blockIdx.y, hk = h / (a.Hq / a.Hkv);
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * a.q_hs;
-    load_rows_pair<D, NW * 64, 4>(ktile, reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + hk * a.k_hs, a.k_ts,
+    load_rows_pair<D, NW * 64, RES_BATCH<D, NW>::value>(ktile, reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + hk * a.k_hs, a.k_ts,
                                   vtile, reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + hk * a.v_hs, a.v_ts, a.Tk);
     __syncthreads();
     const uint32_t dbase = DROP ? drop_base(a.dropout_seed, (uint32_t)(b * a.Hq + h)) : 0u;
@@ -807,7 +812,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(f.q) + b * f.q_bs + h * f.q_hs;
     const bf16_t* O = reinterpret_cast<const bf16_t*>(f.o) + b * f.o_bs + h * f.o_hs;
     const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dout) + b * a.do_bs + h * a.do_hs;
-    load_rows_pair<D, NW * 64, 4>(ktile, reinterpret_cast<const bf16_t*>(f.k) + b * f.k_bs + hk * f.k_hs, f.k_ts,
+    load_rows_pair<D, NW * 64, RES_BATCH<D, NW>::value>(ktile, reinterpret_cast<const bf16_t*>(f.k) + b * f.k_bs + hk * f.k_hs, f.k_ts,
                                   vtile, reinterpret_cast<const bf16_t*>(f.v) + b * f.v_bs + hk * f.v_hs, f.v_ts, f.Tk);
     __syncthreads();
     const uint32_t dbase = DROP ? drop_base(f.dropout_seed, (uint32_t)(b * f.Hq + h)) : 0u;
@@ -973,7 +978,7 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 && !DROP) ? 2 : 1) void attn_bwd
                 const int64_t h = hk * group + hg;
                 const int64_t stat0 = (b * f.Hq + h) * (f.stat_stride ? f.stat_stride : f.Tq);
                 __syncthreads();
-                load_rows_pair<D, NW * 64, 4>(qtile, reinterpret_cast<const bf16_t*>(f.q) + b * f.q_bs + h * f.q_hs, f.q_ts,
+                load_rows_pair<D, NW * 64, RES_BATCH<D, NW>::value>(qtile, reinterpret_cast<const bf16_t*>(f.q) + b * f.q_bs + h * f.q_hs, f.q_ts,
                                               dotile, reinterpret_cast<const bf16_t*>(a.dout) + b * a.do_bs + h * a.do_hs, a.do_ts, f.Tq);
                 for (int64_t i = threadIdx.x; i < ceil32(f.Tq); i += NW * 64) {
                     lse_s[i] = i < f.Tq ? f.lse[stat0 + i] * LOG2E : 0.f;
