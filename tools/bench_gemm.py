@@ -19,6 +19,8 @@ g = torch.Generator().manual_seed(0)
 for name, M, Nn, K, epi in shapes:
     A = torch.randn(M, K, generator=g).to(BF16).cuda()
     B = (torch.randn(Nn, K, generator=g) * 0.05).to(BF16).cuda()
+    if os.environ.get("GEMM_ZERO") == "1":      # zero-filled operands: same instruction stream at a lower power draw (the chip clocks to its power budget)
+        A.zero_(); B.zero_()
     bias = torch.randn(Nn, generator=g).cuda()
     kw = {}
     if epi == N.EPI_RESID:
