@@ -208,10 +208,15 @@ def test_hip_patch_index_map_vs_reference_golden():
         assert idx.dtype == np.int32 and np.array_equal(idx, data["patch_index_map"])
 
 
-def test_product_trainer_replays_reference_trajectory_on_gpu(tmp_path):
+@pytest.mark.parametrize("prompt_stats", ["host", "device"])
+def test_product_trainer_replays_reference_trajectory_on_gpu(tmp_path, prompt_stats):
     """a10 on the device: tasks.get_trainer(...).train() — BaseTask.train_step with the HIP model, HipAdam, bf16 autocast —
     from the reference trainer's initial weights over its batches: 8 per-step losses and the final weights. The reference ran
-    in fp32; the bar is the mixed-precision ladder (loss values within 1 %, every weight within 10 % of the distance it moved)."""
+    in fp32; the bar is the mixed-precision ladder (loss values within 1 %, every weight within 10 % of the distance it moved).
+    prompt_stats = "device": the run trains with the prompts built from the DEVICE statistics kernels (mtl_input_stats, f2) — what the product
+    does; every prompt of every batch must equal the host-built one up to the order inside twin pairs of lags (see above). A swapped twin changes
+    prompt tokens (lag k printed as L - k), which this 2-layer toy model feels: the run is then a different — equally valid — trajectory, so only
+    its level is compared (every loss within 20 %, their mean within 3 % of the reference's; measured: mean 0.7401 vs 0.7415)."""
     from test_host_logic import golden_trainer_setup, load_golden_init
     from med_ts_llm_amd.tasks import get_trainer
     cfg, z, n_batches = golden_trainer_setup(tmp_path, "cuda", "mixed")
@@ -221,12 +226,30 @@ def test_product_trainer_replays_reference_trajectory_on_gpu(tmp_path):
     # the reference trainer ran on the CPU: its prompts carry the CPU's choice inside every twin pair of lags (see above). The
     # product's prompt builder on a host copy of the batch reproduces those strings byte for byte (tests/test_host_logic.py)
     build = trainer.model.build_prompt
-    trainer.model.build_prompt = lambda inputs: build({**inputs, "x_enc": inputs["x_enc"].cpu()})
+    seen = []
+    if prompt_stats == "host":
+        trainer.model.build_prompt = lambda inputs: build({**inputs, "x_enc": inputs["x_enc"].cpu()})
+    else:
+        def build_checked(inputs):
+            dev, host = build(inputs), build({**inputs, "x_enc": inputs["x_enc"].cpu()})
+            Lx = inputs["x_enc"].shape[1]
+            strs = lambda pr: [[q if isinstance(q, str) else "<T>" for q in ps] for ps in pr]
+            assert canonical_prompts(strs(dev), Lx) == canonical_prompts(strs(host), Lx)
+            seen.append(strs(dev) == strs(host))
+            return dev
+        trainer.model.build_prompt = build_checked
     trainer.train()
     losses = np.array([h["train/loss"] for h in trainer.logger.history if "train/loss" in h])
     assert len(losses) == 2 * n_batches == len(z["losses"])
     print("\nloss trajectory  hip:", np.round(losses, 5).tolist(), "\n            reference:", np.round(z["losses"], 5).tolist())
-    assert np.allclose(losses, z["losses"], rtol=1e-2, atol=1e-5), (losses, z["losses"])
+    if seen:
+        print("device-built prompts byte-identical to the host-built ones in", sum(seen), "of", len(seen), "batches")
+    if prompt_stats == "host":
+        assert np.allclose(losses, z["losses"], rtol=1e-2, atol=1e-5), (losses, z["losses"])
+    else:
+        assert len(seen) >= 2 * n_batches
+        assert np.allclose(losses, z["losses"], rtol=0.2) and abs(losses.mean() / z["losses"].mean() - 1.0) < 0.03, (losses, z["losses"])
+        return
     p = dict(trainer.model.named_parameters())
     worst = {}
     for k in z.files:
