@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -37,6 +38,16 @@ Profiler& prof() { static Profiler p; return p; }
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 
+#ifndef MTL_GEMM_FRAG_PIPE
+#define MTL_GEMM_FRAG_PIPE 1      // 0: the compiler-scheduled fragment reads (diagnostic builds)
+#endif
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
@@ -630,6 +641,46 @@ __device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int
 // waves per SIMD the launcher counts on (workgroups per CU by LDS x waves per workgroup / 4 SIMDs): told to the compiler so that an
 // epilogue change cannot silently push a kernel over an occupancy cliff (the 128x192 / 8-wave qkv kernel went 126 -> 136 VGPRs and
 // lost its second workgroup per CU: 38.5 -> 40.9 us)
+// ---- fragment pipeline of the persistent kernel's k-tile (see the call site): inline-asm ds_reads + hand-counted lgkmcnt waits
+constexpr int FRAG_D = 2;                      // prefetch distance in units of 4 MFMAs (one column tile x 4 row tiles x one 32-deep k half)
+template <int KS_, int ROWB>
+__device__ __forceinline__ void frag_read_a(bf16x8 (&afa)[2][4], const uint32_t (&abase)[2]) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(afa[KS_][0]) : "v"(abase[KS_]));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(afa[KS_][1]) : "v"(abase[KS_]), "n"(16 * ROWB));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(afa[KS_][2]) : "v"(abase[KS_]), "n"(32 * ROWB));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(afa[KS_][3]) : "v"(abase[KS_]), "n"(48 * ROWB));
+}
+template <int NI, int NPT, int ROWB, int U>    // unit U = ks * NI + ni -> ring slot U % (FRAG_D + 1)
+__device__ __forceinline__ void frag_read_b(bf16x8 (&bq)[FRAG_D + 1], const uint32_t (&bpair)[2], const uint32_t (&bplain)[2]) {
+    constexpr int ks = U / NI, ni = U % NI;
+    if constexpr (ni < NPT) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[U % (FRAG_D + 1)]) : "v"(bpair[ks]), "n"(((ni >> 1) * 32 + (ni & 1) * 4) * ROWB));
+    else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[U % (FRAG_D + 1)]) : "v"(bplain[ks]), "n"(ni * 16 * ROWB));
+}
+// program order of the reads: A(0) B(0) B(1) | ahead of unit u: [A(1) if unit u + D opens the second k half] B(u + D)
+template <int NI, int NPT, int ROWB, int U>
+__device__ __forceinline__ void frag_units(f32x4 (&acc)[NI][4], bf16x8 (&afa)[2][4], bf16x8 (&bq)[FRAG_D + 1], const uint32_t (&abase)[2],
+                                           const uint32_t (&bpair)[2], const uint32_t (&bplain)[2]) {
+    constexpr int NU = 2 * NI, D = FRAG_D;
+    static_assert(NI >= D, "the second k half's A fragments are requested D units ahead of it");
+    if constexpr (U < NU) {
+        constexpr int ks = U / NI, ni = U % NI, slot = U % (D + 1);
+        if constexpr (U + D < NU) {
+            if constexpr (U + D == NI) frag_read_a<1, ROWB>(afa, abase);
+            frag_read_b<NI, NPT, ROWB, U + D>(bq, bpair, bplain);
+        }
+        // reads younger than B(U): B(U+1) .. B(last), plus A(1)'s four when it was issued behind B(U)
+        constexpr int last = U + D < NU ? U + D : NU - 1;
+        constexpr int younger = (last - U) + ((U < NI && last >= NI) ? 4 : 0);
+        if constexpr (ni == 0)
+            asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(bq[slot]), "+v"(afa[ks][0]), "+v"(afa[ks][1]), "+v"(afa[ks][2]), "+v"(afa[ks][3]) : "n"(younger));
+        else
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bq[slot]) : "n"(younger));
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[slot], afa[ks][mi], acc[ni][mi], 0, 0, 0);
+        frag_units<NI, NPT, ROWB, U + 1>(acc, afa, bq, abase, bpair, bplain);
+    }
+}
+
 constexpr int persist_waves_per_simd(int bm, int bn, int stages, int nw_all, int ks) {
     const int bn_lds = ((bn * 8 + (nw_all / ks) * 64 - 1) / ((nw_all / ks) * 64)) * ((nw_all / ks) * 64) / 8;
     const int lds = ks * stages * (bm + bn_lds) * 128;
@@ -655,6 +706,9 @@ __global__ __launch_bounds__(NW_ALL * 64, persist_waves_per_simd(BM_, BN_, STAGE
     constexpr int NB = (BN_ * CPR + NT - 1) / NT;   // ... B tile (256x96 / 8 waves: the B image is padded to 128 rows; the
     constexpr int BN_PAD = NB * NT / CPR;      //     extra rows re-load clamped rows and are never read)
     constexpr int NL = NA + NB;                // LDS-DMA instructions per wave per stage
+    // fragment pipeline (below): for the instances that run at most two waves per SIMD — with four (128 x 192, 128 x 128 / 8 waves: capped at
+    // 128 VGPRs) the other waves already cover a wave's LDS latency and the pipeline's extra registers only spill (qkv 128 x 192: 34.9 -> 37.3 us)
+    constexpr bool FRAG_PIPE = MTL_GEMM_FRAG_PIPE != 0 && persist_waves_per_simd(BM_, BN_, STAGES, NW_ALL, KS) <= 2;
     constexpr int A_BYTES = BM_ * ROWB, B_BYTES = BN_PAD * ROWB;
     static_assert(BM_ * CPR % NT == 0, "A tile must be whole LDS-DMA instructions");
     constexpr int STAGE = A_BYTES + B_BYTES;
@@ -803,6 +857,26 @@ __global__ __launch_bounds__(NW_ALL * 64, persist_waves_per_simd(BM_, BN_, STAGE
         }
         const char* la = smem + c_buf * STAGE;
         const char* lb = la + A_BYTES;
+        if constexpr (FRAG_PIPE) {
+            // Fragment pipeline inside the wave. The k-tile's MFMAs go in 2 * NI units of 4 (one column tile x 4 row tiles x one 32-deep k
+            // half); the B fragment of unit u + 2 (and, ahead of the second k half, its A fragments) is REQUESTED before unit u issues, so a
+            // wave's ds_read latency runs under its own MFMAs. hipcc's own order is read -> s_waitcnt lgkmcnt(0) -> MFMAs per group (every
+            // group waits out one LDS round trip), and with the reads merely moved up in the source it still waits lgkmcnt(0) behind every
+            // second group. The reads are therefore issued from inline asm (invisible to its counter model) with hand-counted waits: LDS
+            // operations return in order, so "the reads issued after this unit's fragment may stay out" is a counted lgkmcnt. A wait names
+            // the registers the following MFMAs read as in/out operands, so they cannot be scheduled above it; asm statements keep their
+            // order. Measured on the Llama shapes (cold pools, libraries alternated in one call): 256 x 256 plain -3.0 ... -6.7 %.
+            const uint32_t la32 = (uint32_t)(uintptr_t)la, lb32 = (uint32_t)(uintptr_t)lb;       // (flat LDS address: the low half is the LDS offset)
+            const uint32_t pck[2] = {((uint32_t)g ^ (uint32_t)sw) * 16u, ((4u + (uint32_t)g) ^ (uint32_t)sw) * 16u};
+            const uint32_t abase[2] = {la32 + (uint32_t)a_off + pck[0], la32 + (uint32_t)a_off + pck[1]};
+            const uint32_t bpair[2] = {lb32 + (uint32_t)b_off_pair + pck[0], lb32 + (uint32_t)b_off_pair + pck[1]};
+            const uint32_t bplain[2] = {lb32 + (uint32_t)b_off + pck[0], lb32 + (uint32_t)b_off + pck[1]};
+            bf16x8 afa[2][4], bq[FRAG_D + 1];
+            frag_read_a<0, ROWB>(afa, abase);
+            frag_read_b<NI, NPT, ROWB, 0>(bq, bpair, bplain);
+            frag_read_b<NI, NPT, ROWB, 1>(bq, bpair, bplain);
+            frag_units<NI, NPT, ROWB, 0>(acc, afa, bq, abase, bpair, bplain);
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int pc16 = ((ks * 4 + g) ^ sw) * 16;
@@ -818,6 +892,7 @@ __global__ __launch_bounds__(NW_ALL * 64, persist_waves_per_simd(BM_, BN_, STAGE
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
         }
         c_buf = (c_buf + 1 == STAGES) ? 0 : c_buf + 1;
         if (++c_kt == nkt) {
