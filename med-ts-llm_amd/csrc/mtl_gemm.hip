@@ -41,6 +41,9 @@ constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 #ifndef MTL_GEMM_FRAG_PIPE
 #define MTL_GEMM_FRAG_PIPE 1      // 0: the compiler-scheduled fragment reads (diagnostic builds)
 #endif
+#ifndef MTL_GEMM_FRAG_D
+#define MTL_GEMM_FRAG_D 3         // prefetch distance of the fragment pipeline in units of 4 MFMAs
+#endif
 template <int N, int I = 0, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
@@ -641,8 +644,8 @@ __device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int
 // waves per SIMD the launcher counts on (workgroups per CU by LDS x waves per workgroup / 4 SIMDs): told to the compiler so that an
 // epilogue change cannot silently push a kernel over an occupancy cliff (the 128x192 / 8-wave qkv kernel went 126 -> 136 VGPRs and
 // lost its second workgroup per CU: 38.5 -> 40.9 us)
-// ---- fragment pipeline of the persistent kernel's k-tile (see the call site): inline-asm ds_reads + hand-counted lgkmcnt waits
-constexpr int FRAG_D = 2;                      // prefetch distance in units of 4 MFMAs (one column tile x 4 row tiles x one 32-deep k half)
+// ---- fragment pipeline of the persistent kernel's k-tile (see the call site): inline-asm ds_reads + hand-counted lgkmcnt waits.
+// D = prefetch distance in units of 4 MFMAs (one column tile x 4 row tiles x one 32-deep k half); the B fragments live in a ring of D + 1.
 template <int KS_, int ROWB>
 __device__ __forceinline__ void frag_read_a(bf16x8 (&afa)[2][4], const uint32_t (&abase)[2]) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(afa[KS_][0]) : "v"(abase[KS_]));
@@ -650,23 +653,30 @@ __device__ __forceinline__ void frag_read_a(bf16x8 (&afa)[2][4], const uint32_t 
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(afa[KS_][2]) : "v"(abase[KS_]), "n"(32 * ROWB));
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(afa[KS_][3]) : "v"(abase[KS_]), "n"(48 * ROWB));
 }
-template <int NI, int NPT, int ROWB, int U>    // unit U = ks * NI + ni -> ring slot U % (FRAG_D + 1)
-__device__ __forceinline__ void frag_read_b(bf16x8 (&bq)[FRAG_D + 1], const uint32_t (&bpair)[2], const uint32_t (&bplain)[2]) {
+template <int NI, int NPT, int ROWB, int D, int U>    // unit U = ks * NI + ni -> ring slot U % (D + 1)
+__device__ __forceinline__ void frag_read_b(bf16x8 (&bq)[D + 1], const uint32_t (&bpair)[2], const uint32_t (&bplain)[2]) {
     constexpr int ks = U / NI, ni = U % NI;
-    if constexpr (ni < NPT) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[U % (FRAG_D + 1)]) : "v"(bpair[ks]), "n"(((ni >> 1) * 32 + (ni & 1) * 4) * ROWB));
-    else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[U % (FRAG_D + 1)]) : "v"(bplain[ks]), "n"(ni * 16 * ROWB));
+    if constexpr (ni < NPT) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[U % (D + 1)]) : "v"(bpair[ks]), "n"(((ni >> 1) * 32 + (ni & 1) * 4) * ROWB));
+    else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[U % (D + 1)]) : "v"(bplain[ks]), "n"(ni * 16 * ROWB));
 }
-// program order of the reads: A(0) B(0) B(1) | ahead of unit u: [A(1) if unit u + D opens the second k half] B(u + D)
-template <int NI, int NPT, int ROWB, int U>
-__device__ __forceinline__ void frag_units(f32x4 (&acc)[NI][4], bf16x8 (&afa)[2][4], bf16x8 (&bq)[FRAG_D + 1], const uint32_t (&abase)[2],
+template <int NI, int NPT, int ROWB, int D, int U>    // B(0) .. B(D - 1): what is in flight when unit 0 starts
+__device__ __forceinline__ void frag_read_first(bf16x8 (&bq)[D + 1], const uint32_t (&bpair)[2], const uint32_t (&bplain)[2]) {
+    if constexpr (U < D) {
+        frag_read_b<NI, NPT, ROWB, D, U>(bq, bpair, bplain);
+        frag_read_first<NI, NPT, ROWB, D, U + 1>(bq, bpair, bplain);
+    }
+}
+// program order of the reads: A(0) B(0) .. B(D - 1) | ahead of unit u: [A(1) if unit u + D opens the second k half] B(u + D)
+template <int NI, int NPT, int ROWB, int D, int U>
+__device__ __forceinline__ void frag_units(f32x4 (&acc)[NI][4], bf16x8 (&afa)[2][4], bf16x8 (&bq)[D + 1], const uint32_t (&abase)[2],
                                            const uint32_t (&bpair)[2], const uint32_t (&bplain)[2]) {
-    constexpr int NU = 2 * NI, D = FRAG_D;
-    static_assert(NI >= D, "the second k half's A fragments are requested D units ahead of it");
+    constexpr int NU = 2 * NI;
+    static_assert(NI >= D && D >= 1, "the second k half's A fragments are requested D units ahead of it");
     if constexpr (U < NU) {
         constexpr int ks = U / NI, ni = U % NI, slot = U % (D + 1);
         if constexpr (U + D < NU) {
             if constexpr (U + D == NI) frag_read_a<1, ROWB>(afa, abase);
-            frag_read_b<NI, NPT, ROWB, U + D>(bq, bpair, bplain);
+            frag_read_b<NI, NPT, ROWB, D, U + D>(bq, bpair, bplain);
         }
         // reads younger than B(U): B(U+1) .. B(last), plus A(1)'s four when it was issued behind B(U)
         constexpr int last = U + D < NU ? U + D : NU - 1;
@@ -677,7 +687,7 @@ __device__ __forceinline__ void frag_units(f32x4 (&acc)[NI][4], bf16x8 (&afa)[2]
             asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bq[slot]) : "n"(younger));
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[slot], afa[ks][mi], acc[ni][mi], 0, 0, 0);
-        frag_units<NI, NPT, ROWB, U + 1>(acc, afa, bq, abase, bpair, bplain);
+        frag_units<NI, NPT, ROWB, D, U + 1>(acc, afa, bq, abase, bpair, bplain);
     }
 }
 
@@ -871,11 +881,11 @@ __global__ __launch_bounds__(NW_ALL * 64, persist_waves_per_simd(BM_, BN_, STAGE
             const uint32_t abase[2] = {la32 + (uint32_t)a_off + pck[0], la32 + (uint32_t)a_off + pck[1]};
             const uint32_t bpair[2] = {lb32 + (uint32_t)b_off_pair + pck[0], lb32 + (uint32_t)b_off_pair + pck[1]};
             const uint32_t bplain[2] = {lb32 + (uint32_t)b_off + pck[0], lb32 + (uint32_t)b_off + pck[1]};
-            bf16x8 afa[2][4], bq[FRAG_D + 1];
+            constexpr int FD = NI >= MTL_GEMM_FRAG_D ? MTL_GEMM_FRAG_D : NI;
+            bf16x8 afa[2][4], bq[FD + 1];
             frag_read_a<0, ROWB>(afa, abase);
-            frag_read_b<NI, NPT, ROWB, 0>(bq, bpair, bplain);
-            frag_read_b<NI, NPT, ROWB, 1>(bq, bpair, bplain);
-            frag_units<NI, NPT, ROWB, 0>(acc, afa, bq, abase, bpair, bplain);
+            frag_read_first<NI, NPT, ROWB, FD, 0>(bq, bpair, bplain);
+            frag_units<NI, NPT, ROWB, FD, 0>(acc, afa, bq, abase, bpair, bplain);
         } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
