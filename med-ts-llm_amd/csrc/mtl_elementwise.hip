@@ -135,6 +135,43 @@ __global__ void rope_kernel(bf16_t* __restrict__ qkv, int64_t ld, const float* _
     }
 }
 
+// the same rotation with 16-byte accesses: a thread owns 8 consecutive columns i .. i+7 of a head's low half and the matching 8 of its high half
+// (two 16-B loads + two 16-B stores of qkv, 2 x 32 B of cos / sin); D % 16 == 0, 16-B aligned rows. Same rope_pair arithmetic: bit-identical.
+// (the 4-byte form above moved the Llama-2-7B forward pass' 134 MB per layer at 3.4 TB/s)
+__global__ __launch_bounds__(256) void rope_kernel_v8(bf16_t* __restrict__ qkv, int64_t ld, const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                      int64_t M, int64_t T, int n_heads, int D, int inverse, int64_t gr, int64_t gs, int64_t ro) {
+    const int half = D >> 1, cpr = half >> 3;      // 8-column chunks per head half
+    const int per_row = n_heads * cpr;
+    const int64_t total = M * per_row;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = remap_row(idx / per_row, gr, gs, ro);
+        const int rem = (int)(idx % per_row);
+        const int h = rem / cpr, i = (rem % cpr) * 8;
+        const int64_t pos = m % T;
+        bf16_t* base = qkv + m * ld + (int64_t)h * D;
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(base + i);
+        const u32x4 hi = *reinterpret_cast<const u32x4*>(base + half + i);
+        const float4 c0 = *reinterpret_cast<const float4*>(cos_t + pos * D + i), c1 = *reinterpret_cast<const float4*>(cos_t + pos * D + i + 4);
+        float4 s0 = *reinterpret_cast<const float4*>(sin_t + pos * D + i), s1 = *reinterpret_cast<const float4*>(sin_t + pos * D + i + 4);
+        const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        u32x4 ylo, yhi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x1a = __uint_as_float(lo[j] << 16), x1b = __uint_as_float(lo[j] & 0xffff0000u);
+            const float x2a = __uint_as_float(hi[j] << 16), x2b = __uint_as_float(hi[j] & 0xffff0000u);
+            const float sa = inverse ? -sn[2 * j] : sn[2 * j], sb = inverse ? -sn[2 * j + 1] : sn[2 * j + 1];
+            float y1a, y2a, y1b, y2b;
+            rope_pair(x1a, x2a, c[2 * j], sa, y1a, y2a);
+            rope_pair(x1b, x2b, c[2 * j + 1], sb, y1b, y2b);
+            ylo[j] = pack_bf16x2(y1a, y1b);
+            yhi[j] = pack_bf16x2(y2a, y2b);
+        }
+        *reinterpret_cast<u32x4*>(base + i) = ylo;
+        *reinterpret_cast<u32x4*>(base + half + i) = yhi;
+    }
+}
+
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 __global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ h, int64_t M, int64_t F) {
@@ -473,6 +510,11 @@ extern "C" int mtl_rope_inplace_rows(void* qkv, int64_t ld, const float* cos_t, 
     if (!qkv || !cos_t || !sin_t || M <= 0 || T <= 0 || n_rot_heads <= 0) return MTL_ERR_ARG;
     if (D % 4 != 0 || ld % 2 != 0) return MTL_ERR_ALIGN;
     const int64_t items = M * n_rot_heads * (D / 4);
+    if (D % 16 == 0 && ld % 8 == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0 && (reinterpret_cast<uintptr_t>(cos_t) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(sin_t) & 15) == 0)
+        hipLaunchKernelGGL(rope_kernel_v8, dim3(grid_for(items / 4, 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)qkv, ld, cos_t, sin_t, M, T,
+                           (int)n_rot_heads, (int)D, inverse, group_rows, group_stride, row_offset);
+    else
     hipLaunchKernelGGL(rope_kernel, dim3(grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)qkv, ld, cos_t, sin_t, M, T,
                        (int)n_rot_heads, (int)D, inverse, group_rows, group_stride, row_offset);
     MTL_CHECK_LAUNCH();
