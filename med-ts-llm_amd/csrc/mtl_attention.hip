@@ -1077,6 +1077,7 @@ int g_attn_mode = 1;   // 1 = use the resident kernels when they fit, 0 = always
 const int g_attn_wide = getenv("MTL_ATTN_WIDE") ? atoi(getenv("MTL_ATTN_WIDE")) : 1;   // A/B knob: 0 = 64-row workgroups for long sequences too
 // rows from which the 128-row workgroups are used. Forward / dQ from 256 (PSM shape, Tq = 256 of T = 384: 131 -> 97 us, 184 -> 150 us); the
 // dK/dV kernel gains nothing there (190 -> 194 us) and switches at 512.
+const int g_attn_wide_x = getenv("MTL_ATTN_WIDE_X") ? atoi(getenv("MTL_ATTN_WIDE_X")) : 1;   // A/B knob: 128-row workgroups for the non-causal hd-128 (reprogramming) attention
 const int g_attn_wide_min = getenv("MTL_ATTN_WIDE_MIN") ? atoi(getenv("MTL_ATTN_WIDE_MIN")) : 256;
 
 template <typename KernelT>
@@ -1126,6 +1127,16 @@ extern "C" int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream) {
     const dim3 grid((unsigned)((a->Tq + 63) / 64), (unsigned)a->Hq, (unsigned)a->B), block(256);
     const bool drop = a->dropout_p > 0.f;
     if (drop && a->dropout_p >= 1.f) return MTL_ERR_UNSUPPORTED;
+    // the reprogramming cross-attention (R:models/medtsllm.py ReprogrammingLayer: not causal, 1000 batch-shared prototypes as keys, hd 128): every
+    // workgroup streams all keys through its LDS tiles, so 128-row workgroups halve the K / V bytes that leave the L2 (forward 50.6 -> 43.1 us
+    // in-step on the metric workload; MTL_ATTN_WIDE_X=0 switches back)
+    if (!a->causal && a->D == 128 && a->Tq >= 128 && g_attn_wide == 1 && g_attn_wide_x == 1) {
+        const dim3 grid8((unsigned)((a->Tq + 127) / 128), (unsigned)a->Hq, (unsigned)a->B), block8(512);
+        if (drop) MTL_LAUNCH("attn_fwd_kernel<128, false, true, 8>", fl_fwd, 0, (attn_fwd_kernel<128, false, true, 8>), grid8, block8, 0, st, *a);
+        else MTL_LAUNCH("attn_fwd_kernel<128, false, false, 8>", fl_fwd, 0, (attn_fwd_kernel<128, false, false, 8>), grid8, block8, 0, st, *a);
+        MTL_CHECK_LAUNCH();
+        return MTL_OK;
+    }
     if (a->causal && !drop && a->Tq >= g_attn_wide_min && (a->D == 64 || a->D == 128) && g_attn_wide == 1) {      // long sequences: 128 queries per workgroup
         const dim3 grid8((unsigned)((a->Tq + 127) / 128), (unsigned)a->Hq, (unsigned)a->B), block8(512);
         if (a->D == 64) MTL_LAUNCH("attn_fwd_kernel<64, true, false, 8>", fl_fwd, 0, (attn_fwd_kernel<64, true, false, 8>), grid8, block8, 0, st, *a);
@@ -1218,6 +1229,8 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
         MTL_CHECK_LAUNCH();
         return MTL_OK;
     }
+    // (the reprogramming attention's dQ kernel on 128-row workgroups, as its forward runs: 51.3 -> 62.7 us in-step — it is not pipelined and loses
+    //  its second workgroup per CU; measured and left on the 64-row form)
 #define MTL_BWD(DD)                                                                                        \
     if (f.causal && drop) {                                                                                \
         MTL_LAUNCH("attn_bwd_dq_kernel<" #DD ", true, true>", fl_half, 0, (attn_bwd_dq_kernel<DD, true, true>), gq, block, 0, st, *a);                    \
