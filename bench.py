@@ -15,8 +15,10 @@ Extra objects on the JSON line:
   roofline      the dominant MFMA kernel (bf16 GEMM instance with the largest total time): achieved TFLOP/s = algorithmic 2MNK
                 FLOPs / kernel duration, measured in this process in a profiled replay of the same steps right after the timed
                 region: every launch carries its own start/stop event pair (kernel begin -> end on its stream, the duration
-                rocprofv3 --kernel-trace reports). `traffic`: HBM bytes per launch from the committed PMC passes of this workload,
-                null when they were taken with other kernel sources.
+                rocprofv3 --kernel-trace reports). `traffic`: HBM bytes per launch from PMC counters — on the headline line measured
+                by THIS run (N = 1: two rocprofv3 --pmc child passes of the workload after everything else, `traffic_source` says so;
+                --no-live-traffic skips them); on configs[] and as the fall-back, the committed PMC passes of the workload
+                (profiles/pmc_traffic_<workload>.json), null when those were taken with other kernel sources.
   roofline_hbm  the same for the dominant HBM-bound kernel (norm family) against 8 TB/s
   cpu_baseline  the oracle (a plain-torch port of the reference math, pinned to reference goldens) timed on the host cores,
                 rank 0, N = 1 only, on a bounded sample of the same workload (+ BASELINE.json configs[0], the ETTh1-shaped case)
@@ -235,7 +237,71 @@ def pmc_traffic(workload, kernel):
         table = json.load(f)
     if table.get("_meta", {}).get("csrc_sha16") != csrc_sha16():
         return None                      # stale: measured with other kernel sources
-    return table.get(kernel)
+    return table_lookup(table, kernel)
+
+
+def table_lookup(table, kernel):
+    """a PMC table's entry for one of the launch profiler's kernel names: the profiler names an instance by the template arguments that
+    select it ("norm_bwd_kernel<3, false>"), rocprofv3 by all of them ("norm_bwd_kernel<3, false, 1>") — exact match first, then the one
+    entry whose name extends the profiler's argument list"""
+    if kernel in table:
+        return table[kernel]
+    if kernel.endswith(">"):
+        ext = [k for k in table if k.startswith(kernel[:-1] + ",")]
+        if len(ext) == 1:
+            return table[ext[0]]
+    return None
+
+
+def live_pmc_traffic(workload, kernels, timeout_s=150.0):
+    """HBM bytes per launch of `kernels`, measured NOW by this run: two child runs of this very workload (3 steps, nothing else) under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` — separate passes, counters only beside the kernel trace, units and
+    the gfx950 read-side correction as GUIDE MI355X_MICROARCH §HBM prescribes (tools/pmc_traffic.py holds the arithmetic). Returns
+    ({kernel: {...}}, note); ({}, reason) when rocprofv3 is absent, a pass fails or runs out of time — the caller then falls back to the
+    committed table of the same kernel sources."""
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}, "rocprofv3 not found"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_traffic as pt
+    t_start = time.perf_counter()
+    tmp = tempfile.mkdtemp(prefix="mtl_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    per = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", os.path.join(tmp, counter), "-o", "r", "--", sys.executable, os.path.abspath(__file__),
+               "--workload", workload, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-extra-configs", "--no-live-traffic"]
+        p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            rc = p.wait(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)      # the process group this call started, nothing else
+            p.wait()
+            shutil.rmtree(tmp, ignore_errors=True)
+            return {}, f"{counter} pass exceeded {timeout_s:.0f} s"
+        import glob
+        dbs = glob.glob(os.path.join(tmp, counter, "**", "*.db"), recursive=True)
+        if rc != 0 or not dbs:
+            shutil.rmtree(tmp, ignore_errors=True)
+            return {}, f"{counter} pass failed (rc {rc})"
+        per[counter] = {pt.clean(k): v for k, v in pt.per_kernel(dbs[0], counter).items()}
+    shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for k in kernels:
+        fk, n = table_lookup(per["FETCH_SIZE"], k) or (None, 0)
+        wk, _ = table_lookup(per["WRITE_SIZE"], k) or (None, 0)
+        if fk is None or wk is None:
+            continue
+        rd, wr = 2.0 * fk * 1024.0, wk * 1024.0
+        out[k] = {"hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr, "dispatches": n}
+    return out, (f"live: two rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE x2 x 1024 B; WRITE_SIZE x 1024 B) of a 3-step child run of this workload, "
+                 f"mean per launch, {time.perf_counter() - t_start:.0f} s")
 
 
 def roofline_objects(rows, workload):
@@ -519,6 +585,7 @@ def main():
     ap.add_argument("--workload", default="gpt2s_B32_L1024_C12", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC table only (no rocprofv3 child passes)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the Llama-2-7B line that the default run attaches as configs[]")
     ap.add_argument("--full-backward", action="store_true", help="also compute the (unused) prompt-row input gradients")
     ap.add_argument("--replicate-mapping", action="store_true", help="DP: keep the mapping layer replicated (all-reduce its gradient)")
@@ -554,7 +621,23 @@ def main():
         if rank == 0:
             extra2["metric"] = "samples/sec ([B, 1024, 12] windows, interleave covariates: T = 1664, Llama-2-7B frozen backbone) through MedTsLLM fwd+bwd"
             out["configs"].append(extra2)
-    if rank == 0:
+    if rank == 0 and out:
+        committed = f"committed table profiles/pmc_traffic_<workload>.json (separate rocprofv3 --pmc passes of the same kernel sources, csrc_sha16 {csrc_sha16()})"
+        for line in [out] + out.get("configs", []):
+            for key in ("roofline", "roofline_hbm"):
+                if line.get(key):
+                    line[key]["traffic_source"] = committed if line[key]["traffic"] is not None else None
+        if world == 1 and not args.no_live_traffic and not args.no_roofline:
+            # the headline line's traffic is MEASURED by this run (everything above is finished and its memory released)
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            objs = [out[k] for k in ("roofline", "roofline_hbm") if out.get(k)]
+            table, note = live_pmc_traffic(args.workload, [o["kernel"] for o in objs])
+            for o in objs:
+                if o["kernel"] in table:
+                    o["traffic"], o["traffic_source"] = table[o["kernel"]], note
+                elif o["traffic"] is not None:
+                    o["traffic_source"] = f"{committed}; live pass unavailable: {note}"
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

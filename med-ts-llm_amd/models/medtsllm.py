@@ -244,13 +244,14 @@ class MedTsLLM(nn.Module):
                     state_dict[k] = state_dict[k][r0:r1]
         return super().load_state_dict(state_dict, *args, **kwargs)
 
-    def shard_mapping_layer(self, rank, world, group=None):
+    def shard_mapping_layer(self, rank, world, group=None, force=False):
         """Data parallelism: row-shard mapping_layer.{weight [num_tokens, V], bias} over the ranks.
         Rank r keeps rows [r*S/N, (r+1)*S/N) as its own leaf parameters, computes only those prototype rows of
         `source` and all-gathers them (parallel.AllGatherRows). Removes the replicated S x V x d GEMMs (fwd + dW), the
         Adam traffic and 70 % of the gradient all-reduce payload from every rank. Call after .to(device), before the
-        optimiser is built. Returns False (layer stays replicated) when it does not apply."""
-        if world <= 1 or self.word_embeddings.requires_grad or self.num_tokens % world != 0:
+        optimiser is built. Returns False (layer stays replicated) when it does not apply. force: also in a ONE-rank group (the collectives
+        then run against the real backend with a single participant: how the RCCL calls are exercised on a 1-GPU box)."""
+        if (world <= 1 and not force) or self.word_embeddings.requires_grad or self.num_tokens % world != 0:
             return False
         from .. import parallel
         r0, r1 = parallel.shard_range(self.num_tokens, rank, world)

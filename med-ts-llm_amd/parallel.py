@@ -86,12 +86,15 @@ class FlatGradAllReduce:
     The per-rank loss is a mean over the LOCAL batch, so averaging the summed gradients over ranks reproduces the
     single-process gradient of the mean over the GLOBAL batch (equal shard sizes)."""
 
-    def __init__(self, params, group=None, bucket_elems=32 * 1024 * 1024, overlap=True):
+    def __init__(self, params, group=None, bucket_elems=32 * 1024 * 1024, overlap=True, force_collectives=False):
         # row-sharded parameters (p._dp_sharded, see AllGatherRows) already hold globally averaged gradients of rows no
         # other rank owns: they are neither communicated nor averaged again
         self.params = [p for p in params if p.requires_grad and not getattr(p, "_dp_sharded", False) and not getattr(p, "_dp_opt_sharded", False)]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # force_collectives: issue every collective in a ONE-rank group too (sums over one rank, / 1: results unchanged) — the way the
+        # RCCL calls of this class are exercised against the real backend on a 1-GPU box (tests/test_gpu_rccl.py)
+        self._live = self.world > 1 or (force_collectives and dist.is_initialized())
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else "cpu"
         # + one control slot behind the gradients (it travels in the LAST bucket launched): the ranks' pre-emption flag, so that a
@@ -115,7 +118,7 @@ class FlatGradAllReduce:
         cur["n"] += 1                       # the control slot
         self.views = [self._where[id(p)][1] for p in self.params]
         self._hooks = []
-        if overlap and self.world > 1 and hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
+        if overlap and self._live and hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self._arm()
@@ -154,7 +157,7 @@ class FlatGradAllReduce:
 
     @torch.no_grad()
     def __call__(self):
-        if self.world <= 1:
+        if not self._live:
             return
         for b in self.buckets:           # whatever the hooks did not launch (no hooks, unused parameters, ...)
             if b["dirty"]:               # gradients accumulated after the bucket was packed: the in-flight result is stale
@@ -194,8 +197,9 @@ class ShardedUpdate:
     master rows of OTHER ranks go stale locally; `owned_rows(name)` tells a checkpoint writer what to gather (MedTsLLM.state_dict does).
     Results equal the replicated path's up to the summation order of the collective."""
 
-    def __init__(self, named_params, rank, world, group=None, min_numel=1 << 24):
+    def __init__(self, named_params, rank, world, group=None, min_numel=1 << 24, force_collectives=False):
         self.rank, self.world, self.group = rank, world, group
+        self._live = world > 1 or (force_collectives and dist.is_initialized())     # (see FlatGradAllReduce: one-rank RCCL exercise)
         self.items, self._by_param = [], {}
         self._rs = dist.is_initialized() and dist.get_backend(group) == "nccl"
         for name, p in named_params:
@@ -209,7 +213,7 @@ class ShardedUpdate:
                   "gshard": torch.empty_like(p.data[r0:r1])}
             self.items.append(it)
             self._by_param[id(p)] = it
-            if world > 1 and hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
+            if self._live and hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
                 p.register_post_accumulate_grad_hook(lambda q, it=it: self._on_grad(it))
 
     def optimizer_params(self, params):
@@ -256,7 +260,7 @@ class ShardedUpdate:
             if p.grad is None:
                 it["shard"].grad = None
                 continue
-            if self.world > 1:
+            if self._live:
                 if it["dirty"] and it["handle"] is not None:
                     it["handle"].wait()
                     if not self._rs:
@@ -281,7 +285,7 @@ class ShardedUpdate:
         async_op: the all-gathers are only LAUNCHED (RCCL's stream); wait_published(name) must run before the tensor is read again — the model
         calls it right in front of the first GEMM that reads it, so that e.g. the flatten head's 3.4 GB gather (PSM, bf16) travels under the NEXT
         step's whole frozen-backbone forward instead of in front of it."""
-        if self.world <= 1:
+        if not self._live:
             return
         for it in self.items:
             full = it["shadow"] if it["shadow"] is not None else it["p"].data

@@ -327,3 +327,33 @@ def test_derived_window_datasets_pickle():
     assert type(ds).__name__ == "UnivariateClipReconstructionSeries" and getattr(windows, type(ds).__name__) is type(ds)
     back = pickle.loads(pickle.dumps(ds))
     assert len(back) == len(ds) and torch.equal(back[5]["x_enc"], ds[5]["x_enc"])
+
+
+def test_bench_pmc_traffic_arithmetic_and_fallback(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic: (i) the counter arithmetic of tools/pmc_traffic.py on a synthetic rocprofv3 counter table (FETCH_SIZE in KiB,
+    doubled on the read side for gfx950; WRITE_SIZE in KiB; mean per dispatch, several counter rows of one dispatch summed), (ii) the live pass
+    reports WHY it has nothing instead of raising when rocprofv3 cannot run the workload (no GPU here / tool absent) — bench.py then keeps the
+    committed table of the same kernel sources."""
+    import os
+    import sqlite3
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    sys.path.insert(0, str(ROOT))
+    import pmc_traffic as pt
+    db = str(tmp_path / "r_results.db")
+    c = sqlite3.connect(db)
+    c.execute("create table counters_collection (kernel_name text, counter_name text, value real, dispatch_id integer)")
+    kn = "void (anonymous namespace)::norm_fwd_kernel<3, false>(float const*, float*)"
+    rows = [(kn, "FETCH_SIZE", 100.0, 1), (kn, "FETCH_SIZE", 28.0, 1), (kn, "FETCH_SIZE", 120.0, 2), (kn, "WRITE_SIZE", 64.0, 1), ("other(int)", "FETCH_SIZE", 7.0, 3)]
+    c.executemany("insert into counters_collection values (?, ?, ?, ?)", rows)
+    c.commit()
+    c.close()
+    f = {pt.clean(k): v for k, v in pt.per_kernel(db, "FETCH_SIZE").items()}
+    assert f["norm_fwd_kernel<3, false>"] == (124.0, 2) and f["other"] == (7.0, 1)
+    assert pt.per_kernel(db, "WRITE_SIZE")[kn] == (64.0, 1)
+
+    import bench
+    monkeypatch.setattr("shutil.which", lambda name: None)
+    monkeypatch.setattr(os.path, "exists", lambda p, _orig=os.path.exists: False if p.endswith("rocprofv3") else _orig(p))
+    table, why = bench.live_pmc_traffic("gpt2s_B32_L1024_C12", ["norm_fwd_kernel<3, false>"])
+    assert table == {} and "not found" in why
