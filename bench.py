@@ -413,12 +413,16 @@ def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline):
     model.prune_dead_prompt_grads = not args.full_backward
     model.llm_dropout = not args.no_llm_dropout
     model.train()
-    sharded = world > 1 and not args.replicate_mapping and model.shard_mapping_layer(rank, world)
+    # --dp-plumbing (N = 1): the whole data-parallel machinery in a ONE-rank RCCL group — every collective of the N-rank step is issued and
+    # waited for (sums over one rank): what the DP plumbing itself costs per step, apart from the wire
+    force = bool(getattr(args, "dp_plumbing", False)) and world == 1
+    dp = world > 1 or force
+    sharded = dp and not args.replicate_mapping and model.shard_mapping_layer(rank, world, None, force)
     torch.manual_seed(1234 + 7919 * rank)      # rank-specific dropout streams (weights above were built from one seed)
     params = [p for p in model.parameters() if p.requires_grad]
     # DP: row-sharded optimiser step for the big replicated tensors (wide flatten heads, Llama-3's trainable vocabulary): reduce-scatter,
     # Adam on the owned rows, all-gather of the bf16 copy the forward reads
-    su = parallel.ShardedUpdate(list(model.named_parameters()), rank, world) if (world > 1 and not args.replicate_optimizer) else None
+    su = parallel.ShardedUpdate(list(model.named_parameters()), rank, world, force_collectives=force) if (dp and not args.replicate_optimizer) else None
     if su is not None:
         model._opt_shards = su             # (the model waits for asynchronously published rows in front of the GEMM that reads them)
     opt_params = su.optimizer_params(params) if su is not None else params
@@ -435,7 +439,7 @@ def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline):
                 opt.register_shadow(Bf16Shadow(su._by_param[id(sh.param)]["shard"], su.attach_shadow(sh.param, sh.tensor)))
             else:
                 opt.register_shadow(sh)
-    sync = parallel.FlatGradAllReduce(params) if world > 1 else None
+    sync = parallel.FlatGradAllReduce(params, force_collectives=force) if dp else None
     loss_fn = torch.nn.MSELoss() if task != "semantic_segmentation" else torch.nn.CrossEntropyLoss()
     batches = [make_batch(B, L, C_, pred, 1000 + rank * 97 + i, device, task) for i in range(4)]
 
@@ -558,7 +562,10 @@ def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline):
                                    f"step = fwd+loss+bwd+{'allreduce+' if world > 1 else ''}Adam", "global_batch": B * world,
                        "parallelism": f"dp{world}" + (" (mapping layer row-sharded)" if sharded else "")},
             "per_gpu_samples_per_s": round(value / world, 2),
-            "dist_backend": (dist.get_backend() if world > 1 else None),
+            "dist_backend": (dist.get_backend() if dp else None),
+            **({"dp_plumbing": "one-rank RCCL group with every collective of the N-rank step issued (mapping layer 'row-sharded' over the one rank: all-gather + "
+                               "all-reduce; bucketed flat gradient all-reduce from the gradient hooks; reduce-scatter / Adam on owned rows / asynchronous bf16 "
+                               "all-gather for the big tensors): value / the plain N = 1 value = what the DP machinery costs apart from the wire"} if force else {}),
             "final_loss": final_loss,
             "backward": "full (incl. unused prompt-row input gradients)" if args.full_backward else
                         "exact dead-gradient elimination: prompt rows never depend on a trainable parameter, their input gradient is not computed",
@@ -585,6 +592,7 @@ def main():
     ap.add_argument("--workload", default="gpt2s_B32_L1024_C12", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dp-plumbing", action="store_true", help="N = 1 only: run the step with the DP machinery live in a one-rank RCCL group")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC table only (no rocprofv3 child passes)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the Llama-2-7B line that the default run attaches as configs[]")
     ap.add_argument("--full-backward", action="store_true", help="also compute the (unused) prompt-row input gradients")
@@ -600,6 +608,15 @@ def main():
 
     from med_ts_llm_amd import parallel
     rank, world, local_rank = parallel.init_from_env("cuda")
+    if args.dp_plumbing and world == 1 and torch.cuda.is_available():
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        parallel.settle_backend_output()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -638,9 +655,16 @@ def main():
                     o["traffic"], o["traffic_source"] = table[o["kernel"]], note
                 elif o["traffic"] is not None:
                     o["traffic_source"] = f"{committed}; live pass unavailable: {note}"
-        print(json.dumps(out))
-    if world > 1:
+    # the ONE JSON line is the LAST thing on stdout: the process group goes down first (on every rank), the C runtime's buffers — librccl
+    # prints through them — are flushed, and rank 0 gives the other ranks a moment to do the same before it prints
+    if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
+    parallel.flush_c_stdio()
+    if rank == 0 and out:
+        if world > 1:
+            time.sleep(1.0)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

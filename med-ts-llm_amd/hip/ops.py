@@ -598,26 +598,47 @@ class MappingTrainableFn(torch.autograd.Function):
     dWemb[V, d] = Wmap^T[V, S] @ dsource[S, d] — one more NT GEMM with fp32 output."""
 
     @staticmethod
-    def forward(ctx, Wmap, b, Wemb, split_k):
+    def forward(ctx, Wmap, b, Wemb, split_k, sh_map=None, sh_emb=None):
+        """sh_map / sh_emb: hip.optim.Bf16Shadow of Wmap ([S, pad64(V + 1)], zero padding) and of Wemb ([V, d]) that HipAdam keeps current while
+        it updates the masters (MedTsLLM.bf16_shadows). With fresh shadows the per-call fp32 -> bf16 casts of both tables (Llama-3: 2 GB read) become
+        bf16 transposes of the shadows, and under a row-sharded optimiser step (parallel.ShardedUpdate) the shadows are what the ranks exchange:
+        2 B per element on the wire instead of 4, and no rank needs the other ranks' fp32 rows."""
         S, V = Wmap.shape
         d = Wemb.shape[1]
         Vp, Sp = pad64(V + 1), pad64(S)
         dev = Wmap.device
-        wm = torch.empty((S, Vp), dtype=BF16, device=dev)
-        wmT = torch.empty((V, Sp), dtype=BF16, device=dev)
-        cast_pad(Wmap.detach().contiguous().float(), dst=wm, dst_t=wmT)
+        use_m = sh_map is not None and sh_map.param is Wmap and tuple(sh_map.tensor.shape) == (S, Vp) and sh_map.tensor.device == dev
+        use_e = sh_emb is not None and sh_emb.param is Wemb and tuple(sh_emb.tensor.shape) == (V, d) and sh_emb.tensor.device == dev
+        if use_m and sh_map.fresh():
+            wm = sh_map.tensor
+            wmT = transpose_bf16(wm[:, :V], Sp)
+        else:
+            wm = sh_map.tensor if use_m else torch.empty((S, Vp), dtype=BF16, device=dev)
+            wmT = torch.empty((V, Sp), dtype=BF16, device=dev)
+            cast_pad(Wmap.detach().contiguous().float(), dst=wm, dst_t=wmT)
+            if use_m:
+                sh_map.version = Wmap._version
         wm[:, V] = b.detach().to(BF16)
-        we = torch.empty((V, d), dtype=BF16, device=dev)
-        weT = torch.zeros((d, Vp), dtype=BF16, device=dev)
-        cast_pad(Wemb.detach().contiguous().float(), dst=we, dst_t=weT)
+        if use_e and sh_emb.fresh():
+            we = sh_emb.tensor
+            weT = transpose_bf16(we, Vp)                    # [d, Vp], columns >= V zero
+        else:
+            we = sh_emb.tensor if use_e else torch.empty((V, d), dtype=BF16, device=dev)
+            weT = torch.zeros((d, Vp), dtype=BF16, device=dev)
+            cast_pad(Wemb.detach().contiguous().float(), dst=we, dst_t=weT)
+            if use_e:
+                sh_emb.version = Wemb._version
         weT[:, V] = 1.0
         src = gemm_nt(wm, weT, split_k=split_k)
         ctx.save_for_backward(we, wmT)
         ctx.meta = (S, V, d)
+        # `we` may be the PERSISTENT shadow HipAdam rewrites: a backward after an optimiser step must fail loudly (see LinearFn)
+        ctx.shadow_at = (sh_emb, sh_emb.version) if use_e else None
         return src
 
     @staticmethod
     def backward(ctx, dsrc):
+        _check_shadow_unchanged(ctx.shadow_at)
         we, wmT = ctx.saved_tensors
         S, V, d = ctx.meta
         dsrc = dsrc.contiguous()
@@ -625,7 +646,7 @@ class MappingTrainableFn(torch.autograd.Function):
         dsT = transpose_bf16(dsrc, wmT.shape[1])                                               # [d, Sp]
         db = rowsum(dsrc) if ctx.needs_input_grad[1] else None              # row sums of dsrc
         dE = gemm_nt(wmT, dsT, out_dtype=F32) if ctx.needs_input_grad[2] else None            # [V, d]
-        return dW, db, dE, None
+        return dW, db, dE, None, None, None
 
 
 class CrossAttnFn(torch.autograd.Function):

@@ -385,6 +385,18 @@ class MedTsLLM(nn.Module):
             self._map_shadow = sh
         return sh
 
+    def _vocab_shadows(self):
+        """(mapping shadow [S, pad64(V + 1)], word-embedding shadow [V, d]) for the TRAINABLE-vocabulary path (MappingTrainableFn): persistent
+        bf16 copies that HipAdam keeps current — what the forward reads and, under a row-sharded optimiser step, what the ranks exchange."""
+        W, E = self.mapping_layer.weight, self.word_embeddings
+        ent = self.__dict__.get("_vocab_sh")
+        if ent is None or ent[0].param is not W or ent[1].param is not E or ent[0].tensor.device != W.device:
+            from ..hip.optim import Bf16Shadow
+            ent = (Bf16Shadow(W, torch.zeros((W.shape[0], pad64(W.shape[1] + 1)), dtype=torch.bfloat16, device=W.device)),
+                   Bf16Shadow(E, torch.zeros(tuple(E.shape), dtype=torch.bfloat16, device=E.device)))
+            self.__dict__["_vocab_sh"] = ent
+        return ent
+
     def _linear_shadow(self, lin):
         """Persistent bf16 copy [N, pad64(K)] (zero K padding) of a trainable Linear's weight: the operand of its forward GEMM and,
         read K-major, of its input-gradient GEMM. Same contract as _mapping_shadow."""
@@ -433,6 +445,8 @@ class MedTsLLM(nn.Module):
             out = [sh for sh in (self._linear_shadow(m) for m in self._shadowed_linears()) if sh is not None and sh.param.shape[0] % 8 == 0]
         if not self.word_embeddings.requires_grad:
             out.append(self._mapping_shadow())
+        elif self.word_embeddings.is_cuda and self.word_embeddings.dim() == 2 and self.word_embeddings.numel() < (1 << 32):
+            out.extend(self._vocab_shadows())
         return out
 
     def encode_ts(self, x_enc):
@@ -452,7 +466,8 @@ class MedTsLLM(nn.Module):
         self._tap("tokens", tokens)
         if self.word_embeddings.requires_grad:
             self._await_rows(self.mapping_layer.weight, self.word_embeddings)
-            source = MappingTrainableFn.apply(self.mapping_layer.weight, self.mapping_layer.bias, self.word_embeddings, self._map_split_k)
+            sh_map, sh_emb = self._vocab_shadows() if self.word_embeddings.is_cuda else (None, None)
+            source = MappingTrainableFn.apply(self.mapping_layer.weight, self.mapping_layer.bias, self.word_embeddings, self._map_split_k, sh_map, sh_emb)
         else:
             W = self.mapping_layer.weight
             split_k = mapping_split_k(W.shape[0], self.d_llm, self._wT.shape[1])

@@ -27,7 +27,29 @@ def init_from_env(device_type="cuda"):
         # MTL_DIST_BACKEND=gloo lets several ranks share ONE GPU (RCCL refuses that): how the DP path is tested on a 1-GPU box
         backend = os.environ.get("MTL_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if backend == "nccl":
+            settle_backend_output()
     return rank, world, local_rank
+
+
+def flush_c_stdio():
+    """flush the C runtime's stdio buffers of this process (librccl prints through them, Python's sys.stdout does not see that buffer)"""
+    import ctypes
+    import sys
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except (OSError, AttributeError):
+        pass
+    sys.stdout.flush()
+
+
+def settle_backend_output():
+    """RCCL creates its communicator at the FIRST collective and prints a version banner to the C stdout then; with stdout on a pipe that
+    text sits in the C buffer until the process exits — i.e. it lands AFTER whatever the program printed itself (a result line a caller
+    parses from the end of stdout). One barrier right after init creates the communicator, the flush sends the banner out now."""
+    if dist.is_initialized():
+        dist.barrier()
+    flush_c_stdio()
 
 
 def broadcast_object(obj, src=0, group=None):
@@ -95,6 +117,9 @@ class FlatGradAllReduce:
         # force_collectives: issue every collective in a ONE-rank group too (sums over one rank, / 1: results unchanged) — the way the
         # RCCL calls of this class are exercised against the real backend on a 1-GPU box (tests/test_gpu_rccl.py)
         self._live = self.world > 1 or (force_collectives and dist.is_initialized())
+        # RCCL averages inside the collective (ReduceOp.AVG: the sum scaled by 1 / world in its last step) — no separate pass over the flat
+        # buffer afterwards; gloo has no AVG: SUM, then one division
+        self._avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else "cpu"
         # + one control slot behind the gradients (it travels in the LAST bucket launched): the ranks' pre-emption flag, so that a
@@ -139,7 +164,8 @@ class FlatGradAllReduce:
     def _launch(self, b):
         if b is self.buckets[-1]:
             self.flat[-1:].fill_(1.0 if self._flag else 0.0)
-        b["handle"] = dist.all_reduce(self.flat[b["start"]:b["start"] + b["n"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        b["handle"] = dist.all_reduce(self.flat[b["start"]:b["start"] + b["n"]], op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM,
+                                      group=self.group, async_op=True)
 
     @torch.no_grad()
     def _on_grad(self, p):
@@ -149,10 +175,12 @@ class FlatGradAllReduce:
             # The bucket is repacked from the accumulated p.grad and reduced again in __call__.
             b["dirty"] = True
             return
-        view.copy_(p.grad)
         b["packed"].add(id(p))
         b["pending"] -= 1
         if b["pending"] == 0:
+            # the bucket's last gradient has landed: ONE multi-tensor copy packs all of them (a copy kernel per parameter costs more in launches
+            # than in bytes: ~20 tensors of the front end are a few KB each), then the bucket goes out
+            torch._foreach_copy_([v for q, v in b["items"]], [q.grad for q, v in b["items"]])
             self._launch(b)
 
     @torch.no_grad()
@@ -165,16 +193,19 @@ class FlatGradAllReduce:
                     b["handle"].wait()
                 b["handle"], b["packed"] = None, set()
             if b["handle"] is None:
+                # (a bucket is packed as a whole when its last gradient lands; one that never completed — no hooks, unused parameters,
+                # gradient accumulation — is packed here from whatever the parameters hold now)
+                have = [(view, p.grad) for p, view in b["items"] if p.grad is not None]
                 for p, view in b["items"]:
-                    if id(p) not in b["packed"]:
-                        if p.grad is None:
-                            view.zero_()
-                        else:
-                            view.copy_(p.grad)
+                    if p.grad is None:
+                        view.zero_()
+                if have:
+                    torch._foreach_copy_([v for v, g in have], [g for v, g in have])
                 self._launch(b)
         for b in self.buckets:
             b["handle"].wait()
-        self.flat.div_(self.world)
+        if not self._avg:
+            self.flat.div_(self.world)
         for p, view in zip(self.params, self.views):
             p.grad = view                # the optimiser reads the averaged gradient straight from the flat buffer
         self._arm()
@@ -241,7 +272,7 @@ class ShardedUpdate:
     def _reduce(self, it):
         g = it["p"].grad
         if self._rs:
-            it["handle"] = dist.reduce_scatter_tensor(it["gshard"], g.contiguous(), op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            it["handle"] = dist.reduce_scatter_tensor(it["gshard"], g.contiguous(), op=dist.ReduceOp.AVG, group=self.group, async_op=True)   # (RCCL: mean inside the collective)
         else:
             it["handle"] = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
@@ -272,7 +303,7 @@ class ShardedUpdate:
                 it["handle"].wait()
                 if not self._rs:
                     it["gshard"].copy_(p.grad[it["r0"]:it["r1"]])
-                it["gshard"].div_(self.world)
+                    it["gshard"].div_(self.world)
             else:
                 it["gshard"].copy_(p.grad[it["r0"]:it["r1"]])
             it["shard"].grad = it["gshard"]

@@ -20,14 +20,14 @@ def _free_port():
     return p
 
 
-def _build(shard=None):
+def _build(shard=None, kind="gpt2"):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from helpers import hf_cfg, model_config, FakeDataset
     from med_ts_llm_amd.models import model_lookup
     from med_ts_llm_amd.models.backbone import random_state_dict
     from med_ts_llm_amd.utils import dict_to_object
-    cfg = hf_cfg("gpt2")
+    cfg = hf_cfg("gpt2") if kind == "gpt2" else hf_cfg("llama_gqa", vocab=100_100)      # bigvocab: word_embeddings + mapping both train
     sd = random_state_dict(cfg, seed=7, std=0.06)
     off = {"dataset": False, "task": False, "clip": False, "input_stats": False, "examples": False, "input_stats_dim": 0, "input_stats_select": "all"}
     torch.manual_seed(11)
@@ -36,7 +36,7 @@ def _build(shard=None):
     model.fixed_prompt_ids = torch.randint(0, cfg["vocab_size"], (1, 9), generator=torch.Generator().manual_seed(1), dtype=torch.int32)
     model.train()
     if shard is not None:
-        assert model.shard_mapping_layer(*shard) is True
+        assert model.shard_mapping_layer(*shard) is (kind == "gpt2")        # (a trainable vocabulary keeps the mapping layer whole: ShardedUpdate takes it)
     return model
 
 
@@ -160,13 +160,13 @@ def _train3(model, batches, world, rank, sharded):
     return losses, su, opt
 
 
-def _sharded_worker(rank, world, port, q):
+def _sharded_worker(rank, world, port, q, kind="gpt2"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MTL_DIST_BACKEND="gloo")
     import torch.distributed as dist
     from med_ts_llm_amd import parallel
     parallel.init_from_env("cuda")
-    model = _build(shard=(rank, world))
+    model = _build(shard=(rank, world), kind=kind)
     full = [_batch()]
     g = torch.Generator().manual_seed(6)
     full.append({"x_enc": torch.randn(B, L, C, generator=g).cuda(), "y": torch.randn(B, PRED, C, generator=g).cuda()})
@@ -179,6 +179,20 @@ def _sharded_worker(rank, world, port, q):
     shadows = [torch.zeros_like(sh.tensor) for _ in range(world)]
     dist.all_gather(shadows, sh.tensor)
     assert torch.equal(shadows[0], shadows[1])                                                  # what the forward reads: identical on both ranks
+    emb_rows = None
+    if kind != "gpt2":
+        # trainable vocabulary: both vocabulary-side tensors are row-sharded in the optimiser and PUBLISHED AS bf16 (their shadows travel)
+        assert {it["name"] for it in su.items} >= {"word_embeddings", "mapping_layer.weight"}
+        for vsh in model._vocab_shadows():
+            it_v = su._by_param[id(vsh.param)]
+            assert it_v["shadow"] is vsh.tensor and vsh.fresh()
+            both = [torch.zeros_like(vsh.tensor) for _ in range(world)]
+            dist.all_gather(both, vsh.tensor)
+            assert torch.equal(both[0], both[1])
+            own = vsh.param.detach()[it_v["r0"]:it_v["r1"]]
+            assert torch.equal(vsh.tensor[it_v["r0"]:it_v["r1"], :own.shape[1]], own.to(torch.bfloat16))     # bf16(master) on the owned rows
+        it_e = su._by_param[id(model.word_embeddings)]
+        emb_rows = parallel.gather_rows(model.word_embeddings.detach()[it_e["r0"]:it_e["r1"]].contiguous(), world)   # every owner's master rows
     sd = model.state_dict()                                                                     # collective: gathers every owner's master rows
     assert torch.equal(sd["output_projection.linear.weight"].to(torch.bfloat16), sh.tensor[:, :head.weight.shape[1]])
     mine = sd["output_projection.linear.weight"][it["r0"]:it["r1"]]
@@ -186,23 +200,27 @@ def _sharded_worker(rank, world, port, q):
     ls = [torch.zeros(3, device="cuda") for _ in range(world)]
     dist.all_gather(ls, torch.tensor(losses, device="cuda"))
     if rank == 0:
-        q.put((torch.stack(ls).mean(0).cpu().numpy(), {k: v.float().cpu().numpy() for k, v in sd.items()}))
+        out = {k: v.float().cpu().numpy() for k, v in sd.items()}
+        if emb_rows is not None:
+            out["word_embeddings"] = emb_rows.float().cpu().numpy()
+        q.put((torch.stack(ls).mean(0).cpu().numpy(), out))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_optimizer_matches_single_process():
+@pytest.mark.parametrize("kind", ["gpt2", "bigvocab"])
+def test_two_rank_sharded_optimizer_matches_single_process(kind):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, kind)) for r in range(2)]
     for p_ in procs:
         p_.start()
     losses2, sd2 = q.get(timeout=240)
     for p_ in procs:
         p_.join(120)
         assert p_.exitcode == 0
-    model = _build()
+    model = _build(kind=kind)
     full = [_batch()]
     g = torch.Generator().manual_seed(6)
     full.append({"x_enc": torch.randn(B, L, C, generator=g).cuda(), "y": torch.randn(B, PRED, C, generator=g).cuda()})
@@ -212,7 +230,11 @@ def test_two_rank_sharded_optimizer_matches_single_process():
         assert abs(a - float(b)) < 5e-3 * abs(a), (losses1, losses2)
     assert losses1[2] < losses1[0]
     sd1 = model.state_dict()
-    for k in ("output_projection.linear.weight", "mapping_layer.weight", "reprogramming_layer.out_projection.weight"):
+    keys = ["output_projection.linear.weight", "mapping_layer.weight", "reprogramming_layer.out_projection.weight"]
+    if kind != "gpt2":
+        sd1["word_embeddings"] = model.word_embeddings.detach()
+        keys.append("word_embeddings")
+    for k in keys:
         w1, w2 = sd1[k].float().cpu(), torch.from_numpy(sd2[k])
         moved = 3e-3 * (w1.numel() ** 0.5)       # three Adam steps of lr 1e-3 move every element by <= 3e-3
         assert float((w1 - w2).norm()) < 0.1 * moved, k      # the two runs agree to a small fraction of the distance the weights moved

@@ -467,3 +467,65 @@ def test_backbone_stack_at_gpt2_max_positions():
     assert rel_err(dh0[:, lo:], h0r.grad[:, lo:]) < 2 * L3 and torch.all(dh0[:, :lo] == 0)
     with pytest.raises(ValueError):
         bb.run_forward(torch.zeros(1, 1025, d, device="cuda"), 1)
+
+
+def test_trainable_vocabulary_shadows_equal_the_cast_path():
+    """Vocabulary > 100 000 (Llama-3: the sub-sampled word-embedding table and the mapping weight both train, R:models/medtsllm.py:220-222):
+    with the bf16 copies of both tables written by HipAdam (MedTsLLM.bf16_shadows -> MappingTrainableFn reads transposes of the shadows) four
+    training steps give BIT-identical losses and parameters to the same steps with no shadow registered (every forward re-casts the fp32
+    masters, the pre-shadow path); the shadows equal bf16(master) after every step, and an in-place edit of a master is picked up."""
+    from med_ts_llm_amd.hip.optim import HipAdam
+    from med_ts_llm_amd.models import model_lookup
+    from med_ts_llm_amd.models.backbone import random_state_dict
+    from med_ts_llm_amd.utils import dict_to_object
+    cfg = hf_cfg("llama_gqa", vocab=100_100)
+    sd = random_state_dict(cfg, seed=7, std=0.06)
+    off = {"dataset": False, "task": False, "clip": False, "input_stats": False, "examples": False, "input_stats_dim": 0, "input_stats_select": "all"}
+    g = torch.Generator().manual_seed(3)
+    batches = [{"x_enc": torch.randn(2, 64, 2, generator=g).cuda()} for _ in range(2)]
+    runs = []
+    for with_shadows in (True, False):
+        torch.manual_seed(11)
+        model = model_lookup["medtsllm"](dict_to_object(model_config("reconstruction", 64, 64, "concat", "linear", off)), FakeDataset(2),
+                                         backbone_state=(cfg, sd)).to("cuda")
+        model.fixed_prompt_ids = torch.randint(0, cfg["vocab_size"], (1, 9), generator=torch.Generator().manual_seed(1), dtype=torch.int32)
+        model.train()
+        assert model.word_embeddings.requires_grad and tuple(model.word_embeddings.shape) == (100_000, cfg["hidden_size"])
+        opt = HipAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+        shadows = model.bf16_shadows()
+        vocab = [sh for sh in shadows if sh.param is model.word_embeddings or sh.param is model.mapping_layer.weight]
+        assert len(vocab) == 2
+        if with_shadows:
+            for sh in shadows:
+                opt.register_shadow(sh)
+        losses = []
+        for i in range(4):
+            x = batches[i % 2]["x_enc"]
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = torch.nn.functional.mse_loss(model({"x_enc": x}), x)
+            loss.backward()
+            if with_shadows and i > 0:
+                assert all(sh.fresh() for sh in vocab)            # this forward read the optimiser-written copies, no cast
+            opt.step()
+            opt.zero_grad()
+            losses.append(float(loss.detach()))
+            if with_shadows:
+                for sh in vocab:
+                    W = sh.param.detach()
+                    assert sh.fresh() and torch.equal(sh.tensor[:, :W.shape[1]], W.to(torch.bfloat16))
+        runs.append((losses, {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}, model, vocab))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert runs[0][0][-1] < runs[0][0][0]
+    for n in runs[0][1]:
+        assert torch.equal(runs[0][1][n], runs[1][1][n]), n
+    # a master edited behind the optimiser's back: the stale shadow is re-cast by the next forward
+    _, _, model, vocab = runs[0]
+    model.eval()
+    with torch.no_grad():
+        p0 = model(batches[0]).float()
+        model.word_embeddings.mul_(0.5)
+        assert not vocab[1].fresh() or not vocab[0].fresh()
+        p1 = model(batches[0]).float()
+        model.word_embeddings.mul_(2.0)
+        p2 = model(batches[0]).float()
+    assert float((p1 - p0).abs().max()) > 0 and torch.equal(p2, p0)
