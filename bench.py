@@ -129,7 +129,8 @@ def cpu_baseline(hf_cfg, sd, L, C_, pred, n_tok, prompt_ids, max_seconds=30.0, t
     n_out = pred * C_ if task != "semantic_segmentation" else pred * 4
     p = {
         "patch_embedding.value_embedding.tokenConv.weight": torch.randn(32, 16, 3, generator=g) * 0.2,
-        "mapping_layer.weight": torch.randn(1024, hf_cfg["vocab_size"], generator=g) * 0.01,
+        # (vocabularies > 100 000: the reference maps from 100 000 linspace-sampled rows, R:models/medtsllm.py:219-222)
+        "mapping_layer.weight": torch.randn(1024, min(hf_cfg["vocab_size"], 100_000), generator=g) * 0.01,
         "mapping_layer.bias": torch.zeros(1024),
         "reprogramming_layer.query_projection.weight": torch.randn(1024, (C_ if cov == "concat" else 1) * 32, generator=g) * 0.05,
         "reprogramming_layer.query_projection.bias": torch.zeros(1024),
@@ -145,6 +146,10 @@ def cpu_baseline(hf_cfg, sd, L, C_, pred, n_tok, prompt_ids, max_seconds=30.0, t
     P = ((L + 8 - 16) // 8 + 1) * (C_ if cov == "interleave" else 1)
     p["output_projection.linear.weight"] = torch.randn(n_out, 128 * P, generator=g) * 0.01
     p["output_projection.linear.bias"] = torch.zeros(n_out)
+    we_kw = {}
+    if hf_cfg["vocab_size"] > 100_000:      # ... and that sub-sampled table is a TRAINABLE parameter there (Llama-3), so its gradient is part of the step
+        p["word_embeddings"] = O.word_embeddings_of(sd, hf_cfg).detach().float().clone()
+        we_kw = {"word_emb": p["word_embeddings"]}
     for t in p.values():
         t.requires_grad_(True)
     semseg = task == "semantic_segmentation"
@@ -154,7 +159,7 @@ def cpu_baseline(hf_cfg, sd, L, C_, pred, n_tok, prompt_ids, max_seconds=30.0, t
     tok = [[prompt_ids] for _ in range(Bs)]
 
     def step():
-        out = O.medtsllm_forward(b["x_enc"], p, sd, hf_cfg, m, token_ids=tok, pad_token_id=0, training=True)
+        out = O.medtsllm_forward(b["x_enc"], p, sd, hf_cfg, m, token_ids=tok, pad_token_id=0, training=True, **we_kw)
         if semseg:
             torch.nn.functional.cross_entropy(out.permute(0, 2, 1), b["y"]).backward()
         else:

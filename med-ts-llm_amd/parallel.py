@@ -85,12 +85,25 @@ class AllGatherRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, local, rank, world, group):
         ctx.meta = (rank, world, group, local.shape[0])
+        if dist.get_backend(group) == "nccl":
+            # RCCL: ONE collective straight into the full tensor (no per-rank parts, no concatenation) — this exchange sits on the step's
+            # critical path, right in front of the reprogramming layer's key / value projections
+            local = local.contiguous()
+            full = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(full, local, group=group)
+            return full
         return gather_rows(local, world, group)
 
     @staticmethod
     def backward(ctx, d_full):
         rank, world, group, n_loc = ctx.meta
         g = d_full.float().contiguous()
+        if dist.get_backend(group) == "nccl":
+            # reduce-scatter with the mean formed inside the collective: a rank receives the global-mean gradient of ITS rows and nothing else
+            # (half the all-reduce's wire bytes, no slice / divide afterwards)
+            own = torch.empty((n_loc,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+            dist.reduce_scatter_tensor(own, g, op=dist.ReduceOp.AVG, group=group)
+            return own.to(d_full.dtype), None, None, None
         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
         return (g[rank * n_loc:(rank + 1) * n_loc] / world).to(d_full.dtype), None, None, None
 
