@@ -269,6 +269,10 @@ int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream);
 /* A/B knob: 1 (default) lets causal self-attention use the resident-K/V kernels (whole head in LDS, no barrier in the
  * key loop) whenever they fit, 0 forces the chunked kernels. Results agree to rounding. */
 int mtl_attention_tune(int resident);
+/* A/B knob: 1 (default) lets the resident backward of MHA heads of width 64 run as ONE launch when both sides have at most 8 16-row tiles
+ * (the backbone's pruned backward, HF:models/gpt2/modeling_gpt2.py:182-214 differentiated: the head's K, V, Q, dO, O staged once, dQ and
+ * dK / dV from the same LDS tiles); 0 = two launches (dQ, then dK / dV). Results are bit-identical. */
+int mtl_attention_tune_merged(int merged);
 
 /* ------------------------------------------------------------------ norms (fp32 statistics)
  * LayerNorm eps 1e-5 (HF:models/gpt2/modeling_gpt2.py:252,254,497) and LlamaRMSNorm

@@ -1041,6 +1041,240 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 && !DROP) ? 2 : 1) void attn_bwd
     }
 }
 
+// =============================================================================================== resident backward, ONE launch per layer
+// The pruned backward of the backbone (queries = the n_grad patch rows, dK / dV for the patch keys only: <= NW 16-row tiles of each) moves about as many
+// bytes as it computes on: the dQ kernel above fills K | V and gathers Q / dO / O, the dK/dV kernel fills Q | dO and gathers K / V — every operand of
+// the head crosses the memory system twice, in two launches that are each a fill round trip, a few hundred MFMAs per wave and a store. Here the head's
+// five operands (K, V: Tk rows; Q, dO, O: Tq rows) and the row statistics are staged ONCE, all loads in flight together; delta = rowsum(dO . O) is
+// formed from the LDS tiles by all threads; then wave w takes query tile w for dQ (keys up to its diagonal: the LAST wave has the most) and key tile w
+// for dK / dV (queries from its diagonal on: the FIRST wave has the most) — the two phases balance each other inside a wave, and no barrier separates
+// them. Same arithmetic per element as the two kernels (same fragment layouts, MFMA order, mask words): results are bit-identical to theirs.
+// dynamic LDS: K [RK][D+8] | V [RK][D+8] | Q [RQ][D+8] | dO [RQ][D+8] | O [RQ][D+8] | lse2[RQ] | delta[RQ]   (RK = ceil32(Tk), RQ = ceil32(Tq))
+template <int D, int NW, bool DROP = false>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_res_merged_kernel(const mtl_attn_bwd_args a) {
+    constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16, CPR = D / 8, NT = NW * 64, BK = 4, BQ = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const mtl_attn_fwd_args& f = a.f;
+    const int64_t RK = ceil32(f.Tk), RQ = ceil32(f.Tq);
+    bf16_t* ktile = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* vtile = ktile + RK * LDT;
+    bf16_t* qtile = vtile + RK * LDT;
+    bf16_t* dotile = qtile + RQ * LDT;
+    bf16_t* otile = dotile + RQ * LDT;
+    float* lse_s = reinterpret_cast<float*>(otile + RQ * LDT);
+    float* delta_s = lse_s + RQ;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, g = lane >> 4;
+    const int64_t b = blockIdx.z, h = blockIdx.y;          // (MHA only: one key / value head per query head)
+    const bf16_t* Kg = reinterpret_cast<const bf16_t*>(f.k) + b * f.k_bs + h * f.k_hs;
+    const bf16_t* Vg = reinterpret_cast<const bf16_t*>(f.v) + b * f.v_bs + h * f.v_hs;
+    const bf16_t* Qg = reinterpret_cast<const bf16_t*>(f.q) + b * f.q_bs + h * f.q_hs;
+    const bf16_t* Og = reinterpret_cast<const bf16_t*>(f.o) + b * f.o_bs + h * f.o_hs;
+    const bf16_t* dOg = reinterpret_cast<const bf16_t*>(a.dout) + b * a.do_bs + h * a.do_hs;
+    const int64_t stat0 = (b * f.Hq + h) * (f.stat_stride ? f.stat_stride : f.Tq);
+    // ---- stage everything: every global load of a round is issued before its first LDS store (rows past the end are zero-filled)
+    const int64_t totk = RK * CPR, totq = RQ * CPR;
+    for (int64_t bk = 0, bq = 0; bk < totk || bq < totq; bk += (int64_t)BK * NT, bq += (int64_t)BQ * NT) {
+        u32x4 va[BK], vb[BK], vq[BQ], vd[BQ], vo[BQ];
+#pragma unroll
+        for (int i = 0; i < BK; ++i) {
+            const int64_t s = bk + threadIdx.x + (int64_t)i * NT, r = s / CPR;
+            va[i] = (u32x4){0u, 0u, 0u, 0u};
+            vb[i] = va[i];
+            if (s < totk && r < f.Tk) {
+                va[i] = *reinterpret_cast<const u32x4*>(Kg + r * f.k_ts + (s % CPR) * 8);
+                vb[i] = *reinterpret_cast<const u32x4*>(Vg + r * f.v_ts + (s % CPR) * 8);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BQ; ++i) {
+            const int64_t s = bq + threadIdx.x + (int64_t)i * NT, r = s / CPR;
+            vq[i] = (u32x4){0u, 0u, 0u, 0u};
+            vd[i] = vq[i];
+            vo[i] = vq[i];
+            if (s < totq && r < f.Tq) {
+                vq[i] = *reinterpret_cast<const u32x4*>(Qg + r * f.q_ts + (s % CPR) * 8);
+                vd[i] = *reinterpret_cast<const u32x4*>(dOg + r * a.do_ts + (s % CPR) * 8);
+                vo[i] = *reinterpret_cast<const u32x4*>(Og + r * f.o_ts + (s % CPR) * 8);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BK; ++i) {
+            const int64_t s = bk + threadIdx.x + (int64_t)i * NT;
+            if (s < totk) {
+                *reinterpret_cast<u32x4*>(ktile + (s / CPR) * LDT + (s % CPR) * 8) = va[i];
+                *reinterpret_cast<u32x4*>(vtile + (s / CPR) * LDT + (s % CPR) * 8) = vb[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BQ; ++i) {
+            const int64_t s = bq + threadIdx.x + (int64_t)i * NT;
+            if (s < totq) {
+                *reinterpret_cast<u32x4*>(qtile + (s / CPR) * LDT + (s % CPR) * 8) = vq[i];
+                *reinterpret_cast<u32x4*>(dotile + (s / CPR) * LDT + (s % CPR) * 8) = vd[i];
+                *reinterpret_cast<u32x4*>(otile + (s / CPR) * LDT + (s % CPR) * 8) = vo[i];
+            }
+        }
+    }
+    for (int64_t i = threadIdx.x; i < RQ; i += NT) lse_s[i] = i < f.Tq ? f.lse[stat0 + i] * LOG2E : 0.f;
+    __syncthreads();
+    // ---- delta[q] = sum_d dO[q, d] O[q, d] (the bf16-rounded forward output, as the dQ kernel forms it): four threads per row
+    static_assert(D % 32 == 0, "a quarter row is whole 16-byte chunks");
+    for (int64_t q = threadIdx.x >> 2; q < RQ; q += NT / 4) {
+        const int part = threadIdx.x & 3;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < D / 32; ++c) {
+            frag8 d8, o8;
+            // (the columns and the summation order of the dQ kernel's lanes: thread `part` = its lane group g, chunk c = its k-step)
+            d8.v = *reinterpret_cast<const bf16x8*>(dotile + q * LDT + c * 32 + part * 8);
+            o8.v = *reinterpret_cast<const bf16x8*>(otile + q * LDT + c * 32 + part * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc += __uint_as_float(d8.u[e] << 16) * __uint_as_float(o8.u[e] << 16);
+                acc += __uint_as_float(d8.u[e] & 0xffff0000u) * __uint_as_float(o8.u[e] & 0xffff0000u);
+            }
+        }
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if (part == 0) {
+            delta_s[q] = acc;
+            if (q < f.Tq) a.delta[stat0 + q] = acc;
+        }
+    }
+    __syncthreads();
+    const uint32_t dbase = DROP ? drop_base(f.dropout_seed, (uint32_t)(b * f.Hq + h)) : 0u;
+    const uint32_t drop_thr = DROP ? drop_threshold(f.dropout_p) : 0u;
+    const float drop_scale = DROP ? drop_scale_of(drop_thr) : 1.0f;
+    const float c = f.scale * LOG2E;
+    const int64_t coff = f.causal_off;
+    const int nt = (int)((f.Tq + 15) / 16), nkt = (int)((f.Tk - a.kv_row0 + 15) / 16);
+    // ---- dQ of query tile `wave`
+    if (wave < nt) {
+        const int64_t q0 = (int64_t)wave * 16;
+        int64_t qrow = q0 + l15;
+        const bool q_valid = qrow < f.Tq;
+        if (qrow > f.Tq - 1) qrow = f.Tq - 1;
+        const int klim = (int)(qrow + coff < f.Tk - 1 ? qrow + coff : f.Tk - 1);
+        bf16x8 qf[NKS], dof[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            qf[ks] = *reinterpret_cast<const bf16x8*>(qtile + qrow * LDT + ks * 32 + g * 8);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(dotile + qrow * LDT + ks * 32 + g * 8);
+        }
+        const float dl = delta_s[qrow], lse2 = lse_s[qrow];
+        f32x4 dq[NDT];
+#pragma unroll
+        for (int i = 0; i < NDT; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int64_t wave_qmax = ((q0 + 15 < f.Tq - 1) ? q0 + 15 : f.Tq - 1) + coff;
+        const int64_t k_end = (wave_qmax + 1 < f.Tk) ? wave_qmax + 1 : f.Tk;
+        for (int64_t kb = 0; kb < k_end; kb += 32) {
+            float ds[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                const bf16_t* kr = ktile + (kb + t * 16 + l15) * LDT + g * 8;
+                const bf16_t* vr = vtile + (kb + t * 16 + l15) * LDT + g * 8;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(kr + ks * 32), qf[ks], sv, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(vr + ks * 32), dof[ks], dp, 0, 0, 0);
+                }
+                uint2 dw = make_uint2(0u, 0u);
+                if (DROP) dw = drop_quad(dbase, (uint32_t)(qrow + coff), (uint32_t)(kb + t * 16 + g * 4) >> 2);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool masked = (int)kb + t * 16 + g * 4 + r > klim;
+                    const float pv = masked ? 0.f : __builtin_amdgcn_exp2f(sv[r] * c - lse2);
+                    float dpv = dp[r];
+                    if (DROP) dpv = drop_field(dw, (uint32_t)r) >= drop_thr ? dpv * drop_scale : 0.f;
+                    ds[t][r] = pv * (dpv - dl);
+                }
+            }
+            const bf16x8 dsf = pack8(ds[0], ds[1]);
+            const int ra = (int)(kb + g * 4), rb = (int)(kb + 16 + g * 4);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const bf16x8 kt = gather_col(ktile, LDT, ra, rb, dt * 16, l15);
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf, dq[dt], 0, 0, 0);
+            }
+        }
+        if (q_valid) {
+            bf16_t* DQ = reinterpret_cast<bf16_t*>(a.dq) + b * a.dq_bs + h * a.dq_hs + qrow * a.dq_ts;
+            store_grad_row<NDT>(DQ, dq, f.scale, g, a.rope_cos ? a.rope_cos + (qrow + coff) * D : nullptr, a.rope_cos ? a.rope_sin + (qrow + coff) * D : nullptr);
+        }
+    }
+    // ---- dK / dV of key tile `wave` (keys kv_row0 + 16 wave ...)
+    if (wave < nkt) {
+        const int64_t k0 = a.kv_row0 + (int64_t)wave * 16;
+        const int64_t krow = k0 + l15;
+        const int qhi = (int)f.Tq - 1, qlo = (int)(krow - coff);      // queries that see the lane's key
+        const bool quad_ok = (k0 & 3) == 0;
+        const int64_t krc = krow > f.Tk - 1 ? f.Tk - 1 : krow;
+        bf16x8 kf[NKS], vf[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            kf[ks] = *reinterpret_cast<const bf16x8*>(ktile + krc * LDT + ks * 32 + g * 8);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(vtile + krc * LDT + ks * 32 + g * 8);
+        }
+        f32x4 dk[NDT], dv[NDT];
+#pragma unroll
+        for (int i = 0; i < NDT; ++i) {
+            dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const int64_t qs = k0 > coff ? ((k0 - coff) / 32) * 32 : 0;
+        for (int64_t qb = qs; qb < f.Tq; qb += 32) {
+            float p[2][4], ds[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                const bf16_t* qr = qtile + (qb + t * 16 + l15) * LDT + g * 8;
+                const bf16_t* dr = dotile + (qb + t * 16 + l15) * LDT + g * 8;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(qr + ks * 32), kf[ks], sv, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(dr + ks * 32), vf[ks], dp, 0, 0, 0);
+                }
+                uint32_t fld[4] = {0xffffu, 0xffffu, 0xffffu, 0xffffu};
+                if (DROP) {
+                    const uint32_t a0 = (uint32_t)((int)qb + t * 16 + g * 4 + (int)coff);
+                    if (quad_ok) drop_fields_shared(dbase, a0, (uint32_t)krow, fld);
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) fld[r] = drop_field(drop_quad(dbase, a0 + r, (uint32_t)krow >> 2), (uint32_t)krow);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = (int)qb + t * 16 + g * 4 + r;
+                    const bool masked = q > qhi || q < qlo;
+                    const float pv = masked ? 0.f : __builtin_amdgcn_exp2f(sv[r] * c - lse_s[q]);
+                    float keep = 1.0f;
+                    if (DROP) keep = fld[r] >= drop_thr ? drop_scale : 0.f;
+                    p[t][r] = pv * keep;
+                    ds[t][r] = pv * (dp[r] * keep - delta_s[q]);
+                }
+            }
+            const bf16x8 pf = pack8(p[0], p[1]);
+            const bf16x8 dsf = pack8(ds[0], ds[1]);
+            const int ra = (int)(qb + g * 4), rb = (int)(qb + 16 + g * 4);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const bf16x8 dot = gather_col(dotile, LDT, ra, rb, dt * 16, l15);
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pf, dv[dt], 0, 0, 0);
+                const bf16x8 qt = gather_col(qtile, LDT, ra, rb, dt * 16, l15);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf, dk[dt], 0, 0, 0);
+            }
+        }
+        if (krow < f.Tk) {
+            bf16_t* DK = reinterpret_cast<bf16_t*>(a.dk) + b * a.dk_bs + h * a.dk_hs + krow * a.dk_ts;
+            bf16_t* DV = reinterpret_cast<bf16_t*>(a.dv) + b * a.dv_bs + h * a.dv_hs + krow * a.dv_ts;
+            store_grad_row<NDT>(DK, dk, f.scale, g, a.rope_cos ? a.rope_cos + krow * D : nullptr, a.rope_cos ? a.rope_sin + krow * D : nullptr);
+            store_grad_row<NDT>(DV, dv, 1.0f, g, nullptr, nullptr);
+        }
+    }
+}
+
 // fp32 partial slabs [splits][2][Tk][Hkv][D] -> summed bf16 dk / dv (strided)
 __global__ void dkv_convert_kernel(const mtl_attn_bwd_args a, const int splits) {
     const mtl_attn_fwd_args& f = a.f;
@@ -1079,6 +1313,7 @@ const int g_attn_wide = getenv("MTL_ATTN_WIDE") ? atoi(getenv("MTL_ATTN_WIDE")) 
 // dK/dV kernel gains nothing there (190 -> 194 us) and switches at 512.
 const int g_attn_wide_x = getenv("MTL_ATTN_WIDE_X") ? atoi(getenv("MTL_ATTN_WIDE_X")) : 1;   // A/B knob: 128-row workgroups for the non-causal hd-128 (reprogramming) attention
 const int g_attn_wide_min = getenv("MTL_ATTN_WIDE_MIN") ? atoi(getenv("MTL_ATTN_WIDE_MIN")) : 256;
+int g_attn_merged = getenv("MTL_ATTN_MERGED") ? atoi(getenv("MTL_ATTN_MERGED")) : 1;   // A/B knob: 0 = the resident backward as two launches (dQ, then dK / dV)
 
 template <typename KernelT>
 void set_lds(KernelT k, size_t bytes) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); }
@@ -1086,6 +1321,7 @@ void set_lds(KernelT k, size_t bytes) { (void)hipFuncSetAttribute((const void*)k
 }  // namespace
 
 extern "C" int mtl_attention_tune(int resident) { g_attn_mode = resident ? 1 : 0; return MTL_OK; }
+extern "C" int mtl_attention_tune_merged(int merged) { g_attn_merged = merged ? 1 : 0; return MTL_OK; }
 
 namespace {
 
@@ -1173,6 +1409,17 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
     (void)fl_half;
     if (resident_ok(f, f.Tk) && resident_ok(f, f.Tq)) {
         if (a->kv_row0 < 0 || a->kv_row0 >= f.Tk) return MTL_ERR_ARG;
+        // few tiles on both sides (the backbone's pruned backward: n_grad query rows, dK / dV for the patch keys): ONE launch stages the head once
+        const size_t lds_m = (2 * pad32(f.Tk) + 3 * pad32(f.Tq)) * (f.D + 8) * 2 + 2 * pad32(f.Tq) * 4;
+        if (g_attn_merged == 1 && f.D == 64 && f.Hq == f.Hkv && (f.Tq + 15) / 16 <= 8 && (f.Tk - a->kv_row0 + 15) / 16 <= 8 && lds_m <= kLdsBudget) {
+            static std::once_flag once;
+            std::call_once(once, [&] { set_lds(attn_bwd_res_merged_kernel<64, 8, true>, kLdsBudget); set_lds(attn_bwd_res_merged_kernel<64, 8, false>, kLdsBudget); });
+            const dim3 gm(1, (unsigned)f.Hq, (unsigned)f.B);
+            if (f.dropout_p > 0.f) MTL_LAUNCH("attn_bwd_res_merged_kernel<64, 8, true>", 2.0 * fl_half, 0, (attn_bwd_res_merged_kernel<64, 8, true>), gm, dim3(512), lds_m, st, *a);
+            else MTL_LAUNCH("attn_bwd_res_merged_kernel<64, 8, false>", 2.0 * fl_half, 0, (attn_bwd_res_merged_kernel<64, 8, false>), gm, dim3(512), lds_m, st, *a);
+            MTL_CHECK_LAUNCH();
+            return MTL_OK;
+        }
         const size_t lds_q = 2 * pad32(f.Tk) * (f.D + 8) * 2;
         const size_t lds_k = 2 * pad32(f.Tq) * (f.D + 8) * 2 + 2 * pad32(f.Tq) * 4;
         const int npq = (int)(((f.Tq + 15) / 16 + 1) / 2), npk = (int)(((f.Tk - a->kv_row0 + 15) / 16 + 1) / 2);

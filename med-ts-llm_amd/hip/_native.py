@@ -118,6 +118,7 @@ SIGNATURES = {
     "mtl_adam_step": (i32, [C.POINTER(AdamTensor), i32, f32, f32, f32, f32, f32, i32, i64, vp]),
     "mtl_attention_fwd": (i32, [C.POINTER(AttnFwdArgs), vp]),
     "mtl_attention_tune": (i32, [i32]),
+    "mtl_attention_tune_merged": (i32, [i32]),
     "mtl_attention_bwd": (i32, [C.POINTER(AttnBwdArgs), vp]),
     "mtl_norm_fwd": (i32, [vp, vp, vp, vp, i64, vp, i64, i64, f32, i32, i64, i64, i64, i32, vp]),
     "mtl_norm_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, i64, i64, i32, i64, i64, i64, i32, f32, C.c_uint32, vp]),

@@ -248,7 +248,7 @@ def _attn_fwd_args(q, k, v, o, lse, B, Hq, Hkv, Tq, Tk, D, scale, causal, qs, ks
     return a
 
 
-def attention_fwd(q, k, v, Hq, Hkv, D, scale, causal, shared_kv=False, dropout=(0.0, 0), want_o32=False):
+def attention_fwd(q, k, v, Hq, Hkv, D, scale, causal, shared_kv=False, dropout=(0.0, 0), want_o32=False, causal_off=0):
     """q [B,Tq,Hq*D] bf16; k, v [B,Tk,Hkv*D] (or [Tk,Hkv*D] when shared_kv). Views with unit inner stride allowed.
     want_o32 (non-causal): also returns the fp32 output, from which the backward takes delta (pass it as attention_bwd's o32)."""
     B, Tq = q.shape[0], q.shape[1]
@@ -261,11 +261,13 @@ def attention_fwd(q, k, v, Hq, Hkv, D, scale, causal, shared_kv=False, dropout=(
     a = _attn_fwd_args(q, k, v, o, lse, B, Hq, Hkv, Tq, Tk, D, scale, causal, (q.stride(0), q.stride(1), D), ks, vs,
                        (o.stride(0), o.stride(1), D), dropout)
     a.o_f32 = o32.data_ptr() if o32 is not None else None
+    a.causal_off = int(causal_off)          # query row i sits at absolute position i + causal_off (the last Tq rows of a longer sequence)
     check(lib().mtl_attention_fwd(C.byref(a), stream()), "mtl_attention_fwd")
     return (o, lse, o32) if want_o32 else (o, lse)
 
 
-def attention_bwd(q, k, v, o, lse, dout, Hq, Hkv, D, scale, causal, shared_kv=False, dropout=(0.0, 0), dkv_out=None, o32=None, rope=None):
+def attention_bwd(q, k, v, o, lse, dout, Hq, Hkv, D, scale, causal, shared_kv=False, dropout=(0.0, 0), dkv_out=None, o32=None, rope=None,
+                  causal_off=0, kv_row0=0):
     """dkv_out = (dk, dv): write the key / value gradients there (row-strided views of one buffer are fine: the paired K/V
     projection backward then reads both as ONE operand)"""
     B, Tq = q.shape[0], q.shape[1]
@@ -293,6 +295,7 @@ def attention_bwd(q, k, v, o, lse, dout, Hq, Hkv, D, scale, causal, shared_kv=Fa
     b.dk, (b.dk_bs, b.dk_ts, b.dk_hs) = dk.data_ptr(), dks
     b.dv, (b.dv_bs, b.dv_ts, b.dv_hs) = dv.data_ptr(), dks
     b.delta = delta.data_ptr()
+    b.f.causal_off, b.kv_row0 = int(causal_off), int(kv_row0)     # (pruned backward: dk / dv rows below kv_row0 are not written)
     if rope is not None:           # (cos, sin) f32 [positions, D]: inverse rotary embedding of dq / dk in the store epilogues
         b.rope_cos, b.rope_sin = rope[0].data_ptr(), rope[1].data_ptr()
     ws = None

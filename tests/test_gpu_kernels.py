@@ -961,3 +961,42 @@ def test_gemm_dswiglu_epilogue(ops, M, F, K, tune):
         assert torch.equal(out_p[phys.cuda()], out)
         mask = torch.ones(500, dtype=torch.bool); mask[phys] = False
         assert not out_p[mask.cuda()].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Tq,Tk,kv0,pdrop", [(128, 256, 128, 0.1), (128, 256, 128, 0.0), (128, 128, 0, 0.1), (100, 100, 0, 0.0), (48, 112, 64, 0.5), (128, 256, 0, 0.1)])
+def test_attention_backward_one_launch_equals_two(ops, Tq, Tk, kv0, pdrop):
+    """The resident backward of MHA heads of width 64 as ONE launch (attn_bwd_res_merged_kernel: K, V, Q, dO, O of the head staged once, wave w
+    takes query tile w for dQ and key tile w for dK / dV) against the two launches it replaces (dQ, then dK / dV): bit-identical dq, dk, dv on the
+    rows they write — the pruned shape of the metric workload's backward (128 query rows at offset 128 of 256 keys, dK / dV for keys >= 128),
+    full squares, ragged tiles, heavy dropout; and the last case (16 key tiles) must keep taking the two-launch path."""
+    B, H, D, seed = 3, 4, 64, 4242
+    coff = Tk - Tq
+    q = dev(torch.randn(B, Tq, H * D, generator=g(1)).to(BF16))
+    k, v = (dev(torch.randn(B, Tk, H * D, generator=g(i)).to(BF16)) for i in (2, 3))
+    do = dev(torch.randn(B, Tq, H * D, generator=g(4)).to(BF16))
+    scale = 1.0 / math.sqrt(D)
+    o, lse = ops.attention_fwd(q, k, v, H, H, D, scale, True, dropout=(pdrop, seed), causal_off=coff)
+    outs = []
+    for merged in (1, 0):
+        ops.lib().mtl_attention_tune_merged(merged)
+        try:
+            outs.append(ops.attention_bwd(q, k, v, o, lse, do, H, H, D, scale, True, dropout=(pdrop, seed), causal_off=coff, kv_row0=kv0))
+        finally:
+            ops.lib().mtl_attention_tune_merged(1)
+    (dq1, dk1, dv1), (dq0, dk0, dv0) = outs
+    assert torch.equal(dq1, dq0)
+    assert torch.equal(dk1[:, kv0:], dk0[:, kv0:]) and torch.equal(dv1[:, kv0:], dv0[:, kv0:])
+    assert float(dq1.float().abs().max()) > 0 and float(dk1[:, kv0:].float().abs().max()) > 0
+    # and against the fp32 reference of the same (possibly pruned) problem
+    qf, kf, vf = (t.float().cpu().requires_grad_(True) for t in (q, k, v))
+    s = torch.einsum("bqhd,bkhd->bhqk", qf.view(B, Tq, H, D), kf.view(B, Tk, H, D)) * scale
+    mask = torch.arange(Tk)[None, :] > (torch.arange(Tq)[:, None] + coff)
+    p = torch.softmax(s.masked_fill(mask, float("-inf")), -1)
+    if pdrop > 0:
+        from helpers import drop_mult_attention
+        p = p * drop_mult_attention(seed, pdrop, B, H, Tk, Tk)[:, :, coff:, :]
+    ref = torch.einsum("bhqk,bkhd->bqhd", p, vf.view(B, Tk, H, D)).reshape(B, Tq, H * D)
+    ref.backward(do.float().cpu())
+    assert rel_err(dq1.float().cpu(), qf.grad) < TOL_ATTN_BWD
+    assert rel_err(dk1[:, kv0:].float().cpu(), kf.grad[:, kv0:]) < TOL_ATTN_BWD and rel_err(dv1[:, kv0:].float().cpu(), vf.grad[:, kv0:]) < TOL_ATTN_BWD
