@@ -1046,13 +1046,15 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 && !DROP) ? 2 : 1) void attn_bwd
 // bytes as it computes on: the dQ kernel above fills K | V and gathers Q / dO / O, the dK/dV kernel fills Q | dO and gathers K / V — every operand of
 // the head crosses the memory system twice, in two launches that are each a fill round trip, a few hundred MFMAs per wave and a store. Here the head's
 // five operands (K, V: Tk rows; Q, dO, O: Tq rows) and the row statistics are staged ONCE, all loads in flight together; delta = rowsum(dO . O) is
-// formed from the LDS tiles by all threads; then wave w takes query tile w for dQ (keys up to its diagonal: the LAST wave has the most) and key tile w
-// for dK / dV (queries from its diagonal on: the FIRST wave has the most) — the two phases balance each other inside a wave, and no barrier separates
-// them. Same arithmetic per element as the two kernels (same fragment layouts, MFMA order, mask words): results are bit-identical to theirs.
+// formed from the LDS tiles by all threads; then the first half of the workgroup's waves takes one query tile each for dQ while the second half takes
+// one key tile each for dK / dV — 16 waves on the CU (one workgroup fits: 130 KB of LDS), four per SIMD: the same thread-level parallelism the two
+// separate launches get from co-resident workgroups (with 8 waves doing the two phases one after the other the kernel was latency-bound: 31.8 us, a
+// persistent software-pipelined variant of that 33.4 us, against 18.5 + 14.4 us for the two launches). Same arithmetic per element as the two kernels (same fragment layouts, MFMA order, mask words): results are bit-identical to theirs.
 // dynamic LDS: K [RK][D+8] | V [RK][D+8] | Q [RQ][D+8] | dO [RQ][D+8] | O [RQ][D+8] | lse2[RQ] | delta[RQ]   (RK = ceil32(Tk), RQ = ceil32(Tq))
 template <int D, int NW, bool DROP = false>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_res_merged_kernel(const mtl_attn_bwd_args a) {
-    constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16, CPR = D / 8, NT = NW * 64, BK = 4, BQ = 2;
+    constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16, CPR = D / 8, NT = NW * 64, BK = 2048 / NT, BQ = 1024 / NT, NTL = NW / 2;
+    static_assert(NW % 2 == 0 && 2048 % NT == 0 && 1024 % NT == 0, "two wave groups; whole staging chunks per thread");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const mtl_attn_fwd_args& f = a.f;
     const int64_t RK = ceil32(f.Tk), RQ = ceil32(f.Tq);
@@ -1148,8 +1150,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_res_merged_kernel(const mtl_
     const float c = f.scale * LOG2E;
     const int64_t coff = f.causal_off;
     const int nt = (int)((f.Tq + 15) / 16), nkt = (int)((f.Tk - a.kv_row0 + 15) / 16);
-    // ---- dQ of query tile `wave`
-    if (wave < nt) {
+    // ---- waves [0, NTL): dQ of query tile `wave`
+    if (wave < NTL && wave < nt) {
         const int64_t q0 = (int64_t)wave * 16;
         int64_t qrow = q0 + l15;
         const bool q_valid = qrow < f.Tq;
@@ -1203,9 +1205,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_res_merged_kernel(const mtl_
             store_grad_row<NDT>(DQ, dq, f.scale, g, a.rope_cos ? a.rope_cos + (qrow + coff) * D : nullptr, a.rope_cos ? a.rope_sin + (qrow + coff) * D : nullptr);
         }
     }
-    // ---- dK / dV of key tile `wave` (keys kv_row0 + 16 wave ...)
-    if (wave < nkt) {
-        const int64_t k0 = a.kv_row0 + (int64_t)wave * 16;
+    // ---- waves [NTL, NW): dK / dV of key tile `wave - NTL` (keys kv_row0 + 16 (wave - NTL) ...), concurrently with the dQ waves
+    if (wave >= NTL && wave - NTL < nkt) {
+        const int64_t k0 = a.kv_row0 + (int64_t)(wave - NTL) * 16;
         const int64_t krow = k0 + l15;
         const int qhi = (int)f.Tq - 1, qlo = (int)(krow - coff);      // queries that see the lane's key
         const bool quad_ok = (k0 & 3) == 0;
@@ -1413,10 +1415,10 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
         const size_t lds_m = (2 * pad32(f.Tk) + 3 * pad32(f.Tq)) * (f.D + 8) * 2 + 2 * pad32(f.Tq) * 4;
         if (g_attn_merged == 1 && f.D == 64 && f.Hq == f.Hkv && (f.Tq + 15) / 16 <= 8 && (f.Tk - a->kv_row0 + 15) / 16 <= 8 && lds_m <= kLdsBudget) {
             static std::once_flag once;
-            std::call_once(once, [&] { set_lds(attn_bwd_res_merged_kernel<64, 8, true>, kLdsBudget); set_lds(attn_bwd_res_merged_kernel<64, 8, false>, kLdsBudget); });
+            std::call_once(once, [&] { set_lds(attn_bwd_res_merged_kernel<64, 16, true>, kLdsBudget); set_lds(attn_bwd_res_merged_kernel<64, 16, false>, kLdsBudget); });
             const dim3 gm(1, (unsigned)f.Hq, (unsigned)f.B);
-            if (f.dropout_p > 0.f) MTL_LAUNCH("attn_bwd_res_merged_kernel<64, 8, true>", 2.0 * fl_half, 0, (attn_bwd_res_merged_kernel<64, 8, true>), gm, dim3(512), lds_m, st, *a);
-            else MTL_LAUNCH("attn_bwd_res_merged_kernel<64, 8, false>", 2.0 * fl_half, 0, (attn_bwd_res_merged_kernel<64, 8, false>), gm, dim3(512), lds_m, st, *a);
+            if (f.dropout_p > 0.f) MTL_LAUNCH("attn_bwd_res_merged_kernel<64, 16, true>", 2.0 * fl_half, 0, (attn_bwd_res_merged_kernel<64, 16, true>), gm, dim3(1024), lds_m, st, *a);
+            else MTL_LAUNCH("attn_bwd_res_merged_kernel<64, 16, false>", 2.0 * fl_half, 0, (attn_bwd_res_merged_kernel<64, 16, false>), gm, dim3(1024), lds_m, st, *a);
             MTL_CHECK_LAUNCH();
             return MTL_OK;
         }
