@@ -20,6 +20,7 @@ Extra objects on the JSON line:
                 --no-live-traffic skips them); on configs[] and as the fall-back, the committed PMC passes of the workload
                 (profiles/pmc_traffic_<workload>.json), null when those were taken with other kernel sources.
   roofline_hbm  the same for the dominant HBM-bound kernel (norm family) against 8 TB/s
+  roofline_attention  the same for the dominant attention kernel against the MFMA peak (full-rectangle FLOP convention)
   cpu_baseline  the oracle (a plain-torch port of the reference math, pinned to reference goldens) timed on the host cores,
                 rank 0, N = 1 only, on a bounded sample of the same workload (+ BASELINE.json configs[0], the ETTh1-shaped case)
   configs       default run only: the same measurement for BASELINE.json configs[2] (Llama-2-7B backbone), 2 + 5 steps
@@ -323,10 +324,16 @@ def roofline_objects(rows, workload):
     hb = [r for r in rows if r["kind"] == "bytes" and r["kernel"].startswith("norm")]
     roof = obj(max(mf, key=lambda r: r["total_ms"]), MFMA_BF16_PEAK_TFLOPS, "TFLOP/s", 1e12) if mf else None
     roof_hbm = obj(max(hb, key=lambda r: r["total_ms"]), HBM_PEAK_GBS, "GB/s", 1e9) if hb else None
+    # the dominant attention kernel against the same MFMA peak (full-rectangle FLOP convention of SURVEY 8d: a causal kernel executes half of
+    # them): at T = 256 these kernels are latency / fill-bound, at long T (interleave covariates, T = 1664) they are the MFMA-bound flash regime
+    at = [r for r in rows if r["kind"] == "flops" and r["kernel"].startswith("attn")]
+    roof_attn = obj(max(at, key=lambda r: r["total_ms"]), MFMA_BF16_PEAK_TFLOPS, "TFLOP/s", 1e12) if at else None
+    if roof_attn is not None:
+        roof_attn["flops_convention"] = "full rectangle (4 T_q T_k d per head forward; backward kernels 2x split evenly): causal kernels execute about half"
     inst = [{"kernel": r["kernel"], "launches": r["launches"], "avg_us": round(r["total_ms"] / r["launches"] * 1e3, 2),
              **({"tflops": round(r["work"] / (r["total_ms"] * 1e-3) / 1e12, 1)} if r["kind"] == "flops" else
                 {"gbs": round(r["work"] / (r["total_ms"] * 1e-3) / 1e9, 1)})} for r in sorted(rows, key=lambda r: -r["total_ms"])]
-    return roof, roof_hbm, inst
+    return roof, roof_hbm, inst, roof_attn
 
 
 def trainer_loop_rate(model, opt, sync, su, task, device, world, rank, dev_batches, steps, B):
@@ -487,7 +494,7 @@ def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline):
         elapsed = float(t.item())
     final_loss = float(loss.item())
 
-    roofline = roofline_hbm = instances = optimizer_ms = None
+    roofline = roofline_hbm = roofline_attn = instances = optimizer_ms = None
     if want_roofline:
         # profiled replay (outside the timed region). EVERY rank replays the steps — they contain collectives — but only rank 0
         # records: each GEMM / attention / norm / optimiser launch carries its own start/stop event pair
@@ -501,7 +508,7 @@ def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline):
         rows = _native.prof_rows() if rank == 0 else []
         lib.mtl_prof_enable(0)
         if rows:
-            roofline, roofline_hbm, instances = roofline_objects(rows, name)
+            roofline, roofline_hbm, instances, roofline_attn = roofline_objects(rows, name)
             adam = [r for r in rows if r["kernel"].startswith("adam")]
             optimizer_ms = sum(r["total_ms"] for r in adam) / n_replay if adam else None
 
@@ -581,7 +588,8 @@ def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline):
             "algorithmic_tflop_per_step_per_gpu": round(fl / 1e12, 3), "executed_tflop_per_step_per_gpu": round(fl_exec / 1e12, 3),
             "step_mfma_frac": round(fl_exec / (elapsed / steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
             "step_mfma_frac_algorithmic": round(fl / (elapsed / steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-            "optimizer_ms_per_step": optimizer_ms, "roofline": roofline, "roofline_hbm": roofline_hbm, "kernel_instances": instances,
+            "optimizer_ms_per_step": optimizer_ms, "roofline": roofline, "roofline_hbm": roofline_hbm, "roofline_attention": roofline_attn,
+            "kernel_instances": instances,
             "cpu_baseline": cpu,
         }
     del model, opt, sync, batches, sd, params, su, opt_params
@@ -646,14 +654,14 @@ def main():
     if rank == 0 and out:
         committed = f"committed table profiles/pmc_traffic_<workload>.json (separate rocprofv3 --pmc passes of the same kernel sources, csrc_sha16 {csrc_sha16()})"
         for line in [out] + out.get("configs", []):
-            for key in ("roofline", "roofline_hbm"):
+            for key in ("roofline", "roofline_hbm", "roofline_attention"):
                 if line.get(key):
                     line[key]["traffic_source"] = committed if line[key]["traffic"] is not None else None
         if world == 1 and not args.no_live_traffic and not args.no_roofline:
             # the headline line's traffic is MEASURED by this run (everything above is finished and its memory released)
             torch.cuda.synchronize()
             torch.cuda.empty_cache()
-            objs = [out[k] for k in ("roofline", "roofline_hbm") if out.get(k)]
+            objs = [out[k] for k in ("roofline", "roofline_hbm", "roofline_attention") if out.get(k)]
             table, note = live_pmc_traffic(args.workload, [o["kernel"] for o in objs])
             for o in objs:
                 if o["kernel"] in table:
