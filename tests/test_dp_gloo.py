@@ -208,3 +208,60 @@ def test_gradient_accumulation_before_sync_is_not_dropped():
         p_.join(120)
         assert p_.exitcode == 0
     assert dict(q.get(timeout=5) for _ in range(2)) == {0: True, 1: True}
+
+
+def _forced_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    from med_ts_llm_amd import parallel
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    g = torch.Generator().manual_seed(1)
+    x, y = torch.randn(8, 6, generator=g), torch.randn(8, 16, generator=g)
+
+    def run(forced):
+        torch.manual_seed(0)
+        model = torch.nn.Sequential(torch.nn.Linear(6, 32), torch.nn.Tanh(), torch.nn.Linear(32, 16))
+        params = list(model.parameters())
+        su = sync = None
+        if forced:
+            su = parallel.ShardedUpdate(list(model.named_parameters()), 0, 1, min_numel=256, force_collectives=True)
+            assert su._live and [it["name"] for it in su.items] == ["2.weight"]
+            sync = parallel.FlatGradAllReduce(params, bucket_elems=64, force_collectives=True)
+            assert sync._live and sync._hooks and len(sync.buckets) > 1
+        else:
+            assert not parallel.FlatGradAllReduce(params)._live          # a one-rank group stays silent unless forced
+        opt = torch.optim.Adam(su.optimizer_params(params) if su else params, lr=1e-2)
+        for i in range(3):
+            # (one backward per step: on gloo ShardedUpdate reduces p.grad in place and refuses accumulated gradients by design; the
+            #  accumulation path of the reduce-scatter branch is covered on the device, tests/test_gpu_rccl.py)
+            torch.nn.functional.mse_loss(model(x), y).backward()
+            if sync is not None:
+                sync()
+                su.sync()
+            opt.step()
+            if su is not None:
+                su.publish()
+            opt.zero_grad()
+        return [p.detach().clone() for p in model.parameters()]
+
+    try:
+        a, b = run(False), run(True)
+        ok = all(torch.equal(u, v) for u, v in zip(a, b))
+        q.put("ok" if ok else "forced collectives changed the result")
+    except Exception as e:      # noqa: BLE001 — the parent prints it
+        q.put(repr(e))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_group_with_forced_collectives_equals_the_plain_run():
+    """force_collectives (how the RCCL calls are exercised on a 1-GPU box, tests/test_gpu_rccl.py) on the CPU backend: every collective of the
+    N-rank step runs in a one-rank group — hook-launched buckets, reduce / owned-rows update / publish of ShardedUpdate — and three Adam
+    steps end bit-identical to the plain single-process run."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_worker, args=(_free_port(), q))
+    p.start()
+    msg = q.get(timeout=120)
+    p.join(60)
+    assert msg == "ok" and p.exitcode == 0, msg
