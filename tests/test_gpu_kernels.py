@@ -966,8 +966,8 @@ def test_gemm_dswiglu_epilogue(ops, M, F, K, tune):
 @pytest.mark.gpu
 @pytest.mark.parametrize("Tq,Tk,kv0,pdrop", [(128, 256, 128, 0.1), (128, 256, 128, 0.0), (128, 128, 0, 0.1), (100, 100, 0, 0.0), (48, 112, 64, 0.5), (128, 256, 0, 0.1)])
 def test_attention_backward_one_launch_equals_two(ops, Tq, Tk, kv0, pdrop):
-    """The resident backward of MHA heads of width 64 as ONE launch (attn_bwd_res_merged_kernel: K, V, Q, dO, O of the head staged once, wave w
-    takes query tile w for dQ and key tile w for dK / dV) against the two launches it replaces (dQ, then dK / dV): bit-identical dq, dk, dv on the
+    """The resident backward of MHA heads of width 64 as ONE launch (attn_bwd_res_merged_kernel: K, V, Q, dO, O of the head staged once; waves 0-7
+    take one query tile each for dQ while waves 8-15 take one key tile each for dK / dV) against the two launches it replaces (dQ, then dK / dV): bit-identical dq, dk, dv on the
     rows they write — the pruned shape of the metric workload's backward (128 query rows at offset 128 of 256 keys, dK / dV for keys >= 128),
     full squares, ragged tiles, heavy dropout; and the last case (16 key tiles) must keep taking the two-launch path."""
     B, H, D, seed = 3, 4, 64, 4242
