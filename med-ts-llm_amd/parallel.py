@@ -121,7 +121,7 @@ class FlatGradAllReduce:
     The per-rank loss is a mean over the LOCAL batch, so averaging the summed gradients over ranks reproduces the
     single-process gradient of the mean over the GLOBAL batch (equal shard sizes)."""
 
-    def __init__(self, params, group=None, bucket_elems=32 * 1024 * 1024, overlap=True, force_collectives=False):
+    def __init__(self, params, group=None, bucket_elems=32 * 1024 * 1024, overlap=True, force_collectives=False, close_at_elems=4 * 1024 * 1024):
         # row-sharded parameters (p._dp_sharded, see AllGatherRows) already hold globally averaged gradients of rows no
         # other rank owns: they are neither communicated nor averaged again
         self.params = [p for p in params if p.requires_grad and not getattr(p, "_dp_sharded", False) and not getattr(p, "_dp_opt_sharded", False)]
@@ -142,7 +142,11 @@ class FlatGradAllReduce:
         self.buckets, self._where = [], {}
         off, cur = 0, None
         for p in reversed(self.params):
-            if cur is None or (cur["n"] > 0 and cur["n"] + p.numel() > bucket_elems):
+            # a bucket is closed as soon as it holds close_at_elems (16 MB: large enough for RCCL to drive every xGMI link) — NOT only when the next
+            # tensor would overflow bucket_elems: the metric model's 22 M trainable elements fit ONE 32 M bucket, which would leave at the very end
+            # of backward with nothing left to hide under; this way the output head (19 M elements, the first gradients backward produces) travels
+            # under the frozen backbone's whole backward and only the front end's 3 M elements go out last
+            if cur is None or (cur["n"] > 0 and (cur["n"] >= close_at_elems or cur["n"] + p.numel() > bucket_elems)):
                 cur = {"start": off, "n": 0, "items": [], "pending": 0, "handle": None}
                 self.buckets.append(cur)
             view = self.flat[off:off + p.numel()].view_as(p)
