@@ -349,6 +349,14 @@ class MedTsLLM(nn.Module):
             for p in params:
                 su.wait_published(p)
 
+    def _await_unlisted_rows(self):
+        """ShardedUpdate picks tensors by SIZE (setup.shard_optimizer_min_numel is the user's), the model awaits three of them right in front of
+        their first reader (mapping weight, word embeddings, flatten head: the ones that are big at the default threshold). Any OTHER tensor
+        that was sharded — projections, down-sample layer at a small threshold — is awaited here, before the forward reads anything."""
+        su = getattr(self, "_opt_shards", None)
+        if su is not None:
+            su.wait_published(skip=(self.mapping_layer.weight, self.word_embeddings, self.output_projection.linear.weight))
+
     def _prompt_key(self, ids):
         """host-side identity of a shared prompt (no device sync: the ids came from host lists / a host tensor checked once)"""
         if self.fixed_prompt_ids is not None:
@@ -455,6 +463,7 @@ class MedTsLLM(nn.Module):
             x_enc = x_enc.unsqueeze(-1)
         bs, _, C = x_enc.shape
         assert C == self.n_features
+        self._await_unlisted_rows()
         concat = self.covariate_mode == "concat"
         rl = self.reprogramming_layer
         # training.dropout: one host seed per encode, split over the two sites (patch embedding R:models/layers/embed.py:197, attention

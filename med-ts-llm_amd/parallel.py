@@ -12,6 +12,79 @@ import torch
 import torch.distributed as dist
 
 
+# The RCCL-native forms of the exchanges (reduce_scatter_tensor with ReduceOp.AVG, in-place all_gather_into_tensor, ReduceOp.AVG all-reduce)
+# are the default on "nccl"; MTL_DP_NATIVE_COLLECTIVES=0 — or a failed preflight_collectives() — selects the plain forms every backend has
+# (all_reduce SUM + divide, all_gather into parts + copy), which is also what gloo runs.
+_NATIVE = {"enabled": os.environ.get("MTL_DP_NATIVE_COLLECTIVES", "1") != "0", "why": None}
+
+
+def native_collectives(group=None):
+    return bool(_NATIVE["enabled"]) and dist.is_initialized() and dist.get_backend(group) == "nccl"
+
+
+def disable_native_collectives(why):
+    _NATIVE["enabled"], _NATIVE["why"] = False, why
+
+
+def count_ranks(device):
+    """number of ranks that answer an all-reduce of ones (what a bench line reports as rccl_ranks)"""
+    if not dist.is_initialized():
+        return 1
+    t = torch.ones(1, dtype=torch.float32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(round(float(t.item())))
+
+
+def preflight_collectives(device, group=None):
+    """Known-answer test of every RCCL-native exchange the DP path uses, on small tensors, BEFORE the first step: the mean all-reduce with the
+    control slot, reduce_scatter_tensor(AVG) from a full gradient, the in-place all_gather_into_tensor whose input aliases its own slot of
+    the output (fp32 and bf16), and AllGatherRows' pair. Any exception or wrong answer on ANY rank switches every rank to the plain forms
+    (disable_native_collectives) — the decision itself travels through a plain SUM all-reduce, so the ranks agree. Returns (ok, reason)."""
+    if not dist.is_initialized() or dist.get_world_size(group) <= 1:
+        return True, "single rank"
+    if not native_collectives(group):
+        return True, "plain collectives selected (" + (_NATIVE["why"] or "backend / MTL_DP_NATIVE_COLLECTIVES") + ")"
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    why = None
+    try:
+        n = 8 * world
+        # 1. mean all-reduce: rank r contributes r + 1 everywhere -> (world + 1) / 2
+        a = torch.full((n + 1,), float(rank + 1), dtype=torch.float32, device=device)
+        dist.all_reduce(a, op=dist.ReduceOp.AVG, group=group)
+        if not torch.allclose(a, torch.full_like(a, (world + 1) / 2.0)):
+            why = "all_reduce(AVG) wrong"
+        # 2. reduce-scatter (mean) of a [world * 8, 4] gradient whose row i holds i * (rank + 1)
+        g = (torch.arange(n, dtype=torch.float32, device=device)[:, None] * float(rank + 1)).repeat(1, 4).contiguous()
+        own = torch.empty((8, 4), dtype=torch.float32, device=device)
+        dist.reduce_scatter_tensor(own, g, op=dist.ReduceOp.AVG, group=group)
+        want = torch.arange(rank * 8, rank * 8 + 8, dtype=torch.float32, device=device)[:, None].repeat(1, 4) * (world + 1) / 2.0
+        if why is None and not torch.allclose(own, want):
+            why = "reduce_scatter_tensor(AVG) wrong"
+        # 3. in-place all-gather: every rank owns rows [8 r, 8 r + 8) of `full`, input = that slice of the output
+        for dt in (torch.float32, torch.bfloat16):
+            full = torch.full((n, 4), -1.0, dtype=dt, device=device)
+            full[rank * 8:rank * 8 + 8] = float(rank + 1)
+            h = dist.all_gather_into_tensor(full.view(-1), full[rank * 8:rank * 8 + 8].reshape(-1), group=group, async_op=True)
+            h.wait()
+            want = torch.arange(1, world + 1, dtype=torch.float32, device=device).repeat_interleave(8)[:, None].repeat(1, 4).to(dt)
+            if why is None and not torch.equal(full, want):
+                why = f"in-place all_gather_into_tensor ({dt}) wrong"
+        torch.cuda.synchronize() if device.type == "cuda" else None
+    except Exception as e:      # noqa: BLE001 — whatever the backend raises, the answer is the plain mode
+        why = f"{type(e).__name__}: {e}"[:120]
+    bad = torch.tensor([0.0 if why is None else 1.0], dtype=torch.float32, device=device)
+    try:
+        dist.all_reduce(bad, op=dist.ReduceOp.SUM, group=group)
+        n_bad = int(round(float(bad.item())))
+    except Exception as e:      # noqa: BLE001
+        n_bad, why = world, why or f"{type(e).__name__}: {e}"[:120]
+    if n_bad:
+        why = why or f"{n_bad} other rank(s) failed the pre-flight"
+        disable_native_collectives(why)
+        return False, why
+    return True, "native collectives verified"
+
+
 def init_from_env(device_type="cuda"):
     """Initialise the default process group from torchrun's env (RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*).
     Returns (rank, world_size, local_rank). No-op (0, 1, 0) when WORLD_SIZE is unset or 1."""
@@ -26,7 +99,9 @@ def init_from_env(device_type="cuda"):
     if not dist.is_initialized():
         # MTL_DIST_BACKEND=gloo lets several ranks share ONE GPU (RCCL refuses that): how the DP path is tested on a 1-GPU box
         backend = os.environ.get("MTL_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        import datetime
+        # (a rank that never arrives must end the job, not hang it: 10 min covers the slowest first RCCL communicator set-up)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=int(os.environ.get("MTL_DIST_TIMEOUT_MIN", "10"))))
         if backend == "nccl":
             settle_backend_output()
     return rank, world, local_rank
@@ -85,7 +160,7 @@ class AllGatherRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, local, rank, world, group):
         ctx.meta = (rank, world, group, local.shape[0])
-        if dist.get_backend(group) == "nccl":
+        if native_collectives(group):
             # RCCL: ONE collective straight into the full tensor (no per-rank parts, no concatenation) — this exchange sits on the step's
             # critical path, right in front of the reprogramming layer's key / value projections
             local = local.contiguous()
@@ -98,7 +173,7 @@ class AllGatherRows(torch.autograd.Function):
     def backward(ctx, d_full):
         rank, world, group, n_loc = ctx.meta
         g = d_full.float().contiguous()
-        if dist.get_backend(group) == "nccl":
+        if native_collectives(group):
             # reduce-scatter with the mean formed inside the collective: a rank receives the global-mean gradient of ITS rows and nothing else
             # (half the all-reduce's wire bytes, no slice / divide afterwards)
             own = torch.empty((n_loc,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
@@ -132,7 +207,7 @@ class FlatGradAllReduce:
         self._live = self.world > 1 or (force_collectives and dist.is_initialized())
         # RCCL averages inside the collective (ReduceOp.AVG: the sum scaled by 1 / world in its last step) — no separate pass over the flat
         # buffer afterwards; gloo has no AVG: SUM, then one division
-        self._avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self._avg = native_collectives(group)
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else "cpu"
         # + one control slot behind the gradients (it travels in the LAST bucket launched): the ranks' pre-emption flag, so that a
@@ -249,7 +324,7 @@ class ShardedUpdate:
         self.rank, self.world, self.group = rank, world, group
         self._live = world > 1 or (force_collectives and dist.is_initialized())     # (see FlatGradAllReduce: one-rank RCCL exercise)
         self.items, self._by_param = [], {}
-        self._rs = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self._rs = native_collectives(group)
         for name, p in named_params:
             if (not p.requires_grad or getattr(p, "_dp_sharded", False) or p.dim() < 2 or p.numel() < min_numel or p.shape[0] % world
                     or not p.is_contiguous()):
@@ -333,6 +408,13 @@ class ShardedUpdate:
         async_op: the all-gathers are only LAUNCHED (RCCL's stream); wait_published(name) must run before the tensor is read again — the model
         calls it right in front of the first GEMM that reads it, so that e.g. the flatten head's 3.4 GB gather (PSM, bf16) travels under the NEXT
         step's whole frozen-backbone forward instead of in front of it."""
+        # The optimiser updated an nn.Parameter VIEW of the owned rows (and the other ranks' rows arrive through p.data below): the FULL
+        # parameter's autograd version never moves by itself, and every persistent bf16 copy of it (LinearFn / MappingTrainableFn shadows)
+        # trusts `shadow.version == p._version`. Unless the optimiser maintains the copy this class publishes (HipAdam + attach_shadow), the
+        # full parameter is marked changed here, so that the next forward re-casts it from the updated master (torch SGD / Adam under DP).
+        for it in self.items:
+            if it["shadow"] is None:
+                torch.autograd.graph.increment_version(it["p"])
         if not self._live:
             return
         for it in self.items:
@@ -349,9 +431,12 @@ class ShardedUpdate:
                         full[i * per:(i + 1) * per].copy_(t)
                 it["pub"] = None
 
-    def wait_published(self, param=None):
-        """block (stream-ordered on a GPU) until the rows published asynchronously have arrived: for `param` (the full tensor) or for all"""
+    def wait_published(self, param=None, skip=()):
+        """block (stream-ordered on a GPU) until the rows published asynchronously have arrived: for `param` (the full tensor) or for all
+        (except the tensors in `skip`, which their reader awaits itself later)"""
         for it in self.items:
+            if any(it["p"] is q for q in skip):
+                continue
             if (param is None or it["p"] is param) and it.get("pub") is not None:
                 it["pub"].wait()
                 it["pub"] = None

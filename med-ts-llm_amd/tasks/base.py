@@ -61,6 +61,8 @@ class PrintLogger:
         # collectives when the mapping layer is row-sharded (the rows and their Adam moments are gathered): every rank takes part
         if hasattr(self.trainer.optimizer, "wait_deferred"):
             self.trainer.optimizer.wait_deferred()
+        if getattr(self.trainer, "opt_shards", None) is not None:
+            self.trainer.opt_shards.wait_published()       # asynchronously published rows must have landed before they are read / gathered
         model_state = self.trainer.model.state_dict()
         optim_state = self.trainer.optimizer_state()
         if self.trainer.rank != 0:
@@ -370,7 +372,18 @@ class BaseTask(ABC):
 
     def _loss_arrived(self, host):
         self.log_step(host[0])
-        if len(host) > 1 and host[1] > 0:          # some rank was told to stop: every rank sees the same sum at the same step
+        if len(host) > 1 and host[1] > 0 and not getattr(self, "_exiting", False):      # some rank was told to stop: every rank sees the same sum at the same step
+            self._checkpoint_and_exit()
+
+    def _agree_on_stop(self):
+        """DP: a pre-emption notice that arrived outside the training steps (during validation / the final test, after the last step of the
+        run) never rides in a gradient all-reduce. At epoch / validation / test boundaries the ranks therefore agree explicitly — one tiny
+        all-reduce of the flags — and checkpoint + exit together (R:tasks/base.py:277-281 checkpoints immediately; a collective cannot)."""
+        if self.world_size <= 1 or getattr(self, "_exiting", False):
+            return
+        t = torch.tensor([1.0 if self._stop_requested else 0.0], dtype=torch.float32, device=self.device)
+        torch.distributed.all_reduce(t)
+        if float(t.item()) > 0:
             self._checkpoint_and_exit()
 
     def train(self):
@@ -387,10 +400,12 @@ class BaseTask(ABC):
                 self.optimizer.wait_deferred()
             if self.opt_shards is not None:
                 self.opt_shards.wait_published()
+            self._agree_on_stop()
             val_scores = self.val()
             self.epochs_done = epoch + 1
             self.log_epoch(val_scores)
             self.scheduler.step()
+            self._agree_on_stop()
         self.model.eval()
 
     def _eval_loss(self, loader, prefix):
@@ -411,7 +426,9 @@ class BaseTask(ABC):
         return self._eval_loss(self.val_dataloader, "val")
 
     def test(self):
-        return self._eval_loss(self.test_dataloader, "test")
+        scores = self._eval_loss(self.test_dataloader, "test")
+        self._agree_on_stop()
+        return scores
 
     def predict(self, dataloader):
         self.model.eval()
@@ -469,6 +486,9 @@ class BaseTask(ABC):
         self._checkpoint_and_exit()
 
     def _checkpoint_and_exit(self):
+        if getattr(self, "_exiting", False):       # (_flush_losses below re-enters through _loss_arrived while the agreed flag is still up)
+            return
+        self._exiting = True
         print("Interrupted!")
         self._flush_losses()
         self.logger.save_state("latest")

@@ -297,6 +297,15 @@ class MixedWindows(Dataset):
         return (idx * self.step_size, idx * self.step_size + self.pred_len)
 
 
+# every combination exists from import time on (not only once make_series_dataset has run in the parent): a DataLoader worker started with
+# spawn / forkserver imports this module afresh and must find "ClipSemSegSeries", "UnivariateClipReconstructionSeries", ... by name
+for _base in (ForecastSeries, ReconstructionSeries, SemSegSeries, SegmentationSeries):
+    univariate_view(_base)
+    if _base is not ForecastSeries:          # (clip datasets do not support forecasting)
+        univariate_view(_with_clips(_base))
+del _base
+
+
 def make_series_dataset(config, split, source=None):
     cls = {"forecasting": ForecastSeries, "pretraining": ForecastSeries, "reconstruction": ReconstructionSeries,
            "anomaly_detection": ReconstructionSeries, "semantic_segmentation": SemSegSeries, "segmentation": SegmentationSeries}[config.task]

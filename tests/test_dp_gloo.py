@@ -265,3 +265,36 @@ def test_one_rank_group_with_forced_collectives_equals_the_plain_run():
     msg = q.get(timeout=120)
     p.join(60)
     assert msg == "ok" and p.exitcode == 0, msg
+
+
+def test_sharded_update_marks_the_full_parameter_changed_for_torch_optimizers():
+    """the optimiser steps an nn.Parameter VIEW of the owned rows, so the FULL parameter's version counter never moved and every
+    persistent bf16 copy of it (LinearFn / MappingTrainableFn shadows trust shadow.version == W._version) stayed on the step-0 weights under
+    torch SGD / Adam. publish() now bumps the full parameter unless the optimiser maintains the published shadow itself."""
+    from med_ts_llm_amd import parallel
+    from med_ts_llm_amd.hip.optim import Bf16Shadow
+    p = torch.nn.Parameter(torch.randn(8, 4))
+    q = torch.nn.Parameter(torch.randn(8, 4))
+    su = parallel.ShardedUpdate([("p", p), ("q", q)], 0, 1, min_numel=1)
+    su.attach_shadow(q, torch.zeros(8, 4, dtype=torch.bfloat16))          # q's published copy is optimiser-maintained (HipAdam route)
+    sh = Bf16Shadow(p, torch.zeros(8, 4, dtype=torch.bfloat16))
+    sh.version = p._version
+    assert sh.fresh()
+    opt = torch.optim.SGD(su.optimizer_params([p, q]), lr=0.1)
+    before, vq = p.detach().clone(), q._version
+    p.grad, q.grad = torch.ones_like(p), torch.ones_like(q)
+    su.sync()
+    opt.step()
+    su.publish()
+    assert not torch.equal(p.detach(), before)          # the view wrote through to the full tensor ...
+    assert not sh.fresh()                                # ... and the full parameter now says so
+    assert q._version == vq                              # (a shadow the optimiser keeps current is not invalidated)
+
+
+def test_preflight_and_native_switch_on_a_plain_backend(monkeypatch):
+    from med_ts_llm_amd import parallel
+    assert parallel.preflight_collectives(torch.device("cpu")) == (True, "single rank")
+    assert parallel.native_collectives() is False        # no process group / gloo: the plain forms
+    monkeypatch.setitem(parallel._NATIVE, "enabled", True)
+    parallel.disable_native_collectives("test")
+    assert parallel._NATIVE["enabled"] is False and parallel._NATIVE["why"] == "test"

@@ -1,6 +1,6 @@
-"""Data-parallel path on the device with TWO ranks sharing the one GPU of the test box (gloo backend on device tensors —
-RCCL refuses two ranks per GPU; MTL_DIST_BACKEND selects it): the row-sharded mapping layer + flat gradient all-reduce
-+ HIP Adam reproduce the single-process full-batch step."""
+"""Data-parallel path on the device with TWO ranks: one rank per GPU over RCCL ("nccl") when the box has two GPUs; on a 1-GPU box the
+two ranks share the device over gloo (RCCL refuses two ranks per GPU; MTL_DIST_BACKEND selects it). The row-sharded mapping layer + flat
+gradient all-reduce + HIP Adam reproduce the single-process full-batch step."""
 import os
 import socket
 
@@ -18,6 +18,17 @@ def _free_port():
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+def _dist_env(rank, world, port):
+    """torchrun-style environment of one rank; the backend follows the hardware: RCCL with one rank per GPU when there are enough GPUs"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if torch.cuda.device_count() >= world:
+        os.environ.pop("MTL_DIST_BACKEND", None)
+        return "nccl"
+    os.environ["MTL_DIST_BACKEND"] = "gloo"
+    return "gloo"
 
 
 def _build(shard=None, kind="gpt2"):
@@ -66,11 +77,13 @@ def _step(model, inputs, sync):
 
 
 def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                      MTL_DIST_BACKEND="gloo")
+    backend = _dist_env(rank, world, port)
     import torch.distributed as dist
     from med_ts_llm_amd import parallel
-    assert parallel.init_from_env("cuda")[:2] == (rank, world) and dist.get_backend() == "gloo"
+    assert parallel.init_from_env("cuda")[:2] == (rank, world) and dist.get_backend() == backend
+    if backend == "nccl":
+        ok, why = parallel.preflight_collectives(torch.device("cuda", torch.cuda.current_device()))
+        assert ok and parallel.count_ranks(torch.device("cuda", torch.cuda.current_device())) == world, why
     model = _build(shard=(rank, world))
     assert model.mapping_layer.weight.shape[0] == S // world
     inputs = parallel.shard_batch(_batch(), rank, world)
@@ -125,21 +138,26 @@ def test_two_rank_dp_step_matches_single_process():
 
 
 # ---- row-sharded optimiser step on the device: HipAdam on the owned rows, bf16 shadow rows published to the other rank
-def _train3(model, batches, world, rank, sharded):
+def _train3(model, batches, world, rank, sharded, optimizer="hipadam", min_numel=4096):
     from med_ts_llm_amd import parallel
     from med_ts_llm_amd.hip.optim import HipAdam, Bf16Shadow
     params = [p for p in model.parameters() if p.requires_grad]
     su = None
     if sharded:
-        su = parallel.ShardedUpdate(list(model.named_parameters()), rank, world, min_numel=4096)
+        su = parallel.ShardedUpdate(list(model.named_parameters()), rank, world, min_numel=min_numel)
         assert {it["name"] for it in su.items} >= {"output_projection.linear.weight"}
         model._opt_shards = su
-    opt = HipAdam(su.optimizer_params(params) if su else params, lr=1e-3)
-    for sh in model.bf16_shadows():
-        if su is not None and id(sh.param) in su._by_param:
-            opt.register_shadow(Bf16Shadow(su._by_param[id(sh.param)]["shard"], su.attach_shadow(sh.param, sh.tensor)))
-        else:
-            opt.register_shadow(sh)
+    if optimizer == "sgd":
+        # a torch optimiser maintains no bf16 shadow: the forward must notice by itself that the sharded tensors changed (ShardedUpdate.publish
+        # bumps the full parameter's version; before that fix every later forward read the step-0 bf16 weights)
+        opt = torch.optim.SGD(su.optimizer_params(params) if su else params, lr=0.05, momentum=0.9, nesterov=True)
+    else:
+        opt = HipAdam(su.optimizer_params(params) if su else params, lr=1e-3)
+        for sh in model.bf16_shadows():
+            if su is not None and id(sh.param) in su._by_param:
+                opt.register_shadow(Bf16Shadow(su._by_param[id(sh.param)]["shard"], su.attach_shadow(sh.param, sh.tensor)))
+            else:
+                opt.register_shadow(sh)
     sync = parallel.FlatGradAllReduce(params, bucket_elems=20000) if world > 1 else None
     losses = []
     for inputs in batches:
@@ -161,8 +179,7 @@ def _train3(model, batches, world, rank, sharded):
 
 
 def _sharded_worker(rank, world, port, q, kind="gpt2"):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                      MTL_DIST_BACKEND="gloo")
+    _dist_env(rank, world, port)
     import torch.distributed as dist
     from med_ts_llm_amd import parallel
     parallel.init_from_env("cuda")
@@ -238,3 +255,42 @@ def test_two_rank_sharded_optimizer_matches_single_process(kind):
         w1, w2 = sd1[k].float().cpu(), torch.from_numpy(sd2[k])
         moved = 3e-3 * (w1.numel() ** 0.5)       # three Adam steps of lr 1e-3 move every element by <= 3e-3
         assert float((w1 - w2).norm()) < 0.1 * moved, k      # the two runs agree to a small fraction of the distance the weights moved
+
+
+# ---- a torch optimiser on the owned-rows views never moves the FULL parameter's version counter
+def _sgd_worker(rank, world, port, q):
+    _dist_env(rank, world, port)
+    import torch.distributed as dist
+    from med_ts_llm_amd import parallel
+    parallel.init_from_env("cuda")
+    model = _build(shard=(rank, world))
+    full = [_batch()] * 4
+    # threshold low enough that the projections and the down-sample layer are sharded too: tensors the model does NOT await one by one
+    losses, su, _ = _train3(model, [parallel.shard_batch(b, rank, world) for b in full], world, rank, sharded=True, optimizer="sgd", min_numel=1024)
+    names = sorted(it["name"] for it in su.items)
+    ls = [torch.zeros(4, device="cuda") for _ in range(world)]
+    dist.all_gather(ls, torch.tensor(losses, device="cuda"))
+    if rank == 0:
+        q.put((torch.stack(ls).mean(0).cpu().numpy(), names))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_sgd_forward_sees_updated_weights():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sgd_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    losses2, names = q.get(timeout=240)
+    for p_ in procs:
+        p_.join(120)
+        assert p_.exitcode == 0
+    assert "output_projection.linear.weight" in names and len(names) >= 3, names
+    model = _build()
+    losses1, _, _ = _train3(model, [_batch()] * 4, 1, 0, sharded=False, optimizer="sgd")
+    print("\nSGD, same batch four times: single process", [round(x, 5) for x in losses1], "two ranks (sharded update)", [round(float(x), 5) for x in losses2])
+    assert losses1[3] < 0.98 * losses1[0]                      # the single process learns ...
+    for a, b in zip(losses1, losses2):                          # ... and the two ranks follow it step by step (stale bf16 weights would freeze the loss)
+        assert abs(a - float(b)) < 1e-2 * abs(a), (losses1, losses2)

@@ -81,22 +81,32 @@ def test_psm_shaped_anomaly_detection_vs_oracle():
     _check_full_model("llama", "anomaly_detection", 2, 512, 25, 512, "concat", "linear", True, d_model=32, d_ff=128, H=8, num_tokens=1024)
 
 
-def _check_full_model(kind, task, B, L, C, pred, cov, down, prompt_on, d_model=8, d_ff=64, H=2, num_tokens=64, grad_bar=1.5):
+def _check_full_model(kind, task, B, L, C, pred, cov, down, prompt_on, d_model=8, d_ff=64, H=2, num_tokens=64, grad_bar=1.5,
+                      hf=None, sd=None, prompting=None, descriptions=None, llm_layers=-1, dataset=None):
+    """hf / sd: a full backbone config + CPU fp32 state dict instead of the small helpers.hf_cfg(kind) one (tests/test_gpu_realwidth.py);
+    prompting: the config's prompting table as shipped (overrides prompt_on); descriptions: per-sample clip descriptions (`clip` prompts)."""
     from med_ts_llm_amd.models import model_lookup
     from med_ts_llm_amd.models.backbone import random_state_dict
     from med_ts_llm_amd.utils import dict_to_object
     from oracle import medtsllm_oracle as O
 
-    cfg = hf_cfg("llama_gqa", vocab=100_100) if kind == "llama_gqa_bigvocab" else hf_cfg(kind)
-    sd = random_state_dict(cfg, seed=7, std=0.06)
+    if hf is not None:
+        cfg = hf
+    else:
+        cfg = hf_cfg("llama_gqa", vocab=100_100) if kind == "llama_gqa_bigvocab" else hf_cfg(kind)
+    if sd is None:
+        sd = random_state_dict(cfg, seed=7, std=0.06)
     ex_on = prompt_on == "examples"
     prompt_on = bool(prompt_on)
-    prompting = {"dataset": prompt_on, "task": prompt_on, "clip": False, "input_stats": prompt_on, "examples": ex_on,
-                 "input_stats_dim": 0, "input_stats_select": "all"}
+    if prompting is None:
+        prompting = {"dataset": prompt_on, "task": prompt_on, "clip": False, "input_stats": prompt_on, "examples": ex_on,
+                     "input_stats_dim": 0, "input_stats_select": "all"}
+    else:
+        prompt_on = any(prompting.get(k, False) for k in ("dataset", "task", "clip", "input_stats"))
     n_classes = 4 if task == "semantic_segmentation" else 0
-    config = dict_to_object(model_config(task, L, pred, cov, down, prompting, d_model=d_model, d_ff=d_ff, H=H, num_tokens=num_tokens))
+    config = dict_to_object(model_config(task, L, pred, cov, down, prompting, d_model=d_model, d_ff=d_ff, H=H, num_tokens=num_tokens, llm_layers=llm_layers))
     torch.manual_seed(11)
-    model = model_lookup["medtsllm"](config, FakeDataset(C, n_classes), backbone_state=(cfg, sd))
+    model = model_lookup["medtsllm"](config, dataset or FakeDataset(C, n_classes), backbone_state=(cfg, sd))
     model.tokenizer = fixture_tokenizer()
     with torch.no_grad():   # make every trainable weight O(0.1) so all branches matter
         for n, p in model.named_parameters():
@@ -108,6 +118,8 @@ def _check_full_model(kind, task, B, L, C, pred, cov, down, prompt_on, d_model=8
     g = torch.Generator().manual_seed(13)
     x = torch.randn(B, L, C, generator=g) * torch.tensor(([1.0, 2.5, 0.3] * 9)[:C]) + torch.tensor(([0.5, -1.0, 3.0] * 9)[:C])
     inputs = {"x_enc": x.cuda()}
+    if descriptions is not None:
+        inputs["descriptions"] = list(descriptions)
     if ex_on:
         ex = torch.randn(B, 40, C, generator=g) * 0.7 + 0.2
         inputs["examples"] = [("Example segment:", ex[i:i + 1].cuda()) for i in range(B)]
@@ -116,7 +128,7 @@ def _check_full_model(kind, task, B, L, C, pred, cov, down, prompt_on, d_model=8
 
     # ---- oracle on the same weights / prompt ids
     trainable_emb = model.word_embeddings.requires_grad
-    assert trainable_emb == (kind == "llama_gqa_bigvocab") and model.vocab_size == min(cfg["vocab_size"], 100_000)
+    assert trainable_emb == (cfg["vocab_size"] > 100_000) and model.vocab_size == min(cfg["vocab_size"], 100_000)
     p = {n: t.detach().cpu().float().clone().requires_grad_(t.requires_grad) for n, t in model.named_parameters()
          if n != "word_embeddings" or trainable_emb}
     we_kw = {"word_emb": p["word_embeddings"]} if trainable_emb else {}

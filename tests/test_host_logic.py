@@ -1,10 +1,13 @@
 """CPU tests of the host-side logic (no GPU): prompt construction, construction/checkpoint surface, C-ABI symbols,
 and the optimisation-step order (a10) pinned to the reference trainer's loss trajectory."""
 import json
+import os
 import re
+import sys
 from pathlib import Path
 
 import numpy as np
+
 import pytest
 import torch
 
@@ -327,6 +330,58 @@ def test_derived_window_datasets_pickle():
     assert type(ds).__name__ == "UnivariateClipReconstructionSeries" and getattr(windows, type(ds).__name__) is type(ds)
     back = pickle.loads(pickle.dumps(ds))
     assert len(back) == len(ds) and torch.equal(back[5]["x_enc"], ds[5]["x_enc"])
+    # a spawn / forkserver worker imports the module AFRESH (make_series_dataset never ran there): the class must exist from import time on
+    import subprocess
+    import sys
+    blob = tmp = None
+    code = ("import pickle, sys, torch; sys.path.insert(0, %r); import med_ts_llm_amd; ds = pickle.load(open(sys.argv[1], 'rb')); "
+            "print(type(ds).__name__, len(ds), float(ds[5]['x_enc'].sum()))" % str(ROOT))
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".pkl", delete=False) as f:
+        pickle.dump(ds, f)
+        tmp = f.name
+    try:
+        r = subprocess.run([sys.executable, "-c", code, tmp], capture_output=True, text=True, timeout=240)
+    finally:
+        os.unlink(tmp)
+    assert r.returncode == 0, r.stderr[-800:]
+    name, n, tot = r.stdout.split()
+    assert name == "UnivariateClipReconstructionSeries" and int(n) == len(ds) and abs(float(tot) - float(ds[5]["x_enc"].sum())) < 1e-5
+
+
+def test_bench_compact_line_is_small_and_complete():
+    """the driver parses the LAST stdout line of bench.py: r03's 20 KB line (kernel instances, prose) could not be parsed. The compact form of a
+    real full record (profiles/r03_v5c_bench.json: headline + two Llama configs) must stay under 4 KB and carry the contract's fields, the
+    roofline objects as numbers and the CPU baseline."""
+    import json
+    sys.path.insert(0, str(ROOT))
+    import bench
+    with open(ROOT / "profiles" / "r03_v5c_bench.json") as f:
+        full = json.load(f)
+    line = json.dumps(bench.compact_line(full), separators=(",", ":"))
+    assert len(line) < 4096, len(line)
+    c = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in c, k
+    r = c["roofline"]
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and isinstance(r["traffic"], int)
+    assert c["roofline_hbm"]["bound"] == "hbm" and c["roofline_hbm"]["unit"] == "GB/s"
+    assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["cores"] >= 1
+    assert "workload" in c["config"] and "model" not in c["config"]
+    assert len(c["configs"]) == 2 and all("value" in e and "roofline" in e for e in c["configs"])
+    # r03's Llama lines claimed a whole-step MFMA fraction (0.64) above their fastest GEMM's (0.55): the check flags exactly that record
+    assert c["configs"][0]["checks"]["step_frac_le_best_kernel_frac"] is False
+    assert c["checks"]["step_frac_le_best_kernel_frac"] is True
+
+
+def test_causal_fraction_of_the_rectangle():
+    sys.path.insert(0, str(ROOT))
+    import bench
+    # T = 4 keys, the last 2 queries: they see 3 and 4 keys of 4 -> 7 / 8
+    assert abs(bench.causal_fraction("attn_fwd_kernel<128, true, false, 8>", 4, 2) - 7 / 8) < 1e-12
+    assert bench.causal_fraction("attn_fwd_kernel<128, false, true, 8>", 4, 2) == 1.0
+    assert abs(bench.causal_fraction("attn_bwd_dq_res_kernel<64, 8, true>", 256, 256) - 257 / 512) < 1e-12
 
 
 def test_bench_pmc_traffic_arithmetic_and_fallback(tmp_path, monkeypatch):
