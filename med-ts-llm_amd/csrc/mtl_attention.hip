@@ -22,6 +22,14 @@
 namespace {
 
 constexpr int KC = 64;  // keys (or queries, in the dK/dV kernel) per LDS chunk
+// Row padding of every LDS tile, in bf16 elements. 16 (row stride = 8 mod 64 dwords): conflict-free for BOTH read shapes of a tile —
+// the 16-byte fragment rows (ds_read_b128 is serviced in the four non-contiguous 16-lane groups of GUIDE MI355X_MICROARCH "LDS": with a
+// stride of 8 dwords mod 64 each group's 16 slots are distinct) and the transposing gathers (ds_read_b64_tr_b16, two 32-lane groups = 8
+// rows x 32 B: 8 dwords apart). The earlier 8 (stride = 4 mod 64) left the gathers 2-way conflicted (SQ_LDS_BANK_CONFLICT / LDS_ACTIVE =
+// 0.40-0.45 on every attention kernel) and rows 11 / 12 of a fragment read on one slot.
+#ifndef MTL_ATTN_PAD
+#define MTL_ATTN_PAD 16
+#endif
 #ifndef MTL_CONSISTENT_DELTA
 #define MTL_CONSISTENT_DELTA 0     // causal self-attention: 0 = delta = dO . O with the bf16-rounded forward output (measured: the consistent
                                    // form changes nothing there — tools/diag_bias.py: the stack's input gradient is unbiased and on par
@@ -103,7 +111,7 @@ __device__ __forceinline__ bf16x8 gather_col(const bf16_t* tile, int ldt, int ra
 // round trip per iteration (hipcc waits vmcnt(0) in front of every ds_write), which was most of these kernels' time.
 template <int D, int NT = 256>
 __device__ __forceinline__ void load_tile(bf16_t* tile, const bf16_t* src, int64_t src_ts, int64_t row0, int64_t limit) {
-    constexpr int LDT = D + 8, CPR = D / 8, NIT = KC * CPR / NT;
+    constexpr int LDT = D + MTL_ATTN_PAD, CPR = D / 8, NIT = KC * CPR / NT;
     static_assert(KC * CPR % NT == 0 && NIT >= 1, "whole 16-byte chunks per thread");
     u32x4 v[NIT];
 #pragma unroll
@@ -139,13 +147,34 @@ __device__ __forceinline__ void fetch_tile(TileRegs<D, NT>& t, const bf16_t* src
 }
 template <int D, int NT>
 __device__ __forceinline__ void stash_tile(bf16_t* tile, const TileRegs<D, NT>& t) {
-    constexpr int LDT = D + 8, CPR = D / 8, NIT = KC * CPR / NT;
+    constexpr int LDT = D + MTL_ATTN_PAD, CPR = D / 8, NIT = KC * CPR / NT;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
         const int s = threadIdx.x + i * NT;
         *reinterpret_cast<u32x4*>(tile + (s / CPR) * LDT + (s % CPR) * 8) = t.v[i];
     }
 }
+
+// XCD-aware workgroup -> (row block, head, batch) map for the long-sequence kernels. The hardware hands consecutive workgroup ids to the eight XCDs
+// round robin, and each XCD has its own 4 MB L2: with the plain (x = row block, y = head, z = batch) grid the 13 row blocks of one head land on
+// eight different XCDs and every one of those L2s fetches that head's whole K / V (or Q / dO) — 3 GB per forward launch at T = 1664 where 0.45 GB
+// are algorithmic. Launched 1-D (8 * ceil(heads / 8) * nx workgroups): XCD x owns a CONTIGUOUS range of (batch, head) pairs (adjacent query heads
+// of a GQA group share their K / V through the same L2) and walks each head's row blocks back to back, heaviest (most keys) first.
+struct AttnBlock { int64_t x, h, b; bool live; };
+template <bool XMAP>
+__device__ __forceinline__ AttnBlock attn_block(int64_t nx, int64_t ny, int64_t nz, bool heavy_first_is_last) {
+    if constexpr (!XMAP) {
+        return {(int64_t)blockIdx.x, (int64_t)blockIdx.y, (int64_t)blockIdx.z, true};
+    } else {
+        const int64_t L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        const int64_t nh = ny * nz, per = (nh + 7) >> 3;
+        const int64_t hh = xcd * per + slot / nx;
+        const int64_t xr = slot % nx;
+        const bool live = hh < nh && slot / nx < per;
+        return {heavy_first_is_last ? nx - 1 - xr : xr, hh % ny, hh / ny, live};
+    }
+}
+__host__ inline unsigned attn_xmap_grid(int64_t nx, int64_t ny, int64_t nz) { return (unsigned)(8 * ((ny * nz + 7) / 8) * nx); }
 
 #define NEG_BIG (-1.0e30f)
 #define LOG2E 1.4426950408889634f
@@ -157,7 +186,7 @@ __device__ __forceinline__ void stash_tile(bf16_t* tile, const TileRegs<D, NT>& 
 // through L2 (5.6 GB per layer), which is what the kernels spent most of their time on.
 template <int D, bool CAUSAL, bool DROP, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const mtl_attn_fwd_args a) {
-    constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
+    constexpr int LDT = D + MTL_ATTN_PAD, NKS = D / 32, NDT = D / 16;
     __shared__ __attribute__((aligned(16))) bf16_t ktile[KC * LDT];
     __shared__ __attribute__((aligned(16))) bf16_t vtile[KC * LDT];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, g = lane >> 4;   // (wave index in an SGPR: tile offsets, loop bounds and the mask test become scalar)
@@ -306,15 +335,17 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const mtl_attn_fwd_ar
 }
 
 // =============================================================================================== backward: dQ (+ delta)
-template <int D, bool CAUSAL, bool DROP, int NW = 4>
+template <int D, bool CAUSAL, bool DROP, int NW = 4, bool XMAP = false>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const mtl_attn_bwd_args a) {
-    constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
+    constexpr int LDT = D + MTL_ATTN_PAD, NKS = D / 32, NDT = D / 16;
     __shared__ __attribute__((aligned(16))) bf16_t ktile[KC * LDT];
     __shared__ __attribute__((aligned(16))) bf16_t vtile[KC * LDT];
     const mtl_attn_fwd_args& f = a.f;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, g = lane >> 4;   // (wave index in an SGPR: tile offsets, loop bounds and the mask test become scalar)
-    const int64_t b = blockIdx.z, h = blockIdx.y, hk = h / (f.Hq / f.Hkv);
-    const int64_t qblk0 = (int64_t)blockIdx.x * (NW * 16);
+    const AttnBlock blk = attn_block<XMAP>((f.Tq + NW * 16 - 1) / (NW * 16), f.Hq, f.B, CAUSAL);
+    if (!blk.live) return;
+    const int64_t b = blk.b, h = blk.h, hk = h / (f.Hq / f.Hkv);
+    const int64_t qblk0 = blk.x * (NW * 16);
     const int64_t q0 = qblk0 + wave * 16;
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(f.q) + b * f.q_bs + h * f.q_hs;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(f.k) + b * f.k_bs + hk * f.k_hs;
@@ -468,24 +499,27 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const mtl_attn_bwd
 // =============================================================================================== backward: dK, dV
 // One workgroup per (64-key tile, kv head, batch or ALL batches when K/V are batch-shared); loops over the query
 // heads of the GQA group and over 64-query chunks. Lane owns key = lane & 15 of its wave's 16 keys.
-template <int D, bool CAUSAL, bool DROP, int NW = 4>
+template <int D, bool CAUSAL, bool DROP, int NW = 4, bool XMAP = false>
 __global__ __launch_bounds__(NW * 64, (D >= 128 && NW == 4) ? 2 : 1) void attn_bwd_dkv_kernel(const mtl_attn_bwd_args a) {
-    constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
+    constexpr int LDT = D + MTL_ATTN_PAD, NKS = D / 32, NDT = D / 16;
     __shared__ __attribute__((aligned(16))) bf16_t qtile[KC * LDT];
     __shared__ __attribute__((aligned(16))) bf16_t dotile[KC * LDT];
     __shared__ float lse_s[KC], delta_s[KC];
     const mtl_attn_fwd_args& f = a.f;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, g = lane >> 4;   // (wave index in an SGPR: tile offsets, loop bounds and the mask test become scalar)
-    const int64_t hk = blockIdx.y;
+    // (XMAP: 1-D launch, per-sample K / V only — a key block's workgroups of one kv head stay on one XCD, whose L2 then holds that head's Q / dO)
+    const AttnBlock blk = attn_block<XMAP>((f.Tk - a.kv_row0 + NW * 16 - 1) / (NW * 16), f.Hkv, f.B, false);
+    if (!blk.live) return;
+    const int64_t bx = blk.x, hk = blk.h, bz = blk.b;
     const int group = (int)(f.Hq / f.Hkv);
     const bool shared_kv = (f.k_bs == 0);
     // shared K/V (reprogramming attention): blockIdx.z is a CHUNK of the batch; partial dK/dV are accumulated into the
     // fp32 workspace with hardware float atomics and converted afterwards (dkv_convert_kernel)
     const int64_t chunk = shared_kv ? (f.B + gridDim.z - 1) / gridDim.z : 1;
-    const int64_t b_begin = shared_kv ? (int64_t)blockIdx.z * chunk : blockIdx.z;
-    const int64_t b_end = shared_kv ? ((b_begin + chunk < f.B) ? b_begin + chunk : f.B) : blockIdx.z + 1;
+    const int64_t b_begin = shared_kv ? bz * chunk : bz;
+    const int64_t b_end = shared_kv ? ((b_begin + chunk < f.B) ? b_begin + chunk : f.B) : bz + 1;
     const int64_t coff = f.causal_off;
-    const int64_t kblk0 = a.kv_row0 + (int64_t)blockIdx.x * (NW * 16);   // keys below kv_row0 need no gradient (pruned)
+    const int64_t kblk0 = a.kv_row0 + bx * (NW * 16);   // keys below kv_row0 need no gradient (pruned)
     const int64_t k0 = kblk0 + wave * 16;
     int64_t krow = k0 + l15;
     const bool k_valid = krow < f.Tk;
@@ -600,7 +634,7 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 && NW == 4) ? 2 : 1) void attn_b
     if (!k_valid) return;
     if (shared_kv && gridDim.z > 1) {   // partial slab of this batch chunk: [split][2][Tk][Hkv][D] fp32, plain 16-B stores
         const int64_t n = f.Tk * f.Hkv * D;
-        float* wk = a.dkv_ws + (int64_t)blockIdx.z * 2 * n + (krow * f.Hkv + hk) * D;
+        float* wk = a.dkv_ws + bz * 2 * n + (krow * f.Hkv + hk) * D;
         float* wv = wk + n;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
@@ -609,11 +643,259 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 && NW == 4) ? 2 : 1) void attn_b
         }
         return;
     }
-    const int64_t bo = shared_kv ? 0 : (int64_t)blockIdx.z;
+    const int64_t bo = shared_kv ? 0 : bz;
     bf16_t* DK = reinterpret_cast<bf16_t*>(a.dk) + bo * a.dk_bs + hk * a.dk_hs + krow * a.dk_ts;
     bf16_t* DV = reinterpret_cast<bf16_t*>(a.dv) + bo * a.dv_bs + hk * a.dv_hs + krow * a.dv_ts;
     store_grad_row<NDT>(DK, dk, f.scale, g, a.rope_cos ? a.rope_cos + krow * D : nullptr, a.rope_cos ? a.rope_sin + krow * D : nullptr);
     store_grad_row<NDT>(DV, dv, 1.0f, g, nullptr, nullptr);
+}
+
+// =============================================================================================== long sequences: 32 query rows per wave
+// Causal self-attention at T >= 256 when K / V do not fit the LDS (interleave / independent covariates on a Llama backbone: T = 1.7 k .. 6.5 k).
+// The 16-row kernels above read one LDS fragment per MFMA and reduce / rescale per 16 x 32 slab; this family follows GUIDE "Fused attention
+// prefill": v_mfma_f32_32x32x16_bf16 with the scores TRANSPOSED (S^T = K Q^T: lane = one query column, 16 keys of a 32-key tile in its
+// registers), 32 query rows per wave, 64-key chunks through a DOUBLE-BUFFERED LDS ring (one barrier per chunk; the next chunk travels
+// global -> registers under this chunk's MFMAs and is written to the other buffer after the barrier: GUIDE T14), one max / rescale decision per
+// 64 keys, and the exponentiated scores are the B operand of the P V MFMA as they stand (the contraction index of that MFMA is mapped to
+// keys as the accumulator layout hands them out: register r of lane-half hi holds key (r & 3) + 8 (r >> 2) + 4 hi of the tile).
+// Per MAC: half the LDS fragment bytes, half the MFMA issues, a quarter of the cross-lane reductions of the 16-row kernels.
+// LDS rows: K [64][D + 8] (ds_read_b128 rows: stride = 4 * odd dwords -> the four 16-lane groups of a b128 read hit 16 distinct slots),
+//           V [64][D + 32] (ds_read_b64_tr_b16 gathers: a 32-lane group covers 4 rows x 64 B; stride = 16 mod 64 dwords -> no bank twice).
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+#ifndef MTL_W32_DIAG
+#define MTL_W32_DIAG 0      // diagnostic builds only (tools/build_variant.sh): 1 no exp / sum, 2 no P V MFMAs, 4 no Q K MFMAs, 8 no global -> LDS staging in the loop, 16 no barrier
+#endif
+
+template <int D, int NT, int LD>
+__device__ __forceinline__ void stash_tile_ld(bf16_t* tile, const TileRegs<D, NT>& t) {
+    constexpr int CPR = D / 8, NIT = KC * CPR / NT;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int s = threadIdx.x + i * NT;
+        *reinterpret_cast<u32x4*>(tile + (s / CPR) * LD + (s % CPR) * 8) = t.v[i];
+    }
+}
+
+// fetch_tile with the address arithmetic hoisted out of the chunk loop: a thread's NIT source pointers are formed once (row0 = 0) and every chunk
+// adds chunk * KC * stride to them; only a chunk that crosses the end of the sequence (wave-uniform test) takes the clamping form. The 64-bit
+// multiplies of the general form cost ~60 VALU instructions per chunk and thread — a fifth of the loop's issue slots.
+template <int D, int NT>
+struct TilePtrs { const bf16_t* p[KC * (D / 8) / NT]; };
+template <int D, int NT>
+__device__ __forceinline__ void tile_ptrs(TilePtrs<D, NT>& tp, const bf16_t* src, int64_t src_ts) {
+    constexpr int CPR = D / 8, NIT = KC * CPR / NT;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int s = threadIdx.x + i * NT;
+        tp.p[i] = src + (int64_t)(s / CPR) * src_ts + (s % CPR) * 8;
+    }
+}
+template <int D, int NT>
+__device__ __forceinline__ void fetch_tile_at(TileRegs<D, NT>& t, const TilePtrs<D, NT>& tp, const bf16_t* src, int64_t src_ts, int64_t row0, int64_t limit) {
+    constexpr int NIT = KC * (D / 8) / NT;
+    if (row0 + KC <= limit) {
+        const int64_t off = row0 * src_ts;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) t.v[i] = *reinterpret_cast<const u32x4*>(tp.p[i] + off);
+    } else {
+        fetch_tile<D, NT>(t, src, src_ts, row0, limit);
+    }
+}
+
+// row maximum / sum across the two lane halves (lanes l and l + 32 hold the same query)
+__device__ __forceinline__ float halves_max(float v) {
+    const uint32_t w = __float_as_uint(v);
+    auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+__device__ __forceinline__ float halves_sum(float v) {
+    const uint32_t w = __float_as_uint(v);
+    auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
+template <int D, bool CAUSAL, int NW, bool XMAP = false>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_w32_kernel(const mtl_attn_fwd_args a) {
+    constexpr int LDK = D + 8, LDV = D + 32, NKS = D / 16, NDB = D / 32, NT = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t* kbuf = reinterpret_cast<bf16_t*>(smem_raw);      // [2][KC * LDK]
+    bf16_t* vbuf = kbuf + 2 * KC * LDK;                      // [2][KC * LDV]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31, hi = lane >> 5;
+    const AttnBlock blk = attn_block<XMAP>((a.Tq + NW * 32 - 1) / (NW * 32), a.Hq, a.B, CAUSAL);
+    if (!blk.live) return;
+    const int64_t b = blk.b, h = blk.h, hk = h / (a.Hq / a.Hkv);
+    const int64_t qblk0 = blk.x * (NW * 32);
+    const int64_t q0 = qblk0 + wave * 32;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * a.q_hs;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + hk * a.k_hs;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + hk * a.v_hs;
+
+    int64_t qrow = q0 + l31;
+    const bool q_valid = qrow < a.Tq;
+    if (qrow > a.Tq - 1) qrow = a.Tq - 1;
+    bf16x8 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + qrow * a.q_ts + ks * 16 + hi * 8);
+
+    f32x16 o[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    const float c = a.scale * LOG2E;
+    float m_run = NEG_BIG, l_run = 0.f;      // l_run: this lane's 16-of-32 keys per tile only; the halves are added at the end
+
+    const int64_t coff = a.causal_off;
+    const int klim = (int)((CAUSAL && qrow + coff < a.Tk - 1) ? qrow + coff : a.Tk - 1);   // last visible key of the lane's query
+    int64_t k_end = a.Tk;
+    if (CAUSAL) {
+        const int64_t lim = (qblk0 + NW * 32 < a.Tq ? qblk0 + NW * 32 : a.Tq) + coff;  // keys <= last query of the block
+        k_end = lim < a.Tk ? lim : a.Tk;
+    }
+    const int64_t wave_qmin = q0 + coff;
+    const int64_t wave_qmax = ((q0 + 31 < a.Tq - 1) ? q0 + 31 : a.Tq - 1) + coff;
+    const bool wave_live = q0 < a.Tq;
+
+    TileRegs<D, NT> rk, rv;
+    TilePtrs<D, NT> pk, pv;
+    tile_ptrs<D, NT>(pk, K, a.k_ts);
+    tile_ptrs<D, NT>(pv, V, a.v_ts);
+    fetch_tile_at<D, NT>(rk, pk, K, a.k_ts, 0, a.Tk);
+    fetch_tile_at<D, NT>(rv, pv, V, a.v_ts, 0, a.Tk);
+    stash_tile_ld<D, NT, LDK>(kbuf, rk);
+    stash_tile_ld<D, NT, LDV>(vbuf, rv);
+    // The query fragments were requested before chunk 0 and have landed by now (the stores above waited for every load). Tell the compiler: its
+    // wait counters are in-order, and with the fragments still "pending" on the loop's entry edge it guards every first use inside the loop
+    // with vmcnt(7 - ks) — i.e. each Q K^T MFMA waited for one of the CURRENT iteration's prefetch loads to come back from L2 / HBM.
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[ks]));
+    if (KC < k_end) {
+        fetch_tile_at<D, NT>(rk, pk, K, a.k_ts, KC, a.Tk);
+        fetch_tile_at<D, NT>(rv, pv, V, a.v_ts, KC, a.Tk);
+    }
+    int cur = 0;
+    for (int64_t kc0 = 0; kc0 < k_end; kc0 += KC, cur ^= 1) {
+        if (!(MTL_W32_DIAG & 16)) __syncthreads();        // chunk kc0 is visible in buffer `cur`; every wave has finished reading the other buffer
+        if (!(MTL_W32_DIAG & 8) && kc0 + KC < k_end) {
+            stash_tile_ld<D, NT, LDK>(kbuf + (cur ^ 1) * KC * LDK, rk);
+            stash_tile_ld<D, NT, LDV>(vbuf + (cur ^ 1) * KC * LDV, rv);
+            if (kc0 + 2 * KC < k_end) {      // two chunks ahead: flies under this chunk's and the next chunk's MFMAs
+                fetch_tile_at<D, NT>(rk, pk, K, a.k_ts, kc0 + 2 * KC, a.Tk);
+                fetch_tile_at<D, NT>(rv, pv, V, a.v_ts, kc0 + 2 * KC, a.Tk);
+            }
+        }
+        if (!wave_live || (CAUSAL && kc0 > wave_qmax)) continue;     // every key of the chunk lies above this wave's diagonal (wave-uniform)
+        const bf16_t* kt = kbuf + cur * KC * LDK;
+        const bf16_t* vt = vbuf + cur * KC * LDV;
+        // ---- S^T = K Q^T for the two 32-key tiles of the chunk. Fragment reads run TWO MFMAs ahead of their use through a three-deep register
+        // ring, and the two tiles' accumulator chains alternate (hipcc by itself emits read -> wait -> MFMA per fragment on one chain: every
+        // MFMA then waits out an LDS round trip). sched_barrier pins the order; the waits that come out are counted ones (lgkmcnt(2)).
+        f32x16 s[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+        {
+            const bf16_t* kr = kt + l31 * LDK + hi * 8;
+            constexpr int RING = 4;                  // fragments requested RING - 1 units ahead of their MFMA
+            bf16x8 kf[RING];
+#pragma unroll
+            for (int i = 0; i < RING - 1; ++i) kf[i] = *reinterpret_cast<const bf16x8*>(kr + (i & 1) * 32 * LDK + (i >> 1) * 16);
+#pragma unroll
+            for (int i = 0; i < 2 * NKS; ++i) {      // i = 2 ks + t
+                constexpr int A = RING - 1;
+                if (i + A < 2 * NKS) kf[(i + A) % RING] = *reinterpret_cast<const bf16x8*>(kr + ((i + A) & 1) * 32 * LDK + ((i + A) >> 1) * 16);
+                if (!(MTL_W32_DIAG & 4)) s[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % RING], qf[i >> 1], s[i & 1], 0, 0, 0);
+                else s[i & 1][i & 15] += __builtin_bit_cast(float, ((u32x4)__builtin_bit_cast(u32x4, kf[i % RING]))[0]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- online softmax over the chunk's 64 keys (this lane: 2 x 16 of them). The maximum is taken on the raw scores (c > 0) and the
+        // scale rides in the exponent's FMA: one v_max3 per pair, one v_fma + v_exp + v_add per element
+        const bool need_mask = (kc0 + KC > a.Tk) || (CAUSAL && kc0 + KC - 1 > wave_qmin);
+        if (need_mask) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = (int)kc0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key > klim) s[t][r] = NEG_BIG;
+                }
+        }
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+        mx = halves_max(mx) * c;           // (NEG_BIG * c stays far below every real score)
+        const float m_new = fmaxf(m_run, mx);
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (!(MTL_W32_DIAG & 1)) {
+                    s[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], c, -m_new));
+                    psum += s[t][r];
+                }
+            }
+        if (__any(m_new != m_run)) {   // rescale only when some row's running max moved (wave-uniform branch)
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+            m_run = m_new;
+        }
+        l_run += psum;
+        // ---- O^T += V^T P^T: contraction block (t, cb) = keys 32 t + 16 cb + {(j & 3) + 8 (j >> 2) + 4 hi}: registers 8 cb .. 8 cb + 7 of tile t
+        bf16x8 pf[4];
+#pragma unroll
+        for (int tc = 0; tc < 4; ++tc) {
+            const int t = tc >> 1, cb = tc & 1;
+            frag8 f;
+            f.u = (u32x4){pack_bf16x2(s[t][8 * cb + 0], s[t][8 * cb + 1]), pack_bf16x2(s[t][8 * cb + 2], s[t][8 * cb + 3]),
+                          pack_bf16x2(s[t][8 * cb + 4], s[t][8 * cb + 5]), pack_bf16x2(s[t][8 * cb + 6], s[t][8 * cb + 7])};
+            pf[tc] = f.v;
+        }
+        {
+            // 16-lane gather group: d half of the 32-row block (lane bit 4), key half hi (lane bit 5). Unit i = tc * NDB + db: consecutive MFMAs
+            // go to DIFFERENT accumulators, their V^T fragments are gathered two units ahead
+            const bf16_t* vg = vt + (4 * hi + ((lane & 15) >> 2)) * LDV + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+            auto vfrag = [&](int i) __attribute__((always_inline)) {
+                const bf16_t* p = vg + (i / NDB) * 16 * LDV + (i % NDB) * 32;
+                union { bf16x8 v; s16x4 h[2]; } f;
+                f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+                f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 8 * LDV));
+                return f.v;
+            };
+            constexpr int RING = 4;
+            bf16x8 vf[RING];
+#pragma unroll
+            for (int i = 0; i < RING - 1; ++i) vf[i] = vfrag(i);
+#pragma unroll
+            for (int i = 0; i < 4 * NDB; ++i) {
+                constexpr int A = RING - 1;
+                if (i + A < 4 * NDB) vf[(i + A) % RING] = vfrag(i + A);
+                if (!(MTL_W32_DIAG & 2)) o[i % NDB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % RING], pf[i / NDB], o[i % NDB], 0, 0, 0);
+                else o[i % NDB][i & 15] += __builtin_bit_cast(float, ((u32x4)__builtin_bit_cast(u32x4, vf[i % RING]))[0]) + __builtin_bit_cast(float, ((u32x4)__builtin_bit_cast(u32x4, pf[i / NDB]))[1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    l_run = halves_sum(l_run);
+    if (!q_valid) return;
+    const float inv_l = 1.0f / l_run;
+    bf16_t* O = reinterpret_cast<bf16_t*>(a.o) + b * a.o_bs + h * a.o_hs + qrow * a.o_ts;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {      // registers 4 rg .. 4 rg + 3 = feature columns 32 db + 8 rg + 4 hi + {0, 1, 2, 3}
+            u32x2 pk = {pack_bf16x2(o[db][4 * rg] * inv_l, o[db][4 * rg + 1] * inv_l), pack_bf16x2(o[db][4 * rg + 2] * inv_l, o[db][4 * rg + 3] * inv_l)};
+            *reinterpret_cast<u32x2*>(O + db * 32 + rg * 8 + hi * 4) = pk;
+        }
+    if (hi == 0 && a.lse) a.lse[(b * a.Hq + h) * (a.stat_stride ? a.stat_stride : a.Tq) + qrow] = (m_run + __builtin_amdgcn_logf(l_run)) * LN2;
 }
 
 // =============================================================================================== resident variants
@@ -628,7 +910,7 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 && NW == 4) ? 2 : 1) void attn_b
 __device__ __forceinline__ int64_t ceil32(int64_t v) { return (v + 31) & ~(int64_t)31; }
 template <int D, int NT, int BATCH = 8>
 __device__ __forceinline__ void load_rows(bf16_t* tile, const bf16_t* src, int64_t src_ts, int64_t rows) {
-    constexpr int LDT = D + 8, CPR = D / 8;
+    constexpr int LDT = D + MTL_ATTN_PAD, CPR = D / 8;
     const int64_t total = ceil32(rows) * CPR;
     for (int64_t base = 0; base < total; base += (int64_t)BATCH * NT) {
         u32x4 v[BATCH];
@@ -656,7 +938,7 @@ struct RES_BATCH { static constexpr int value = (D >= 128 && NW >= 8) ? 8 : 4; }
 template <int D, int NT, int BATCH>
 __device__ __forceinline__ void load_rows_pair(bf16_t* tile_a, const bf16_t* src_a, int64_t ts_a, bf16_t* tile_b, const bf16_t* src_b,
                                                int64_t ts_b, int64_t rows) {
-    constexpr int LDT = D + 8, CPR = D / 8;
+    constexpr int LDT = D + MTL_ATTN_PAD, CPR = D / 8;
     const int64_t total = ceil32(rows) * CPR;
     for (int64_t base = 0; base < total; base += (int64_t)BATCH * NT) {
         u32x4 va[BATCH], vb[BATCH];
@@ -684,7 +966,7 @@ __device__ __forceinline__ void load_rows_pair(bf16_t* tile_a, const bf16_t* src
 
 template <int D, int NW, bool DROP = false>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fwd_args a) {
-    constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
+    constexpr int LDT = D + MTL_ATTN_PAD, NKS = D / 32, NDT = D / 16;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* ktile = reinterpret_cast<bf16_t*>(smem_raw);
     bf16_t* vtile = ktile + ceil32(a.Tk) * LDT;
@@ -802,7 +1084,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fw
 
 template <int D, int NW, bool DROP = false>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn_bwd_args a) {
-    constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
+    constexpr int LDT = D + MTL_ATTN_PAD, NKS = D / 32, NDT = D / 16;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const mtl_attn_fwd_args& f = a.f;
     bf16_t* ktile = reinterpret_cast<bf16_t*>(smem_raw);
@@ -929,7 +1211,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn
 // dynamic LDS: Q tile [Tq][D+8] | dO tile [Tq][D+8] | lse2[Tq] | delta[Tq]
 template <int D, int NW, bool DROP = false>
 __global__ __launch_bounds__(NW * 64, (D >= 128 && !DROP) ? 2 : 1) void attn_bwd_dkv_res_kernel(const mtl_attn_bwd_args a) {
-    constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16;
+    constexpr int LDT = D + MTL_ATTN_PAD, NKS = D / 32, NDT = D / 16;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const mtl_attn_fwd_args& f = a.f;
     bf16_t* qtile = reinterpret_cast<bf16_t*>(smem_raw);
@@ -1053,7 +1335,7 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 && !DROP) ? 2 : 1) void attn_bwd
 // dynamic LDS: K [RK][D+8] | V [RK][D+8] | Q [RQ][D+8] | dO [RQ][D+8] | O [RQ][D+8] | lse2[RQ] | delta[RQ]   (RK = ceil32(Tk), RQ = ceil32(Tq))
 template <int D, int NW, bool DROP = false>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_res_merged_kernel(const mtl_attn_bwd_args a) {
-    constexpr int LDT = D + 8, NKS = D / 32, NDT = D / 16, CPR = D / 8, NT = NW * 64, BK = 2048 / NT, BQ = 1024 / NT, NTL = NW / 2;
+    constexpr int LDT = D + MTL_ATTN_PAD, NKS = D / 32, NDT = D / 16, CPR = D / 8, NT = NW * 64, BK = 2048 / NT, BQ = 1024 / NT, NTL = NW / 2;
     static_assert(NW % 2 == 0 && 2048 % NT == 0 && 1024 % NT == 0, "two wave groups; whole staging chunks per thread");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const mtl_attn_fwd_args& f = a.f;
@@ -1315,6 +1597,9 @@ const int g_attn_wide = getenv("MTL_ATTN_WIDE") ? atoi(getenv("MTL_ATTN_WIDE")) 
 // dK/dV kernel gains nothing there (190 -> 194 us) and switches at 512.
 const int g_attn_wide_x = getenv("MTL_ATTN_WIDE_X") ? atoi(getenv("MTL_ATTN_WIDE_X")) : 1;   // A/B knob: 128-row workgroups for the non-causal hd-128 (reprogramming) attention
 const int g_attn_wide_min = getenv("MTL_ATTN_WIDE_MIN") ? atoi(getenv("MTL_ATTN_WIDE_MIN")) : 256;
+const int g_attn_xmap = getenv("MTL_ATTN_XMAP") ? atoi(getenv("MTL_ATTN_XMAP")) : 1;   // A/B knob: 0 = plain (row block, head, batch) grids for the long-sequence kernels
+const int g_attn_w32_nw = getenv("MTL_ATTN_W32_NW") ? atoi(getenv("MTL_ATTN_W32_NW")) : 0;   // A/B knob: 4 / 8 waves per workgroup of the 32-row kernels (0 = automatic)
+const int g_attn_w32 = getenv("MTL_ATTN_W32") ? atoi(getenv("MTL_ATTN_W32")) : 1;   // A/B knob: 0 = the 16-rows-per-wave kernels for long causal sequences
 int g_attn_merged = getenv("MTL_ATTN_MERGED") ? atoi(getenv("MTL_ATTN_MERGED")) : 1;   // A/B knob: 0 = the resident backward as two launches (dQ, then dK / dV)
 
 template <typename KernelT>
@@ -1330,7 +1615,7 @@ namespace {
 size_t pad32(int64_t v) { return (size_t)((v + 31) & ~(int64_t)31); }
 bool resident_ok(const mtl_attn_fwd_args& f, int64_t rows) {
     return g_attn_mode == 1 && f.causal && f.k_bs != 0 && f.dropout_p < 1.f && (f.D == 64 || f.D == 128) &&
-           2 * pad32(rows) * (f.D + 8) * 2 + 2 * pad32(rows) * 4 <= kLdsBudget;
+           2 * pad32(rows) * (f.D + MTL_ATTN_PAD) * 2 + 2 * pad32(rows) * 4 <= kLdsBudget;
 }
 
 }  // namespace
@@ -1344,7 +1629,7 @@ extern "C" int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream) {
     const double fl_fwd = 4.0 * (double)a->B * a->Hq * a->Tq * a->Tk * a->D;
     (void)fl_fwd;
     if (resident_ok(*a, a->Tk)) {
-        const size_t lds = 2 * pad32(a->Tk) * (a->D + 8) * 2;
+        const size_t lds = 2 * pad32(a->Tk) * (a->D + MTL_ATTN_PAD) * 2;
         const int npairs = (int)(((a->Tq + 15) / 16 + 1) / 2);
         if (a->D == 64 && a->dropout_p > 0.f) {
             static std::once_flag once; std::call_once(once, [&] { set_lds(attn_fwd_res_kernel<64, 8, true>, kLdsBudget); });
@@ -1372,6 +1657,32 @@ extern "C" int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream) {
         const dim3 grid8((unsigned)((a->Tq + 127) / 128), (unsigned)a->Hq, (unsigned)a->B), block8(512);
         if (drop) MTL_LAUNCH("attn_fwd_kernel<128, false, true, 8>", fl_fwd, 0, (attn_fwd_kernel<128, false, true, 8>), grid8, block8, 0, st, *a);
         else MTL_LAUNCH("attn_fwd_kernel<128, false, false, 8>", fl_fwd, 0, (attn_fwd_kernel<128, false, false, 8>), grid8, block8, 0, st, *a);
+        MTL_CHECK_LAUNCH();
+        return MTL_OK;
+    }
+    if (a->causal && !drop && a->Tq >= g_attn_wide_min && (a->D == 64 || a->D == 128) && g_attn_wide == 1 && g_attn_w32 == 1) {
+        // long sequences: 32 query rows per wave on 32x32x16 MFMAs, double-buffered 64-key chunks. 8 waves = 256 queries per workgroup from 512 rows on:
+        // every staged K / V chunk then serves twice the queries (the global -> LDS staging of 3 GB per launch at T = 1664 was a fifth of the kernel)
+        const int nww = (g_attn_w32_nw == 4 || g_attn_w32_nw == 8) ? g_attn_w32_nw : 4;
+        const int64_t nx = (a->Tq + nww * 32 - 1) / (nww * 32);
+        const dim3 gridw(g_attn_xmap ? attn_xmap_grid(nx, a->Hq, a->B) : (unsigned)nx, g_attn_xmap ? 1u : (unsigned)a->Hq, g_attn_xmap ? 1u : (unsigned)a->B), blockw(nww * 64);
+        const size_t lds = (size_t)2 * KC * ((a->D + 8) + (a->D + 32)) * 2;
+        static std::once_flag once;
+        std::call_once(once, [&] {
+            set_lds(attn_fwd_w32_kernel<64, true, 4, false>, kLdsBudget); set_lds(attn_fwd_w32_kernel<128, true, 4, false>, kLdsBudget);
+            set_lds(attn_fwd_w32_kernel<64, true, 4, true>, kLdsBudget); set_lds(attn_fwd_w32_kernel<128, true, 4, true>, kLdsBudget);
+            set_lds(attn_fwd_w32_kernel<64, true, 8, false>, kLdsBudget); set_lds(attn_fwd_w32_kernel<128, true, 8, false>, kLdsBudget);
+            set_lds(attn_fwd_w32_kernel<64, true, 8, true>, kLdsBudget); set_lds(attn_fwd_w32_kernel<128, true, 8, true>, kLdsBudget);
+        });
+#define MTL_W32(DD, NN, XX) MTL_LAUNCH("attn_fwd_w32_kernel<" #DD ", true, " #NN ">", fl_fwd, 0, (attn_fwd_w32_kernel<DD, true, NN, XX>), gridw, blockw, lds, st, *a)
+        if (a->D == 64) {
+            if (nww == 8) { if (g_attn_xmap) MTL_W32(64, 8, true); else MTL_W32(64, 8, false); }
+            else { if (g_attn_xmap) MTL_W32(64, 4, true); else MTL_W32(64, 4, false); }
+        } else {
+            if (nww == 8) { if (g_attn_xmap) MTL_W32(128, 8, true); else MTL_W32(128, 8, false); }
+            else { if (g_attn_xmap) MTL_W32(128, 4, true); else MTL_W32(128, 4, false); }
+        }
+#undef MTL_W32
         MTL_CHECK_LAUNCH();
         return MTL_OK;
     }
@@ -1412,7 +1723,7 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
     if (resident_ok(f, f.Tk) && resident_ok(f, f.Tq)) {
         if (a->kv_row0 < 0 || a->kv_row0 >= f.Tk) return MTL_ERR_ARG;
         // few tiles on both sides (the backbone's pruned backward: n_grad query rows, dK / dV for the patch keys): ONE launch stages the head once
-        const size_t lds_m = (2 * pad32(f.Tk) + 3 * pad32(f.Tq)) * (f.D + 8) * 2 + 2 * pad32(f.Tq) * 4;
+        const size_t lds_m = (2 * pad32(f.Tk) + 3 * pad32(f.Tq)) * (f.D + MTL_ATTN_PAD) * 2 + 2 * pad32(f.Tq) * 4;
         if (g_attn_merged == 1 && f.D == 64 && f.Hq == f.Hkv && (f.Tq + 15) / 16 <= 8 && (f.Tk - a->kv_row0 + 15) / 16 <= 8 && lds_m <= kLdsBudget) {
             static std::once_flag once;
             std::call_once(once, [&] { set_lds(attn_bwd_res_merged_kernel<64, 16, true>, kLdsBudget); set_lds(attn_bwd_res_merged_kernel<64, 16, false>, kLdsBudget); });
@@ -1422,8 +1733,8 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
             MTL_CHECK_LAUNCH();
             return MTL_OK;
         }
-        const size_t lds_q = 2 * pad32(f.Tk) * (f.D + 8) * 2;
-        const size_t lds_k = 2 * pad32(f.Tq) * (f.D + 8) * 2 + 2 * pad32(f.Tq) * 4;
+        const size_t lds_q = 2 * pad32(f.Tk) * (f.D + MTL_ATTN_PAD) * 2;
+        const size_t lds_k = 2 * pad32(f.Tq) * (f.D + MTL_ATTN_PAD) * 2 + 2 * pad32(f.Tq) * 4;
         const int npq = (int)(((f.Tq + 15) / 16 + 1) / 2), npk = (int)(((f.Tk - a->kv_row0 + 15) / 16 + 1) / 2);
         if (f.dropout_p > 0.f && f.D == 64) {
             static std::once_flag once;
@@ -1466,6 +1777,21 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
         const dim3 gq8((unsigned)((f.Tq + 127) / 128), (unsigned)f.Hq, (unsigned)f.B), gk8((unsigned)((f.Tk - a->kv_row0 + 127) / 128), (unsigned)f.Hkv, (unsigned)f.B), block8(512);
         const bool wide_kv = f.Tk - a->kv_row0 >= 512;
         const dim3 gk4((unsigned)((f.Tk - a->kv_row0 + 63) / 64), (unsigned)f.Hkv, (unsigned)f.B);
+        if (g_attn_xmap) {      // XCD-aware 1-D grids (attn_block): a head's row blocks share one L2
+            const dim3 xq(attn_xmap_grid((f.Tq + 127) / 128, f.Hq, f.B)), xk8(attn_xmap_grid((f.Tk - a->kv_row0 + 127) / 128, f.Hkv, f.B)),
+                       xk4(attn_xmap_grid((f.Tk - a->kv_row0 + 63) / 64, f.Hkv, f.B));
+            if (f.D == 64) {
+                MTL_LAUNCH("attn_bwd_dq_kernel<64, true, false, 8>", fl_half, 0, (attn_bwd_dq_kernel<64, true, false, 8, true>), xq, block8, 0, st, *a);
+                if (wide_kv) MTL_LAUNCH("attn_bwd_dkv_kernel<64, true, false, 8>", fl_half, 0, (attn_bwd_dkv_kernel<64, true, false, 8, true>), xk8, block8, 0, st, *a);
+                else MTL_LAUNCH("attn_bwd_dkv_kernel<64, true, false>", fl_half, 0, (attn_bwd_dkv_kernel<64, true, false, 4, true>), xk4, dim3(256), 0, st, *a);
+            } else {
+                MTL_LAUNCH("attn_bwd_dq_kernel<128, true, false, 8>", fl_half, 0, (attn_bwd_dq_kernel<128, true, false, 8, true>), xq, block8, 0, st, *a);
+                if (wide_kv) MTL_LAUNCH("attn_bwd_dkv_kernel<128, true, false, 8>", fl_half, 0, (attn_bwd_dkv_kernel<128, true, false, 8, true>), xk8, block8, 0, st, *a);
+                else MTL_LAUNCH("attn_bwd_dkv_kernel<128, true, false>", fl_half, 0, (attn_bwd_dkv_kernel<128, true, false, 4, true>), xk4, dim3(256), 0, st, *a);
+            }
+            MTL_CHECK_LAUNCH();
+            return MTL_OK;
+        }
         if (f.D == 64) {
             MTL_LAUNCH("attn_bwd_dq_kernel<64, true, false, 8>", fl_half, 0, (attn_bwd_dq_kernel<64, true, false, 8>), gq8, block8, 0, st, *a);
             if (wide_kv) MTL_LAUNCH("attn_bwd_dkv_kernel<64, true, false, 8>", fl_half, 0, (attn_bwd_dkv_kernel<64, true, false, 8>), gk8, block8, 0, st, *a);
