@@ -785,7 +785,7 @@ def main():
             out["configs"] = [extra]
         # the same backbone with interleave covariates -> T = 1664 per sample (flash attention regime)
         stage("start llama2_7b_semseg_interleave_B16_L1024_C12")
-        extra2 = run_workload("llama2_7b_semseg_interleave_B16_L1024_C12", args, ctx, steps=3, warmup=1, want_cpu=full and not args.no_cpu_baseline,
+        extra2 = run_workload("llama2_7b_semseg_interleave_B16_L1024_C12", args, ctx, steps=3, warmup=2, want_cpu=full and not args.no_cpu_baseline,
                               want_roofline=not args.no_roofline, legs=full, stage=stage)
         if rank == 0:
             extra2["metric"] = "samples/sec ([B, 1024, 12] windows, interleave covariates: T = 1664, Llama-2-7B frozen backbone) through MedTsLLM fwd+bwd"

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MTL_ABI_VERSION 12
+#define MTL_ABI_VERSION 13
 
 enum { MTL_OK = 0, MTL_ERR_ARG = -1, MTL_ERR_ALIGN = -2, MTL_ERR_UNSUPPORTED = -3, MTL_ERR_LAUNCH = -4,
        MTL_ERR_WORKSPACE = -5 };
@@ -208,7 +208,7 @@ int mtl_rowsum_bf16(const void* src, int64_t ld_src, float* dst, int64_t R, int6
  * `step` (1-based, after increment, as torch does). weight_decay: decoupled = 0 -> Adam's L2 (g += wd*p),
  * 1 -> AdamW (p *= 1 - lr*wd). `shadow` (optional) receives the bf16 copy of the UPDATED p viewed as
  * [n / cols, cols] with row stride ld_shadow (the autocast weight copy the next forward needs). */
-#define MTL_ADAM_MAX_TENSORS 24
+#define MTL_ADAM_MAX_TENSORS 24   /* (the table travels as a kernel argument: 24 x 72 B) */
 typedef struct mtl_adam_tensor {
     float* p;
     const float* g;
@@ -218,6 +218,8 @@ typedef struct mtl_adam_tensor {
     void* shadow;        /* bf16 or NULL */
     int64_t cols;        /* used with shadow */
     int64_t ld_shadow;
+    int64_t param_dtype; /* MTL_F32 (default) | MTL_BF16: p and g are bf16 storage (setup.dtype = "bf16", R:tasks/base.py:261-262 casts the
+                          * whole model); m and v stay fp32, the update is formed in fp32 and p is rounded once (RNE) */
 } mtl_adam_tensor;
 int mtl_adam_step(const mtl_adam_tensor* tensors, int count, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int decoupled, int64_t step, void* stream);

@@ -27,9 +27,12 @@ constexpr int KC = 64;  // keys (or queries, in the dK/dV kernel) per LDS chunk
 // stride of 8 dwords mod 64 each group's 16 slots are distinct) and the transposing gathers (ds_read_b64_tr_b16, two 32-lane groups = 8
 // rows x 32 B: 8 dwords apart). The earlier 8 (stride = 4 mod 64) left the gathers 2-way conflicted (SQ_LDS_BANK_CONFLICT / LDS_ACTIVE =
 // 0.40-0.45 on every attention kernel) and rows 11 / 12 of a fragment read on one slot.
+// hd 64 / 32 keep 8: their stride (36 / 20 dwords) is already conflict-free for both shapes, and 16 would push the resident hd-64 dK/dV kernel
+// from two workgroups per CU to one (84 KB of LDS: 35.9 -> 46.6 us at T = 256, profiles/r04_attn_longT_experiments.txt).
 #ifndef MTL_ATTN_PAD
 #define MTL_ATTN_PAD 16
 #endif
+__host__ __device__ constexpr int attn_pad(int D) { return D >= 128 ? MTL_ATTN_PAD : 8; }
 #ifndef MTL_CONSISTENT_DELTA
 #define MTL_CONSISTENT_DELTA 0     // causal self-attention: 0 = delta = dO . O with the bf16-rounded forward output (measured: the consistent
                                    // form changes nothing there — tools/diag_bias.py: the stack's input gradient is unbiased and on par
@@ -111,7 +114,7 @@ __device__ __forceinline__ bf16x8 gather_col(const bf16_t* tile, int ldt, int ra
 // round trip per iteration (hipcc waits vmcnt(0) in front of every ds_write), which was most of these kernels' time.
 template <int D, int NT = 256>
 __device__ __forceinline__ void load_tile(bf16_t* tile, const bf16_t* src, int64_t src_ts, int64_t row0, int64_t limit) {
-    constexpr int LDT = D + MTL_ATTN_PAD, CPR = D / 8, NIT = KC * CPR / NT;
+    constexpr int LDT = D + attn_pad(D), CPR = D / 8, NIT = KC * CPR / NT;
     static_assert(KC * CPR % NT == 0 && NIT >= 1, "whole 16-byte chunks per thread");
     u32x4 v[NIT];
 #pragma unroll
@@ -147,7 +150,7 @@ __device__ __forceinline__ void fetch_tile(TileRegs<D, NT>& t, const bf16_t* src
 }
 template <int D, int NT>
 __device__ __forceinline__ void stash_tile(bf16_t* tile, const TileRegs<D, NT>& t) {
-    constexpr int LDT = D + MTL_ATTN_PAD, CPR = D / 8, NIT = KC * CPR / NT;
+    constexpr int LDT = D + attn_pad(D), CPR = D / 8, NIT = KC * CPR / NT;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
         const int s = threadIdx.x + i * NT;
@@ -186,7 +189,7 @@ __host__ inline unsigned attn_xmap_grid(int64_t nx, int64_t ny, int64_t nz) { re
 // through L2 (5.6 GB per layer), which is what the kernels spent most of their time on.
 template <int D, bool CAUSAL, bool DROP, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const mtl_attn_fwd_args a) {
-    constexpr int LDT = D + MTL_ATTN_PAD, NKS = D / 32, NDT = D / 16;
+    constexpr int LDT = D + attn_pad(D), NKS = D / 32, NDT = D / 16;
     __shared__ __attribute__((aligned(16))) bf16_t ktile[KC * LDT];
     __shared__ __attribute__((aligned(16))) bf16_t vtile[KC * LDT];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, g = lane >> 4;   // (wave index in an SGPR: tile offsets, loop bounds and the mask test become scalar)
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const mtl_attn_fwd_ar
 // =============================================================================================== backward: dQ (+ delta)
 template <int D, bool CAUSAL, bool DROP, int NW = 4, bool XMAP = false>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const mtl_attn_bwd_args a) {
-    constexpr int LDT = D + MTL_ATTN_PAD, NKS = D / 32, NDT = D / 16;
+    constexpr int LDT = D + attn_pad(D), NKS = D / 32, NDT = D / 16;
     __shared__ __attribute__((aligned(16))) bf16_t ktile[KC * LDT];
     __shared__ __attribute__((aligned(16))) bf16_t vtile[KC * LDT];
     const mtl_attn_fwd_args& f = a.f;
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const mtl_attn_bwd
 // heads of the GQA group and over 64-query chunks. Lane owns key = lane & 15 of its wave's 16 keys.
 template <int D, bool CAUSAL, bool DROP, int NW = 4, bool XMAP = false>
 __global__ __launch_bounds__(NW * 64, (D >= 128 && NW == 4) ? 2 : 1) void attn_bwd_dkv_kernel(const mtl_attn_bwd_args a) {
-    constexpr int LDT = D + MTL_ATTN_PAD, NKS = D / 32, NDT = D / 16;
+    constexpr int LDT = D + attn_pad(D), NKS = D / 32, NDT = D / 16;
     __shared__ __attribute__((aligned(16))) bf16_t qtile[KC * LDT];
     __shared__ __attribute__((aligned(16))) bf16_t dotile[KC * LDT];
     __shared__ float lse_s[KC], delta_s[KC];
@@ -910,7 +913,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_w32_kernel(
 __device__ __forceinline__ int64_t ceil32(int64_t v) { return (v + 31) & ~(int64_t)31; }
 template <int D, int NT, int BATCH = 8>
 __device__ __forceinline__ void load_rows(bf16_t* tile, const bf16_t* src, int64_t src_ts, int64_t rows) {
-    constexpr int LDT = D + MTL_ATTN_PAD, CPR = D / 8;
+    constexpr int LDT = D + attn_pad(D), CPR = D / 8;
     const int64_t total = ceil32(rows) * CPR;
     for (int64_t base = 0; base < total; base += (int64_t)BATCH * NT) {
         u32x4 v[BATCH];
@@ -938,7 +941,7 @@ struct RES_BATCH { static constexpr int value = (D >= 128 && NW >= 8) ? 8 : 4; }
 template <int D, int NT, int BATCH>
 __device__ __forceinline__ void load_rows_pair(bf16_t* tile_a, const bf16_t* src_a, int64_t ts_a, bf16_t* tile_b, const bf16_t* src_b,
                                                int64_t ts_b, int64_t rows) {
-    constexpr int LDT = D + MTL_ATTN_PAD, CPR = D / 8;
+    constexpr int LDT = D + attn_pad(D), CPR = D / 8;
     const int64_t total = ceil32(rows) * CPR;
     for (int64_t base = 0; base < total; base += (int64_t)BATCH * NT) {
         u32x4 va[BATCH], vb[BATCH];
@@ -966,7 +969,7 @@ __device__ __forceinline__ void load_rows_pair(bf16_t* tile_a, const bf16_t* src
 
 template <int D, int NW, bool DROP = false>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fwd_args a) {
-    constexpr int LDT = D + MTL_ATTN_PAD, NKS = D / 32, NDT = D / 16;
+    constexpr int LDT = D + attn_pad(D), NKS = D / 32, NDT = D / 16;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* ktile = reinterpret_cast<bf16_t*>(smem_raw);
     bf16_t* vtile = ktile + ceil32(a.Tk) * LDT;
@@ -1084,7 +1087,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fw
 
 template <int D, int NW, bool DROP = false>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn_bwd_args a) {
-    constexpr int LDT = D + MTL_ATTN_PAD, NKS = D / 32, NDT = D / 16;
+    constexpr int LDT = D + attn_pad(D), NKS = D / 32, NDT = D / 16;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const mtl_attn_fwd_args& f = a.f;
     bf16_t* ktile = reinterpret_cast<bf16_t*>(smem_raw);
@@ -1211,7 +1214,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(const mtl_attn
 // dynamic LDS: Q tile [Tq][D+8] | dO tile [Tq][D+8] | lse2[Tq] | delta[Tq]
 template <int D, int NW, bool DROP = false>
 __global__ __launch_bounds__(NW * 64, (D >= 128 && !DROP) ? 2 : 1) void attn_bwd_dkv_res_kernel(const mtl_attn_bwd_args a) {
-    constexpr int LDT = D + MTL_ATTN_PAD, NKS = D / 32, NDT = D / 16;
+    constexpr int LDT = D + attn_pad(D), NKS = D / 32, NDT = D / 16;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const mtl_attn_fwd_args& f = a.f;
     bf16_t* qtile = reinterpret_cast<bf16_t*>(smem_raw);
@@ -1335,7 +1338,7 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 && !DROP) ? 2 : 1) void attn_bwd
 // dynamic LDS: K [RK][D+8] | V [RK][D+8] | Q [RQ][D+8] | dO [RQ][D+8] | O [RQ][D+8] | lse2[RQ] | delta[RQ]   (RK = ceil32(Tk), RQ = ceil32(Tq))
 template <int D, int NW, bool DROP = false>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_res_merged_kernel(const mtl_attn_bwd_args a) {
-    constexpr int LDT = D + MTL_ATTN_PAD, NKS = D / 32, NDT = D / 16, CPR = D / 8, NT = NW * 64, BK = 2048 / NT, BQ = 1024 / NT, NTL = NW / 2;
+    constexpr int LDT = D + attn_pad(D), NKS = D / 32, NDT = D / 16, CPR = D / 8, NT = NW * 64, BK = 2048 / NT, BQ = 1024 / NT, NTL = NW / 2;
     static_assert(NW % 2 == 0 && 2048 % NT == 0 && 1024 % NT == 0, "two wave groups; whole staging chunks per thread");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const mtl_attn_fwd_args& f = a.f;
@@ -1615,7 +1618,7 @@ namespace {
 size_t pad32(int64_t v) { return (size_t)((v + 31) & ~(int64_t)31); }
 bool resident_ok(const mtl_attn_fwd_args& f, int64_t rows) {
     return g_attn_mode == 1 && f.causal && f.k_bs != 0 && f.dropout_p < 1.f && (f.D == 64 || f.D == 128) &&
-           2 * pad32(rows) * (f.D + MTL_ATTN_PAD) * 2 + 2 * pad32(rows) * 4 <= kLdsBudget;
+           2 * pad32(rows) * (f.D + attn_pad((int)f.D)) * 2 + 2 * pad32(rows) * 4 <= kLdsBudget;
 }
 
 }  // namespace
@@ -1629,7 +1632,7 @@ extern "C" int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream) {
     const double fl_fwd = 4.0 * (double)a->B * a->Hq * a->Tq * a->Tk * a->D;
     (void)fl_fwd;
     if (resident_ok(*a, a->Tk)) {
-        const size_t lds = 2 * pad32(a->Tk) * (a->D + MTL_ATTN_PAD) * 2;
+        const size_t lds = 2 * pad32(a->Tk) * (a->D + attn_pad((int)a->D)) * 2;
         const int npairs = (int)(((a->Tq + 15) / 16 + 1) / 2);
         if (a->D == 64 && a->dropout_p > 0.f) {
             static std::once_flag once; std::call_once(once, [&] { set_lds(attn_fwd_res_kernel<64, 8, true>, kLdsBudget); });
@@ -1723,7 +1726,7 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
     if (resident_ok(f, f.Tk) && resident_ok(f, f.Tq)) {
         if (a->kv_row0 < 0 || a->kv_row0 >= f.Tk) return MTL_ERR_ARG;
         // few tiles on both sides (the backbone's pruned backward: n_grad query rows, dK / dV for the patch keys): ONE launch stages the head once
-        const size_t lds_m = (2 * pad32(f.Tk) + 3 * pad32(f.Tq)) * (f.D + MTL_ATTN_PAD) * 2 + 2 * pad32(f.Tq) * 4;
+        const size_t lds_m = (2 * pad32(f.Tk) + 3 * pad32(f.Tq)) * (f.D + attn_pad((int)f.D)) * 2 + 2 * pad32(f.Tq) * 4;
         if (g_attn_merged == 1 && f.D == 64 && f.Hq == f.Hkv && (f.Tq + 15) / 16 <= 8 && (f.Tk - a->kv_row0 + 15) / 16 <= 8 && lds_m <= kLdsBudget) {
             static std::once_flag once;
             std::call_once(once, [&] { set_lds(attn_bwd_res_merged_kernel<64, 16, true>, kLdsBudget); set_lds(attn_bwd_res_merged_kernel<64, 16, false>, kLdsBudget); });
@@ -1733,8 +1736,8 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
             MTL_CHECK_LAUNCH();
             return MTL_OK;
         }
-        const size_t lds_q = 2 * pad32(f.Tk) * (f.D + MTL_ATTN_PAD) * 2;
-        const size_t lds_k = 2 * pad32(f.Tq) * (f.D + MTL_ATTN_PAD) * 2 + 2 * pad32(f.Tq) * 4;
+        const size_t lds_q = 2 * pad32(f.Tk) * (f.D + attn_pad((int)f.D)) * 2;
+        const size_t lds_k = 2 * pad32(f.Tq) * (f.D + attn_pad((int)f.D)) * 2 + 2 * pad32(f.Tq) * 4;
         const int npq = (int)(((f.Tq + 15) / 16 + 1) / 2), npk = (int)(((f.Tk - a->kv_row0 + 15) / 16 + 1) / 2);
         if (f.dropout_p > 0.f && f.D == 64) {
             static std::once_flag once;

@@ -37,7 +37,10 @@ __global__ __launch_bounds__(THREADS) void adam_multi_kernel(const AdamTable tab
     while (ti + 1 < tab.count && b >= tab.first_block[ti + 1]) ++ti;
     const mtl_adam_tensor t = tab.t[ti];
     const int64_t base = (int64_t)(b - tab.first_block[ti]) * CHUNK;
-    const bool vec = (((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0;
+    const bool p16 = t.param_dtype == MTL_BF16;          // setup.dtype = "bf16": the parameter (and its gradient) ARE bf16; moments stay fp32
+    const bf16_t* gp16 = reinterpret_cast<const bf16_t*>(t.g);
+    bf16_t* pp16 = reinterpret_cast<bf16_t*>(t.p);
+    const bool vec = !p16 && (((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0;
     bf16_t* sh = reinterpret_cast<bf16_t*>(t.shadow);
 #pragma unroll
     for (int i = 0; i < VEC_PER_THREAD; ++i) {
@@ -57,7 +60,8 @@ __global__ __launch_bounds__(THREADS) void adam_multi_kernel(const AdamTable tab
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const bool ok = e < nv;
-                pp[e] = ok ? t.p[e0 + e] : 0.f; gg[e] = ok ? t.g[e0 + e] : 0.f;
+                if (p16) { pp[e] = ok ? bf16_to_f32(pp16[e0 + e]) : 0.f; gg[e] = ok ? bf16_to_f32(gp16[e0 + e]) : 0.f; }
+                else { pp[e] = ok ? t.p[e0 + e] : 0.f; gg[e] = ok ? t.g[e0 + e] : 0.f; }
                 mm[e] = ok ? t.m[e0 + e] : 0.f; vv[e] = ok ? t.v[e0 + e] : 0.f;
             }
         }
@@ -70,7 +74,11 @@ __global__ __launch_bounds__(THREADS) void adam_multi_kernel(const AdamTable tab
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (e < nv) { t.p[e0 + e] = pp[e]; t.m[e0 + e] = mm[e]; t.v[e0 + e] = vv[e]; }
+                if (e < nv) {
+                    if (p16) pp16[e0 + e] = f32_to_bf16(pp[e]);      // one rounding per step (torch.optim.Adam on bf16 tensors rounds every intermediate)
+                    else t.p[e0 + e] = pp[e];
+                    t.m[e0 + e] = mm[e]; t.v[e0 + e] = vv[e];
+                }
         }
         if (sh) {   // bf16 shadow [rows, ld_shadow] of the fp32 [rows, cols] weight (n < 2^32 checked on the host)
             const uint32_t cols = (uint32_t)t.cols;
@@ -114,7 +122,8 @@ extern "C" int mtl_adam_step(const mtl_adam_tensor* tensors, int count, float lr
             tab.t[tab.count] = t;
             tab.first_block[tab.count] = blocks;
             blocks += (int)((t.n + CHUNK - 1) / CHUNK);
-            bytes += (double)t.n * (28.0 + (t.shadow ? 2.0 : 0.0));      // p, g, m, v read; p, m, v written (+ bf16 shadow)
+            if (t.param_dtype != MTL_F32 && t.param_dtype != MTL_BF16) return MTL_ERR_ARG;
+            bytes += (double)t.n * ((t.param_dtype == MTL_BF16 ? 22.0 : 28.0) + (t.shadow ? 2.0 : 0.0));      // p, g, m, v read; p, m, v written (+ bf16 shadow)
             ++tab.count;
         }
         tab.first_block[tab.count] = blocks;

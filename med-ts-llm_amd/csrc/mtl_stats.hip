@@ -11,6 +11,8 @@
 // broken towards the smaller lag.
 #include "mtl_common.h"
 
+#include <mutex>
+
 namespace {
 
 __device__ __forceinline__ float block_reduce(float v, float* red, int op) {   // op 0 sum, 1 min, 2 max; blockDim = 256
@@ -27,15 +29,19 @@ __device__ __forceinline__ float block_reduce(float v, float* red, int op) {   /
 
 // one workgroup per selected series (b, c). dynamic LDS: xs[L] | cos[L] | sin[L] | red[4]
 // out_stats [B, Cs, 4] = (min, max, median, trend 0/1); corr_ws [B, Cs, L/2 + 1] = the power spectrum |X[k]|^2
+// TABLE = false (windows beyond 13 650 points: the two tables no longer fit the 160 KB LDS next to the series): the twiddles are evaluated per term —
+// the same sincospif of the same reduced index, so both variants produce identical bits.
+template <bool TABLE>
 __global__ __launch_bounds__(256) void series_stats_kernel(const float* __restrict__ x, float* __restrict__ out_stats, float* __restrict__ corr_ws,
                                                            int L, int C, int c0, int Cs) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;
     float* ct = lds + L;
-    float* sn = ct + L;
-    float* red = sn + L;
+    float* sn = TABLE ? ct + L : ct;
+    float* red = TABLE ? sn + L : lds + L;
     const int bc = blockIdx.x, b = bc / Cs, c = c0 + bc % Cs, tid = threadIdx.x;
-    for (int m = tid; m < L; m += 256) sincospif(2.0f * (float)m / (float)L, &sn[m], &ct[m]);
+    if (TABLE)
+        for (int m = tid; m < L; m += 256) sincospif(2.0f * (float)m / (float)L, &sn[m], &ct[m]);
     const float* src = x + (int64_t)b * L * C + c;
     float mn = INFINITY, mx = -INFINITY;
     for (int t = tid; t < L; t += 256) {
@@ -72,8 +78,11 @@ __global__ __launch_bounds__(256) void series_stats_kernel(const float* __restri
         float re = 0.f, im = 0.f;
         int m = 0;
         for (int t = 0; t < L; ++t) {
-            re += xs[t] * ct[m];
-            im += xs[t] * sn[m];
+            float cv, sv;
+            if (TABLE) { cv = ct[m]; sv = sn[m]; }
+            else sincospif(2.0f * (float)m / (float)L, &sv, &cv);
+            re += xs[t] * cv;
+            im += xs[t] * sv;
             m += kk;
             if (m >= L) m -= L;
         }
@@ -83,12 +92,13 @@ __global__ __launch_bounds__(256) void series_stats_kernel(const float* __restri
 
 // one workgroup per sample: channel-mean power spectrum -> inverse real transform of irfft's default length n = 2 (nh - 1) for lags
 // 0 .. n/2, mirrored -> top-k by (value desc, lag asc). dynamic LDS: pw[nh] | cos[n] | corr[n]; out_lags [B, n_lags] (floats: exact below 2^24)
+template <bool TABLE>
 __global__ __launch_bounds__(256) void top_lags_kernel(const float* __restrict__ corr_ws, float* __restrict__ out_lags, int L, int Cs, int n_lags) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int nh = L / 2 + 1, n = 2 * (nh - 1);
     float* pw = lds;
     float* ct = pw + nh;
-    float* corr = ct + n;
+    float* corr = TABLE ? ct + n : ct;
     __shared__ float bv[4];
     __shared__ int bi[4];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -97,13 +107,14 @@ __global__ __launch_bounds__(256) void top_lags_kernel(const float* __restrict__
         for (int c = 0; c < Cs; ++c) s += corr_ws[((int64_t)b * Cs + c) * nh + k];
         pw[k] = s / (float)Cs;       // (irfft is linear: the mean over channels commutes with it)
     }
-    for (int m = tid; m < n; m += 256) ct[m] = cospif(2.0f * (float)m / (float)n);
+    if (TABLE)
+        for (int m = tid; m < n; m += 256) ct[m] = cospif(2.0f * (float)m / (float)n);
     __syncthreads();
     for (int j = tid; j <= n / 2; j += 256) {
         float acc = 0.f;
         int m = j;
         for (int k = 1; k < nh - 1; ++k) {
-            acc += pw[k] * ct[m];
+            acc += pw[k] * (TABLE ? ct[m] : cospif(2.0f * (float)m / (float)n));
             m += j;
             if (m >= n) m -= n;
         }
@@ -147,13 +158,29 @@ extern "C" int mtl_input_stats(const float* x, float* out_stats, float* out_lags
     if (!x || !out_stats || !out_lags || !workspace || B <= 0 || L < 2 || C <= 0 || channel >= C || n_lags <= 0 || n_lags > L) return MTL_ERR_ARG;
     const int c0 = channel < 0 ? 0 : (int)channel, Cs = channel < 0 ? (int)C : 1;
     if (workspace_bytes < mtl_input_stats_workspace_bytes(B, L, Cs)) return MTL_ERR_WORKSPACE;
-    const size_t lds = (size_t)(3 * L + 4) * sizeof(float);
-    if (lds > 64 * 1024 || n_lags > 2 * (L / 2)) return MTL_ERR_UNSUPPORTED;       // L <= 5460
+    // LDS: series + cos + sin tables while they fit the 160 KB (L <= 13 300), the series alone beyond that (twiddles per term, L <= 39 900);
+    // the lag kernel: spectrum + cos table + correlation (L <= 15 900), or without the table (L <= 26 600)
+    constexpr size_t kLds = 156 * 1024;
+    if (n_lags > 2 * (L / 2)) return MTL_ERR_UNSUPPORTED;
+    const size_t lds_tab = (size_t)(3 * L + 4) * sizeof(float), lds_plain = (size_t)(L + 4) * sizeof(float);
+    const size_t lag_tab = (size_t)(L / 2 + 1 + 4 * (L / 2)) * sizeof(float), lag_plain = (size_t)(L / 2 + 1 + 2 * (L / 2)) * sizeof(float);
+    if (lds_plain > kLds || lag_plain > kLds) return MTL_ERR_UNSUPPORTED;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute((const void*)series_stats_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+        (void)hipFuncSetAttribute((const void*)series_stats_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+        (void)hipFuncSetAttribute((const void*)top_lags_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+        (void)hipFuncSetAttribute((const void*)top_lags_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+    });
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(series_stats_kernel, dim3((unsigned)(B * Cs)), dim3(256), lds, st, x, out_stats, reinterpret_cast<float*>(workspace), (int)L,
-                       (int)C, c0, Cs);
-    hipLaunchKernelGGL(top_lags_kernel, dim3((unsigned)B), dim3(256), (size_t)(L / 2 + 1 + 4 * (L / 2)) * sizeof(float), st, reinterpret_cast<const float*>(workspace), out_lags,
-                       (int)L, Cs, (int)n_lags);
+    if (lds_tab <= kLds)
+        hipLaunchKernelGGL(series_stats_kernel<true>, dim3((unsigned)(B * Cs)), dim3(256), lds_tab, st, x, out_stats, reinterpret_cast<float*>(workspace), (int)L, (int)C, c0, Cs);
+    else
+        hipLaunchKernelGGL(series_stats_kernel<false>, dim3((unsigned)(B * Cs)), dim3(256), lds_plain, st, x, out_stats, reinterpret_cast<float*>(workspace), (int)L, (int)C, c0, Cs);
+    if (lag_tab <= kLds)
+        hipLaunchKernelGGL(top_lags_kernel<true>, dim3((unsigned)B), dim3(256), lag_tab, st, reinterpret_cast<const float*>(workspace), out_lags, (int)L, Cs, (int)n_lags);
+    else
+        hipLaunchKernelGGL(top_lags_kernel<false>, dim3((unsigned)B), dim3(256), lag_plain, st, reinterpret_cast<const float*>(workspace), out_lags, (int)L, Cs, (int)n_lags);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }

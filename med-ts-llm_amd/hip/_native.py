@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("MTL_LIB_PATH") or os.path.join(_HERE, "libmedtsllm_hi
 MTL_F32, MTL_BF16 = 0, 1
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM, EPI_SWIGLU, EPI_DSWIGLU = 0, 1, 2, 3, 4, 5, 6
 ARCH_GPT2, ARCH_LLAMA = 0, 1
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 i64, vp, f32, i32 = C.c_int64, C.c_void_p, C.c_float, C.c_int
 
@@ -48,7 +48,7 @@ class BackboneDropout(C.Structure):
 
 
 class AdamTensor(C.Structure):
-    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("n", i64), ("shadow", vp), ("cols", i64), ("ld_shadow", i64)]
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("n", i64), ("shadow", vp), ("cols", i64), ("ld_shadow", i64), ("param_dtype", i64)]
 
 
 ADAM_MAX_TENSORS = 24

@@ -58,13 +58,14 @@ class HipAdam(torch.optim.Optimizer):
             for p in group["params"]:
                 if p.grad is None:
                     continue
-                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
-                    raise N.MtlError("HipAdam needs contiguous fp32 parameters on the GPU (no CPU fallback)")
+                if not (p.is_cuda and p.dtype in (torch.float32, torch.bfloat16) and p.is_contiguous()):
+                    raise N.MtlError("HipAdam needs contiguous fp32 (or, with setup.dtype = \"bf16\", bf16) parameters on the GPU (no CPU fallback)")
                 st = self.state[p]
                 if not st:
                     st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    # moments are fp32 also for bf16 parameters (setup.dtype = "bf16"): the update is formed in fp32 and the parameter rounded once
+                    st["exp_avg"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
                 st["step"] = int(st["step"]) + 1
                 by_step.setdefault(st["step"], []).append(p)
             batches = []
@@ -96,12 +97,13 @@ class HipAdam(torch.optim.Optimizer):
         for i, p in enumerate(ps):
             st = self.state[p]
             g = p.grad
-            if g.dtype != torch.float32 or not g.is_contiguous():
-                g = g.float().contiguous()
+            if g.dtype != p.dtype or not g.is_contiguous():
+                g = g.to(p.dtype).contiguous()
             keep.append(g)
             sh = self._shadows.get(id(p))
             arr[i].p, arr[i].g, arr[i].m, arr[i].v = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
             arr[i].n = p.numel()
+            arr[i].param_dtype = N.MTL_BF16 if p.dtype == torch.bfloat16 else N.MTL_F32
             if sh is not None:
                 arr[i].shadow, arr[i].cols, arr[i].ld_shadow = sh.tensor.data_ptr(), p.shape[1], sh.tensor.stride(0)
             else:

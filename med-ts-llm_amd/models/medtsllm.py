@@ -375,6 +375,8 @@ class MedTsLLM(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, inputs):
         pred = self.predict(inputs)
+        if inputs["x_enc"].dtype == BF16 and pred.dtype != BF16:
+            pred = pred.to(BF16)        # setup.dtype = "bf16": bf16 inputs and parameters give a bf16 prediction (R:tasks/base.py:205-208,261-262)
         if not self.training:   # R:models/medtsllm.py:251-259
             if self.task == "semantic_segmentation":
                 pred = F.softmax(pred, dim=-1) if self.n_classes > 2 else torch.sigmoid(pred)

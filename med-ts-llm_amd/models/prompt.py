@@ -55,7 +55,7 @@ def _fmt_trend(x):
 def _device_stats_fit(x_enc, n_lags):
     """shapes mtl_input_stats accepts (csrc/mtl_stats.hip returns MTL_ERR_UNSUPPORTED beyond them)"""
     L = x_enc.shape[1]
-    return L <= 5460 and n_lags <= 2 * (L // 2)
+    return L <= 26_600 and n_lags <= 2 * (L // 2)
 
 
 def input_stats_prompts(x_enc, input_stats_dim, input_stats_select="all", n_lags=N_LAGS):
@@ -87,8 +87,9 @@ def input_stats_prompts(x_enc, input_stats_dim, input_stats_select="all", n_lags
         lg = host[1].reshape(-1)[: B_ * n_lags].view(B_, n_lags).double()
         packed = torch.cat([st[:, :, 0], st[:, :, 1], st[:, :, 2], st[:, :, 3], lg], dim=1).tolist()
     if packed is None:
-        # CPU tensors, and windows the statistics kernel does not take (it keeps one channel-mean series per sample in LDS: L <= 5460,
-        # n_lags <= 2 * (L // 2)): the reference's own reductions + rFFT round trip on whatever device x_enc lives on
+        # CPU tensors (host logic, CPU tests), and windows the statistics kernel does not take (it keeps a sample's series and its
+        # correlation in the 160 KB LDS: L <= 26 600 — thirteen times the longest window of the shipped configurations; n_lags <= 2 * (L // 2)):
+        # the reference's own reductions + rFFT round trip on whatever device x_enc lives on
         with torch.no_grad():
             # one packed D2H copy (= one stream sync) instead of the reference's five .tolist() calls; float64 holds every
             # value exactly (fp32/bf16 statistics, 0/1 trends, integer lags), so the formatted strings are unchanged

@@ -85,13 +85,17 @@ class BaseTask(ABC):
         self.task = config.task
         self.device = self.get_device()
         self.dtype = self.get_dtype()
-        if self.dtype != torch.float32:
-            # R:tasks/base.py:261-264 casts the whole model AND the inputs to bf16 / fp16. The HIP path keeps fp32 master weights, an fp32
-            # residual stream and fp32 optimiser moments with bf16 GEMM / attention operands — that IS setup.dtype = "mixed"; a pure
-            # 16-bit master copy is not implemented (HipAdam updates fp32 masters only). Refuse here, not inside the first optimiser step.
-            raise ValueError(f"setup.dtype = {config.setup.dtype!r} (pure 16-bit parameters) is not supported by the MI355X path: use "
-                             "\"mixed\" (fp32 masters, bf16 operands — the reference's default) or \"fp32\"")
+        if self.dtype == torch.float16:
+            # R:tasks/base.py:263-264 casts the whole model AND the inputs to fp16. Not built: the kernels' 16-bit operand type is bf16.
+            raise ValueError(f"setup.dtype = {config.setup.dtype!r} (fp16 parameters) is not supported by the MI355X path: use "
+                             "\"mixed\" (fp32 masters, bf16 operands — the reference's default), \"bf16\" or \"fp32\"")
+        # setup.dtype = "bf16" (R:tasks/base.py:261-262,205-208: the whole model and every floating-point input are cast to bf16, no autocast):
+        # the trainable parameters ARE bf16 here too (checkpoints, optimiser updates, gradients in bf16; Adam's moments stay fp32), the inputs
+        # arrive in bf16 and the prediction leaves in bf16. Between those roundings the kernels run exactly as in "mixed" (bf16 MFMA operands,
+        # fp32 accumulation / residual stream / statistics), i.e. closer to fp32 than the reference's bf16 ATen ops.
         self.rank, self.world_size, self.local_rank = parallel.init_from_env(self.device.type)
+        if self.dtype == torch.bfloat16 and self.world_size > 1:
+            raise NotImplementedError("setup.dtype = \"bf16\" with data parallelism: the gradient buckets are fp32 views (use \"mixed\")")
         if self.device.type == "cuda" and self.world_size > 1:
             self.device = torch.device("cuda", self.local_rank % torch.cuda.device_count())
         set_seed(self.config.setup.seed)

@@ -94,9 +94,10 @@ def golden_loss(pred, target, task):
     import torch.nn.functional as F
     if task == "semantic_segmentation":
         return F.cross_entropy(pred.permute(0, 2, 1), torch.as_tensor(target).long())
+    ft = pred.dtype if pred.dtype == torch.bfloat16 else torch.float32      # (setup.dtype = "bf16": prepare_batch hands bf16 targets over)
     if task == "segmentation":
-        return F.binary_cross_entropy_with_logits(pred, torch.as_tensor(target).float())
-    return F.mse_loss(pred, torch.as_tensor(target).float())
+        return F.binary_cross_entropy_with_logits(pred, torch.as_tensor(target).to(ft))
+    return F.mse_loss(pred, torch.as_tensor(target).to(ft))
 
 
 # ----------------------------------------------------------------------------- GPU-test model configs (HIP-friendly sizes)

@@ -526,7 +526,9 @@ def test_input_stats_vs_reference_goldens(ops):
         assert torch.equal(s[:, :, 2], xs.median(dim=1).values)                      # LOWER median, like torch.median
         assert torch.equal(s[:, :, 3] > 0, xs.diff(dim=1).sum(dim=1) > 0)
     # sizes of the metric workload, odd lengths, ties in the data (repeated values -> the median's rank window is wide)
-    for (B, L, C) in ((4, 1024, 12), (3, 101, 2), (2, 64, 1)):
+    # ... and windows beyond the first version's 5460-point limit: 13 904 points (the series kernel drops its twiddle tables: 3 L floats no longer
+    # fit the LDS) and 20 000 (both kernels table-free) — models/prompt.py has no torch stand-in on device tensors any more
+    for (B, L, C) in ((4, 1024, 12), (3, 101, 2), (2, 64, 1), (1, 13904, 2), (1, 20000, 1)):
         x = torch.randn(B, L, C, generator=g(L)) + torch.linspace(-1, 1, L)[None, :, None] * torch.tensor([1.0, -1.0] * 6)[:C]
         x[:, 7::7, 0] = x[:, 3:4, 0]            # repeated values (not at t = 0: the trend is the sign of x[L-1] - x[0] up to round-off)
         st, lg, _ = ops.input_stats(dev(x), -1, 5)
