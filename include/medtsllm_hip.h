@@ -12,7 +12,8 @@
  *     PyTorch-allocated outputs/workspaces and the stream (hipStream_t as void*).
  *   - bf16 tensors are raw uint16 storage; row-major; `ld*` are row strides in ELEMENTS.
  *   - return 0 on success, negative MTL_ERR_* otherwise (mtl_strerror gives the text).
- *   - re-entrant / thread-compatible: no mutable globals except the opt-in, mutex-guarded launch profiler.
+ *   - re-entrant / thread-compatible: no mutable globals except the opt-in, mutex-guarded launch profiler; every A/B knob is a per-call
+ *     field of an argument struct (tune_*), environment diagnostics are read once and constant afterwards.
  */
 #ifndef MEDTSLLM_HIP_H
 #define MEDTSLLM_HIP_H
@@ -103,6 +104,14 @@ typedef struct {
      * A pruned backward (mtl_backbone_bwd's n_grad) never reads the other rows; inference passes bwd_first_row = bwd_group_rows
      * and writes none. bwd_group_rows == 0 -> every row. */
     int64_t bwd_group_rows, bwd_first_row;
+    /* Tile configuration of THIS call (A/B runs and tests; production passes zeros = the library's own choice). No process state:
+     * tune_mode 0 automatic | 1 one output tile per workgroup | 2 persistent flat-K kernel; tune_bm tile rows (128, 256), tune_bn tile
+     * columns (64, 96, 128, 192, 256), tune_stages LDS ring depth (2, 3), tune_waves waves per workgroup (4, 8, 16); each 0 = automatic.
+     * Instantiated combinations: 128x64/4w/{2,3}, 128x96/4w/{2,3}, 128x96/8w/2 (two k-groups; needs at most one tile per CU and an even
+     * number of 64-wide k-tiles >= 4), 128x128/{4,8}w/2, 128x128/8w/3, 128x192/8w/2, 256x96/8w/{2,3}, 256x128/16w/{2,3}, 256x192/8w/2,
+     * 256x256/8w/2; anything else makes mtl_gemm_nt return MTL_ERR_UNSUPPORTED. Results agree in every configuration up to the fp32
+     * summation order (two k-groups and their per-XCD k rotation change it). */
+    int tune_mode, tune_bm, tune_bn, tune_stages, tune_waves;
 } mtl_gemm_args;
 size_t mtl_gemm_workspace_bytes(int64_t M, int64_t N, int split_k);
 /* split_k the library would pick for a problem: > 1 only for few output tiles with a long K (the flatten head, small weight
@@ -143,17 +152,10 @@ typedef struct mtl_prof_row {
 } mtl_prof_row;
 int mtl_prof_enable(int on);
 int mtl_prof_read(mtl_prof_row* rows, int cap);
-/* Experiment knob for A/B runs: mode 0 = one output tile per workgroup, 1 = persistent flat-K (default);
- * bm / bn = tile rows (128, 256) / columns (64, 96, 128, 192, 256), stages = LDS ring depth (2, 3), waves per workgroup (4, 8, 16);
- * 0 = automatic. Instantiated combinations: 128x64/4w/{2,3}, 128x96/4w/{2,3}, 128x96/8w/2 (two k-groups; needs at most one tile
- * per CU and an even number of 64-wide k-tiles >= 4), 128x128/{4,8}w/2, 128x128/8w/3, 128x192/8w/2, 256x96/8w/{2,3}, 256x128/16w/{2,3},
- * 256x192/8w/2, 256x256/8w/2; anything else makes mtl_gemm_nt return MTL_ERR_UNSUPPORTED. Results agree in every mode up to the
- * fp32 summation order (two k-groups and their per-XCD k rotation change it).
- * Diagnostics read from the environment once per process (in-step A/B runs; never needed in production):
+/* Diagnostics read from the environment once per process (in-step A/B runs; never needed in production; constant afterwards):
  *   MTL_GEMM_RULES_OFF=<mask>  switch single automatic launch rules off (1 GELU 256x192, 2 residual 256x96, 4 two k-groups,
  *                              8 per-XCD k rotation, 16 balanced tile-group height)
  *   MTL_GEMM_FORCE="epi,N,bm,bn,stages,waves"  force one tile configuration for the launches of one epilogue and N */
-int mtl_gemm_tune(int mode, int bm, int bn, int stages, int waves);
 /* Host-only (no device call): the tile order the persistent GEMM would use for a grid of tiles_m x tiles_n tiles of bm x bn with
  * per_cu resident workgroups per CU: bits 0-7 rows of a tile group, bit 8 per-XCD k rotation, bit 9 per-XCD column rotation
  * (negative: error code). Lets the CPU test suite check that every order visits every tile exactly once. */
@@ -250,6 +252,10 @@ typedef struct {
      * are near-uniform (reprogramming attention); with the fp32 O it is the rounding of the individual P V products,
      * sqrt(Tk) times smaller, and the extra pass over K / V that the bf16 route needs to rebuild delta is not run. */
     float* o_f32;
+    /* per-call kernel selection for A/B runs and tests (0 = the library's own choice; no process state): bit 0 = never the K/V-resident
+     * kernels (whole head in LDS, no barrier in the key loop) — the chunked ones; bit 1 = the resident backward of hd-64 MHA heads as two
+     * launches (dQ, then dK / dV) instead of the merged one. Results agree to rounding (bit 1: bit-identical). */
+    int tune;
 } mtl_attn_fwd_args;
 int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream);
 typedef struct {
@@ -268,13 +274,7 @@ typedef struct {
     const float* rope_cos; const float* rope_sin;
 } mtl_attn_bwd_args;
 int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream);
-/* A/B knob: 1 (default) lets causal self-attention use the resident-K/V kernels (whole head in LDS, no barrier in the
- * key loop) whenever they fit, 0 forces the chunked kernels. Results agree to rounding. */
-int mtl_attention_tune(int resident);
-/* A/B knob: 1 (default) lets the resident backward of MHA heads of width 64 run as ONE launch when both sides have at most 8 16-row tiles
- * (the backbone's pruned backward, HF:models/gpt2/modeling_gpt2.py:182-214 differentiated: the head's K, V, Q, dO, O staged once, dQ and
- * dK / dV from the same LDS tiles); 0 = two launches (dQ, then dK / dV). Results are bit-identical. */
-int mtl_attention_tune_merged(int merged);
+
 
 /* ------------------------------------------------------------------ norms (fp32 statistics)
  * LayerNorm eps 1e-5 (HF:models/gpt2/modeling_gpt2.py:252,254,497) and LlamaRMSNorm

@@ -1594,7 +1594,8 @@ namespace {
 
 // resident-K/V path: causal, per-sample K/V, >= 4 rows, and both tiles fit the 160 KiB LDS
 constexpr size_t kLdsBudget = 156 * 1024;
-int g_attn_mode = 1;   // 1 = use the resident kernels when they fit, 0 = always the chunked kernels (A/B knob)
+// (per-call knobs: mtl_attn_fwd_args.tune bit 0 = chunked kernels only, bit 1 = resident backward as two launches; the environment
+//  switches below are read once and constant afterwards)
 const int g_attn_wide = getenv("MTL_ATTN_WIDE") ? atoi(getenv("MTL_ATTN_WIDE")) : 1;   // A/B knob: 0 = 64-row workgroups for long sequences too
 // rows from which the 128-row workgroups are used. Forward / dQ from 256 (PSM shape, Tq = 256 of T = 384: 131 -> 97 us, 184 -> 150 us); the
 // dK/dV kernel gains nothing there (190 -> 194 us) and switches at 512.
@@ -1603,21 +1604,19 @@ const int g_attn_wide_min = getenv("MTL_ATTN_WIDE_MIN") ? atoi(getenv("MTL_ATTN_
 const int g_attn_xmap = getenv("MTL_ATTN_XMAP") ? atoi(getenv("MTL_ATTN_XMAP")) : 1;   // A/B knob: 0 = plain (row block, head, batch) grids for the long-sequence kernels
 const int g_attn_w32_nw = getenv("MTL_ATTN_W32_NW") ? atoi(getenv("MTL_ATTN_W32_NW")) : 0;   // A/B knob: 4 / 8 waves per workgroup of the 32-row kernels (0 = automatic)
 const int g_attn_w32 = getenv("MTL_ATTN_W32") ? atoi(getenv("MTL_ATTN_W32")) : 1;   // A/B knob: 0 = the 16-rows-per-wave kernels for long causal sequences
-int g_attn_merged = getenv("MTL_ATTN_MERGED") ? atoi(getenv("MTL_ATTN_MERGED")) : 1;   // A/B knob: 0 = the resident backward as two launches (dQ, then dK / dV)
+const int g_attn_merged = getenv("MTL_ATTN_MERGED") ? atoi(getenv("MTL_ATTN_MERGED")) : 1;   // A/B knob: 0 = the resident backward as two launches (dQ, then dK / dV)
 
 template <typename KernelT>
 void set_lds(KernelT k, size_t bytes) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); }
 
 }  // namespace
 
-extern "C" int mtl_attention_tune(int resident) { g_attn_mode = resident ? 1 : 0; return MTL_OK; }
-extern "C" int mtl_attention_tune_merged(int merged) { g_attn_merged = merged ? 1 : 0; return MTL_OK; }
 
 namespace {
 
 size_t pad32(int64_t v) { return (size_t)((v + 31) & ~(int64_t)31); }
 bool resident_ok(const mtl_attn_fwd_args& f, int64_t rows) {
-    return g_attn_mode == 1 && f.causal && f.k_bs != 0 && f.dropout_p < 1.f && (f.D == 64 || f.D == 128) &&
+    return !(f.tune & 1) && f.causal && f.k_bs != 0 && f.dropout_p < 1.f && (f.D == 64 || f.D == 128) &&
            2 * pad32(rows) * (f.D + attn_pad((int)f.D)) * 2 + 2 * pad32(rows) * 4 <= kLdsBudget;
 }
 
@@ -1727,7 +1726,7 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
         if (a->kv_row0 < 0 || a->kv_row0 >= f.Tk) return MTL_ERR_ARG;
         // few tiles on both sides (the backbone's pruned backward: n_grad query rows, dK / dV for the patch keys): ONE launch stages the head once
         const size_t lds_m = (2 * pad32(f.Tk) + 3 * pad32(f.Tq)) * (f.D + attn_pad((int)f.D)) * 2 + 2 * pad32(f.Tq) * 4;
-        if (g_attn_merged == 1 && f.D == 64 && f.Hq == f.Hkv && (f.Tq + 15) / 16 <= 8 && (f.Tk - a->kv_row0 + 15) / 16 <= 8 && lds_m <= kLdsBudget) {
+        if (g_attn_merged == 1 && !(f.tune & 2) && f.D == 64 && f.Hq == f.Hkv && (f.Tq + 15) / 16 <= 8 && (f.Tk - a->kv_row0 + 15) / 16 <= 8 && lds_m <= kLdsBudget) {
             static std::once_flag once;
             std::call_once(once, [&] { set_lds(attn_bwd_res_merged_kernel<64, 16, true>, kLdsBudget); set_lds(attn_bwd_res_merged_kernel<64, 16, false>, kLdsBudget); });
             const dim3 gm(1, (unsigned)f.Hq, (unsigned)f.B);

@@ -1192,17 +1192,21 @@ int tile_order(int tiles_m, int tiles_n, int bm, int bn, int per_cu, int64_t K, 
 
 bool aligned(const void* ptr, size_t a) { return (reinterpret_cast<uintptr_t>(ptr) % a) == 0; }
 
-// experiment knobs (mtl_gemm_tune): mode 0 = one tile per workgroup, 1 = persistent flat-K; bn = 0 auto / 64 / 128
-struct Tuning { int mode = 1; int bn = 0; int stages = 0; int waves = 0; int bm = 0; int num_cu = 0; };
-Tuning& tuning() { static Tuning t; return t; }
-int num_cus() {
-    Tuning& t = tuning();
-    if (t.num_cu == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        t.num_cu = n;
-    }
-    return t.num_cu;
+// per-call experiment knobs (mtl_gemm_args.tune_*): mode 0 = one tile per workgroup, 1 = persistent flat-K (the default); 0 = automatic elsewhere
+struct Tuning { int mode = 1; int bn = 0; int stages = 0; int waves = 0; int bm = 0; };
+Tuning call_tuning(const mtl_gemm_args& p) {
+    Tuning t;
+    t.mode = p.tune_mode == 1 ? 0 : 1;
+    t.bm = p.tune_bm; t.bn = p.tune_bn; t.stages = p.tune_stages; t.waves = p.tune_waves;
+    return t;
+}
+int num_cus() {       // (constant of the device, cached once)
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
 }
 
 // kernel name of a launch for the profiler; MTL_PROF_SHAPES=1 appends the problem size (per-shape rows: tools/gemm_shapes.py)
@@ -1223,10 +1227,11 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st, int fbm = 0, int 
     char kname[128];
     // the persistent kernel has the wave-level epilogue only: 16-B aligned rows, or (plain fp32 store, no bias) dword stores
     const bool dword_ok = EPI == MTL_EPI_STORE && CDT == MTL_F32 && !p.bias && aligned(p.C, 4) && p.c_group_rows == 0;
-    if (S == 1 && tuning().mode == 1 && (vec_ok || dword_ok) && p.N >= 4) {
+    const Tuning tn = call_tuning(p);
+    if (S == 1 && tn.mode == 1 && (vec_ok || dword_ok) && p.N >= 4) {
         const int ncu = num_cus();
         // tile choice, measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_ab*.txt)
-        int bm = fbm ? fbm : tuning().bm, bn = fbn ? fbn : tuning().bn, stages = fstages ? fstages : tuning().stages, nw = fnw ? fnw : tuning().waves;
+        int bm = fbm ? fbm : tn.bm, bn = fbn ? fbn : tn.bn, stages = fstages ? fstages : tn.stages, nw = fnw ? fnw : tn.waves;
         const int t128 = tiles_m * tiles_n;            // grid size in 128x128 tiles
         // Llama-class grids: 256x128 / 16 waves / 3 stages reaches 1.04-1.12 PF/s (also the M = B*n_grad backward GEMMs with long K)
         if (bm == 0) bm = (t128 >= 8 * ncu || (t128 >= 4 * ncu && p.K >= 4096)) ? 256 : 128;
@@ -1266,14 +1271,14 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st, int fbm = 0, int 
             static const char* spec = getenv("MTL_GEMM_FORCE");
             static int f[6] = {-1, 0, 0, 0, 0, 0};
             static const bool parsed = spec && sscanf(spec, "%d,%d,%d,%d,%d,%d", &f[0], &f[1], &f[2], &f[3], &f[4], &f[5]) == 6;
-            if (parsed && f[0] == EPI && f[1] == p.N && tuning().bm == 0) { bm = f[2]; bn = f[3]; stages = f[4]; nw = f[5]; }
+            if (parsed && f[0] == EPI && f[1] == p.N && tn.bm == 0) { bm = f[2]; bn = f[3]; stages = f[4]; nw = f[5]; }
         }
         // 256 x 256 grids whose last round of tiles would leave most CUs idle: the columns that fill WHOLE rounds go in this launch, the
         // remaining columns in a second one with half-width tiles (256 x 128 / 16 waves / 3 stages: twice the tiles for the same columns).
         // Llama-2 gate|up with the prompt-row cache: [4096 x 22016 x 4096] = 16 x 86 tiles = 5.375 rounds of 256 -> 5 rounds + 96 half-width
         // pairs on 192 of the 256 CUs (rule 128 of MTL_GEMM_RULES_OFF switches it off). Column-split only: the outputs are disjoint column
         // ranges of the same buffers. Not for the residual epilogue (its dropout mask is indexed by the absolute column).
-        if (bm == 256 && bn == 256 && fbm == 0 && tuning().bm == 0 && !(rules_off() & 128) && p.N % 256 == 0 &&
+        if (bm == 256 && bn == 256 && fbm == 0 && tn.bm == 0 && !(rules_off() & 128) && p.N % 256 == 0 &&
             (EPI == MTL_EPI_STORE || EPI == MTL_EPI_GELU || EPI == MTL_EPI_DGELU || EPI == MTL_EPI_SWIGLU || EPI == MTL_EPI_DSWIGLU)) {
             const int tm256 = (int)((p.M + 255) / 256), tn256 = (int)(p.N / 256);
             if (tm256 <= ncu && ncu % tm256 == 0) {
@@ -1347,7 +1352,7 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st, int fbm = 0, int 
     } else {
         const int ws_vec = (p.N % 4 == 0) && aligned(p.workspace, 16);
         const int nkt_total = (int)(p.K / BK);
-        if (tuning().mode == 1 && ws_vec && nkt_total % S == 0) {
+        if (tn.mode == 1 && ws_vec && nkt_total % S == 0) {
             // persistent split-K: S x tiles work items of K/S each through the 128x128 / 8-wave pipeline (mapping GEMM:
             // K = padded vocabulary; the one-tile-per-workgroup kernel below reached 395 TF/s on it)
             auto go = [&](auto bmv, auto bnv) {
@@ -1445,18 +1450,6 @@ extern "C" int mtl_gemm_tile_order(int tiles_m, int tiles_n, int bm, int bn, int
     return tile_order(tiles_m, tiles_n, bm, bn, per_cu, K, one_tile_per_wg != 0);
 }
 
-extern "C" int mtl_gemm_tune(int mode, int bm, int bn, int stages, int waves) {
-    if ((mode != 0 && mode != 1) || (bm != 0 && bm != 128 && bm != 256) || (bn != 0 && bn != 64 && bn != 128 && bn != 96 && bn != 192 && bn != 256) ||
-        (stages != 0 && (stages < 2 || stages > 5)) || (waves != 0 && waves != 4 && waves != 8 && waves != 16))
-        return MTL_ERR_ARG;
-    tuning().mode = mode;
-    tuning().bm = bm;
-    tuning().bn = bn;
-    tuning().stages = stages;
-    tuning().waves = waves;
-    return MTL_OK;
-}
-
 namespace mtlprof {
 bool enabled() { return prof().on.load(std::memory_order_relaxed); }
 bool begin(hipEvent_t* e0, hipEvent_t* e1) {
@@ -1548,6 +1541,10 @@ extern "C" int mtl_gemm_nt(const mtl_gemm_args* a, void* stream) {
     if (p.M >= (int64_t)1 << 31 || p.a_group_rows >= (int64_t)1 << 31 || p.c_group_rows >= (int64_t)1 << 31) return MTL_ERR_ARG;
     if (p.bwd_group_rows < 0 || p.bwd_group_rows >= (int64_t)1 << 31 || p.bwd_first_row < 0 || p.bwd_first_row > p.bwd_group_rows) return MTL_ERR_ARG;
     if (p.c_dtype != MTL_F32 && p.c_dtype != MTL_BF16) return MTL_ERR_ARG;
+    if (p.tune_mode < 0 || p.tune_mode > 2 || (p.tune_bm != 0 && p.tune_bm != 128 && p.tune_bm != 256) ||
+        (p.tune_bn != 0 && p.tune_bn != 64 && p.tune_bn != 128 && p.tune_bn != 96 && p.tune_bn != 192 && p.tune_bn != 256) ||
+        (p.tune_stages != 0 && (p.tune_stages < 2 || p.tune_stages > 5)) || (p.tune_waves != 0 && p.tune_waves != 4 && p.tune_waves != 8 && p.tune_waves != 16))
+        return MTL_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int S = p.split_k > 1 ? p.split_k : 1;
     if (S > 1) {

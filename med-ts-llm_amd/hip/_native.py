@@ -29,7 +29,8 @@ class GemmArgs(C.Structure):
                 ("c_group_rows", i64), ("c_group_stride", i64), ("c_row_offset", i64),
                 ("bias", vp), ("epilogue", i32), ("aux_in", vp), ("ld_aux_in", i64), ("aux_out", vp), ("ld_aux_out", i64),
                 ("alpha", f32), ("split_k", i32), ("workspace", vp), ("workspace_bytes", C.c_size_t),
-                ("drop_p", f32), ("drop_seed", C.c_uint32), ("bwd_group_rows", i64), ("bwd_first_row", i64)]
+                ("drop_p", f32), ("drop_seed", C.c_uint32), ("bwd_group_rows", i64), ("bwd_first_row", i64),
+                ("tune_mode", i32), ("tune_bm", i32), ("tune_bn", i32), ("tune_stages", i32), ("tune_waves", i32)]
 
 
 class GemmXtArgs(C.Structure):
@@ -61,7 +62,7 @@ class AttnFwdArgs(C.Structure):
                 ("o", vp), ("o_bs", i64), ("o_ts", i64), ("o_hs", i64),
                 ("lse", vp), ("B", i64), ("Hq", i64), ("Hkv", i64), ("Tq", i64), ("Tk", i64), ("D", i64),
                 ("scale", f32), ("causal", i32), ("causal_off", i64), ("stat_stride", i64),
-                ("dropout_p", f32), ("dropout_seed", C.c_uint32), ("o_f32", vp)]
+                ("dropout_p", f32), ("dropout_seed", C.c_uint32), ("o_f32", vp), ("tune", i32)]
 
 
 class AttnBwdArgs(C.Structure):
@@ -102,7 +103,6 @@ SIGNATURES = {
     "mtl_gemm_xt": (i32, [C.POINTER(GemmXtArgs), vp]),
     "mtl_gemm_nt": (i32, [C.POINTER(GemmArgs), vp]),
     "mtl_prof_enable": (i32, [i32]),
-    "mtl_gemm_tune": (i32, [i32, i32, i32, i32, i32]),
     "mtl_gemm_tile_order": (i32, [i32, i32, i32, i32, i32, i64, i32]),
     "mtl_prof_read": (i32, [C.POINTER(ProfRow), i32]),
     "mtl_cast_pad_f32_bf16": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, vp]),
@@ -117,8 +117,6 @@ SIGNATURES = {
     "mtl_channel_mix_bwd": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, i64, i64, i64, i64, i64, vp]),
     "mtl_adam_step": (i32, [C.POINTER(AdamTensor), i32, f32, f32, f32, f32, f32, i32, i64, vp]),
     "mtl_attention_fwd": (i32, [C.POINTER(AttnFwdArgs), vp]),
-    "mtl_attention_tune": (i32, [i32]),
-    "mtl_attention_tune_merged": (i32, [i32]),
     "mtl_attention_bwd": (i32, [C.POINTER(AttnBwdArgs), vp]),
     "mtl_norm_fwd": (i32, [vp, vp, vp, vp, i64, vp, i64, i64, f32, i32, i64, i64, i64, i32, vp]),
     "mtl_norm_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, i64, i64, i32, i64, i64, i64, i32, f32, C.c_uint32, vp]),

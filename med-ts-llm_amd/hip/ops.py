@@ -4,6 +4,7 @@ PyTorch here is plumbing only: device memory (caching allocator), the current st
 All device arithmetic of the hot path runs in libmedtsllm_hip.so; nothing in this file falls back to ATen math for
 a kernel that failed to load — `_native.lib()` raises instead.
 """
+import contextlib
 import ctypes as C
 import math
 import os
@@ -46,6 +47,34 @@ def _req(cond, msg):
 
 
 # =============================================================================================== raw wrappers
+# ---- per-call kernel selection for A/B runs and tests. The LIBRARY keeps no such state (mtl_gemm_args.tune_*, mtl_attn_fwd_args.tune travel
+# with every call); these context managers only decide what this module puts into the calls it builds while they are active.
+_TUNE = {"gemm": (0, 0, 0, 0, 0), "attn": 0}
+
+
+@contextlib.contextmanager
+def gemm_tune(bm=0, bn=0, stages=0, waves=0, one_tile=False):
+    """force one tile configuration for the gemm_nt calls inside the block: bm x bn tile, LDS ring depth, waves per workgroup (0 = automatic);
+    one_tile = the one-output-tile-per-workgroup kernel instead of the persistent one"""
+    old = _TUNE["gemm"]
+    _TUNE["gemm"] = (1 if one_tile else (2 if (bm or bn or stages or waves) else 0), bm, bn, stages, waves)
+    try:
+        yield
+    finally:
+        _TUNE["gemm"] = old
+
+
+@contextlib.contextmanager
+def attention_tune(resident=True, merged=True):
+    """resident=False: the chunked attention kernels even where K / V fit the LDS; merged=False: the resident backward as two launches"""
+    old = _TUNE["attn"]
+    _TUNE["attn"] = (0 if resident else 1) | (0 if merged else 2)
+    try:
+        yield
+    finally:
+        _TUNE["attn"] = old
+
+
 def gemm_nt(A, B, out=None, out_dtype=BF16, bias=None, epilogue=N.EPI_STORE, aux_in=None, aux_out=None, alpha=1.0,
             split_k=0, M=None, a_rows=None, c_rows=None, drop=(0.0, 0), bwd_rows=None):
     """C[M,N] = epi(alpha * A[M,K] @ B[N,K]^T + bias). A, B bf16 with unit inner stride, K % 64 == 0.
@@ -73,6 +102,7 @@ def gemm_nt(A, B, out=None, out_dtype=BF16, bias=None, epilogue=N.EPI_STORE, aux
     if split_k == 0:
         split_k = lib().mtl_gemm_auto_split_k(M, Nn, K, epilogue)
     g.alpha, g.split_k = alpha, split_k
+    g.tune_mode, g.tune_bm, g.tune_bn, g.tune_stages, g.tune_waves = _TUNE["gemm"]
     g.drop_p, g.drop_seed = float(drop[0]), int(drop[1]) & 0xFFFFFFFF      # MTL_EPI_RESID only (resid_pdrop)
     if bwd_rows is not None:       # GELU / SWIGLU: (group_rows, first_row) of the rows whose backward-only output is stored
         g.bwd_group_rows, g.bwd_first_row = bwd_rows
@@ -245,6 +275,7 @@ def _attn_fwd_args(q, k, v, o, lse, B, Hq, Hkv, Tq, Tk, D, scale, causal, qs, ks
     a.lse = lse.data_ptr()
     a.B, a.Hq, a.Hkv, a.Tq, a.Tk, a.D = B, Hq, Hkv, Tq, Tk, D
     a.scale, a.causal = scale, 1 if causal else 0
+    a.tune = _TUNE["attn"]
     return a
 
 

@@ -182,13 +182,10 @@ def test_attention_chunked_equals_resident(ops, B, T, Hq, Hkv, D):
     do = torch.randn(B, T, Hq * D, generator=g(4)).to(BF16).cuda()
     scale = 1.0 / math.sqrt(D)
     res = {}
-    try:
-        for mode in (1, 0):
-            _native.lib().mtl_attention_tune(mode)
+    for mode in (1, 0):
+        with ops.attention_tune(resident=bool(mode)):        # per-call field of the argument struct: the library keeps no such switch
             o, lse = ops.attention_fwd(q, k, v, Hq, Hkv, D, scale, True)
             res[mode] = (o, lse) + ops.attention_bwd(q, k, v, o, lse, do, Hq, Hkv, D, scale, True)
-    finally:
-        _native.lib().mtl_attention_tune(1)
     for a, b in zip(res[0], res[1]):
         assert rel_err(a.float(), b.float()) < 5e-3
     ref = ref_attention(q.float().cpu(), k.float().cpu(), v.float().cpu(), Hq, Hkv, D, scale, True)
@@ -206,13 +203,10 @@ def test_attention_backward_fused_inverse_rope(ops, B, T, H, Hkv, D, resident):
     ang = torch.cat([pos * inv, pos * inv], dim=1)
     cos, sin = ang.cos().contiguous().cuda(), ang.sin().contiguous().cuda()
     scale = 1.0 / math.sqrt(D)
-    ops.lib().mtl_attention_tune(resident)
-    try:
+    with ops.attention_tune(resident=bool(resident)):
         o, lse = ops.attention_fwd(q, k, v, H, Hkv, D, scale, True)
         dq0, dk0, dv0 = ops.attention_bwd(q, k, v, o, lse, do, H, Hkv, D, scale, True)
         dq1, dk1, dv1 = ops.attention_bwd(q, k, v, o, lse, do, H, Hkv, D, scale, True, rope=(cos, sin))
-    finally:
-        ops.lib().mtl_attention_tune(1)
     want_q = ops.rope_inplace(dq0.reshape(B * T, H * D).clone(), cos, sin, T, H, D, inverse=True).view_as(dq0)
     want_k = ops.rope_inplace(dk0.reshape(B * T, Hkv * D).clone(), cos, sin, T, Hkv, D, inverse=True).view_as(dk0)
     assert torch.equal(dq1, want_q) and torch.equal(dk1, want_k) and torch.equal(dv1, dv0)
@@ -749,12 +743,9 @@ def test_attention_causal_dropout(ops, pdrop, resident):
     s = s.masked_fill(~torch.ones(T, T, dtype=torch.bool).tril(), float("-inf"))
     ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1) * mult, vf.view(B, T, H, D)).reshape(B, T, H * D)
     ref.backward(do.float())
-    ops.lib().mtl_attention_tune(resident)        # K/V-resident kernels, or the chunked ones
-    try:
+    with ops.attention_tune(resident=bool(resident)):        # K/V-resident kernels, or the chunked ones
         o, lse = ops.attention_fwd(dev(q), dev(k), dev(v), H, H, D, scale, True, dropout=(pdrop, seed))
         dq, dk, dv = ops.attention_bwd(dev(q), dev(k), dev(v), o, lse, dev(do), H, H, D, scale, True, dropout=(pdrop, seed))
-    finally:
-        ops.lib().mtl_attention_tune(1)
     assert rel_err(o.float(), ref) < TOL_ATTN_FWD
     assert rel_err(dq.float(), qf.grad) < TOL_ATTN_BWD and rel_err(dk.float(), kf.grad) < TOL_ATTN_BWD and rel_err(dv.float(), vf.grad) < TOL_ATTN_BWD
 
@@ -772,7 +763,7 @@ def test_transpose_with_column_sums(ops):
 @pytest.mark.parametrize("cfg", [(128, 64, 2, 4), (128, 96, 2, 4), (128, 96, 3, 4), (128, 128, 2, 8), (128, 128, 3, 8), (128, 128, 2, 4),
                                  (128, 192, 2, 8), (256, 128, 3, 16), (256, 128, 2, 16), (256, 192, 2, 8), (256, 96, 3, 8), (256, 96, 2, 8)])
 def test_gemm_every_tile_configuration(ops, cfg):
-    """each persistent-kernel tile configuration, forced through mtl_gemm_tune, on ragged shapes (edge tiles in M and N)
+    """each persistent-kernel tile configuration, forced through mtl_gemm_args.tune_* (ops.gemm_tune), on ragged shapes (edge tiles in M and N)
     with the plain, residual and accumulate epilogues; the launch heuristic only ever picks among these"""
     lib = ops.lib()
     for (M, Nn, K) in [(300, 260, 128), (37, 100, 64), (515, 388, 320)]:
@@ -781,13 +772,10 @@ def test_gemm_every_tile_configuration(ops, cfg):
         bias = torch.randn(Nn, generator=g(K)).cuda()
         res = torch.randn(M, Nn, generator=g(7)).cuda()
         lin = A.double().cpu() @ B.double().cpu().t()
-        lib.mtl_gemm_tune(1, *cfg)
-        try:
+        with ops.gemm_tune(*cfg):
             plain = ops.gemm_nt(A, B, bias=bias)
             resid = ops.gemm_nt(A, B, bias=bias, epilogue=ops.N.EPI_RESID, aux_in=res, out_dtype=F32)
             accum = ops.gemm_nt(A, B, epilogue=ops.N.EPI_ACCUM, out=res.clone())
-        finally:
-            lib.mtl_gemm_tune(1, 0, 0, 0, 0)
         assert rel_err(plain.float(), lin + bias.double().cpu()) < TOL_BF16
         assert rel_err(resid, res.double().cpu() + rb((lin + bias.double().cpu()).float()).double()) < 1e-4   # a few bf16 rounding ties
         assert rel_err(accum, res.double().cpu() + lin) < 1e-5
@@ -817,11 +805,8 @@ def test_gemm_bf16_epilogues_on_every_tile_configuration(ops, cfg):
             return (ops.gemm_nt(A, B, bias=bias), act, pre, ops.gemm_nt(A, B, epilogue=ops.N.EPI_DGELU, aux_in=pre_in), sgu, sact, dgu)
 
         ref = run()
-        lib.mtl_gemm_tune(1, *cfg)
-        try:
+        with ops.gemm_tune(*cfg):
             out = run()
-        finally:
-            lib.mtl_gemm_tune(1, 0, 0, 0, 0)
         lin = A.double().cpu() @ B.double().cpu().t() + bias.double().cpu()
         assert rel_err(out[0].float(), lin) < TOL_BF16
         for a, b in zip(out, ref):
@@ -846,11 +831,8 @@ def test_gemm_tile_order_whole_rows_per_xcd(ops, cfg, tiles_m):
             K = 256                                         # ... and an even number (>= 4) of 64-wide k-tiles
         A = torch.randn(M, K, generator=g(M + tiles_n)).to(BF16).cuda()
         B = (torch.randn(Nn, K, generator=g(Nn)) * 0.2).to(BF16).cuda()
-        lib.mtl_gemm_tune(1, *cfg)
-        try:
+        with ops.gemm_tune(*cfg):
             out = ops.gemm_nt(A, B, out_dtype=F32)
-        finally:
-            lib.mtl_gemm_tune(1, 0, 0, 0, 0)
         ref = A.double().cpu() @ B.double().cpu().t()
         assert rel_err(out, ref) < 1e-5, (cfg, tiles_m, tiles_n)
 
@@ -868,12 +850,9 @@ def test_gemm_two_k_groups(ops, M, Nn, K):
     pre = torch.randn(M, Nn, generator=g(8)).to(BF16).cuda()
     outs = {}
     for cfg in [(128, 96, 2, 4), (128, 96, 2, 8)]:
-        lib.mtl_gemm_tune(1, *cfg)
-        try:
+        with ops.gemm_tune(*cfg):
             outs[cfg] = (ops.gemm_nt(A, B, bias=bias), ops.gemm_nt(A, B, bias=bias, epilogue=ops.N.EPI_RESID, aux_in=res, out_dtype=F32),
                          ops.gemm_nt(A, B, epilogue=ops.N.EPI_ACCUM, out=res.clone()), ops.gemm_nt(A, B, epilogue=ops.N.EPI_DGELU, aux_in=pre))
-        finally:
-            lib.mtl_gemm_tune(1, 0, 0, 0, 0)
     lin = A.double().cpu() @ B.double().cpu().t()
     assert rel_err(outs[(128, 96, 2, 8)][0].float(), lin + bias.double().cpu()) < TOL_BF16
     for a, b in zip(outs[(128, 96, 2, 4)], outs[(128, 96, 2, 8)]):
@@ -946,12 +925,8 @@ def test_gemm_dswiglu_epilogue(ops, M, F, K, tune):
     dh = ops.gemm_nt(dy, wp)
     ref = ops.swiglu_bwd(gu, dh, interleaved=True)
     out = torch.zeros(M, 2 * F, dtype=BF16, device="cuda")
-    try:
-        if tune is not None:
-            lib.mtl_gemm_tune(1, *tune)
+    with ops.gemm_tune(*(tune or ())):
         ops.gemm_nt(dy, wp, out=out, epilogue=ops.N.EPI_DSWIGLU, aux_in=gu)
-    finally:
-        lib.mtl_gemm_tune(1, 0, 0, 0, 0)
     assert rel_err(out.float(), ref.float()) < 1e-3                        # same roundings; __expf vs expf in the sigmoid
     # pruned backward: logical row m lives at physical row (m // 60) * 100 + 40 + m % 60 of the saved pairs and of the output
     if M == 300:
@@ -981,11 +956,8 @@ def test_attention_backward_one_launch_equals_two(ops, Tq, Tk, kv0, pdrop):
     o, lse = ops.attention_fwd(q, k, v, H, H, D, scale, True, dropout=(pdrop, seed), causal_off=coff)
     outs = []
     for merged in (1, 0):
-        ops.lib().mtl_attention_tune_merged(merged)
-        try:
+        with ops.attention_tune(merged=bool(merged)):
             outs.append(ops.attention_bwd(q, k, v, o, lse, do, H, H, D, scale, True, dropout=(pdrop, seed), causal_off=coff, kv_row0=kv0))
-        finally:
-            ops.lib().mtl_attention_tune_merged(1)
     (dq1, dk1, dv1), (dq0, dk0, dv0) = outs
     assert torch.equal(dq1, dq0)
     assert torch.equal(dk1[:, kv0:], dk0[:, kv0:]) and torch.equal(dv1[:, kv0:], dv0[:, kv0:])

@@ -406,6 +406,14 @@ def test_bench_pmc_traffic_arithmetic_and_fallback(tmp_path, monkeypatch):
     f = {pt.clean(k): v for k, v in pt.per_kernel(db, "FETCH_SIZE").items()}
     assert f["norm_fwd_kernel<3, false>"] == (124.0, 2) and f["other"] == (7.0, 1)
     assert pt.per_kernel(db, "WRITE_SIZE")[kn] == (64.0, 1)
+    # warm-up / set-up dispatches are dropped at the optimiser launch that ends the warm-up step (same rule as tools/rocprof_summary.py)
+    c = sqlite3.connect(db)
+    adam = "(anonymous namespace)::adam_multi_kernel(AdamTable, AdamHyper)"
+    c.executemany("insert into counters_collection values (?, ?, ?, ?)", [(adam, "FETCH_SIZE", 1.0, 4), (kn, "FETCH_SIZE", 50.0, 5), (adam, "FETCH_SIZE", 1.0, 6)])
+    c.commit()
+    c.close()
+    f1 = {pt.clean(k): v for k, v in pt.per_kernel(db, "FETCH_SIZE", warmup_steps=1).items()}
+    assert f1["norm_fwd_kernel<3, false>"] == (50.0, 1) and f1["adam_multi_kernel"] == (1.0, 1) and "other" not in f1
 
     import bench
     monkeypatch.setattr("shutil.which", lambda name: None)

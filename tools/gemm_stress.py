@@ -1,5 +1,5 @@
 """Randomised cross-check of every persistent-GEMM tile configuration x epilogue on ragged shapes (GPU box).
-Forces each configuration through mtl_gemm_tune and compares with a float64 reference of the same bf16-rounded operands."""
+Forces each configuration through mtl_gemm_args.tune_* (ops.gemm_tune) and compares with a float64 reference of the same bf16-rounded operands."""
 import sys, os, itertools, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -42,11 +42,8 @@ for cfg in cfgs:
                 kw = dict(out=c0.clone())
                 ref = c0.double().cpu() + lin
                 tol = 1e-5
-            lib.mtl_gemm_tune(1, *cfg)
-            try:
+            with ops.gemm_tune(*cfg):
                 out = ops.gemm_nt(A, B, bias=bias, epilogue=epi, **kw)
-            finally:
-                lib.mtl_gemm_tune(1, 0, 0, 0, 0)
             err = float((out.double().cpu() - ref).norm() / (ref.norm() + 1e-30))
             if not err < tol or (epi == N.EPI_GELU and float((kw["aux_out"].double().cpu() - lin).norm() / lin.norm()) > 4e-3):
                 bad += 1

@@ -12,16 +12,17 @@ if model is None:
     import inspect
     model = inspect.unwrap(T.model)()
 lib = N.lib()
+from med_ts_llm_amd.hip import ops as ops_mod
 x, y = T._x(4), torch.randn(T.B, T.PRED, T.C, generator=torch.Generator().manual_seed(5)).cuda()
 
 
 def grads(cfg, prune):
-    lib.mtl_gemm_tune(1, *cfg)
+    ops_mod._TUNE["gemm"] = (2 if any(cfg) else 0,) + tuple(cfg)      # (reaches the Linear layers' GEMMs; the stack's own launches choose by themselves)
     model.prune_dead_prompt_grads = prune
     try:
         return T._grads(model, x, y)[1]
     finally:
-        lib.mtl_gemm_tune(1, 0, 0, 0, 0)
+        ops_mod._TUNE["gemm"] = (0, 0, 0, 0, 0)
         model.prune_dead_prompt_grads = True
 
 
