@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from helpers import hf_cfg, rel_err
+from helpers import LONGT_GRAD_FACTOR
 from test_gpu_model import _check_full_model, L3
 
 pytestmark = pytest.mark.gpu
@@ -27,7 +28,7 @@ def test_long_sequence_modes_vs_oracle(kind, task, B, L, C, pred, cov, prompt_on
     # gradient bar 2 x (instead of 1.5 x) the reference-mixed arithmetic's own error: the key / query projection gradients of the reprogramming
     # layer collect ~1800 query rows per sample against 64 shared prototypes here — the error ratio of two bf16 paths scatters between 0.8 and 2.0
     # from one tile configuration to the next (measured on this case: 1.58e-2 vs 7.9e-3 for key_projection.weight, bar 1.5e-2)
-    _check_full_model(kind, task, B, L, C, pred, cov, "linear", prompt_on, grad_bar=2.0)
+    _check_full_model(kind, task, B, L, C, pred, cov, "linear", prompt_on, grad_bar=LONGT_GRAD_FACTOR)
 
 
 @pytest.mark.parametrize("kind,T", [("llama_hd128", 3328), ("llama_gqa", 3328), ("llama_gqa_hd128", 1664), ("llama", 1664)])

@@ -8,7 +8,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import rel_err, hf_cfg, model_config, FakeDataset, fixture_tokenizer, oracle_mcfg, golden_loss, cancellation_checks
+from helpers import (rel_err, hf_cfg, model_config, FakeDataset, fixture_tokenizer, oracle_mcfg, golden_loss, cancellation_checks,
+                     MIXED_FACTOR, GRAD_FLOOR, EXACT_SUM, fwd_bar, grad_factor)
 
 pytestmark = pytest.mark.gpu
 BF16 = torch.bfloat16
@@ -81,7 +82,7 @@ def test_psm_shaped_anomaly_detection_vs_oracle():
     _check_full_model("llama", "anomaly_detection", 2, 512, 25, 512, "concat", "linear", True, d_model=32, d_ff=128, H=8, num_tokens=1024)
 
 
-def _check_full_model(kind, task, B, L, C, pred, cov, down, prompt_on, d_model=8, d_ff=64, H=2, num_tokens=64, grad_bar=1.5,
+def _check_full_model(kind, task, B, L, C, pred, cov, down, prompt_on, d_model=8, d_ff=64, H=2, num_tokens=64, grad_bar=MIXED_FACTOR,
                       hf=None, sd=None, prompting=None, descriptions=None, llm_layers=-1, dataset=None, pure_bf16=False):
     """hf / sd: a full backbone config + CPU fp32 state dict instead of the small helpers.hf_cfg(kind) one (tests/test_gpu_realwidth.py);
     prompting: the config's prompting table as shipped (overrides prompt_on); descriptions: per-sample clip descriptions (`clip` prompts).
@@ -158,7 +159,7 @@ def _check_full_model(kind, task, B, L, C, pred, cov, down, prompt_on, d_model=8
     with torch.autocast("cpu", dtype=torch.bfloat16):
         ref16 = O.medtsllm_forward(x, p16, sd, cfg, m, token_ids=tok_ids, pad_token_id=model.tokenizer.pad_token_id, training=True, **we_kw16)
     self_err = rel_err(ref16.float(), ref)
-    bar = 1.5 * max(self_err, 4e-3)
+    bar = fwd_bar(self_err)
     e = rel_err(pred_hip, ref)
     print(f"\n[{kind}/{cov}] pred: hip-vs-fp32 {e:.3e}  reference-mixed-vs-fp32 {self_err:.3e}")
     assert e < bar, (e, self_err)
@@ -176,10 +177,10 @@ def _check_full_model(kind, task, B, L, C, pred, cov, down, prompt_on, d_model=8
     loss = golden_loss(pred_hip, tgt.cuda().to(pred_hip.dtype) if (pure_bf16 and tgt.is_floating_point()) else tgt.cuda(), task)
     loss.backward()
     grads = {n: t.grad for n, t in model.named_parameters() if t.requires_grad}
-    exact, cond = cancellation_checks(tap, grads, 1e-2)
+    exact, cond = cancellation_checks(tap, grads, GRAD_FLOOR)
     for n, (e_abs, mass) in exact.items():      # sums with cancellation: exactly the fp64 reduction of the path's own upstream gradient
         # (bf16 parameters carry bf16 gradients: one more rounding of 2^-9 of each element, on the scale of the sum's L1 mass / sqrt(rows))
-        assert e_abs <= (4e-3 if pure_bf16 else 2e-5) * mass + 1e-9, ("exact", n, e_abs, mass)
+        assert e_abs <= (4e-3 if pure_bf16 else EXACT_SUM) * mass + 1e-9, ("exact", n, e_abs, mass)
     model.debug_tap = None
     bad = {}
     for n, t in model.named_parameters():
@@ -198,7 +199,7 @@ def _check_full_model(kind, task, B, L, C, pred, cov, down, prompt_on, d_model=8
         # and the ratio of two error samples scatters: 3 x, on the larger of the two scales. tests/test_gpu_golden.py bounds the
         # scatter the other way with an aggregate criterion over all gradients of a case.
         small = t.numel() < 4096
-        if e_hip > (3.0 if small else grad_bar) * max(e_ref, 1e-2, cond.get(n, 0.0) / scale if small else 0.0):
+        if e_hip > grad_factor(t.numel(), grad_bar) * max(e_ref, GRAD_FLOOR, cond.get(n, 0.0) / scale if small else 0.0):
             bad[n] = (e_hip, e_ref)
     assert not bad, bad
 

@@ -11,13 +11,15 @@ autocast (= the reference's dtype "mixed" arithmetic) on the same model, small t
     attention, the 16384 -> 4096 flatten head — on the metric-shaped [L = 1024, C = 12] windows;
   * Llama-3-8B width (GQA 32 / 8, ffn 14336, vocabulary 128 256 -> 100 000 TRAINABLE sub-sampled rows);
   * GPT-2-small at its full depth (12 layers of 768);
+  * BASELINE.json configs[3]'s PSM geometry (25 channels, L = 2048, the 1.68 G-parameter flatten head) and the `interleave` long-sequence mode
+    (T = 1536 + prompt: the 32-rows-per-wave forward attention, chunked backward) at the Llama-2-7B width;
   * the four shipped reference configurations at their own hyper-parameters (R:configs/datasets/ludb.toml:6-7,35-44,
     bidmc.toml:6-7,36-45, ecgmit-anom.toml, ecgmit-seg.toml; the toml files do not travel, the numbers are typed in), on the Llama-2-7B width.
 """
 import pytest
 import torch
 
-from helpers import FakeDataset
+from helpers import FakeDataset, LONGT_GRAD_FACTOR
 from test_gpu_model import _check_full_model
 
 pytestmark = pytest.mark.gpu
@@ -77,6 +79,21 @@ def test_shipped_reference_configuration_vs_oracle(name):
     _check_full_model("llama2_7b", task, B, L, C, L, cov, "linear", True, d_model=32, d_ff=d_ff, H=8, num_tokens=1024,
                       hf=LLAMA2_7B_2L, sd=_state("llama2", LLAMA2_7B_2L), prompting=prompting, descriptions=desc,
                       dataset=FakeDataset(C, 4 if task == "semantic_segmentation" else 0))
+
+
+def test_psm_geometry_llama2_7b_width_vs_oracle():
+    """BASELINE.json configs[3] geometry: PSM anomaly detection = reconstruction of 25-channel L = 2048 windows — concat width 25 * 32 = 800 (padded to 832 for
+    the query GEMM), P = 256 patch rows (T = 256 + prompt: the resident hd-128 attention no longer fits, the chunked / 32-row kernels run), and the
+    1.68 G-parameter flatten head (128 * 256 = 32768 -> 2048 * 25 = 51200: every fp32 tensor of it is > 2^31 bytes) with its gradient against the oracle's"""
+    _check_full_model("llama2_7b", "anomaly_detection", 2, 2048, 25, 2048, "concat", "linear", True, d_model=32, d_ff=128, H=8, num_tokens=1024,
+                      hf=LLAMA2_7B_2L, sd=_state("llama2", LLAMA2_7B_2L), prompting=SHIPPED_PROMPTS)
+
+
+def test_interleave_covariates_llama2_7b_width_vs_oracle():
+    """SURVEY 8f-4 at the real width: `interleave` covariates put every channel's patches into the LLM sequence — 12 * 128 = 1536 patch rows + the prompt:
+    the long-sequence attention kernels (32 query rows per wave forward, chunked backward, XCD-aware launch) inside the full model, B = 1"""
+    _check_full_model("llama2_7b", "semantic_segmentation", 1, 1024, 12, 1024, "interleave", "linear", True, d_model=32, d_ff=128, H=8, num_tokens=1024,
+                      hf=LLAMA2_7B_2L, sd=_state("llama2", LLAMA2_7B_2L), prompting=SHIPPED_PROMPTS, grad_bar=LONGT_GRAD_FACTOR)
 
 
 def test_llama3_8b_width_trainable_vocabulary_vs_oracle():
