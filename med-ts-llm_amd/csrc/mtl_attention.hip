@@ -901,6 +901,192 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_w32_kernel(
     if (hi == 0 && a.lse) a.lse[(b * a.Hq + h) * (a.stat_stride ? a.stat_stride : a.Tq) + qrow] = (m_run + __builtin_amdgcn_logf(l_run)) * LN2;
 }
 
+// ---- dQ of the long causal sequences in the same structure (32 query rows per wave, 32x32x16 MFMAs, double-buffered 64-key chunks).
+// Per 32-key tile: S^T = K Q^T and dP^T = V dO^T (two accumulator chains, alternating), p = exp2(s c - lse2), dS = p (dP - delta), and
+// dQ^T += K^T dS^T with the K^T fragments gathered from the SAME K tile (row stride D + 16: 2-way conflicts for both of its read shapes; a
+// second image of K would cost the second workgroup per CU). delta = dO . O is formed from the wave's own fragments and written for the dK/dV kernel.
+template <int NDB>
+__device__ __forceinline__ void store_grad_row_w32(bf16_t* dst, const f32x16 (&v)[NDB], float scale, int hi, const float* cos_row, const float* sin_row) {
+    // lane (query, hi): register 4 rg + e of block db = feature column 32 db + 8 rg + 4 hi + e; the rotary partner column + D/2 is block db + NDB/2
+    if (cos_row) {
+#pragma unroll
+        for (int db = 0; db < NDB / 2; ++db)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int col = db * 32 + rg * 8 + hi * 4;
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(cos_row + col), s4 = *reinterpret_cast<const f32x4*>(sin_row + col);
+                float y1[4], y2[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    rope_pair(bf16_to_f32(f32_to_bf16(v[db][4 * rg + e] * scale)), bf16_to_f32(f32_to_bf16(v[db + NDB / 2][4 * rg + e] * scale)), c4[e], -s4[e], y1[e], y2[e]);
+                *reinterpret_cast<u32x2*>(dst + col) = (u32x2){pack_bf16x2(y1[0], y1[1]), pack_bf16x2(y1[2], y1[3])};
+                *reinterpret_cast<u32x2*>(dst + col + NDB * 16) = (u32x2){pack_bf16x2(y2[0], y2[1]), pack_bf16x2(y2[2], y2[3])};
+            }
+        return;
+    }
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+            *reinterpret_cast<u32x2*>(dst + db * 32 + rg * 8 + hi * 4) =
+                (u32x2){pack_bf16x2(v[db][4 * rg] * scale, v[db][4 * rg + 1] * scale), pack_bf16x2(v[db][4 * rg + 2] * scale, v[db][4 * rg + 3] * scale)};
+}
+
+template <int D, int NW, bool XMAP = false>
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_w32_kernel(const mtl_attn_bwd_args a) {
+    constexpr int LDK = D + 16, LDV = D + 8, NKS = D / 16, NDB = D / 32, NT = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t* kbuf = reinterpret_cast<bf16_t*>(smem_raw);      // [2][KC * LDK]
+    bf16_t* vbuf = kbuf + 2 * KC * LDK;                      // [2][KC * LDV]
+    const mtl_attn_fwd_args& f = a.f;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31, hi = lane >> 5;
+    const AttnBlock blk = attn_block<XMAP>((f.Tq + NW * 32 - 1) / (NW * 32), f.Hq, f.B, true);
+    if (!blk.live) return;
+    const int64_t b = blk.b, h = blk.h, hk = h / (f.Hq / f.Hkv);
+    const int64_t qblk0 = blk.x * (NW * 32);
+    const int64_t q0 = qblk0 + wave * 32;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(f.q) + b * f.q_bs + h * f.q_hs;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(f.k) + b * f.k_bs + hk * f.k_hs;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(f.v) + b * f.v_bs + hk * f.v_hs;
+    const bf16_t* O = reinterpret_cast<const bf16_t*>(f.o) + b * f.o_bs + h * f.o_hs;
+    const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dout) + b * a.do_bs + h * a.do_hs;
+
+    int64_t qrow = q0 + l31;
+    const bool q_valid = qrow < f.Tq;
+    if (qrow > f.Tq - 1) qrow = f.Tq - 1;
+    bf16x8 qf[NKS], dof[NKS];
+    float dl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        qf[ks] = *reinterpret_cast<const bf16x8*>(Q + qrow * f.q_ts + ks * 16 + hi * 8);
+        frag8 d8, o8;
+        d8.v = *reinterpret_cast<const bf16x8*>(dO + qrow * a.do_ts + ks * 16 + hi * 8);
+        o8.v = *reinterpret_cast<const bf16x8*>(O + qrow * f.o_ts + ks * 16 + hi * 8);
+        dof[ks] = d8.v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dl += __uint_as_float(d8.u[e] << 16) * __uint_as_float(o8.u[e] << 16);
+            dl += __uint_as_float(d8.u[e] & 0xffff0000u) * __uint_as_float(o8.u[e] & 0xffff0000u);
+        }
+    }
+    dl = halves_sum(dl);                                    // delta = dO . O over the whole row (the two lane halves hold disjoint columns)
+    const int64_t stat_idx = (b * f.Hq + h) * (f.stat_stride ? f.stat_stride : f.Tq) + qrow;
+    const float c = f.scale * LOG2E;
+    const float lse2 = f.lse[stat_idx] * LOG2E;             // exp(s * scale - lse) == exp2(s * c - lse2)
+    if (hi == 0 && q_valid) a.delta[stat_idx] = dl;
+
+    f32x16 dq[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+
+    const int64_t coff = f.causal_off;
+    const int klim = (int)((qrow + coff < f.Tk - 1) ? qrow + coff : f.Tk - 1);   // last visible key of the lane's query
+    int64_t k_end = f.Tk;
+    {
+        const int64_t lim = (qblk0 + NW * 32 < f.Tq ? qblk0 + NW * 32 : f.Tq) + coff;
+        k_end = lim < f.Tk ? lim : f.Tk;
+    }
+    const int64_t wave_qmin = q0 + coff;
+    const int64_t wave_qmax = ((q0 + 31 < f.Tq - 1) ? q0 + 31 : f.Tq - 1) + coff;
+    const bool wave_live = q0 < f.Tq;
+
+    TileRegs<D, NT> rk, rv;
+    TilePtrs<D, NT> pk, pv;
+    tile_ptrs<D, NT>(pk, K, f.k_ts);
+    tile_ptrs<D, NT>(pv, V, f.v_ts);
+    fetch_tile_at<D, NT>(rk, pk, K, f.k_ts, 0, f.Tk);
+    fetch_tile_at<D, NT>(rv, pv, V, f.v_ts, 0, f.Tk);
+    stash_tile_ld<D, NT, LDK>(kbuf, rk);
+    stash_tile_ld<D, NT, LDV>(vbuf, rv);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));      // landed (see attn_fwd_w32_kernel)
+    if (KC < k_end) {
+        fetch_tile_at<D, NT>(rk, pk, K, f.k_ts, KC, f.Tk);
+        fetch_tile_at<D, NT>(rv, pv, V, f.v_ts, KC, f.Tk);
+    }
+    int cur = 0;
+    for (int64_t kc0 = 0; kc0 < k_end; kc0 += KC, cur ^= 1) {
+        __syncthreads();
+        if (kc0 + KC < k_end) {
+            stash_tile_ld<D, NT, LDK>(kbuf + (cur ^ 1) * KC * LDK, rk);
+            stash_tile_ld<D, NT, LDV>(vbuf + (cur ^ 1) * KC * LDV, rv);
+            if (kc0 + 2 * KC < k_end) {
+                fetch_tile_at<D, NT>(rk, pk, K, f.k_ts, kc0 + 2 * KC, f.Tk);
+                fetch_tile_at<D, NT>(rv, pv, V, f.v_ts, kc0 + 2 * KC, f.Tk);
+            }
+        }
+        if (!wave_live || kc0 > wave_qmax) continue;
+        const bf16_t* kt = kbuf + cur * KC * LDK;
+        const bf16_t* vt = vbuf + cur * KC * LDV;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int64_t kb = kc0 + t * 32;
+            if (kb >= k_end || kb > wave_qmax) continue;       // (wave-uniform)
+            // ---- S^T (chain 0) and dP^T (chain 1) of the tile: fragments of K and V rows alternate through one ring, three units ahead
+            f32x16 sd[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sd[0][r] = 0.f; sd[1][r] = 0.f; }
+            {
+                const bf16_t* kr = kt + (t * 32 + l31) * LDK + hi * 8;
+                const bf16_t* vr = vt + (t * 32 + l31) * LDV + hi * 8;
+                constexpr int RING = 4, A = RING - 1;
+                bf16x8 fr[RING];
+#pragma unroll
+                for (int i = 0; i < A; ++i) fr[i] = *reinterpret_cast<const bf16x8*>(((i & 1) ? vr : kr) + (i >> 1) * 16);
+#pragma unroll
+                for (int i = 0; i < 2 * NKS; ++i) {          // i = 2 ks + which (0: K row x Q, 1: V row x dO)
+                    if (i + A < 2 * NKS) fr[(i + A) % RING] = *reinterpret_cast<const bf16x8*>((((i + A) & 1) ? vr : kr) + ((i + A) >> 1) * 16);
+                    sd[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % RING], (i & 1) ? dof[i >> 1] : qf[i >> 1], sd[i & 1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // ---- dS = p (dP - delta): this lane's 16 keys of the tile, key(r) = kb + (r & 3) + 8 (r >> 2) + 4 hi
+            const bool need_mask = (kb + 32 > f.Tk) || (kb + 31 > wave_qmin);
+            float ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sd[0][r], c, -lse2));
+                if (need_mask && (int)kb + (r & 3) + 8 * (r >> 2) + 4 * hi > klim) p = 0.f;
+                ds[r] = p * (sd[1][r] - dl);
+            }
+            bf16x8 dsf[2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                frag8 fpk;
+                fpk.u = (u32x4){pack_bf16x2(ds[8 * cb + 0], ds[8 * cb + 1]), pack_bf16x2(ds[8 * cb + 2], ds[8 * cb + 3]),
+                                pack_bf16x2(ds[8 * cb + 4], ds[8 * cb + 5]), pack_bf16x2(ds[8 * cb + 6], ds[8 * cb + 7])};
+                dsf[cb] = fpk.v;
+            }
+            // ---- dQ^T += K^T dS^T: unit i = cb * NDB + db, K^T fragments gathered three units ahead
+            {
+                const bf16_t* kg = kt + (t * 32 + 4 * hi + ((lane & 15) >> 2)) * LDK + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+                auto kfrag = [&](int i) __attribute__((always_inline)) {
+                    const bf16_t* p = kg + (i / NDB) * 16 * LDK + (i % NDB) * 32;
+                    union { bf16x8 v; s16x4 h[2]; } fu;
+                    fu.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+                    fu.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 8 * LDK));
+                    return fu.v;
+                };
+                constexpr int RING = 4, A = RING - 1;
+                bf16x8 kf[RING];
+#pragma unroll
+                for (int i = 0; i < A; ++i) kf[i] = kfrag(i);
+#pragma unroll
+                for (int i = 0; i < 2 * NDB; ++i) {
+                    if (i + A < 2 * NDB) kf[(i + A) % RING] = kfrag(i + A);
+                    dq[i % NDB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % RING], dsf[i / NDB], dq[i % NDB], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    if (!q_valid) return;
+    bf16_t* DQ = reinterpret_cast<bf16_t*>(a.dq) + b * a.dq_bs + h * a.dq_hs + qrow * a.dq_ts;
+    store_grad_row_w32<NDB>(DQ, dq, f.scale, hi, a.rope_cos ? a.rope_cos + (qrow + coff) * D : nullptr, a.rope_cos ? a.rope_sin + (qrow + coff) * D : nullptr);
+}
+
 // =============================================================================================== resident variants
 // Causal self-attention of the backbone at T <= 256..512: the whole K and V of one (batch, head) fit in LDS, so a
 // workgroup pays the global-load latency ONCE, synchronises once, and every wave then streams through the keys with no
@@ -1779,15 +1965,26 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
         const dim3 gq8((unsigned)((f.Tq + 127) / 128), (unsigned)f.Hq, (unsigned)f.B), gk8((unsigned)((f.Tk - a->kv_row0 + 127) / 128), (unsigned)f.Hkv, (unsigned)f.B), block8(512);
         const bool wide_kv = f.Tk - a->kv_row0 >= 512;
         const dim3 gk4((unsigned)((f.Tk - a->kv_row0 + 63) / 64), (unsigned)f.Hkv, (unsigned)f.B);
+        // dQ on the 32-rows-per-wave kernel (4 waves = 128 queries per workgroup) from 512 query rows on: -7 % at T = 1664 (843 -> 782 us, hd 128), -4 % at
+        // T = 3328; at the PSM shape (Tq = 256 of T = 384) the 16-row kernel is faster (125 vs 132 us) and stays
+        const bool dq_w32 = g_attn_w32 == 1 && g_attn_xmap && f.Tq >= 512;
+        if (dq_w32) {
+            const size_t lds = (size_t)2 * KC * ((f.D + 16) + (f.D + 8)) * 2;
+            static std::once_flag once;
+            std::call_once(once, [&] { set_lds(attn_bwd_dq_w32_kernel<64, 4, true>, kLdsBudget); set_lds(attn_bwd_dq_w32_kernel<128, 4, true>, kLdsBudget); });
+            const dim3 xq(attn_xmap_grid((f.Tq + 127) / 128, f.Hq, f.B));
+            if (f.D == 64) MTL_LAUNCH("attn_bwd_dq_w32_kernel<64, 4>", fl_half, 0, (attn_bwd_dq_w32_kernel<64, 4, true>), xq, dim3(256), lds, st, *a);
+            else MTL_LAUNCH("attn_bwd_dq_w32_kernel<128, 4>", fl_half, 0, (attn_bwd_dq_w32_kernel<128, 4, true>), xq, dim3(256), lds, st, *a);
+        }
         if (g_attn_xmap) {      // XCD-aware 1-D grids (attn_block): a head's row blocks share one L2
             const dim3 xq(attn_xmap_grid((f.Tq + 127) / 128, f.Hq, f.B)), xk8(attn_xmap_grid((f.Tk - a->kv_row0 + 127) / 128, f.Hkv, f.B)),
                        xk4(attn_xmap_grid((f.Tk - a->kv_row0 + 63) / 64, f.Hkv, f.B));
             if (f.D == 64) {
-                MTL_LAUNCH("attn_bwd_dq_kernel<64, true, false, 8>", fl_half, 0, (attn_bwd_dq_kernel<64, true, false, 8, true>), xq, block8, 0, st, *a);
+                if (!dq_w32) MTL_LAUNCH("attn_bwd_dq_kernel<64, true, false, 8>", fl_half, 0, (attn_bwd_dq_kernel<64, true, false, 8, true>), xq, block8, 0, st, *a);
                 if (wide_kv) MTL_LAUNCH("attn_bwd_dkv_kernel<64, true, false, 8>", fl_half, 0, (attn_bwd_dkv_kernel<64, true, false, 8, true>), xk8, block8, 0, st, *a);
                 else MTL_LAUNCH("attn_bwd_dkv_kernel<64, true, false>", fl_half, 0, (attn_bwd_dkv_kernel<64, true, false, 4, true>), xk4, dim3(256), 0, st, *a);
             } else {
-                MTL_LAUNCH("attn_bwd_dq_kernel<128, true, false, 8>", fl_half, 0, (attn_bwd_dq_kernel<128, true, false, 8, true>), xq, block8, 0, st, *a);
+                if (!dq_w32) MTL_LAUNCH("attn_bwd_dq_kernel<128, true, false, 8>", fl_half, 0, (attn_bwd_dq_kernel<128, true, false, 8, true>), xq, block8, 0, st, *a);
                 if (wide_kv) MTL_LAUNCH("attn_bwd_dkv_kernel<128, true, false, 8>", fl_half, 0, (attn_bwd_dkv_kernel<128, true, false, 8, true>), xk8, block8, 0, st, *a);
                 else MTL_LAUNCH("attn_bwd_dkv_kernel<128, true, false>", fl_half, 0, (attn_bwd_dkv_kernel<128, true, false, 4, true>), xk4, dim3(256), 0, st, *a);
             }
