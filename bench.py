@@ -731,7 +731,8 @@ def main():
     t_start = time.perf_counter()
 
     def stage(msg):
-        print(f"[bench +{time.perf_counter() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
+        if os.environ.get("RANK", "0") == "0":       # (progress notes: rank 0 only, stderr only)
+            print(f"[bench +{time.perf_counter() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_spawn(args)
