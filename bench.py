@@ -718,6 +718,7 @@ def main():
     ap.add_argument("--dp-plumbing", action="store_true", help="N = 1 only: run the step with the DP machinery live in a one-rank RCCL group")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC table only (no rocprofv3 child passes)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the Llama-2-7B summaries that the default run attaches as configs[]")
+    ap.add_argument("--extra-configs-dp", action="store_true", help="attach the extra configs under --gpus N > 1 as well (default: N = 1 only)")
     ap.add_argument("--full-detail", action="store_true", help="also: CPU baselines of the extra configs (extrapolated Llama figures, BASELINE.json configs[0]), "
                                                                "trainer-loop and predict legs of every config (the default run keeps to ~1 min)")
     ap.add_argument("--full-backward", action="store_true", help="also compute the (unused) prompt-row input gradients")
@@ -775,22 +776,32 @@ def main():
     full = args.full_detail
     stage(f"start {args.workload}")
     out = run_workload(args.workload, args, ctx, args.steps, args.warmup, not args.no_cpu_baseline, not args.no_roofline, legs=True, stage=stage)
-    if args.workload == "gpt2s_B32_L1024_C12" and not args.no_extra_configs:
-        # BASELINE.json configs[2] (LUDB-shaped semantic segmentation on a frozen Llama-2-7B) on the same GPUs, right after the headline
-        # workload's timed region: the configuration where the backbone GEMMs are large enough for the >= 40 % MFMA target
-        stage("start llama2_7b_semseg_B32_L1024_C12")
-        extra = run_workload("llama2_7b_semseg_B32_L1024_C12", args, ctx, steps=5, warmup=2, want_cpu=full and not args.no_cpu_baseline,
-                             want_roofline=not args.no_roofline, legs=full, stage=stage)
-        if rank == 0:
-            extra["metric"] = "samples/sec ([B, 1024, 12] windows, Llama-2-7B frozen backbone) through MedTsLLM fwd+bwd"
-            out["configs"] = [extra]
-        # the same backbone with interleave covariates -> T = 1664 per sample (flash attention regime)
-        stage("start llama2_7b_semseg_interleave_B16_L1024_C12")
-        extra2 = run_workload("llama2_7b_semseg_interleave_B16_L1024_C12", args, ctx, steps=3, warmup=2, want_cpu=full and not args.no_cpu_baseline,
-                              want_roofline=not args.no_roofline, legs=full, stage=stage)
-        if rank == 0:
-            extra2["metric"] = "samples/sec ([B, 1024, 12] windows, interleave covariates: T = 1664, Llama-2-7B frozen backbone) through MedTsLLM fwd+bwd"
-            out["configs"].append(extra2)
+    # Extra configs ride on the N = 1 run only: at N > 1 the line is the scaling record of the headline workload — every additional model under DP
+    # is more first-contact RCCL surface that could take the headline down with it (--extra-configs-dp asks for them anyway). Each extra is
+    # fenced: a failure there is reported in the line's place, never instead of the headline.
+    if args.workload == "gpt2s_B32_L1024_C12" and not args.no_extra_configs and (world == 1 or args.extra_configs_dp):
+        extras = [
+            # BASELINE.json configs[2] (LUDB-shaped semantic segmentation on a frozen Llama-2-7B): the configuration where the backbone GEMMs are
+            # large enough for the >= 40 % MFMA target
+            ("llama2_7b_semseg_B32_L1024_C12", 5, 2, "samples/sec ([B, 1024, 12] windows, Llama-2-7B frozen backbone) through MedTsLLM fwd+bwd"),
+            # the same backbone with interleave covariates -> T = 1664 per sample (flash attention regime)
+            ("llama2_7b_semseg_interleave_B16_L1024_C12", 3, 2,
+             "samples/sec ([B, 1024, 12] windows, interleave covariates: T = 1664, Llama-2-7B frozen backbone) through MedTsLLM fwd+bwd"),
+        ]
+        for wl, n_steps, n_warm, metric in extras:
+            stage(f"start {wl}")
+            try:
+                extra = run_workload(wl, args, ctx, steps=n_steps, warmup=n_warm, want_cpu=full and not args.no_cpu_baseline,
+                                     want_roofline=not args.no_roofline, legs=full, stage=stage)
+            except Exception as e:      # noqa: BLE001 — the headline is already measured: keep it
+                if world > 1:
+                    raise               # (a rank that stops taking part in collectives would hang the others: fail the run loudly instead)
+                stage(f"{wl} FAILED: {type(e).__name__}: {e}")
+                torch.cuda.empty_cache()
+                continue
+            if rank == 0:
+                extra["metric"] = metric
+                out.setdefault("configs", []).append(extra)
     if rank == 0 and out:
         out["rccl_ranks"], out["dp_mode"] = rccl_ranks, dp_mode
         committed = f"committed table profiles/pmc_traffic_<workload>.json (separate rocprofv3 --pmc passes of the same kernel sources, csrc_sha16 {csrc_sha16()})"
