@@ -507,7 +507,8 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 && NW == 4) ? 2 : 1) void attn_b
     constexpr int LDT = D + attn_pad(D), NKS = D / 32, NDT = D / 16;
     __shared__ __attribute__((aligned(16))) bf16_t qtile[KC * LDT];
     __shared__ __attribute__((aligned(16))) bf16_t dotile[KC * LDT];
-    __shared__ float lse_s[KC], delta_s[KC];
+    __shared__ __attribute__((aligned(16))) float lse_s[KC];
+    __shared__ __attribute__((aligned(16))) float delta_s[KC];
     const mtl_attn_fwd_args& f = a.f;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, g = lane >> 4;   // (wave index in an SGPR: tile offsets, loop bounds and the mask test become scalar)
     // (XMAP: 1-D launch, per-sample K / V only — a key block's workgroups of one kv head stay on one XCD, whose L2 then holds that head's Q / dO)
@@ -609,16 +610,21 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 && NW == 4) ? 2 : 1) void attn_b
                                 for (int r = 0; r < 4; ++r) fld[r] = drop_field(drop_quad(dbase_h, a0 + r, (uint32_t)krow >> 2), (uint32_t)krow);
                             }
                         }
+                        // the lane's four queries' statistics in two 16-byte reads, the exponential UNCONDITIONAL and a select afterwards: with the LDS
+                        // reads inside the conditional hipcc emitted a BRANCH per element (two ds_read_b32 + an lgkmcnt(0) wait each: eight serialized
+                        // LDS round trips per slab between the MFMA groups)
+                        const int ql0 = sub * 32 + t * 16 + g * 4;
+                        const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_s + ql0), dl4 = *reinterpret_cast<const f32x4*>(delta_s + ql0);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int ql = sub * 32 + t * 16 + g * 4 + r;
-                            const int q = (int)qc0 + ql;
+                            const int q = (int)qc0 + ql0 + r;
                             const bool masked = q > qhi || q < qlo;
-                            const float pv = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse_s[ql]);
+                            const float e = __builtin_amdgcn_exp2f(s[r] * c - lse4[r]);
+                            const float pv = masked ? 0.f : e;
                             float keep = 1.0f;
                             if (DROP) keep = fld[r] >= drop_thr ? drop_scale : 0.f;
                             p[t][r] = pv * keep;                               // feeds dV = (dropped P)^T dO
-                            ds[t][r] = pv * (dp[r] * keep - delta_s[ql]);      // feeds dK
+                            ds[t][r] = pv * (dp[r] * keep - dl4[r]);           // feeds dK
                         }
                     }
                     const bf16x8 pf = pack8(p[0], p[1]);
@@ -1481,15 +1487,19 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 && !DROP) ? 2 : 1) void attn_bwd
                             for (int r = 0; r < 4; ++r) fld[r] = drop_field(drop_quad(dbase_h, a0 + r, (uint32_t)krow >> 2), (uint32_t)krow);
                         }
                     }
+                    // (statistics as two 16-byte reads, unconditional exponential + select: see attn_bwd_dkv_kernel)
+                    const int q0 = (int)qb + t * 16 + g * 4;
+                    const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_s + q0), dl4 = *reinterpret_cast<const f32x4*>(delta_s + q0);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int q = (int)qb + t * 16 + g * 4 + r;
+                        const int q = q0 + r;
                         const bool masked = q > qhi || q < qlo;
-                        const float pv = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c - lse_s[q]);
+                        const float e = __builtin_amdgcn_exp2f(s[r] * c - lse4[r]);
+                        const float pv = masked ? 0.f : e;
                         float keep = 1.0f;
                         if (DROP) keep = fld[r] >= drop_thr ? drop_scale : 0.f;
                         p[t][r] = pv * keep;                               // feeds dV = (dropped P)^T dO
-                        ds[t][r] = pv * (dp[r] * keep - delta_s[q]);       // feeds dK
+                        ds[t][r] = pv * (dp[r] * keep - dl4[r]);           // feeds dK
                     }
                 }
                 const bf16x8 pf = pack8(p[0], p[1]);
@@ -1717,15 +1727,18 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_res_merged_kernel(const mtl_
                         for (int r = 0; r < 4; ++r) fld[r] = drop_field(drop_quad(dbase, a0 + r, (uint32_t)krow >> 2), (uint32_t)krow);
                     }
                 }
+                const int q0 = (int)qb + t * 16 + g * 4;
+                const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_s + q0), dl4 = *reinterpret_cast<const f32x4*>(delta_s + q0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int q = (int)qb + t * 16 + g * 4 + r;
+                    const int q = q0 + r;
                     const bool masked = q > qhi || q < qlo;
-                    const float pv = masked ? 0.f : __builtin_amdgcn_exp2f(sv[r] * c - lse_s[q]);
+                    const float e = __builtin_amdgcn_exp2f(sv[r] * c - lse4[r]);
+                    const float pv = masked ? 0.f : e;
                     float keep = 1.0f;
                     if (DROP) keep = fld[r] >= drop_thr ? drop_scale : 0.f;
                     p[t][r] = pv * keep;
-                    ds[t][r] = pv * (dp[r] * keep - delta_s[q]);
+                    ds[t][r] = pv * (dp[r] * keep - dl4[r]);
                 }
             }
             const bf16x8 pf = pack8(p[0], p[1]);
