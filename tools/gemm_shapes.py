@@ -13,12 +13,14 @@ def main():
     wl = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "gpt2s_B32_L1024_C12"
     extra = [a for a in sys.argv[1:] if a != wl]
     env = dict(os.environ, MTL_PROF_SHAPES="1")
+    import tempfile
+    detail = os.path.join(tempfile.mkdtemp(prefix="mtl_shapes_", dir="/tmp"), "detail.json")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--steps", "5", "--warmup", "3", "--no-cpu-baseline",
-                          "--no-extra-configs"] + extra, env=env, capture_output=True, text=True)
-    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    if not line:
+                          "--no-extra-configs", "--no-live-traffic", "--detail-file", detail] + extra, env=env, capture_output=True, text=True)
+    if not os.path.exists(detail):      # (the stdout line is the compact one; the kernel instances live in the detail record)
         sys.exit(out.stdout + out.stderr)
-    d = json.loads(line[-1])
+    with open(detail) as f:
+        d = json.load(f)
     print(f"# {wl}: {d['value']:.1f} {d['unit']}, {d['ms_per_step']:.3f} ms/step; per profiled step ({d.get('profiled_steps', '?')} steps)")
     steps = d.get("profiled_steps") or 5
     tot = 0.0
