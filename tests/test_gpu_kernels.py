@@ -213,6 +213,45 @@ def test_attention_backward_fused_inverse_rope(ops, B, T, H, Hkv, D, resident):
     assert not torch.equal(dq1, dq0)
 
 
+@pytest.mark.parametrize("B,T,Tq,Hq,Hkv,D", [(1, 700, 700, 2, 2, 128), (2, 1000, 870, 4, 2, 64), (1, 1664, 1536, 2, 1, 128), (1, 515, 515, 2, 2, 64)])
+def test_attention_long_causal_ragged(ops, B, T, Tq, Hq, Hkv, D):
+    """the long-sequence kernels (32 query rows per wave on 32x32x16 MFMAs for the forward and dQ, chunked dK / dV, XCD-aware 1-D launch) on shapes that
+    are NOT multiples of their 128-row workgroups / 64-key chunks, with the queries being the LAST Tq rows of a T-key sequence (prompt-row cache,
+    pruned backward: causal_off = kv_row0 = T - Tq), MHA and GQA, hd 64 / 128 — against fp32 math; and the inverse rotary embedding fused into the dQ / dK
+    store epilogues == mtl_rope_inplace(inverse) on the plain gradients, bit for bit"""
+    off = T - Tq
+    q = torch.randn(B, Tq, Hq * D, generator=g(1)).to(BF16)
+    k = torch.randn(B, T, Hkv * D, generator=g(2)).to(BF16)
+    v = torch.randn(B, T, Hkv * D, generator=g(3)).to(BF16)
+    do = torch.randn(B, Tq, Hq * D, generator=g(4)).to(BF16)
+    scale = 1.0 / math.sqrt(D)
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    qh = qf.view(B, Tq, Hq, D).transpose(1, 2)
+    kh = kf.view(B, T, Hkv, D).transpose(1, 2).repeat_interleave(Hq // Hkv, dim=1)
+    vh = vf.view(B, T, Hkv, D).transpose(1, 2).repeat_interleave(Hq // Hkv, dim=1)
+    sc = (qh @ kh.transpose(-1, -2)) * scale
+    vis = torch.arange(T)[None, :] <= (torch.arange(Tq)[:, None] + off)          # key k visible to query i iff k <= i + off
+    ref = (torch.softmax(sc.masked_fill(~vis, float("-inf")), dim=-1) @ vh).transpose(1, 2).reshape(B, Tq, Hq * D)
+    ref.backward(do.float())
+    o, lse = ops.attention_fwd(dev(q), dev(k), dev(v), Hq, Hkv, D, scale, True, causal_off=off)
+    assert rel_err(o.float(), ref) < TOL_ATTN_FWD
+    lse_ref = torch.logsumexp(sc.masked_fill(~vis, float("-inf")), dim=-1)
+    assert rel_err(lse, lse_ref) < 1e-4
+    dq, dk, dv = ops.attention_bwd(dev(q), dev(k), dev(v), o, lse, dev(do), Hq, Hkv, D, scale, True, causal_off=off, kv_row0=off)
+    assert rel_err(dq.float(), qf.grad) < TOL_ATTN_BWD
+    assert rel_err(dk.float()[:, off:], kf.grad[:, off:]) < TOL_ATTN_BWD and rel_err(dv.float()[:, off:], vf.grad[:, off:]) < TOL_ATTN_BWD
+    # fused inverse RoPE (query row i sits at position i + off, key row j at position j)
+    pos = torch.arange(T).float()[:, None]
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+    ang = torch.cat([pos * inv, pos * inv], dim=1)
+    cos, sin = ang.cos().contiguous().cuda(), ang.sin().contiguous().cuda()
+    dq1, dk1, dv1 = ops.attention_bwd(dev(q), dev(k), dev(v), o, lse, dev(do), Hq, Hkv, D, scale, True, causal_off=off, kv_row0=off, rope=(cos, sin))
+    want_q = ops.rope_inplace(dq.reshape(B * Tq, Hq * D).clone(), cos[off:].contiguous(), sin[off:].contiguous(), Tq, Hq, D, inverse=True).view_as(dq)
+    want_k = ops.rope_inplace(dk.reshape(B * T, Hkv * D).clone(), cos, sin, T, Hkv, D, inverse=True).view_as(dk)
+    assert torch.equal(dq1, want_q)
+    assert torch.equal(dk1[:, off:], want_k[:, off:]) and torch.equal(dv1[:, off:], dv[:, off:])
+
+
 def test_attention_fused_qkv_views(ops):
     """strided q/k/v views into one fused [B,T,(Hq+2Hkv)*D] buffer, as the backbone uses them"""
     B, T, Hq, Hkv, D = 2, 80, 4, 2, 64
