@@ -1,14 +1,15 @@
 """The REAL reference at the widths it is run at: tests/golden/rw_*.{npz,json} were captured by importing /root/reference
-(tests/golden/make_realwidth_golden.py) with a GPT-2-small-width and a Llama-2-7B-width backbone (two layers each), on the metric workload's
+(tests/golden/make_realwidth_golden.py) with a GPT-2-small-width, a Llama-2-7B-width and a Llama-3-8B-width backbone (two layers each), on the metric workload's
 window geometry ([L = 1024, C = 12], d_model 32, d_ff 128, 8 heads, 1024 prototypes, dataset + task prompt). Every weight is formula-generated
 (helpers.rw_backbone_state / rw_trainable_values — the generator imported the same functions), so the fixtures hold inputs, expected outputs,
 sampled stage tensors and gradient summaries only.
 
 Until round 4 the real-width comparisons (tests/test_gpu_realwidth.py) were HIP vs the ORACLE, and the oracle itself was pinned to the reference
 only at d_llm 128: these tests close that gap.
-  * CPU suite: the oracle against the reference at both widths (fp32, <= 2e-5 — the L1 rung of SURVEY.md 8c);
-  * GPU suite: the HIP path against the reference at both widths (bar = 1.5 x the reference's own bf16-autocast deviation, exactly as
-    tests/test_gpu_golden.py).
+  * CPU suite: the oracle against the reference at GPT-2-small and Llama-2-7B width (fp32, <= 2e-5 — the L1 rung of SURVEY.md 8c);
+  * GPU suite: the HIP path against the reference at all three widths (bar = 1.5 x the reference's own bf16-autocast deviation, exactly as
+    tests/test_gpu_golden.py), and the oracle against the Llama-3-8B-width fixture (GQA, vocabulary 128 256 -> 100 000 trainable rows) on the
+    GPU box's host cores (12 GB, minutes: too large for the CPU suite).
 """
 import numpy as np
 import pytest
@@ -34,13 +35,14 @@ def _oracle_vs_reference(name):
     assert rel_err(mean, data["revin_mean"]) < 1e-6 and rel_err(stdev, data["revin_stdev"]) < 1e-6
     pe = O.patch_embed(O.revin_norm(x, mean, stdev), p["patch_embedding.value_embedding.tokenConv.weight"], meta["patch_len"], meta["stride"])
     assert rel_err(_sample(meta, "patch_embed_out", pe), data["patch_embed_out"]) < TOL
+    we_kw = {"word_emb": p["word_embeddings"]} if "word_embeddings" in p else {}        # trainable table (vocabulary > 100 000)
     pred, inter = O.medtsllm_forward(x, p, backbone, bcfg, m, token_ids=meta["prompt_token_ids"], pad_token_id=meta["pad_token_id"],
-                                     training=True, return_intermediates=True)
+                                     training=True, return_intermediates=True, **we_kw)
     assert inter["llm_inputs_embeds"].shape[1] == meta["T"]
     assert rel_err(_sample(meta, "llm_inputs_embeds", inter["llm_inputs_embeds"]), data["llm_inputs_embeds"]) < TOL
     with torch.no_grad():
         last = O.backbone_forward(inter["llm_inputs_embeds"], backbone, bcfg)[:, -meta["n_patches"]:, :]
-        src = O.source_embeddings(O.word_embeddings_of(backbone, bcfg), p["mapping_layer.weight"], p["mapping_layer.bias"])
+        src = O.source_embeddings(p["word_embeddings"] if we_kw else O.word_embeddings_of(backbone, bcfg), p["mapping_layer.weight"], p["mapping_layer.bias"])
     assert rel_err(_sample(meta, "llm_last_hidden", last), data["llm_last_hidden"]) < TOL
     assert rel_err(_sample(meta, "source_embeddings", src), data["source_embeddings"]) < TOL
     assert rel_err(_sample(meta, "pred_train", pred), data["pred_train"]) < TOL
@@ -64,7 +66,7 @@ def _oracle_vs_reference(name):
             n_checked += 1
     assert n_checked == len(p)
     with torch.no_grad():
-        pe_eval = O.medtsllm_forward(x, p, backbone, bcfg, m, token_ids=meta["prompt_token_ids"], pad_token_id=meta["pad_token_id"], training=False)
+        pe_eval = O.medtsllm_forward(x, p, backbone, bcfg, m, token_ids=meta["prompt_token_ids"], pad_token_id=meta["pad_token_id"], training=False, **we_kw)
     assert rel_err(pe_eval, data["pred_eval"]) < TOL
 
 
@@ -75,6 +77,13 @@ def test_oracle_vs_reference_gpt2_small_width():
 def test_oracle_vs_reference_llama2_7b_width():
     """0.54 G backbone weights + a [1024, 32000] mapping layer in fp32 on the host: ~1 min, ~6 GB"""
     _oracle_vs_reference("llama2_7b_2l_semseg")
+
+
+@pytest.mark.gpu
+def test_oracle_vs_reference_llama3_8b_width():
+    """GQA 32 / 8, ffn 14336, vocabulary 128 256 -> 100 000 TRAINABLE rows: 1.1 G fp32 numbers with their gradients, ~3 min on host cores — on the
+    GPU box's host for its size only (no device code runs)"""
+    _oracle_vs_reference("llama3_8b_2l_recon")
 
 
 @pytest.mark.gpu
