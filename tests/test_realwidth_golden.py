@@ -1,21 +1,21 @@
 """The REAL reference at the widths it is run at: tests/golden/rw_*.{npz,json} were captured by importing /root/reference
-(tests/golden/make_realwidth_golden.py) with a GPT-2-small-width, a Llama-2-7B-width and a Llama-3-8B-width backbone (two layers each), on the metric workload's
-window geometry ([L = 1024, C = 12], d_model 32, d_ff 128, 8 heads, 1024 prototypes, dataset + task prompt). Every weight is formula-generated
+(tests/golden/make_realwidth_golden.py) with a GPT-2-small-width (two layers, and the full 12), a Llama-2-7B-width and a Llama-3-8B-width backbone (two
+layers each), on the metric workload's window geometry ([L = 1024, C = 12], d_model 32, d_ff 128, 8 heads, 1024 prototypes, dataset + task prompt) plus
+`independent` / `add` / `weighted-average` covariates, the `truncate` down-sample, input-statistics prompts and the segmentation / reconstruction heads. Every weight is formula-generated
 (helpers.rw_backbone_state / rw_trainable_values — the generator imported the same functions), so the fixtures hold inputs, expected outputs,
 sampled stage tensors and gradient summaries only.
 
 Until round 4 the real-width comparisons (tests/test_gpu_realwidth.py) were HIP vs the ORACLE, and the oracle itself was pinned to the reference
 only at d_llm 128: these tests close that gap.
-  * CPU suite: the oracle against the reference at GPT-2-small and Llama-2-7B width (fp32, <= 2e-5 — the L1 rung of SURVEY.md 8c);
-  * GPU suite: the HIP path against the reference at all three widths (bar = 1.5 x the reference's own bf16-autocast deviation, exactly as
-    tests/test_gpu_golden.py), and the oracle against the Llama-3-8B-width fixture (GQA, vocabulary 128 256 -> 100 000 trainable rows) on the
-    GPU box's host cores (12 GB, minutes: too large for the CPU suite).
+  * CPU suite: the oracle against the reference on five of the seven fixtures (fp32, <= 2e-5 — the L1 rung of SURVEY.md 8c);
+  * GPU suite: the HIP path against the reference on all seven (bar = 1.5 x the reference's own bf16-autocast deviation, exactly as
+    tests/test_gpu_golden.py), and the oracle against the two largest fixtures on the GPU box's host cores (6 - 12 GB, minutes: too large for the CPU suite).
 """
 import numpy as np
 import pytest
 import torch
 
-from helpers import RW_CASES, load_rw_case, oracle_mcfg, golden_loss, rel_err, abs_err, big_grad_summary, fixture_tokenizer
+from helpers import RW_CASES, RW_CASES_CPU, load_rw_case, oracle_mcfg, golden_loss, rel_err, abs_err, big_grad_summary, fixture_tokenizer
 
 TOL = 2e-5         # fp32 reductions over K = 50 257 / 16 384 / 11 008 in two different summation orders
 
@@ -70,20 +70,19 @@ def _oracle_vs_reference(name):
     assert rel_err(pe_eval, data["pred_eval"]) < TOL
 
 
-def test_oracle_vs_reference_gpt2_small_width():
-    _oracle_vs_reference("gpt2s_2l_fc")
-
-
-def test_oracle_vs_reference_llama2_7b_width():
-    """0.54 G backbone weights + a [1024, 32000] mapping layer in fp32 on the host: ~1 min, ~6 GB"""
-    _oracle_vs_reference("llama2_7b_2l_semseg")
+@pytest.mark.parametrize("name", RW_CASES_CPU)
+def test_oracle_vs_reference_real_width(name):
+    """GPT-2-small width: the metric model cut to two layers and at its full 12, `independent` covariates with input-statistics prompts, `add` with the
+    `truncate` down-sample and the boundary-segmentation head; Llama-2-7B width (0.54 G backbone weights + a [1024, 32000] mapping layer: ~1 min, ~6 GB)"""
+    _oracle_vs_reference(name)
 
 
 @pytest.mark.gpu
-def test_oracle_vs_reference_llama3_8b_width():
-    """GQA 32 / 8, ffn 14336, vocabulary 128 256 -> 100 000 TRAINABLE rows: 1.1 G fp32 numbers with their gradients, ~3 min on host cores — on the
-    GPU box's host for its size only (no device code runs)"""
-    _oracle_vs_reference("llama3_8b_2l_recon")
+@pytest.mark.parametrize("name", [n for n in RW_CASES if n not in RW_CASES_CPU])
+def test_oracle_vs_reference_real_width_large(name):
+    """Llama-2-7B width with `weighted-average` covariates; Llama-3-8B width (GQA 32 / 8, ffn 14336, vocabulary 128 256 -> 100 000 TRAINABLE rows:
+    1.1 G fp32 numbers with their gradients, ~3 min) — on the GPU box's host for their size only (no device code runs)"""
+    _oracle_vs_reference(name)
 
 
 @pytest.mark.gpu
