@@ -98,3 +98,96 @@ def test_hip_vs_reference_real_width(name):
     assert not unexpected and set(missing) <= {"word_embeddings"}, (missing, unexpected)
     del backbone, params
     check_hip_vs_golden(model.to("cuda"), meta, data, bcfg, name)
+
+
+# ----------------------------------------------------------------------------- a10 at the real width: the reference TRAINER's 8-step run
+def _rw_trainer_setup(tmp_path, device, dtype, model_key="medtsllm"):
+    """what the product trainer needs to replay tests/golden/rw_trainer_gpt2s_2l_fc (make_realwidth_golden.run_trainer): the formula-generated backbone as
+    an HF directory, a dataset that yields the reference's 16 windows in its order, the reference run's configuration"""
+    import json
+    from pathlib import Path
+    from torch.utils.data import Dataset
+    from helpers import GOLDEN, RW_BACKBONES, rw_backbone_state, write_hf_dir
+    from med_ts_llm_amd.tasks.synthetic import register_dataset
+    from med_ts_llm_amd.utils import dict_to_object
+    meta = json.loads((GOLDEN / "rw_trainer_gpt2s_2l_fc.json").read_text())
+    z = np.load(GOLDEN / "rw_trainer_gpt2s_2l_fc.npz")
+    bcfg = RW_BACKBONES[meta["backbone"]]
+    d = write_hf_dir(Path(tmp_path) / "llm_rw", bcfg, rw_backbone_state(bcfg))
+    xs, ys = torch.from_numpy(z["x_enc"]), torch.from_numpy(z["y"])
+
+    class GoldenWindows(Dataset):
+        description, n_features, n_classes, task_description = meta["dataset_description"], meta["C"], 0, None
+
+        def __len__(self):
+            return xs.shape[0]
+
+        def __getitem__(self, i):
+            return {"x_enc": xs[i], "y": ys[i]}
+
+    register_dataset("golden_trainer_rw", lambda config, split: GoldenWindows())
+    cfg = dict_to_object({
+        "DEBUG": True, "task": "forecasting", "model": model_key, "history_len": meta["L"], "pred_len": meta["pred_len"],
+        "data": {"dataset": "golden_trainer_rw"},
+        "training": {"epochs": meta["epochs"], "batch_size": meta["batch_size"], "optimizer": "adam", "learning_rate": meta["learning_rate"], "dropout": 0.0,
+                     "loss": "mse", "eval_metric": "loss", "eval_metric_direction": "min", "shuffle": False},
+        "tasks": {"segmentation": {"mode": "boundary-prediction"}},
+        "models": {"timellm": {
+            "d_model": meta["d_model"], "d_ff": meta["d_ff"], "n_heads": meta["n_heads"], "num_tokens": meta["num_tokens"],
+            "covariate_mode": "concat", "embedding_downsample_mode": "linear", "patching": {"patch_len": 16, "stride": 8}, "prompting": meta["prompting"],
+            "llm": {"enabled": True, "llm": str(d), "llm_layers": -1, "load_in_4bit": False, "load_in_8bit": False}}},
+        "setup": {"seed": 0, "device": device, "dtype": dtype, "num_workers": 0, "logger": "print", "quiet": True}})
+    return cfg, z, meta
+
+
+def _rw_trainer_run(trainer, z, meta):
+    """formula-generated initial weights in, train, -> (losses, {name: distance to the reference's final value / distance the reference moved, over the stored sample})"""
+    from helpers import rw_trainable_values
+    init = rw_trainable_values([(n, tuple(s)) for n, s in meta["param_table"].items()])
+    assert {n: tuple(q.shape) for n, q in trainer.model.named_parameters() if q.requires_grad} == {n: tuple(s) for n, s in meta["param_table"].items()}
+    missing, unexpected = trainer.model.load_state_dict(init, strict=False)
+    assert not unexpected and set(missing) <= {"word_embeddings"}, (missing, unexpected)
+    trainer.train()
+    losses = np.array([h["train/loss"] for h in trainer.logger.history if "train/loss" in h])
+    p = dict(trainer.model.named_parameters())
+    off = {}
+    for n, s in meta["sampled"].items():
+        if n.endswith("key_projection.bias"):
+            continue       # analytically-zero gradient: Adam turns pure round-off into +-lr steps (not reproducible, also not in the reference)
+        got = p[n].detach().float().cpu().flatten()[::s].double()
+        off[n] = float((got - torch.from_numpy(z["final." + n]).double()).norm()) / (float(z["movedsample." + n]) + 1e-30)
+    assert trainer.step == int(z["step_counter"])
+    return losses, off
+
+
+def test_product_trainer_replays_reference_trajectory_at_gpt2_small_width(tmp_path):
+    """CPU suite: the product trainer (loop, loss, optimiser construction, step order) with the device math swapped for the pinned oracle"""
+    from med_ts_llm_amd.models import model_lookup
+    from med_ts_llm_amd.tasks import get_trainer
+    from helpers import register_oracle_math_model
+    key = register_oracle_math_model()
+    try:
+        cfg, z, meta = _rw_trainer_setup(tmp_path, "cpu", "fp32", key)
+        losses, off = _rw_trainer_run(get_trainer("DEBUG-golden-rw", cfg), z, meta)
+    finally:
+        del model_lookup[key]
+    print("\nlosses", np.round(losses, 6).tolist(), "\nreference", np.round(z["losses"], 6).tolist(), "\nfinal weights off / moved:", {k: round(v, 5) for k, v in off.items()})
+    # (importing the reference's tasks package sets float32 matmul precision "medium": the golden trajectory carries ~3e-4 of CPU matmul noise)
+    assert len(losses) == len(z["losses"]) and np.allclose(losses, z["losses"], rtol=1e-3, atol=1e-6), (losses, z["losses"])
+    assert max(off.values()) < 0.08, off       # (measured <= 0.048: the value projection, whose gradient is a cancellation-prone sum — DESIGN §3)
+
+
+@pytest.mark.gpu
+def test_hip_trainer_replays_reference_trajectory_at_gpt2_small_width(tmp_path):
+    """GPU suite: tasks.get_trainer(...).train() with the HIP model, HipAdam and bf16 mixed arithmetic against the reference trainer's fp32 run; the
+    reference's own dtype = "mixed" run of the same 8 steps (losses_mixed in the fixture) deviates by up to 8e-4 relative per loss"""
+    from med_ts_llm_amd.tasks import get_trainer
+    cfg, z, meta = _rw_trainer_setup(tmp_path, "cuda", "mixed")
+    trainer = get_trainer("DEBUG-golden-rw-gpu", cfg)
+    assert trainer.device.type == "cuda" and trainer.mixed and type(trainer.optimizer).__name__ == "HipAdam"
+    losses, off = _rw_trainer_run(trainer, z, meta)
+    mixed_dev = float(np.max(np.abs(z["losses_mixed"] / z["losses"] - 1.0)))
+    print("\nlosses", np.round(losses, 6).tolist(), "\nreference", np.round(z["losses"], 6).tolist(), f"\nreference mixed-vs-fp32 max relative loss deviation {mixed_dev:.2e}",
+          "\nfinal weights off / moved:", {k: round(v, 4) for k, v in off.items()})
+    assert len(losses) == len(z["losses"]) and np.allclose(losses, z["losses"], rtol=max(3e-3, 3 * mixed_dev)), (losses, z["losses"])
+    assert max(off.values()) < 0.10, off
