@@ -7,9 +7,9 @@ sampled stage tensors and gradient summaries only.
 
 Until round 4 the real-width comparisons (tests/test_gpu_realwidth.py) were HIP vs the ORACLE, and the oracle itself was pinned to the reference
 only at d_llm 128: these tests close that gap.
-  * CPU suite: the oracle against the reference on five of the seven fixtures (fp32, <= 2e-5 — the L1 rung of SURVEY.md 8c);
+  * CPU suite: the oracle against the reference on the four GPT-2-small-width fixtures (fp32, <= 2e-5 — the L1 rung of SURVEY.md 8c);
   * GPU suite: the HIP path against the reference on all seven (bar = 1.5 x the reference's own bf16-autocast deviation, exactly as
-    tests/test_gpu_golden.py), and the oracle against the two largest fixtures on the GPU box's host cores (6 - 12 GB, minutes: too large for the CPU suite).
+    tests/test_gpu_golden.py), and the oracle against the three Llama-width fixtures on the GPU box's host cores (6 - 12 GB, minutes: too large for the CPU suite).
 """
 import numpy as np
 import pytest
@@ -73,15 +73,16 @@ def _oracle_vs_reference(name):
 @pytest.mark.parametrize("name", RW_CASES_CPU)
 def test_oracle_vs_reference_real_width(name):
     """GPT-2-small width: the metric model cut to two layers and at its full 12, `independent` covariates with input-statistics prompts, `add` with the
-    `truncate` down-sample and the boundary-segmentation head; Llama-2-7B width (0.54 G backbone weights + a [1024, 32000] mapping layer: ~1 min, ~6 GB)"""
+    `truncate` down-sample and the boundary-segmentation head"""
     _oracle_vs_reference(name)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", [n for n in RW_CASES if n not in RW_CASES_CPU])
 def test_oracle_vs_reference_real_width_large(name):
-    """Llama-2-7B width with `weighted-average` covariates; Llama-3-8B width (GQA 32 / 8, ffn 14336, vocabulary 128 256 -> 100 000 TRAINABLE rows:
-    1.1 G fp32 numbers with their gradients, ~3 min) — on the GPU box's host for their size only (no device code runs)"""
+    """Llama-2-7B width (0.54 G backbone weights + a [1024, 32000] mapping layer: 1 - 2 min, ~6 GB; semantic segmentation on concat covariates,
+    anomaly detection on `weighted-average` ones); Llama-3-8B width (GQA 32 / 8, ffn 14336, vocabulary 128 256 -> 100 000 TRAINABLE rows: 1.1 G fp32
+    numbers with their gradients, ~3 min) — on the GPU box's host for their size only (no device code runs)"""
     _oracle_vs_reference(name)
 
 
