@@ -77,9 +77,16 @@ def test_oracle_vs_reference_real_width(name):
     _oracle_vs_reference(name)
 
 
+LARGE_OPT_IN = ("llama2_7b_2l_wavg_ad", "llama3_8b_2l_recon")      # run with MTL_LARGE_ORACLE=1 (here: 60 s and 135 s, green in round 4) — the default
+                                                                    # `-m gpu` run keeps one Llama-width oracle check so that it stays within minutes
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", [n for n in RW_CASES if n not in RW_CASES_CPU])
 def test_oracle_vs_reference_real_width_large(name):
+    import os
+    if name in LARGE_OPT_IN and not os.environ.get("MTL_LARGE_ORACLE"):
+        pytest.skip("opt-in (MTL_LARGE_ORACLE=1): 6 - 12 GB and minutes of host time")
     """Llama-2-7B width (0.54 G backbone weights + a [1024, 32000] mapping layer: 1 - 2 min, ~6 GB; semantic segmentation on concat covariates,
     anomaly detection on `weighted-average` ones); Llama-3-8B width (GQA 32 / 8, ffn 14336, vocabulary 128 256 -> 100 000 TRAINABLE rows: 1.1 G fp32
     numbers with their gradients, ~3 min) — on the GPU box's host for their size only (no device code runs)"""
