@@ -89,7 +89,7 @@ def test_hip_model_vs_reference_golden(name):
     check_hip_vs_golden(model, meta, data, bcfg, name)
 
 
-def check_hip_vs_golden(model, meta, data, bcfg, name):
+def check_hip_vs_golden(model, meta, data, bcfg, name, grad_bar=MIXED_FACTOR):
     """one train-mode forward + backward and one eval forward of the HIP model against a fixture captured from the reference (case_*.npz of
     make_golden.py, rw_*.npz of make_realwidth_golden.py: there meta["sampled"][key] = s says the fixture holds every s-th element of that tensor)"""
     B, C, P_, cm = meta["B"], meta["C"], None, meta["covariate_mode"]
@@ -179,13 +179,13 @@ def check_hip_vs_golden(model, meta, data, bcfg, name):
     for k in data:
         if k.startswith("grad."):
             n = k[len("grad."):]
-            check(k, grads[n], data[k], GRAD_FLOOR, cond.get(n, 0.0), grad_factor(data[k].size))
+            check(k, grads[n], data[k], GRAD_FLOOR, cond.get(n, 0.0), grad_factor(data[k].size, grad_bar))
             n_checked += 1
         elif k.startswith("gradnorm."):           # 100 000-wide gradients: projections along both axes + strided slices
             n = k[len("gradnorm."):]
             norm, prow, pcol, sample = big_grad_summary(grads[n], meta["synth"]["stride"])
             self_rel = float(data["selferr.grad." + n]) / float(data[k])
-            tol = MIXED_FACTOR * max(self_rel, GRAD_FLOOR)
+            tol = grad_bar * max(self_rel, GRAD_FLOOR)
             report[f"grad.{n}[norm]"] = (abs(norm - float(data[k])) / float(data[k]), tol)
             for what, got, key in (("rows", prow, "gradproj_rows." + n), ("cols", pcol, "gradproj_cols." + n), ("sample", sample, "gradsample." + n)):
                 want = data[key]
