@@ -298,6 +298,12 @@ def live_pmc_traffic(workload, kernels, timeout_s=150.0):
             return {}, f"{counter} pass failed (rc {rc})"
         per[counter] = {pt.clean(k): v for k, v in pt.per_kernel(dbs[0], counter, warmup_steps=1).items()}      # (the child's warm-up step and set-up dropped)
     shutil.rmtree(tmp, ignore_errors=True)
+    # every dispatch of the two counted steps summed: the step-level HBM traffic (roofline_step)
+    n_steps = 2
+    step_rd = 2.0 * 1024.0 * sum(v * n for v, n in per["FETCH_SIZE"].values()) / n_steps
+    step_wr = 1024.0 * sum(v * n for v, n in per["WRITE_SIZE"].values()) / n_steps
+    live_pmc_traffic.last_step = {"hbm_read_bytes": step_rd, "hbm_write_bytes": step_wr, "hbm_bytes": step_rd + step_wr,
+                                  "dispatches_per_step": sum(n for _, n in per["FETCH_SIZE"].values()) / n_steps}
     out = {}
     for k in kernels:
         fk, n = table_lookup(per["FETCH_SIZE"], k) or (None, 0)
@@ -310,11 +316,27 @@ def live_pmc_traffic(workload, kernels, timeout_s=150.0):
                  f"mean per launch over the two steps after the warm-up step, {time.perf_counter() - t_start:.0f} s")
 
 
+def roofline_step(step_traffic, line, note):
+    """the WHOLE step against the HBM roofline (the GPT-2 step is HBM-bound as a whole): bytes every dispatch of one step moved
+    (PMC, live: the two counted steps of the child run, all kernels summed) / the timed region's step time, and the step's arithmetic intensity next
+    to the ridge (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B)."""
+    if not step_traffic:
+        return None
+    b = step_traffic["hbm_bytes"]
+    sec = line["ms_per_step"] * 1e-3
+    fl = line["executed_tflop_per_step_per_gpu"] * 1e12
+    return {"bound": "hbm", "bytes_per_step": int(b), "read_bytes_per_step": int(step_traffic["hbm_read_bytes"]), "write_bytes_per_step": int(step_traffic["hbm_write_bytes"]),
+            "achieved": round(b / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b / sec / 1e9 / HBM_PEAK_GBS, 4),
+            "flop_per_byte": round(fl / b, 1), "ridge_flop_per_byte": round(MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9), 1),
+            "dispatches_per_step": round(step_traffic["dispatches_per_step"], 1), "traffic_src": "live", "source": note}
+
+
 def causal_fraction(kernel, T, Tq):
     """executed / full-rectangle work of a CAUSAL attention launch whose Tq queries are the last rows of a T-key sequence: query i (0-based
     among the Tq) sees T - Tq + i + 1 keys. 1.0 for the non-causal (reprogramming) instances. Tile granularity is ignored (the kernels
     also execute the masked half of the 32-key slabs on the diagonal: < 2 % at T = 1664)."""
-    causal = ("_res" in kernel) or (", true," in kernel.split("<", 1)[-1][:12])
+    # (the resident and the 32-rows-per-wave kernels exist only as causal instances; the others carry CAUSAL as their second template argument)
+    causal = ("_res" in kernel) or ("_w32" in kernel) or (", true," in kernel.split("<", 1)[-1][:12])
     if not causal or not T or not Tq:
         return 1.0
     return (Tq * (T - Tq) + Tq * (Tq + 1) / 2.0) / (Tq * T)
@@ -668,12 +690,14 @@ def compact_line(out):
     c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                              "dtype", "data")}
     c["config"] = {"workload": _short_workload(out), "global_batch": out["config"]["global_batch"], "parallelism": out["config"]["parallelism"]}
-    for k in ("per_gpu_samples_per_s", "dist_backend", "rccl_ranks", "dp_mode"):
+    for k in ("per_gpu_samples_per_s", "dist_backend", "rccl_ranks", "dp_mode", "dp_modes"):
         if out.get(k) is not None:
             c[k] = out[k]
     c["roofline"] = _roof_compact(out.get("roofline"))
     c["roofline_hbm"] = _roof_compact(out.get("roofline_hbm"))
     c["roofline_attention"] = _roof_compact(out.get("roofline_attention"))
+    rs = out.get("roofline_step")
+    c["roofline_step"] = {k: v for k, v in rs.items() if k != "source"} if rs else None
     cb = out.get("cpu_baseline")
     if cb:
         c["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "host_cores": cb.get("host_cores"), "kind": cb["kind"],
@@ -724,6 +748,7 @@ def main():
     ap.add_argument("--full-backward", action="store_true", help="also compute the (unused) prompt-row input gradients")
     ap.add_argument("--replicate-mapping", action="store_true", help="DP: keep the mapping layer replicated (all-reduce its gradient)")
     ap.add_argument("--replicate-optimizer", action="store_true", help="DP: no row-sharded optimiser step for the big tensors (all-reduce + replicated Adam)")
+    ap.add_argument("--single-dp-mode", action="store_true", help="N > 1: time only the selected DP mode (default: the plain all-reduce mode first, then the sharded one)")
     ap.add_argument("--no-llm-dropout", action="store_true", help="GPT-2: switch the frozen LLM's train-mode dropouts (0.1) off")
     ap.add_argument("--optimizer-overlap", action="store_true", help="update the tail's parameters on a side stream under the next step (measured flat; off by default)")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the HIP multi-tensor Adam")
@@ -774,8 +799,52 @@ def main():
         stage(f"DP pre-flight: {'ok' if ok else why}; {rccl_ranks} ranks answered; mode = {dp_mode}")
 
     full = args.full_detail
+    # N > 1: BOTH DP modes in one run, the plain one first — north_star's split: replicated trainables, ONE bucketed all-reduce of
+    # their gradients — then the default sharded mode, which gives the headline `value` when it completes. The sharded leg runs under a watchdog: if it
+    # raises or exceeds its time budget (a hung collective cannot be caught), the line is printed with the plain figure as `value` and says so, so a
+    # scaling record can tell WHICH exchange failed instead of losing the run.
+    plain_leg = None
+    if world > 1 and not args.single_dp_mode and not (args.replicate_mapping and args.replicate_optimizer):
+        import copy
+        a2 = copy.copy(args)
+        a2.replicate_mapping = a2.replicate_optimizer = True
+        stage(f"start {args.workload} [dp mode: plain all-reduce]")
+        t_leg = time.perf_counter()
+        plain_leg = run_workload(args.workload, a2, ctx, args.steps, args.warmup, False, False, legs=False, stage=stage)
+        t_leg = time.perf_counter() - t_leg
+        if rank == 0:
+            plain_leg["rccl_ranks"], plain_leg["dp_mode"] = rccl_ranks, "plain all-reduce"
+        budget = max(180.0, 15.0 * t_leg)
+
+        def give_up():
+            if rank == 0:
+                plain_leg["dp_mode"] = f"plain all-reduce (the sharded leg did not finish within {budget:.0f} s: its figure is missing)"
+                plain_leg["dp_modes"] = {"plain_allreduce": plain_leg["value"], "sharded": None}
+                print(json.dumps(compact_line(plain_leg), separators=(",", ":")), flush=True)
+            os._exit(0)        # (every rank: the line above carries the failure; a non-zero worker would make the launcher kill rank 0 before it prints)
+        import threading
+        watchdog = threading.Timer(budget, give_up)
+        watchdog.daemon = True
+        watchdog.start()
     stage(f"start {args.workload}")
-    out = run_workload(args.workload, args, ctx, args.steps, args.warmup, not args.no_cpu_baseline, not args.no_roofline, legs=True, stage=stage)
+    try:
+        out = run_workload(args.workload, args, ctx, args.steps, args.warmup, not args.no_cpu_baseline, not args.no_roofline, legs=True, stage=stage)
+    except Exception as e:      # noqa: BLE001
+        if plain_leg is None:
+            raise
+        if rank != 0:            # rank 0 may be blocked in a collective this rank just left: its watchdog prints the plain line; wait for our own
+            time.sleep(budget + 30.0)
+            os._exit(0)
+        stage(f"sharded leg FAILED: {type(e).__name__}: {e}")
+        plain_leg["dp_mode"] = f"plain all-reduce (the sharded leg raised {type(e).__name__}: {str(e)[:80]})"
+        plain_leg["dp_modes"] = {"plain_allreduce": plain_leg["value"], "sharded": None}
+        print(json.dumps(compact_line(plain_leg), separators=(",", ":")), flush=True)
+        os._exit(0)
+    if plain_leg is not None:
+        watchdog.cancel()
+        if rank == 0:
+            out["dp_modes"] = {"plain_allreduce": plain_leg["value"], "sharded": out["value"],
+                               "what": "whole-job samples/s of the same step in both DP modes, measured back to back in this run; `value` is the sharded (default) one"}
     # Extra configs ride on the N = 1 run only: at N > 1 the line is the scaling record of the headline workload — every additional model under DP
     # is more first-contact RCCL surface that could take the headline down with it (--extra-configs-dp asks for them anyway). Each extra is
     # fenced: a failure there is reported in the line's place, never instead of the headline.
@@ -821,6 +890,7 @@ def main():
                     o["traffic"], o["traffic_source"] = table[o["kernel"]], note
                 elif o["traffic"] is not None:
                     o["traffic_source"] = f"{committed}; live pass unavailable: {note}"
+            out["roofline_step"] = roofline_step(getattr(live_pmc_traffic, "last_step", None), out, note)
     # the ONE JSON line is the LAST thing on stdout: the process group goes down first (on every rank), the C runtime's buffers — librccl
     # prints through them — are flushed, and rank 0 gives the other ranks a moment to do the same before it prints
     if dist.is_initialized():

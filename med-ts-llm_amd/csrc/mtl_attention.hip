@@ -32,7 +32,10 @@ constexpr int KC = 64;  // keys (or queries, in the dK/dV kernel) per LDS chunk
 #ifndef MTL_ATTN_PAD
 #define MTL_ATTN_PAD 16
 #endif
-__host__ __device__ constexpr int attn_pad(int D) { return D >= 128 ? MTL_ATTN_PAD : 8; }
+#ifndef MTL_ATTN_PAD64
+#define MTL_ATTN_PAD64 8
+#endif
+__host__ __device__ constexpr int attn_pad(int D) { return D >= 128 ? MTL_ATTN_PAD : MTL_ATTN_PAD64; }
 #ifndef MTL_CONSISTENT_DELTA
 #define MTL_CONSISTENT_DELTA 0     // causal self-attention: 0 = delta = dO . O with the bf16-rounded forward output (measured: the consistent
                                    // form changes nothing there — tools/diag_bias.py: the stack's input gradient is unbiased and on par
@@ -1781,6 +1784,9 @@ int check_fwd(const mtl_attn_fwd_args& f) {
     if (!f.q || !f.k || !f.v || !f.o) return MTL_ERR_ARG;
     if (f.B <= 0 || f.Hq <= 0 || f.Hkv <= 0 || f.Tq <= 0 || f.Tk <= 0 || f.Hq % f.Hkv != 0) return MTL_ERR_ARG;
     if (f.D != 32 && f.D != 64 && f.D != 128) return MTL_ERR_UNSUPPORTED;
+    // a query row whose FIRST key chunk is entirely masked would average masked keys into its output (the running maximum then equals the mask value):
+    // with causal_off >= 0 every query row sees key 0, so every row's first chunk holds a visible key
+    if (f.causal && f.causal_off < 0) return MTL_ERR_ARG;
     const int64_t st[] = {f.q_bs, f.q_ts, f.q_hs, f.k_bs, f.k_ts, f.k_hs, f.v_bs, f.v_ts, f.v_hs, f.o_bs, f.o_ts, f.o_hs};
     for (int64_t s : st) if (s % 8 != 0) return MTL_ERR_ALIGN;
     if (((uintptr_t)f.q % 16) || ((uintptr_t)f.k % 16) || ((uintptr_t)f.v % 16) || ((uintptr_t)f.o % 16)) return MTL_ERR_ALIGN;
@@ -1861,9 +1867,9 @@ extern "C" int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream) {
         MTL_CHECK_LAUNCH();
         return MTL_OK;
     }
-    if (a->causal && !drop && a->Tq >= g_attn_wide_min && (a->D == 64 || a->D == 128) && g_attn_wide == 1 && g_attn_w32 == 1) {
-        // long sequences: 32 query rows per wave on 32x32x16 MFMAs, double-buffered 64-key chunks. 8 waves = 256 queries per workgroup from 512 rows on:
-        // every staged K / V chunk then serves twice the queries (the global -> LDS staging of 3 GB per launch at T = 1664 was a fifth of the kernel)
+    if (a->causal && !drop && !a->o_f32 && a->Tq >= g_attn_wide_min && (a->D == 64 || a->D == 128) && g_attn_wide == 1 && g_attn_w32 == 1) {
+        // long sequences: 32 query rows per wave on 32x32x16 MFMAs, double-buffered 64-key chunks, 4 waves = 128 queries per workgroup (8 waves measured
+        // slower: profiles/r04_attn_longT_experiments.txt). The kernel has no fp32 output copy: a caller asking for o_f32 gets the 16-row kernel below.
         const int nww = (g_attn_w32_nw == 4 || g_attn_w32_nw == 8) ? g_attn_w32_nw : 4;
         const int64_t nx = (a->Tq + nww * 32 - 1) / (nww * 32);
         const dim3 gridw(g_attn_xmap ? attn_xmap_grid(nx, a->Hq, a->B) : (unsigned)nx, g_attn_xmap ? 1u : (unsigned)a->Hq, g_attn_xmap ? 1u : (unsigned)a->B), blockw(nww * 64);

@@ -15,65 +15,87 @@ __device__ __forceinline__ int64_t remap_row(int64_t m, int64_t group_rows, int6
     return (m / group_rows) * group_stride + off + (m % group_rows);
 }
 
-template <int NV, bool RMS>
+#ifndef MTL_NORM_RPW
+#define MTL_NORM_RPW 1      // rows per wave of the forward kernel (narrow rows): all rows' loads are in flight before the first reduction
+#endif
+template <int NV, bool RMS, int RPW = 1>
 __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                        int64_t ld_y, float* __restrict__ stats, int64_t M, int d, float eps,
                                                        int64_t group_rows, int64_t group_stride, int64_t row_offset, int stats_physical) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    const int64_t prow = remap_row(row, group_rows, group_stride, row_offset);
-    const float* xr = x + prow * (int64_t)d;
-    float4 v[NV];
-    float s = 0.f;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= M) return;
+    float4 v[RPW][NV];
+    int64_t prow[RPW];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (c < d) {
-            v[i] = *reinterpret_cast<const float4*>(xr + c);
-            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-        } else {
-            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < RPW; ++j) {
+        const int64_t row = row0 + j < M ? row0 + j : M - 1;
+        prow[j] = remap_row(row, group_rows, group_stride, row_offset);
+        const float* xr = x + prow[j] * (int64_t)d;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            v[j][i] = c < d ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    // narrow rows: the affine parameters are requested with the rows (one round trip for everything); wide rows (NV float4 of the row per lane)
+    // fetch them where they are used, as before — they hit the L2 and would otherwise double the live registers
+    constexpr bool PRE = NV <= 4;
+    float4 gm[PRE ? NV : 1], bt[PRE ? NV : 1];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            gm[i] = c < d ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bt[i] = (!RMS && c < d) ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     const float inv_d = 1.0f / (float)d;
-    float mean = 0.f;
-    if (!RMS) mean = wave_sum(s) * inv_d;
-    float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (c < d) {
-            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
-            q += (a * a + b * b) + (cc * cc + dd * dd);
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(q) * inv_d + eps);
-    bf16_t* yr = y + row * ld_y;
+    for (int j = 0; j < RPW; ++j) {
+        if (row0 + j >= M) break;
+        const int64_t row = row0 + j;
+        float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (c < d) {
-            const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
-            float o0, o1, o2, o3;
-            if (RMS) {
-                // HF LlamaRMSNorm: weight * (x * rsqrt(var + eps)).to(input_dtype) ; input dtype is fp32 here
-                o0 = gm.x * (v[i].x * rstd); o1 = gm.y * (v[i].y * rstd);
-                o2 = gm.z * (v[i].z * rstd); o3 = gm.w * (v[i].w * rstd);
-            } else {
-                const float4 bt = *reinterpret_cast<const float4*>(beta + c);
-                o0 = (v[i].x - mean) * rstd * gm.x + bt.x; o1 = (v[i].y - mean) * rstd * gm.y + bt.y;
-                o2 = (v[i].z - mean) * rstd * gm.z + bt.z; o3 = (v[i].w - mean) * rstd * gm.w + bt.w;
+        for (int i = 0; i < NV; ++i) s += (v[j][i].x + v[j][i].y) + (v[j][i].z + v[j][i].w);      // (columns >= d hold zeros)
+        float mean = 0.f;
+        if (!RMS) mean = wave_sum(s) * inv_d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < d) {
+                const float a = v[j][i].x - mean, b = v[j][i].y - mean, cc = v[j][i].z - mean, dd = v[j][i].w - mean;
+                q += (a * a + b * b) + (cc * cc + dd * dd);
             }
-            u32x2 pk = {pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)};
-            *reinterpret_cast<u32x2*>(yr + c) = pk;
         }
-    }
-    if (lane == 0 && stats) {
-        const int64_t srow = stats_physical ? prow : row;
-        stats[srow * 2] = mean;
-        stats[srow * 2 + 1] = rstd;
+        const float rstd = rsqrtf(wave_sum(q) * inv_d + eps);
+        bf16_t* yr = y + row * ld_y;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < d) {
+                float o0, o1, o2, o3;
+                const float4 g4 = PRE ? gm[PRE ? i : 0] : *reinterpret_cast<const float4*>(gamma + c);
+                if (RMS) {
+                    // HF LlamaRMSNorm: weight * (x * rsqrt(var + eps)).to(input_dtype) ; input dtype is fp32 here
+                    o0 = g4.x * (v[j][i].x * rstd); o1 = g4.y * (v[j][i].y * rstd);
+                    o2 = g4.z * (v[j][i].z * rstd); o3 = g4.w * (v[j][i].w * rstd);
+                } else {
+                    const float4 b4 = PRE ? bt[PRE ? i : 0] : *reinterpret_cast<const float4*>(beta + c);
+                    o0 = (v[j][i].x - mean) * rstd * g4.x + b4.x; o1 = (v[j][i].y - mean) * rstd * g4.y + b4.y;
+                    o2 = (v[j][i].z - mean) * rstd * g4.z + b4.z; o3 = (v[j][i].w - mean) * rstd * g4.w + b4.w;
+                }
+                u32x2 pk = {pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)};
+                *reinterpret_cast<u32x2*>(yr + c) = pk;
+            }
+        }
+        if (lane == 0 && stats) {
+            const int64_t srow = stats_physical ? prow[j] : row;
+            stats[srow * 2] = mean;
+            stats[srow * 2 + 1] = rstd;
+        }
     }
 }
 
@@ -181,17 +203,19 @@ extern "C" int mtl_norm_fwd(const float* x, const float* gamma, const float* bet
     if (!x || !gamma || !y || M <= 0 || d <= 0 || (!rms && !beta)) return MTL_ERR_ARG;
     if (d % 4 != 0 || ld_y % 4 != 0) return MTL_ERR_ALIGN;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)((M + 3) / 4)), block(256);
+    const dim3 block(256);
     auto go = [&](auto nv) -> int {
         constexpr int NV = decltype(nv)::value;
+        constexpr int RPW = NV <= 4 ? MTL_NORM_RPW : 1;      // (wide rows already keep NV float4 per lane in flight)
+        const dim3 grid((unsigned)((M + 4 * RPW - 1) / (4 * RPW)));
         char kname[64];
         snprintf(kname, sizeof kname, "norm_fwd_kernel<%d, %s>", NV, rms ? "true" : "false");
         const double bytes = (double)M * d * (4 + 2) + (stats ? (double)M * 8 : 0.0);      // fp32 row in, bf16 row out, 2 statistics
         if (rms)
-            MTL_LAUNCH(kname, bytes, 1, (norm_fwd_kernel<NV, true>), grid, block, 0, st, x, gamma, beta, (bf16_t*)y, ld_y, stats, M, (int)d,
+            MTL_LAUNCH(kname, bytes, 1, (norm_fwd_kernel<NV, true, RPW>), grid, block, 0, st, x, gamma, beta, (bf16_t*)y, ld_y, stats, M, (int)d,
                        eps, group_rows, group_stride, row_offset, stats_physical);
         else
-            MTL_LAUNCH(kname, bytes, 1, (norm_fwd_kernel<NV, false>), grid, block, 0, st, x, gamma, beta, (bf16_t*)y, ld_y, stats, M, (int)d,
+            MTL_LAUNCH(kname, bytes, 1, (norm_fwd_kernel<NV, false, RPW>), grid, block, 0, st, x, gamma, beta, (bf16_t*)y, ld_y, stats, M, (int)d,
                        eps, group_rows, group_stride, row_offset, stats_physical);
         MTL_CHECK_LAUNCH();
         return MTL_OK;

@@ -47,6 +47,21 @@ class HipAdam(torch.optim.Optimizer):
             torch.cuda.current_stream().wait_event(self._late_done)
             self._late_done = None
 
+    def load_state_dict(self, state_dict):
+        """torch's Optimizer.load_state_dict casts every floating-point state tensor to its parameter's dtype; the moments of bf16 parameters
+        (setup.dtype = "bf16") must stay fp32 — the kernel reads and writes them as float*."""
+        super().load_state_dict(state_dict)
+        # (re-widening the narrowed copies would keep their bf16 rounding: take the moments from the saved tensors themselves)
+        mine = [p for g in self.param_groups for p in g["params"]]
+        saved = [i for g in state_dict["param_groups"] for i in g["params"]]
+        for idx, p in zip(saved, mine):
+            rec = state_dict["state"].get(idx)
+            if not rec:
+                continue
+            for k in ("exp_avg", "exp_avg_sq"):
+                if torch.is_tensor(rec.get(k)):
+                    self.state[p][k] = rec[k].detach().to(device=p.device, dtype=torch.float32).contiguous().clone()
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -96,6 +111,10 @@ class HipAdam(torch.optim.Optimizer):
         keep = []
         for i, p in enumerate(ps):
             st = self.state[p]
+            for k in ("exp_avg", "exp_avg_sq"):
+                m = st[k]
+                if not (m.is_cuda and m.dtype == torch.float32 and m.is_contiguous() and m.numel() == p.numel()):
+                    raise N.MtlError(f"HipAdam: state['{k}'] must be a contiguous fp32 GPU tensor of the parameter's size (got {m.dtype}, {tuple(m.shape)})")
             g = p.grad
             if g.dtype != p.dtype or not g.is_contiguous():
                 g = g.to(p.dtype).contiguous()

@@ -98,6 +98,10 @@ class BaseTask(ABC):
             raise NotImplementedError("setup.dtype = \"bf16\" with data parallelism: the gradient buckets are fp32 views (use \"mixed\")")
         if self.device.type == "cuda" and self.world_size > 1:
             self.device = torch.device("cuda", self.local_rank % torch.cuda.device_count())
+        if self.world_size > 1:
+            # known-answer test of every RCCL-native exchange BEFORE the objects that use them are built (FlatGradAllReduce / ShardedUpdate read the
+            # decision at construction): a failure on any rank switches all ranks to the plain all-reduce / all-gather forms
+            self.dp_preflight = parallel.preflight_collectives(self.device)
         set_seed(self.config.setup.seed)
         self.build_datasets()
         self.build_dataloaders()
@@ -254,7 +258,9 @@ class BaseTask(ABC):
                         v = v[shard[2]:shard[3]]
                     elif id(p) in owned_rows and v.shape[0] != p.shape[0]:
                         v = v[owned_rows[id(p)][0]:owned_rows[id(p)][1]]
-                    v = v.to(device=p.device, dtype=p.dtype if v.is_floating_point() else v.dtype).contiguous().clone()
+                    # HipAdam keeps fp32 moments also for bf16 parameters (setup.dtype = "bf16"; mtl_adam_step reads m / v as float*): never narrow them
+                    fdt = torch.float32 if type(self.optimizer).__name__ == "HipAdam" else p.dtype
+                    v = v.to(device=p.device, dtype=fdt if v.is_floating_point() else v.dtype).contiguous().clone()
                 st[k] = v
             self.optimizer.state[p] = st
         return True

@@ -332,8 +332,10 @@ def test_finetuning_trainer_replays_reference_on_gpu(tmp_path):
     T._check_final(tr, z, tol_each=0.25, tol_all=0.10)
 
 
-def test_resume_restores_hip_adam_state_on_gpu(tmp_path):
-    """checkpoint -> from_run_id -> one more epoch == an uninterrupted run, with HipAdam's moments travelling through the checkpoint"""
+@pytest.mark.parametrize("dtype", ["mixed", "bf16"])
+def test_resume_restores_hip_adam_state_on_gpu(tmp_path, dtype):
+    """checkpoint -> from_run_id -> one more epoch == an uninterrupted run, with HipAdam's moments travelling through the checkpoint.
+    setup.dtype = "bf16": bf16 parameters, but the moments stay fp32 through save / load (mtl_adam_step reads them as float*)"""
     import test_datasets_trainer as T
     from med_ts_llm_amd.tasks import get_trainer, task_lookup
     G = (dict(np.load(T.GOLDEN / "datasets.npz")), json.loads((T.GOLDEN / "datasets.json").read_text()))
@@ -343,7 +345,7 @@ def test_resume_restores_hip_adam_state_on_gpu(tmp_path):
     def cfg(epochs):
         return T.base_cfg("reconstruction", "bidmc", llm_dir=llm, epochs=epochs,
                           extra={"DEBUG": False, "paths": {"logdir": str(tmp_path / "logs")},
-                                 "setup": {"seed": 0, "device": "cuda", "dtype": "mixed", "num_workers": 0, "logger": "print", "quiet": True}})
+                                 "setup": {"seed": 0, "device": "cuda", "dtype": dtype, "num_workers": 0, "logger": "print", "quiet": True}})
     full = get_trainer("run-full", cfg(2))
     init = {k: v.detach().clone() for k, v in full.model.state_dict().items()}
     full.train()
@@ -353,6 +355,12 @@ def test_resume_restores_hip_adam_state_on_gpu(tmp_path):
     resumed = task_lookup["reconstruction"].from_run_id("run-part", cfg={"training": cfg(2).training.to_dict()}, basepath=str(tmp_path / "logs"))
     assert type(resumed.optimizer).__name__ == "HipAdam" and all(int(st["step"]) == 2 for st in resumed.optimizer.state.values())
     assert resumed.epochs_done == 1
+    for q, st in resumed.optimizer.state.items():
+        assert q.dtype == (torch.bfloat16 if dtype == "bf16" else torch.float32)
+        assert st["exp_avg"].dtype == torch.float32 and st["exp_avg_sq"].dtype == torch.float32 and st["exp_avg"].numel() == q.numel()
+    # torch's own Optimizer.load_state_dict narrows floating state to the parameter dtype: HipAdam's override widens it again
+    resumed.optimizer.load_state_dict(resumed.optimizer.state_dict())
+    assert all(st["exp_avg"].dtype == torch.float32 for st in resumed.optimizer.state.values())
     resumed.train()                              # continues with epoch 2 of 2
     for (n, a), (_, b) in zip(full.model.named_parameters(), resumed.model.named_parameters()):
         if a.requires_grad:

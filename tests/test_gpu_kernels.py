@@ -252,6 +252,19 @@ def test_attention_long_causal_ragged(ops, B, T, Tq, Hq, Hkv, D):
     assert torch.equal(dk1[:, off:], want_k[:, off:]) and torch.equal(dv1[:, off:], dv[:, off:])
 
 
+def test_attention_rejects_negative_causal_offset(ops):
+    """causal_off < 0 would leave some query rows without any visible key in their first chunk (the 32-row kernel then averages masked keys in:
+    ADVICE r04): the C-ABI refuses it instead, forward and backward"""
+    from med_ts_llm_amd.hip._native import MtlError
+    B, T, H, D = 1, 320, 2, 64
+    q, k, v = (dev(torch.randn(B, T, H * D, generator=g(i)).to(BF16)) for i in (1, 2, 3))
+    with pytest.raises(MtlError):
+        ops.attention_fwd(q, k, v, H, H, D, 0.125, True, causal_off=-64)
+    o, lse = ops.attention_fwd(q, k, v, H, H, D, 0.125, True)
+    with pytest.raises(MtlError):
+        ops.attention_bwd(q, k, v, o, lse, q, H, H, D, 0.125, True, causal_off=-64)
+
+
 def test_attention_fused_qkv_views(ops):
     """strided q/k/v views into one fused [B,T,(Hq+2Hkv)*D] buffer, as the backbone uses them"""
     B, T, Hq, Hkv, D = 2, 80, 4, 2, 64

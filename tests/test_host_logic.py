@@ -382,6 +382,9 @@ def test_causal_fraction_of_the_rectangle():
     assert abs(bench.causal_fraction("attn_fwd_kernel<128, true, false, 8>", 4, 2) - 7 / 8) < 1e-12
     assert bench.causal_fraction("attn_fwd_kernel<128, false, true, 8>", 4, 2) == 1.0
     assert abs(bench.causal_fraction("attn_bwd_dq_res_kernel<64, 8, true>", 256, 256) - 257 / 512) < 1e-12
+    # the 32-rows-per-wave long-sequence kernels are causal-only and carry no "true" in their launch labels
+    assert abs(bench.causal_fraction("attn_bwd_dq_w32_kernel<128, 4>", 4, 2) - 7 / 8) < 1e-12
+    assert abs(bench.causal_fraction("attn_fwd_w32_kernel<64, true, 4>", 4, 2) - 7 / 8) < 1e-12
 
 
 def test_bench_pmc_traffic_arithmetic_and_fallback(tmp_path, monkeypatch):
@@ -420,3 +423,14 @@ def test_bench_pmc_traffic_arithmetic_and_fallback(tmp_path, monkeypatch):
     monkeypatch.setattr(os.path, "exists", lambda p, _orig=os.path.exists: False if p.endswith("rocprofv3") else _orig(p))
     table, why = bench.live_pmc_traffic("gpt2s_B32_L1024_C12", ["norm_fwd_kernel<3, false>"])
     assert table == {} and "not found" in why
+
+
+def test_synth_generators_agree():
+    """helpers.synth_table_torch / synth_tensor (int64 torch arithmetic, multi-threaded, device-capable: what regenerates the 6.7 G weights of the
+    full-depth Llama fixtures) == helpers.synth_table (numpy uint64: what the committed fixtures were generated with), bit for bit"""
+    import numpy as np
+    import helpers as H
+    for rows, cols, salt, scale, row0 in [(1000, 4096, 1003, 0.07, 0), (17, 11008, 5, 0.2, 123456), (1, 100000, 11, 2.0, 0), (300, 3, 7, 0.035, 99990),
+                                          (128256 - 128000, 64, 1000, 0.07, 128000)]:
+        assert np.array_equal(H.synth_table(rows, cols, salt, scale, row0=row0), H.synth_table_torch(rows, cols, salt, scale, row0=row0).numpy())
+    assert np.array_equal(H.synth_tensor(20000, 5, 9, 0.3, block=8192).numpy(), H.synth_table(20000, 5, 9, 0.3))

@@ -27,7 +27,7 @@ def _sample(meta, key, t):
 
 def _oracle_vs_reference(name):
     from oracle import medtsllm_oracle as O
-    meta, data, bcfg, backbone, params = load_rw_case(name)
+    meta, data, bcfg, backbone, params = load_rw_case(name)      # (host tensors: the oracle is the CPU restatement, also on the GPU box)
     m = oracle_mcfg(meta)
     p = {n: v.clone().requires_grad_(True) for n, v in params.items()}
     x = torch.from_numpy(data["x_enc"])
@@ -77,20 +77,25 @@ def test_oracle_vs_reference_real_width(name):
     _oracle_vs_reference(name)
 
 
-LARGE_OPT_IN = ("llama2_7b_2l_wavg_ad", "llama2_7b_2l_interleave_seg", "llama3_8b_2l_recon")      # run with MTL_LARGE_ORACLE=1 (here: 1 - 5 min each, green in round 4) — the default
-                                                                    # `-m gpu` run keeps one Llama-width oracle check so that it stays within minutes
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", [n for n in RW_CASES if n not in RW_CASES_CPU])
 def test_oracle_vs_reference_real_width_large(name):
-    import os
-    if name in LARGE_OPT_IN and not os.environ.get("MTL_LARGE_ORACLE"):
-        pytest.skip("opt-in (MTL_LARGE_ORACLE=1): 6 - 12 GB and minutes of host time")
-    """Llama-2-7B width (0.54 G backbone weights + a [1024, 32000] mapping layer: 1 - 2 min, ~6 GB; semantic segmentation on concat covariates,
-    anomaly detection on `weighted-average` ones); Llama-3-8B width (GQA 32 / 8, ffn 14336, vocabulary 128 256 -> 100 000 TRAINABLE rows: 1.1 G fp32
-    numbers with their gradients, ~3 min) — on the GPU box's host for their size only (no device code runs)"""
+    """The oracle against the reference at the Llama widths — and at the FULL depth of BASELINE.json configs[2] (32 layers of Llama-2-7B, 6.6 G
+    formula-generated weights) — on the GPU box's host cores for their size only (no device code runs): 6 - 30 GB of fp32 weights, a [1024, 32000]
+    mapping layer, Llama-3-8B's 100 000 TRAINABLE vocabulary rows with their gradients. Every case runs in the default `-m gpu` suite since round 5
+    (the weights come from helpers.synth_table_torch, multi-threaded: the numpy generator alone took minutes per case); the build container's 8 cores
+    take 1 - 10 minutes per case, hence the gpu marker."""
     _oracle_vs_reference(name)
+
+
+@pytest.mark.gpu
+def test_device_weight_generator_is_the_host_generator():
+    """the formula-generated weights written straight into HBM (what the full-depth cases load) == numpy's, bit for bit"""
+    import helpers as H
+    for rows, cols, salt, scale, row0 in [(777, 4096, 1003, 0.07, 0), (5, 11008, 1005, 0.07, 4090), (1, 4096, 1290, 0.2, 0), (300, 64, 1000, 0.07, 127990)]:
+        assert np.array_equal(H.synth_table(rows, cols, salt, scale, row0=row0), H.synth_table_torch(rows, cols, salt, scale, row0=row0, device="cuda").cpu().numpy())
+    a = H.synth_tensor(20000, 96, 9, 0.3, device="cuda").cpu()
+    assert torch.equal(a, H.synth_tensor(20000, 96, 9, 0.3))
 
 
 @pytest.mark.gpu
@@ -98,7 +103,7 @@ def test_oracle_vs_reference_real_width_large(name):
 def test_hip_vs_reference_real_width(name):
     from med_ts_llm_amd.models import model_lookup
     from test_gpu_golden import check_hip_vs_golden, _cfg_from_meta, _DS
-    meta, data, bcfg, backbone, params = load_rw_case(name)
+    meta, data, bcfg, backbone, params = load_rw_case(name, device="cuda")       # (backbone weights generated in HBM: bit-identical to the host generator)
     model = model_lookup["medtsllm"](_cfg_from_meta(meta), _DS(meta), backbone_state=(bcfg, backbone))
     model.tokenizer = fixture_tokenizer()
     assert {n: tuple(q.shape) for n, q in model.named_parameters() if q.requires_grad} == {n: tuple(s) for n, s in meta["param_table"].items()}
