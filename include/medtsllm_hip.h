@@ -12,8 +12,12 @@
  *     PyTorch-allocated outputs/workspaces and the stream (hipStream_t as void*).
  *   - bf16 tensors are raw uint16 storage; row-major; `ld*` are row strides in ELEMENTS.
  *   - return 0 on success, negative MTL_ERR_* otherwise (mtl_strerror gives the text).
- *   - re-entrant / thread-compatible: no mutable globals except the opt-in, mutex-guarded launch profiler; every A/B knob is a per-call
- *     field of an argument struct (tune_*), environment diagnostics are read once and constant afterwards.
+ *   - re-entrant / thread-compatible: no mutable globals except the opt-in, mutex-guarded launch profiler. Per-call A/B knobs are fields of the
+ *     argument structs (mtl_gemm_args.tune_*, mtl_attn_fwd_args.tune). In addition the library reads these ENVIRONMENT variables, each ONCE (first use)
+ *     and constant afterwards — diagnostic dispatch switches for in-step A/B runs, none changes what is computed beyond the summation order of a
+ *     differently tiled kernel: MTL_ATTN_WIDE, MTL_ATTN_WIDE_X, MTL_ATTN_WIDE_MIN, MTL_ATTN_XMAP, MTL_ATTN_W32, MTL_ATTN_W32_NW, MTL_ATTN_MERGED
+ *     (csrc/mtl_attention.hip), MTL_GEMM_RULES_OFF, MTL_GEMM_G, MTL_GEMM_FORCE, MTL_PROF_SHAPES (csrc/mtl_gemm.hip), MTL_ROPE_FUSE (csrc/mtl_backbone.hip).
+ *     Unset (the product's state), every dispatch rule is the measured default.
  */
 #ifndef MEDTSLLM_HIP_H
 #define MEDTSLLM_HIP_H

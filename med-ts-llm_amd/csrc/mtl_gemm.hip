@@ -41,12 +41,6 @@ constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 #ifndef MTL_GEMM_FRAG_PIPE
 #define MTL_GEMM_FRAG_PIPE 1      // 0: the compiler-scheduled fragment reads (diagnostic builds)
 #endif
-#ifndef MTL_GEMM_RESID_PF
-#define MTL_GEMM_RESID_PF 0       // k-steps before a tile's end at which the residual epilogue's operands are requested (0: in the epilogue)
-#endif
-#ifndef MTL_GEMM_RESID_PF_ROWS
-#define MTL_GEMM_RESID_PF_ROWS 4  // how many of a lane's 4 row tiles are prefetched (registers: 4 per row tile and column tile)
-#endif
 #ifndef MTL_GEMM_FRAG_D
 #define MTL_GEMM_FRAG_D 3         // prefetch distance of the fragment pipeline in units of 4 MFMAs
 #endif
@@ -225,24 +219,20 @@ __device__ __forceinline__ void epi_cols(const mtl_gemm_args& p, int64_t n_wave,
     }
 }
 
-template <int EPI, int CDT, int NI, bool FULL, int NPTW, int T0, int WHAT = 3>      // WHAT: bit 0 = the bias, bit 1 = the per-element operand
+template <int EPI, int CDT, int NI, bool FULL, int NPTW, int T0>
 __device__ __forceinline__ void epi_load(const mtl_gemm_args& p, const EpiRows& r, int64_t n_base, const int g, EpiAux<EPI, NI>& a) {
     int64_t ncol[NI];
     bool nok[NI];
     epi_cols<NI, FULL, NPTW, T0>(p, n_base, g, ncol, nok);
-    if constexpr (WHAT & 1) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) a.b4[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) {                   // uniform branch around ALL bias loads
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) a.b4[ni] = *reinterpret_cast<const float4*>(p.bias + ncol[ni]);
     }
-    }
-    if constexpr ((WHAT & 6) && (EPI == MTL_EPI_RESID || EPI == MTL_EPI_ACCUM || EPI == MTL_EPI_DGELU || EPI == MTL_EPI_DSWIGLU)) {
-        // (bit 1 alone: row tiles 0 .. MTL_GEMM_RESID_PF_ROWS - 1; bit 2 alone: the others)
-        constexpr int MI0 = (WHAT & 6) == 4 ? MTL_GEMM_RESID_PF_ROWS : 0, MI1 = (WHAT & 6) == 2 ? MTL_GEMM_RESID_PF_ROWS : 4;
+    if constexpr (EPI == MTL_EPI_RESID || EPI == MTL_EPI_ACCUM || EPI == MTL_EPI_DGELU || EPI == MTL_EPI_DSWIGLU) {
 #pragma unroll
-        for (int mi = MI0; mi < MI1; ++mi)
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 if constexpr (EPI == MTL_EPI_RESID) a.res[ni][mi] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.aux_in) + r.crow[mi] * p.ld_aux_in + ncol[ni]);
@@ -430,9 +420,9 @@ __device__ __forceinline__ void epi_store(const mtl_gemm_args& p, const EpiRows&
 // the next k-step's first ds_read, draining the LDS-DMA pipeline.)
 // Column tiles go NCH at a time (<= 4 in one piece; wider wave tiles 2 at a time: 64x96 .. 64x144 per wave); an odd count (NI = 9) ends with ONE
 // unpaired column tile. Per chunk: wait for its auxiliary operands, math in place, ISSUE THE NEXT CHUNK'S LOADS (into the same registers), stores.
-template <int EPI, int CDT, int NI, bool FULL, bool PAIR = false, bool PRE = false>
+template <int EPI, int CDT, int NI, bool FULL, bool PAIR = false>
 __device__ __forceinline__ void epilogue_wave(const mtl_gemm_args& p, int64_t m_first, int64_t n_base, const int g, f32x4 (&acc)[NI][4],
-                                              const bool dword_stores = false, EpiAux<EPI, (NI > 4 ? 2 : NI)>* pre = nullptr) {
+                                              const bool dword_stores = false) {
     // PIPE (bias-only epilogues: plain store, GELU, SwiGLU): chunk c + 1's bias loads go out between chunk c's math and its stores, so the wait
     // for them does not drain chunk c's stores (in-step A/B inside one process: GELU GEMM 256x192 54.4 -> 50.7 us, plain 256x256 340.9 -> 337.5 us).
     // Residual-type epilogues (16 B of auxiliary operand per output quad) keep load -> math -> store per chunk: what they wait for is the
@@ -445,11 +435,9 @@ __device__ __forceinline__ void epilogue_wave(const mtl_gemm_args& p, int64_t m_
     constexpr int NPTW = PAIR ? (NI & ~1) : 0; // paired column tiles of the wave's sub-tile
     static_assert(NFULL >= 1 && NFULL <= 4 && NTAIL <= 1, "chunk schedule");
     const EpiRows r = epi_rows<EPI, FULL>(p, m_first);
-    EpiAux<EPI, NCH> a_own;
-    EpiAux<EPI, NCH>& a = PRE ? *pre : a_own;      // PRE: chunk 0's operands were requested from inside the main loop (MTL_GEMM_RESID_PF)
+    EpiAux<EPI, NCH> a;
     EpiAux<EPI, NTAIL ? NTAIL : 1> at;
-    if constexpr (!PRE) epi_load<EPI, CDT, NCH, FULL, NPTW, 0>(p, r, n_base, g, a);
-    else epi_load<EPI, CDT, NCH, FULL, NPTW, 0, (MTL_GEMM_RESID_PF_ROWS < 4 ? 5 : 1)>(p, r, n_base, g, a);      // (the bias: a few L2-resident lines; the rows not prefetched)
+    epi_load<EPI, CDT, NCH, FULL, NPTW, 0>(p, r, n_base, g, a);
     // edge tiles: hipcc sinks the bias/residual math into the predicated store blocks, which leaves the load results "pending" at the
     // merge and costs a vmcnt(0) before every later ds_read; a compiler-visible wait per chunk settles it (edge tiles only).
 #define MTL_EPI_NEXT(C)                                                                                                                  \
@@ -813,11 +801,6 @@ __global__ __launch_bounds__(NW_ALL * 64, persist_waves_per_simd(BM_, BN_, STAGE
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // epilogue of a finished item: the fused one, or (SPLIT) a raw fp32 store into the item's workspace slab
-    // MTL_GEMM_RESID_PF = n > 0 (residual epilogue, one tile per workgroup, interior tile, one epilogue chunk): the fp32 residual tile and the bias
-    // are requested n k-steps before the tile's last one, so the epilogue starts with its operands in registers instead of a cold round trip
-    constexpr bool CAN_PF = MTL_GEMM_RESID_PF > 0 && EPI == MTL_EPI_RESID && !SPLIT && KS == 1 && NI <= 4;
-    EpiAux<EPI, (NI > 4 ? 2 : NI)> pre;
-    bool have_pre = false;
     auto finish = [&](int item) {
         int tm, tn;
         const int slab = SPLIT ? item / tiles_mn : 0;
@@ -825,12 +808,6 @@ __global__ __launch_bounds__(NW_ALL * 64, persist_waves_per_simd(BM_, BN_, STAGE
         if (col_rot) { tn += col_rot; if (tn >= tiles_n) tn -= tiles_n; }
         const int64_t m0 = (int64_t)tm * BM_, n0 = (int64_t)tn * BN_;
         const bool full = m0 + BM_ <= p.M && n0 + BN_ <= p.N;
-        if constexpr (CAN_PF) {
-            if (have_pre) {
-                epilogue_wave<EPI, CDT, NI, true, PAIR, true>(p, m0 + wr * 64 + l15, n0 + wc * WCOLS, g, acc, vec_ok_i == 0, &pre);
-                return;
-            }
-        }
         if constexpr (SPLIT) {
             mtl_gemm_args q = p;
             q.C = reinterpret_cast<float*>(p.workspace) + (int64_t)slab * p.M * p.N;
@@ -881,19 +858,6 @@ __global__ __launch_bounds__(NW_ALL * 64, persist_waves_per_simd(BM_, BN_, STAGE
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
             done_tile = -1;
-        }
-        if constexpr (CAN_PF) {
-            if (my_count == 1 && total > MTL_GEMM_RESID_PF && it == total - MTL_GEMM_RESID_PF) {
-                int tm, tn;
-                tile_coords(t0 + slot, tiles_m, tiles_n, gm, tm, tn);
-                if (col_rot) { tn += col_rot; if (tn >= tiles_n) tn -= tiles_n; }
-                const int64_t m0 = (int64_t)tm * BM_, n0 = (int64_t)tn * BN_;
-                if (m0 + BM_ <= p.M && n0 + BN_ <= p.N) {
-                    const EpiRows r = epi_rows<EPI, true>(p, m0 + wr * 64 + l15);
-                    epi_load<EPI, CDT, NI, true, (PAIR ? (NI & ~1) : 0), 0, 2>(p, r, n0 + wc * WCOLS, g, pre);
-                    have_pre = true;
-                }
-            }
         }
         if (it + STAGES - 1 < total) {
             if (s_kt == 0) set_sources(t0 + slot + s_i * xblocks);

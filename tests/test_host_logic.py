@@ -434,3 +434,15 @@ def test_synth_generators_agree():
                                           (128256 - 128000, 64, 1000, 0.07, 128000)]:
         assert np.array_equal(H.synth_table(rows, cols, salt, scale, row0=row0), H.synth_table_torch(rows, cols, salt, scale, row0=row0).numpy())
     assert np.array_equal(H.synth_tensor(20000, 5, 9, 0.3, block=8192).numpy(), H.synth_table(20000, 5, 9, 0.3))
+
+
+def test_header_lists_every_environment_switch_of_the_library():
+    """include/medtsllm_hip.h claims to name every environment variable the shipped library reads: compare with the sources"""
+    import re
+    src = "".join((ROOT / "med-ts-llm_amd" / "csrc" / f).read_text() for f in
+                  ("mtl_gemm.hip", "mtl_attention.hip", "mtl_backbone.hip", "mtl_norm.hip", "mtl_elementwise.hip", "mtl_tokenizer.hip", "mtl_optim.hip",
+                   "mtl_stats.hip", "mtl_common.h"))
+    read = set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', src))
+    head = (ROOT / "include" / "medtsllm_hip.h").read_text()
+    listed = set(re.findall(r"\bMTL_[A-Z0-9_]+\b", head[head.index("ENVIRONMENT variables"):head.index("Unset (the product's state)")]))
+    assert read == listed, (sorted(read - listed), sorted(listed - read))

@@ -27,8 +27,21 @@ def _sample(meta, key, t):
 
 def _oracle_vs_reference(name):
     from oracle import medtsllm_oracle as O
-    meta, data, bcfg, backbone, params = load_rw_case(name)      # (host tensors: the oracle is the CPU restatement, also on the GPU box)
+    # the oracle is the CPU restatement, also on the GPU box: every tensor it sees lives on the host. Only the SYNTHESIS of the formula-generated backbone
+    # weights runs on the device when there is one (bit-identical to the host generator: test_device_weight_generator_is_the_host_generator) — 6.6 G
+    # numbers take minutes on the host and seconds in HBM
+    meta, data, bcfg, backbone, params = load_rw_case(name, device="cuda" if torch.cuda.is_available() else "cpu")
+    backbone = {k: v.cpu() for k, v in backbone.items()}
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+    torch.set_num_threads(min(64, torch.get_num_threads()))      # (256 host threads on [512, 4096]-sized operands only contend)
     m = oracle_mcfg(meta)
+    # full-depth stacks: fp32 summation-order noise (the oracle's GEMMs on 64 threads vs the reference's on the build container's 8) is amplified through
+    # 32 random-weight layers exactly as the bf16 noise is (x 12 at the last hidden state: profiles/r05_fulldepth_reference_parity.txt) — 4 x the bars of
+    # the two-layer cases (measured: 7.9e-5 on one gradient projection of the Llama-3-8B stack, everything else < 5e-5)
+    deep = 4.0 if bcfg.get("num_hidden_layers", 0) >= 16 else 1.0
+    TOL = globals()["TOL"] * deep
+    GTOL = 5e-5 * deep
     p = {n: v.clone().requires_grad_(True) for n, v in params.items()}
     x = torch.from_numpy(data["x_enc"])
     mean, stdev = O.revin_stats(x)
@@ -47,22 +60,22 @@ def _oracle_vs_reference(name):
     assert rel_err(_sample(meta, "source_embeddings", src), data["source_embeddings"]) < TOL
     assert rel_err(_sample(meta, "pred_train", pred), data["pred_train"]) < TOL
     loss = golden_loss(pred, data["target"], meta["task"])
-    assert abs(loss.item() - float(data["loss"])) < 1e-5 * max(1.0, abs(float(data["loss"])))
+    assert abs(loss.item() - float(data["loss"])) < 1e-5 * deep * max(1.0, abs(float(data["loss"])))
     loss.backward()
     n_checked = 0
     for k, v in data.items():
         if k.startswith("grad."):
             n = k[len("grad."):]
             # (the key bias has an analytically-zero gradient — softmax shift invariance — hence the absolute floor)
-            assert abs_err(p[n].grad, v) < 5e-5 * float(np.linalg.norm(v)) + 1e-7, (n, rel_err(p[n].grad, v))
+            assert abs_err(p[n].grad, v) < GTOL * float(np.linalg.norm(v)) + 1e-7, (n, rel_err(p[n].grad, v))
             n_checked += 1
         elif k.startswith("gradnorm."):
             n = k[len("gradnorm."):]
             g = p[n].grad
             norm, prow, pcol, sample = big_grad_summary(g.reshape(g.shape[0], -1), meta["synth"]["stride"])
-            assert abs(norm - float(v)) < 5e-5 * float(v), n
+            assert abs(norm - float(v)) < GTOL * float(v), n
             for got, want in ((prow, data["gradproj_rows." + n]), (pcol, data["gradproj_cols." + n]), (sample, data["gradsample." + n])):
-                assert abs_err(got, want) < 5e-5 * float(np.linalg.norm(want)) + 1e-7, (n, rel_err(got, want))
+                assert abs_err(got, want) < GTOL * float(np.linalg.norm(want)) + 1e-7, (n, rel_err(got, want))
             n_checked += 1
     assert n_checked == len(p)
     with torch.no_grad():
