@@ -36,6 +36,17 @@ constexpr int KC = 64;  // keys (or queries, in the dK/dV kernel) per LDS chunk
 #define MTL_ATTN_PAD64 8
 #endif
 __host__ __device__ constexpr int attn_pad(int D) { return D >= 128 ? MTL_ATTN_PAD : MTL_ATTN_PAD64; }
+// The resident hd-64 FORWARD and the one-launch (merged) BACKWARD — the two attention kernels of the metric step — pad their rows by 16: the stride of
+// 40 dwords is conflict-free for both read shapes under the lane groups of GUIDE MI355X_MICROARCH "LDS" (ds_read_b128: the 16 four-dword slots
+// (10 r + g) mod 16 of a group's rows {0-3, 12-15} x g and {4-11} x (g + 1) are distinct; ds_read_b64_tr_b16: 8 rows x 8 dwords at 40 r mod 64 tile the 64
+// banks), whereas stride 36 collides 7 of 16 slots per b128 group (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.43 - 0.45). Both still
+// fit as before (forward: 2 x 80 KB per CU; merged backward: 141 KB, one workgroup per CU either way). Time: unchanged within noise (19.7 -> 19.6 - 19.9 us,
+// 28.5 -> 28.1 - 28.3 us, profiles/r05_experiments_flat.txt) — the kernels are VALU-issue-bound — so the padding is picked from the conflict counter.
+// The other hd-64 kernels keep 8: the two-launch resident dK/dV kernel would lose its second workgroup per CU (profiles/r04_attn_longT_experiments.txt).
+#ifndef MTL_ATTN_PAD64_RES
+#define MTL_ATTN_PAD64_RES 16
+#endif
+__host__ __device__ constexpr int attn_pad_res(int D) { return D >= 128 ? MTL_ATTN_PAD : MTL_ATTN_PAD64_RES; }
 #ifndef MTL_CONSISTENT_DELTA
 #define MTL_CONSISTENT_DELTA 0     // causal self-attention: 0 = delta = dO . O with the bf16-rounded forward output (measured: the consistent
                                    // form changes nothing there — tools/diag_bias.py: the stack's input gradient is unbiased and on par
@@ -1133,10 +1144,10 @@ template <int D, int NW>
 struct RES_BATCH { static constexpr int value = (D >= 128 && NW >= 8) ? 8 : 4; };
 
 // two matrices (K and V, or Q and dO) in ONE round trip: every load of both is issued before the first LDS store
-template <int D, int NT, int BATCH>
+template <int D, int NT, int BATCH, int PAD = attn_pad(D)>
 __device__ __forceinline__ void load_rows_pair(bf16_t* tile_a, const bf16_t* src_a, int64_t ts_a, bf16_t* tile_b, const bf16_t* src_b,
                                                int64_t ts_b, int64_t rows) {
-    constexpr int LDT = D + attn_pad(D), CPR = D / 8;
+    constexpr int LDT = D + PAD, CPR = D / 8;
     const int64_t total = ceil32(rows) * CPR;
     for (int64_t base = 0; base < total; base += (int64_t)BATCH * NT) {
         u32x4 va[BATCH], vb[BATCH];
@@ -1164,14 +1175,14 @@ __device__ __forceinline__ void load_rows_pair(bf16_t* tile_a, const bf16_t* src
 
 template <int D, int NW, bool DROP = false>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(const mtl_attn_fwd_args a) {
-    constexpr int LDT = D + attn_pad(D), NKS = D / 32, NDT = D / 16;
+    constexpr int LDT = D + attn_pad_res(D), NKS = D / 32, NDT = D / 16;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* ktile = reinterpret_cast<bf16_t*>(smem_raw);
     bf16_t* vtile = ktile + ceil32(a.Tk) * LDT;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, g = lane >> 4;   // (wave index in an SGPR: tile offsets, loop bounds and the mask test become scalar)
     const int64_t b = blockIdx.z, h = blockIdx.y, hk = h / (a.Hq / a.Hkv);
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + b * a.q_bs + h * a.q_hs;
-    load_rows_pair<D, NW * 64, RES_BATCH<D, NW>::value>(ktile, reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + hk * a.k_hs, a.k_ts,
+    load_rows_pair<D, NW * 64, RES_BATCH<D, NW>::value, attn_pad_res(D)>(ktile, reinterpret_cast<const bf16_t*>(a.k) + b * a.k_bs + hk * a.k_hs, a.k_ts,
                                   vtile, reinterpret_cast<const bf16_t*>(a.v) + b * a.v_bs + hk * a.v_hs, a.v_ts, a.Tk);
     __syncthreads();
     const uint32_t dbase = DROP ? drop_base(a.dropout_seed, (uint32_t)(b * a.Hq + h)) : 0u;
@@ -1537,7 +1548,7 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 && !DROP) ? 2 : 1) void attn_bwd
 // dynamic LDS: K [RK][D+8] | V [RK][D+8] | Q [RQ][D+8] | dO [RQ][D+8] | O [RQ][D+8] | lse2[RQ] | delta[RQ]   (RK = ceil32(Tk), RQ = ceil32(Tq))
 template <int D, int NW, bool DROP = false>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_res_merged_kernel(const mtl_attn_bwd_args a) {
-    constexpr int LDT = D + attn_pad(D), NKS = D / 32, NDT = D / 16, CPR = D / 8, NT = NW * 64, BK = 2048 / NT, BQ = 1024 / NT, NTL = NW / 2;
+    constexpr int LDT = D + attn_pad_res(D), NKS = D / 32, NDT = D / 16, CPR = D / 8, NT = NW * 64, BK = 2048 / NT, BQ = 1024 / NT, NTL = NW / 2;
     static_assert(NW % 2 == 0 && 2048 % NT == 0 && 1024 % NT == 0, "two wave groups; whole staging chunks per thread");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const mtl_attn_fwd_args& f = a.f;
@@ -1822,7 +1833,7 @@ namespace {
 size_t pad32(int64_t v) { return (size_t)((v + 31) & ~(int64_t)31); }
 bool resident_ok(const mtl_attn_fwd_args& f, int64_t rows) {
     return !(f.tune & 1) && f.causal && f.k_bs != 0 && f.dropout_p < 1.f && (f.D == 64 || f.D == 128) &&
-           2 * pad32(rows) * (f.D + attn_pad((int)f.D)) * 2 + 2 * pad32(rows) * 4 <= kLdsBudget;
+           2 * pad32(rows) * (f.D + attn_pad_res((int)f.D)) * 2 + 2 * pad32(rows) * 4 <= kLdsBudget;       // (the wider of the two paddings)
 }
 
 }  // namespace
@@ -1836,7 +1847,7 @@ extern "C" int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream) {
     const double fl_fwd = 4.0 * (double)a->B * a->Hq * a->Tq * a->Tk * a->D;
     (void)fl_fwd;
     if (resident_ok(*a, a->Tk)) {
-        const size_t lds = 2 * pad32(a->Tk) * (a->D + attn_pad((int)a->D)) * 2;
+        const size_t lds = 2 * pad32(a->Tk) * (a->D + attn_pad_res((int)a->D)) * 2;
         const int npairs = (int)(((a->Tq + 15) / 16 + 1) / 2);
         if (a->D == 64 && a->dropout_p > 0.f) {
             static std::once_flag once; std::call_once(once, [&] { set_lds(attn_fwd_res_kernel<64, 8, true>, kLdsBudget); });
@@ -1930,7 +1941,7 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
     if (resident_ok(f, f.Tk) && resident_ok(f, f.Tq)) {
         if (a->kv_row0 < 0 || a->kv_row0 >= f.Tk) return MTL_ERR_ARG;
         // few tiles on both sides (the backbone's pruned backward: n_grad query rows, dK / dV for the patch keys): ONE launch stages the head once
-        const size_t lds_m = (2 * pad32(f.Tk) + 3 * pad32(f.Tq)) * (f.D + attn_pad((int)f.D)) * 2 + 2 * pad32(f.Tq) * 4;
+        const size_t lds_m = (2 * pad32(f.Tk) + 3 * pad32(f.Tq)) * (f.D + attn_pad_res((int)f.D)) * 2 + 2 * pad32(f.Tq) * 4;
         if (g_attn_merged == 1 && !(f.tune & 2) && f.D == 64 && f.Hq == f.Hkv && (f.Tq + 15) / 16 <= 8 && (f.Tk - a->kv_row0 + 15) / 16 <= 8 && lds_m <= kLdsBudget) {
             static std::once_flag once;
             std::call_once(once, [&] { set_lds(attn_bwd_res_merged_kernel<64, 16, true>, kLdsBudget); set_lds(attn_bwd_res_merged_kernel<64, 16, false>, kLdsBudget); });

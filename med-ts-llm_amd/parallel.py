@@ -98,7 +98,16 @@ def init_from_env(device_type="cuda"):
         torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     if not dist.is_initialized():
         # MTL_DIST_BACKEND=gloo lets several ranks share ONE GPU (RCCL refuses that): how the DP path is tested on a 1-GPU box
-        backend = os.environ.get("MTL_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
+        default = "nccl" if device_type == "cuda" else "gloo"
+        # more ranks on this node than it has GPUs (the driver's `torch.distributed.run --nproc-per-node N` on a smaller box): RCCL would fail with
+        # "Duplicate GPU detected"; the ranks share devices over gloo instead — a functional run, said on stderr and visible as dist_backend
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        if device_type == "cuda" and torch.cuda.is_available() and local_world > torch.cuda.device_count() and "MTL_DIST_BACKEND" not in os.environ:
+            default = "gloo"
+            if rank == 0:
+                import sys
+                print(f"[parallel] {local_world} local ranks on {torch.cuda.device_count()} GPU(s): using gloo (RCCL refuses two ranks per device)", file=sys.stderr, flush=True)
+        backend = os.environ.get("MTL_DIST_BACKEND", default)
         import datetime
         # (a rank that never arrives must end the job, not hang it: 10 min covers the slowest first RCCL communicator set-up)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=int(os.environ.get("MTL_DIST_TIMEOUT_MIN", "10"))))
