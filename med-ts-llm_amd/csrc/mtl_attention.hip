@@ -1840,6 +1840,11 @@ bool resident_ok(const mtl_attn_fwd_args& f, int64_t rows) {
 
 extern "C" int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream) {
     if (!a) return MTL_ERR_ARG;
+#ifdef MTL_DIAG_ATTN_NODROP      // diagnostic builds only: the causal self-attention without its dropout (what the mask costs in-step; WRONG results)
+    mtl_attn_fwd_args nodrop = *a;
+    if (nodrop.causal) nodrop.dropout_p = 0.f;
+    a = &nodrop;
+#endif
     const int rc = check_fwd(*a);
     if (rc != MTL_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -1924,6 +1929,11 @@ extern "C" int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream) {
 
 extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
     if (!a) return MTL_ERR_ARG;
+#ifdef MTL_DIAG_ATTN_NODROP
+    mtl_attn_bwd_args nodrop = *a;
+    if (nodrop.f.causal) nodrop.f.dropout_p = 0.f;
+    a = &nodrop;
+#endif
     const mtl_attn_fwd_args& f = a->f;
     const int rc = check_fwd(f);
     if (rc != MTL_OK) return rc;

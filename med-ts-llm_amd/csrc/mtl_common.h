@@ -79,6 +79,9 @@ __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { 
 // elements (the first version hashed every PAIR with 12). Statistics of the fields (keep rate, neighbour / row / stream correlations,
 // chi-square of the bytes) were checked on the host replica before adoption (tests/helpers.py::drop_u16, tests/test_host_logic.py).
 __device__ __forceinline__ uint2 drop_quad(uint32_t base, uint32_t a, uint32_t quad) {
+#ifdef MTL_DIAG_NOHASH      // diagnostic builds only (tools/build_variant.sh): what the hash itself costs a kernel — every element kept, WRONG results
+    return make_uint2(0xffffffffu ^ (base & 1u), 0xffffffffu ^ (a & 1u));
+#endif
     uint32_t h = mad24(a, 0x9E3779u, base) ^ __umul24(quad, 0x85EBCBu);
     h ^= h >> 15; h = mad24(h, 0xC2B2AFu, h >> 24);
     h ^= h >> 13;
