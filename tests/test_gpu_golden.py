@@ -183,7 +183,7 @@ def check_hip_vs_golden(model, meta, data, bcfg, name, grad_bar=MIXED_FACTOR):
             n_checked += 1
         elif k.startswith("gradnorm."):           # 100 000-wide gradients: projections along both axes + strided slices
             n = k[len("gradnorm."):]
-            norm, prow, pcol, sample = big_grad_summary(grads[n], meta["synth"]["stride"])
+            norm, prow, pcol, sample = big_grad_summary(grads[n].reshape(grads[n].shape[0], -1), meta["synth"]["stride"])      # (a 51 200-long bias is summarised as [n, 1])
             self_rel = float(data["selferr.grad." + n]) / float(data[k])
             tol = grad_bar * max(self_rel, GRAD_FLOOR)
             report[f"grad.{n}[norm]"] = (abs(norm - float(data[k])) / float(data[k]), tol)
