@@ -707,6 +707,9 @@ def compact_line(out):
     c["roofline"] = _roof_compact(out.get("roofline"))
     c["roofline_hbm"] = _roof_compact(out.get("roofline_hbm"))
     c["roofline_attention"] = _roof_compact(out.get("roofline_attention"))
+    # every HBM-bound kernel family beside the dominant one (roofline_hbm picks the norm kernel with the largest total time; the other direction and Adam here)
+    c["hbm_kernels"] = [{"kernel": r["kernel"], "us": r["avg_us"], "frac": round(r["gbs"] / HBM_PEAK_GBS, 3)}
+                        for r in (out.get("kernel_instances") or []) if "gbs" in r and r["kernel"].startswith(("norm", "adam"))][:3]
     rs = out.get("roofline_step")
     c["roofline_step"] = {k: v for k, v in rs.items() if k != "source"} if rs else None
     cb = out.get("cpu_baseline")
