@@ -15,7 +15,7 @@
  *   - re-entrant / thread-compatible: no mutable globals except the opt-in, mutex-guarded launch profiler. Per-call A/B knobs are fields of the
  *     argument structs (mtl_gemm_args.tune_*, mtl_attn_fwd_args.tune). In addition the library reads these ENVIRONMENT variables, each ONCE (first use)
  *     and constant afterwards — diagnostic dispatch switches for in-step A/B runs, none changes what is computed beyond the summation order of a
- *     differently tiled kernel: MTL_ATTN_WIDE, MTL_ATTN_WIDE_X, MTL_ATTN_WIDE_MIN, MTL_ATTN_XMAP, MTL_ATTN_W32, MTL_ATTN_W32_NW, MTL_ATTN_MERGED
+ *     differently tiled kernel: MTL_ATTN_WIDE, MTL_ATTN_WIDE_X, MTL_ATTN_WIDE_MIN, MTL_ATTN_XMAP, MTL_ATTN_W32, MTL_ATTN_W32_NW, MTL_ATTN_MERGED, MTL_ATTN_D128
  *     (csrc/mtl_attention.hip), MTL_GEMM_RULES_OFF, MTL_GEMM_G, MTL_GEMM_FORCE, MTL_PROF_SHAPES (csrc/mtl_gemm.hip), MTL_ROPE_FUSE (csrc/mtl_backbone.hip).
  *     Unset (the product's state), every dispatch rule is the measured default.
  */

@@ -1820,6 +1820,10 @@ const int g_attn_wide_min = getenv("MTL_ATTN_WIDE_MIN") ? atoi(getenv("MTL_ATTN_
 const int g_attn_xmap = getenv("MTL_ATTN_XMAP") ? atoi(getenv("MTL_ATTN_XMAP")) : 1;   // A/B knob: 0 = plain (row block, head, batch) grids for the long-sequence kernels
 const int g_attn_w32_nw = getenv("MTL_ATTN_W32_NW") ? atoi(getenv("MTL_ATTN_W32_NW")) : 0;   // A/B knob: 4 / 8 waves per workgroup of the 32-row kernels (0 = automatic)
 const int g_attn_w32 = getenv("MTL_ATTN_W32") ? atoi(getenv("MTL_ATTN_W32")) : 1;   // A/B knob: 0 = the 16-rows-per-wave kernels for long causal sequences
+// hd-128 causal self-attention without dropout (the Llama stacks) where K / V WOULD fit the LDS: the 32-rows-per-wave forward and the 8-wave chunked dQ
+// kernel beat their resident twins from 128 query rows on, and so does the chunked dK/dV kernel under GQA or with more than 128 key rows (round 5,
+// tools/diag/attn_matrix.sh: Llama-2 cached shape forward 57.5 -> 42.0 us, dQ 66.8 -> 53.2; Llama-3 GQA dK/dV 52.9 -> 32.6). 0 = the resident kernels.
+const int g_attn_d128 = getenv("MTL_ATTN_D128") ? atoi(getenv("MTL_ATTN_D128")) : 1;
 const int g_attn_merged = getenv("MTL_ATTN_MERGED") ? atoi(getenv("MTL_ATTN_MERGED")) : 1;   // A/B knob: 0 = the resident backward as two launches (dQ, then dK / dV)
 
 template <typename KernelT>
@@ -1851,7 +1855,8 @@ extern "C" int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream) {
     // algorithmic FLOPs, full-rectangle convention: S = Q K^T and O = P V, 2 * Tq * Tk * D each per head
     const double fl_fwd = 4.0 * (double)a->B * a->Hq * a->Tq * a->Tk * a->D;
     (void)fl_fwd;
-    if (resident_ok(*a, a->Tk)) {
+    const bool d128_fwd = g_attn_d128 == 1 && a->causal && a->D == 128 && a->dropout_p == 0.f && !a->o_f32 && a->Tq >= 128 && a->k_bs != 0 && g_attn_wide == 1 && g_attn_w32 == 1;
+    if (resident_ok(*a, a->Tk) && !d128_fwd) {
         const size_t lds = 2 * pad32(a->Tk) * (a->D + attn_pad_res((int)a->D)) * 2;
         const int npairs = (int)(((a->Tq + 15) / 16 + 1) / 2);
         if (a->D == 64 && a->dropout_p > 0.f) {
@@ -1883,7 +1888,7 @@ extern "C" int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream) {
         MTL_CHECK_LAUNCH();
         return MTL_OK;
     }
-    if (a->causal && !drop && !a->o_f32 && a->Tq >= g_attn_wide_min && (a->D == 64 || a->D == 128) && g_attn_wide == 1 && g_attn_w32 == 1) {
+    if (a->causal && !drop && !a->o_f32 && (a->Tq >= g_attn_wide_min || d128_fwd) && (a->D == 64 || a->D == 128) && g_attn_wide == 1 && g_attn_w32 == 1) {
         // long sequences: 32 query rows per wave on 32x32x16 MFMAs, double-buffered 64-key chunks, 4 waves = 128 queries per workgroup (8 waves measured
         // slower: profiles/r04_attn_longT_experiments.txt). The kernel has no fp32 output copy: a caller asking for o_f32 gets the 16-row kernel below.
         const int nww = (g_attn_w32_nw == 4 || g_attn_w32_nw == 8) ? g_attn_w32_nw : 4;
@@ -1982,8 +1987,18 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
         } else {
             static std::once_flag once;
             std::call_once(once, [&] { set_lds(attn_bwd_dq_res_kernel<128, 8>, kLdsBudget); set_lds(attn_bwd_dkv_res_kernel<128, 4>, kLdsBudget); });
-            MTL_LAUNCH("attn_bwd_dq_res_kernel<128, 8, false>", fl_half, 0, (attn_bwd_dq_res_kernel<128, 8>), dim3((unsigned)((npq + 7) / 8), (unsigned)f.Hq, (unsigned)f.B), dim3(512), lds_q, st, *a);
-            MTL_LAUNCH("attn_bwd_dkv_res_kernel<128, 4, false>", fl_half, 0, (attn_bwd_dkv_res_kernel<128, 4>), dim3((unsigned)((npk + 3) / 4), (unsigned)f.Hkv, (unsigned)f.B), dim3(256), lds_k, st, *a);
+            // hd 128 without dropout (Llama): per kernel, the faster of the resident and the chunked form (g_attn_d128 above). dQ: the 8-wave chunked
+            // kernel from 128 query rows on. dK/dV: resident only for MHA with at most 128 key rows to differentiate (the pruned / cached backward);
+            // GQA (a K/V head serves 4 query heads: the resident kernel's one workgroup per KV head leaves CUs idle) and the full backward go chunked.
+            // Both dQ kernels write delta for whichever dK/dV kernel follows.
+            const bool rules = g_attn_d128 == 1 && f.Tq >= 128 && g_attn_wide == 1 && g_attn_xmap == 1 && f.k_bs != 0;
+            const int64_t nkeys = f.Tk - a->kv_row0;
+            const bool dq_chunked = rules, dkv_chunked = rules && (f.Hq != f.Hkv || nkeys > 128);
+            if (dq_chunked) MTL_LAUNCH("attn_bwd_dq_kernel<128, true, false, 8>", fl_half, 0, (attn_bwd_dq_kernel<128, true, false, 8, true>), dim3(attn_xmap_grid((f.Tq + 127) / 128, f.Hq, f.B)), dim3(512), 0, st, *a);
+            else MTL_LAUNCH("attn_bwd_dq_res_kernel<128, 8, false>", fl_half, 0, (attn_bwd_dq_res_kernel<128, 8>), dim3((unsigned)((npq + 7) / 8), (unsigned)f.Hq, (unsigned)f.B), dim3(512), lds_q, st, *a);
+            if (dkv_chunked && nkeys >= 512) MTL_LAUNCH("attn_bwd_dkv_kernel<128, true, false, 8>", fl_half, 0, (attn_bwd_dkv_kernel<128, true, false, 8, true>), dim3(attn_xmap_grid((nkeys + 127) / 128, f.Hkv, f.B)), dim3(512), 0, st, *a);
+            else if (dkv_chunked) MTL_LAUNCH("attn_bwd_dkv_kernel<128, true, false>", fl_half, 0, (attn_bwd_dkv_kernel<128, true, false, 4, true>), dim3(attn_xmap_grid((nkeys + 63) / 64, f.Hkv, f.B)), dim3(256), 0, st, *a);
+            else MTL_LAUNCH("attn_bwd_dkv_res_kernel<128, 4, false>", fl_half, 0, (attn_bwd_dkv_res_kernel<128, 4>), dim3((unsigned)((npk + 3) / 4), (unsigned)f.Hkv, (unsigned)f.B), dim3(256), lds_k, st, *a);
         }
         MTL_CHECK_LAUNCH();
         return MTL_OK;

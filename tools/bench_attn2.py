@@ -20,6 +20,8 @@ q, k, v = qkv[:, T - Tq:, :H * D], qkv[..., H * D:(H + Hkv) * D], qkv[..., (H + 
 do = torch.randn(B, Tq, H * D, generator=g).to(torch.bfloat16).cuda()
 scale = 1 / math.sqrt(D)
 lib = N.lib()
+if os.environ.get("ATTN_CHUNKED") == "1":      # the non-resident kernels (32-rows-per-wave / chunked) also where K / V would fit the LDS
+    ops._TUNE["attn"] = 1
 o, lse = ops.attention_fwd(q, k, v, H, Hkv, D, scale, True, causal_off=T - Tq)
 ops.attention_bwd(q, k, v, o, lse, do, H, Hkv, D, scale, True, causal_off=T - Tq, kv_row0=T - Tq)
 torch.cuda.synchronize()
