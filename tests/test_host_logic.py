@@ -375,6 +375,31 @@ def test_bench_compact_line_is_small_and_complete():
     assert c["checks"]["step_frac_le_best_kernel_frac"] is True
 
 
+def test_bench_round5_fields_on_the_compact_line():
+    """roofline_step (bytes of ALL dispatches of a step against 8 TB/s, FLOP per byte next to the ridge), the list of HBM-bound kernels and,
+    under N > 1, both DP modes' figures ride on the ONE line and it stays under 4 KB"""
+    import json
+    sys.path.insert(0, str(ROOT))
+    import bench
+    with open(ROOT / "profiles" / "r03_v5c_bench.json") as f:
+        full = json.load(f)
+    step = {"hbm_read_bytes": 10.4e9, "hbm_write_bytes": 5.6e9, "hbm_bytes": 16.0e9, "dispatches_per_step": 219.5}
+    rs = bench.roofline_step(step, full, "live: two rocprofv3 passes")
+    sec = full["ms_per_step"] * 1e-3
+    assert rs["bound"] == "hbm" and rs["bytes_per_step"] == 16_000_000_000 and abs(rs["achieved"] - 16.0 / sec) < 0.1
+    assert abs(rs["frac"] - rs["achieved"] / 8000.0) < 1e-3 and abs(rs["ridge_flop_per_byte"] - 312.5) < 1e-9
+    assert abs(rs["flop_per_byte"] - full["executed_tflop_per_step_per_gpu"] * 1e12 / 16.0e9) < 0.1
+    assert bench.roofline_step(None, full, "x") is None
+    full["roofline_step"] = rs
+    full["dp_modes"] = {"plain_allreduce": 40000.0, "sharded": 43000.0, "what": "both modes back to back"}
+    c = json.loads(json.dumps(bench.compact_line(full), separators=(",", ":")))
+    assert len(json.dumps(c, separators=(",", ":"))) < 4096
+    assert c["roofline_step"]["bytes_per_step"] == 16_000_000_000 and "source" not in c["roofline_step"]
+    assert c["dp_modes"]["plain_allreduce"] == 40000.0
+    assert all(h["kernel"].startswith(("norm", "adam")) and 0 < h["frac"] < 1 for h in c["hbm_kernels"]) and len(c["hbm_kernels"]) >= 2
+    assert all("step_mfma_frac_algorithmic" not in e for e in c["configs"])       # (with the prompt-row cache that figure is not a utilisation: detail file only)
+
+
 def test_causal_fraction_of_the_rectangle():
     sys.path.insert(0, str(ROOT))
     import bench

@@ -9,7 +9,10 @@ lib = N.lib()
 BF16 = torch.bfloat16
 shapes = [("qkv   ", 8192, 2304, 768, N.EPI_STORE), ("aproj ", 8192, 768, 768, N.EPI_RESID), ("fc    ", 8192, 3072, 768, N.EPI_GELU),
           ("mproj ", 8192, 768, 3072, N.EPI_RESID), ("b_dact", 4096, 3072, 768, N.EPI_DGELU), ("b_dxfc", 4096, 768, 3072, N.EPI_STORE), ("b_dO", 4096, 768, 768, N.EPI_STORE), ("dact  ", 8192, 3072, 768, N.EPI_DGELU), ("dx_fc ", 8192, 768, 3072, N.EPI_STORE),
-          ("dx_qkv", 8192, 768, 2304, N.EPI_STORE), ("b_dxqkv", 4096, 768, 2304, N.EPI_STORE), ("llama_qkv", 8192, 12288, 4096, N.EPI_STORE), ("llama_down", 8192, 4096, 11008, N.EPI_RESID), ("llama_gateup", 8192, 22016, 4096, N.EPI_STORE), ("llama_dx", 4096, 4096, 12288, N.EPI_STORE), ("llama_oproj", 8192, 4096, 4096, N.EPI_RESID), ("llama_dgu", 4096, 11008, 4096, N.EPI_STORE)]
+          ("dx_qkv", 8192, 768, 2304, N.EPI_STORE), ("b_dxqkv", 4096, 768, 2304, N.EPI_STORE), ("llama_qkv", 8192, 12288, 4096, N.EPI_STORE), ("llama_down", 8192, 4096, 11008, N.EPI_RESID), ("llama_gateup", 8192, 22016, 4096, N.EPI_STORE), ("llama_dx", 4096, 4096, 12288, N.EPI_STORE), ("llama_oproj", 8192, 4096, 4096, N.EPI_RESID), ("llama_dgu", 4096, 11008, 4096, N.EPI_STORE),
+          # the prompt-row-cached Llama step's M = 4096 shapes (round 5 sweep)
+          ("l4k_qkv", 4096, 12288, 4096, N.EPI_STORE), ("l4k_sq", 4096, 4096, 4096, N.EPI_STORE), ("l4k_dqkv", 4096, 4096, 12288, N.EPI_STORE),
+          ("l4k_dgu", 4096, 4096, 22016, N.EPI_STORE), ("l4k_oproj", 4096, 4096, 4096, N.EPI_RESID), ("l4k_down", 4096, 4096, 11008, N.EPI_RESID)]
 if len(sys.argv) > 1:
     shapes = [s for s in shapes if s[0].strip() in sys.argv[1:]]
 variants = [(1, 256, 128, 3, 16), (1, 256, 192, 2, 8), (1, 256, 256, 2, 8)]
