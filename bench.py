@@ -274,7 +274,7 @@ def live_pmc_traffic(workload, kernels, timeout_s=150.0):
     """HBM bytes per launch of `kernels`, measured NOW by this run: two child runs of this very workload (3 steps, nothing else) under
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` — separate passes, counters only beside the kernel trace, units and
     the gfx950 read-side correction as GUIDE MI355X_MICROARCH §HBM prescribes (tools/pmc_traffic.py holds the arithmetic). Returns
-    ({kernel: {...}}, note); ({}, reason) when rocprofv3 is absent, a pass fails or runs out of time — the caller then falls back to the
+    ({kernel: {...}}, note, step totals for roofline_step); ({}, reason, None) when rocprofv3 is absent, a pass fails or runs out of time — the caller then falls back to the
     committed table of the same kernel sources."""
     import shutil
     import signal
@@ -282,7 +282,7 @@ def live_pmc_traffic(workload, kernels, timeout_s=150.0):
     import tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return {}, "rocprofv3 not found"
+        return {}, "rocprofv3 not found", None
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_traffic as pt
     t_start = time.perf_counter()
@@ -301,20 +301,20 @@ def live_pmc_traffic(workload, kernels, timeout_s=150.0):
             os.killpg(p.pid, signal.SIGKILL)      # the process group this call started, nothing else
             p.wait()
             shutil.rmtree(tmp, ignore_errors=True)
-            return {}, f"{counter} pass exceeded {timeout_s:.0f} s"
+            return {}, f"{counter} pass exceeded {timeout_s:.0f} s", None
         import glob
         dbs = glob.glob(os.path.join(tmp, counter, "**", "*.db"), recursive=True)
         if rc != 0 or not dbs:
             shutil.rmtree(tmp, ignore_errors=True)
-            return {}, f"{counter} pass failed (rc {rc})"
+            return {}, f"{counter} pass failed (rc {rc})", None
         per[counter] = {pt.clean(k): v for k, v in pt.per_kernel(dbs[0], counter, warmup_steps=1).items()}      # (the child's warm-up step and set-up dropped)
     shutil.rmtree(tmp, ignore_errors=True)
     # every dispatch of the two counted steps summed: the step-level HBM traffic (roofline_step)
     n_steps = 2
     step_rd = 2.0 * 1024.0 * sum(v * n for v, n in per["FETCH_SIZE"].values()) / n_steps
     step_wr = 1024.0 * sum(v * n for v, n in per["WRITE_SIZE"].values()) / n_steps
-    live_pmc_traffic.last_step = {"hbm_read_bytes": step_rd, "hbm_write_bytes": step_wr, "hbm_bytes": step_rd + step_wr,
-                                  "dispatches_per_step": sum(n for _, n in per["FETCH_SIZE"].values()) / n_steps}
+    step = {"hbm_read_bytes": step_rd, "hbm_write_bytes": step_wr, "hbm_bytes": step_rd + step_wr,
+            "dispatches_per_step": sum(n for _, n in per["FETCH_SIZE"].values()) / n_steps}
     out = {}
     for k in kernels:
         fk, n = table_lookup(per["FETCH_SIZE"], k) or (None, 0)
@@ -324,7 +324,7 @@ def live_pmc_traffic(workload, kernels, timeout_s=150.0):
         rd, wr = 2.0 * fk * 1024.0, wk * 1024.0
         out[k] = {"hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr, "dispatches": n}
     return out, (f"live: two rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE x2 x 1024 B; WRITE_SIZE x 1024 B) of a 3-step child run of this workload, "
-                 f"mean per launch over the two steps after the warm-up step, {time.perf_counter() - t_start:.0f} s")
+                 f"mean per launch over the two steps after the warm-up step, {time.perf_counter() - t_start:.0f} s"), step
 
 
 def roofline_step(step_traffic, line, note):
@@ -899,13 +899,13 @@ def main():
             torch.cuda.empty_cache()
             stage("live PMC passes")
             objs = [out[k] for k in ("roofline", "roofline_hbm", "roofline_attention") if out.get(k)]
-            table, note = live_pmc_traffic(args.workload, [o["kernel"] for o in objs])
+            table, note, step_traffic = live_pmc_traffic(args.workload, [o["kernel"] for o in objs])
             for o in objs:
                 if o["kernel"] in table:
                     o["traffic"], o["traffic_source"] = table[o["kernel"]], note
                 elif o["traffic"] is not None:
                     o["traffic_source"] = f"{committed}; live pass unavailable: {note}"
-            out["roofline_step"] = roofline_step(getattr(live_pmc_traffic, "last_step", None), out, note)
+            out["roofline_step"] = roofline_step(step_traffic, out, note)
     # the ONE JSON line is the LAST thing on stdout: the process group goes down first (on every rank), the C runtime's buffers — librccl
     # prints through them — are flushed, and rank 0 gives the other ranks a moment to do the same before it prints
     if dist.is_initialized():

@@ -446,7 +446,8 @@ def test_bench_pmc_traffic_arithmetic_and_fallback(tmp_path, monkeypatch):
     import bench
     monkeypatch.setattr("shutil.which", lambda name: None)
     monkeypatch.setattr(os.path, "exists", lambda p, _orig=os.path.exists: False if p.endswith("rocprofv3") else _orig(p))
-    table, why = bench.live_pmc_traffic("gpt2s_B32_L1024_C12", ["norm_fwd_kernel<3, false>"])
+    table, why, step = bench.live_pmc_traffic("gpt2s_B32_L1024_C12", ["norm_fwd_kernel<3, false>"])
+    assert step is None
     assert table == {} and "not found" in why
 
 
