@@ -213,7 +213,10 @@ def test_attention_backward_fused_inverse_rope(ops, B, T, H, Hkv, D, resident):
     assert not torch.equal(dq1, dq0)
 
 
-@pytest.mark.parametrize("B,T,Tq,Hq,Hkv,D", [(1, 700, 700, 2, 2, 128), (2, 1000, 870, 4, 2, 64), (1, 1664, 1536, 2, 1, 128), (1, 515, 515, 2, 2, 64)])
+@pytest.mark.parametrize("B,T,Tq,Hq,Hkv,D", [(1, 700, 700, 2, 2, 128), (2, 1000, 870, 4, 2, 64), (1, 1664, 1536, 2, 1, 128), (1, 515, 515, 2, 2, 64),
+                                             # round 5: hd 128 takes the 32-row forward / chunked dQ (GQA or > 128 key rows: also dK/dV) from 128 query rows on, also
+                                             # where K / V would fit the LDS — the cached Llama shape, ragged sizes below 256 rows, MHA with <= 128 key rows (resident dK/dV)
+                                             (2, 256, 128, 4, 4, 128), (2, 200, 130, 4, 2, 128), (1, 150, 150, 2, 1, 128), (1, 300, 129, 2, 2, 128)])
 def test_attention_long_causal_ragged(ops, B, T, Tq, Hq, Hkv, D):
     """the long-sequence kernels (32 query rows per wave on 32x32x16 MFMAs for the forward and dQ, chunked dK / dV, XCD-aware 1-D launch) on shapes that
     are NOT multiples of their 128-row workgroups / 64-key chunks, with the queries being the LAST Tq rows of a T-key sequence (prompt-row cache,
