@@ -41,6 +41,9 @@ constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 #ifndef MTL_GEMM_FRAG_PIPE
 #define MTL_GEMM_FRAG_PIPE 1      // 0: the compiler-scheduled fragment reads (diagnostic builds)
 #endif
+#ifndef MTL_XT_LA
+#define MTL_XT_LA 2               // k-steps of register-staged look-ahead in gemm_xt_kernel
+#endif
 #ifndef MTL_GEMM_FRAG_D
 #define MTL_GEMM_FRAG_D 3         // prefetch distance of the fragment pipeline in units of 4 MFMAs
 #endif
@@ -1039,10 +1042,12 @@ __global__ __launch_bounds__(256, 2) void gemm_xt_kernel(const xt_args p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bool want_cs = AT && p.a_colsum != nullptr && n0 == 0;
-    // TWO k-steps of look-ahead (64 KB of loads in flight per workgroup): with one, a step lasts as long as a load round trip
-    u32x4 va[2][NCH], vb[2][NCH];
+    // LA k-steps of look-ahead (LA x 32 KB of loads in flight per workgroup): with one, a step lasts as long as a load round trip
+    constexpr int LA = MTL_XT_LA;
+    static_assert(LA >= 2 && LA <= 4, "look-ahead depth");
+    u32x4 va[LA][NCH], vb[LA][NCH];
 #pragma unroll
-    for (int d = 0; d < 2; ++d) {
+    for (int d = 0; d < LA; ++d) {
         fetch(p.A, p.lda, AT, m0, p.M, k_begin + d * KC, va[d]);      // (rows past k_end load zeros)
         fetch(p.B, p.ldb, BT, n0, p.N, k_begin + d * KC, vb[d]);
     }
@@ -1059,8 +1064,8 @@ __global__ __launch_bounds__(256, 2) void gemm_xt_kernel(const xt_args p) {
                 }
         }
         __syncthreads();                              // (this buffer was last read before the previous barrier)
-        fetch(p.A, p.lda, AT, m0, p.M, k0 + 2 * KC, ra);
-        fetch(p.B, p.ldb, BT, n0, p.N, k0 + 2 * KC, rb);
+        fetch(p.A, p.lda, AT, m0, p.M, k0 + LA * KC, ra);
+        fetch(p.B, p.ldb, BT, n0, p.N, k0 + LA * KC, rb);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[4], bfr[4];
@@ -1077,9 +1082,13 @@ __global__ __launch_bounds__(256, 2) void gemm_xt_kernel(const xt_args p) {
                 for (int mi = 0; mi < 4; ++mi) acc[nj][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nj], af[mi], acc[nj][mi], 0, 0, 0);
         }
     };
-    for (int64_t k0 = k_begin; k0 < k_end; k0 += 2 * KC) {
-        step(k0, 0, va[0], vb[0]);
-        if (k0 + KC < k_end) step(k0 + KC, 1, va[1], vb[1]);
+    // register set i % LA, LDS buffer i % 2 for step i: unrolled over lcm(LA, 2) steps so that both indices are compile-time constants
+    constexpr int UN = (LA % 2 == 0) ? LA : 2 * LA;
+    for (int64_t k0 = k_begin; k0 < k_end; k0 += UN * KC) {
+        static_for<UN>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int I = decltype(ic)::value;
+            if (I == 0 || k0 + I * KC < k_end) step(k0 + I * KC, I & 1, va[I % LA], vb[I % LA]);
+        });
     }
     // lane owns row m0 + wr*64 + mi*16 + l15 and the four columns n0 + wc*64 + nj*16 + g*4 .. +3
     const bool vec = (p.N % 4 == 0) && (p.ldc % 4 == 0);
