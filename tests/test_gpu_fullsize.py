@@ -26,7 +26,7 @@ LLAMA2_7B = {"model_type": "llama", "vocab_size": 32000, "hidden_size": 4096, "i
 LLAMA3_8B = {"model_type": "llama", "vocab_size": 128256, "hidden_size": 4096, "intermediate_size": 14336, "num_hidden_layers": 32,
              "num_attention_heads": 32, "num_key_value_heads": 8, "rms_norm_eps": 1e-5, "rope_theta": 500000.0}
 NTOK = 128
-DEPTH_FACTOR = 2.0
+DEPTH_FACTOR = 3.0
 REPORT = {}
 
 
