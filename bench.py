@@ -561,7 +561,7 @@ def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline, legs=T
         lib = _native.lib()
         n_replay = min(steps, 5)
         if rank == 0:
-            lib.mtl_prof_enable(1)
+            lib.mtl_prof_enable(2 if os.environ.get("MTL_PROF_SHAPES") else 1)      # (tools/gemm_shapes.py: per-shape GEMM rows; read here, not by the library)
         for i in range(n_replay):
             step(i)
         torch.cuda.synchronize()

@@ -12,12 +12,12 @@
  *     PyTorch-allocated outputs/workspaces and the stream (hipStream_t as void*).
  *   - bf16 tensors are raw uint16 storage; row-major; `ld*` are row strides in ELEMENTS.
  *   - return 0 on success, negative MTL_ERR_* otherwise (mtl_strerror gives the text).
- *   - re-entrant / thread-compatible: no mutable globals except the opt-in, mutex-guarded launch profiler. Per-call A/B knobs are fields of the
- *     argument structs (mtl_gemm_args.tune_*, mtl_attn_fwd_args.tune). In addition the library reads these ENVIRONMENT variables, each ONCE (first use)
- *     and constant afterwards — diagnostic dispatch switches for in-step A/B runs, none changes what is computed beyond the summation order of a
- *     differently tiled kernel: MTL_ATTN_WIDE, MTL_ATTN_WIDE_X, MTL_ATTN_WIDE_MIN, MTL_ATTN_XMAP, MTL_ATTN_W32, MTL_ATTN_W32_NW, MTL_ATTN_MERGED, MTL_ATTN_D128
- *     (csrc/mtl_attention.hip), MTL_GEMM_RULES_OFF, MTL_GEMM_G, MTL_GEMM_FORCE, MTL_PROF_SHAPES (csrc/mtl_gemm.hip), MTL_ROPE_FUSE (csrc/mtl_backbone.hip).
- *     Unset (the product's state), every dispatch rule is the measured default.
+ *   - re-entrant / thread-compatible: no mutable globals except the opt-in, mutex-guarded launch profiler, and NO environment variable is read
+ *     by the product build (no getenv in the shipped .so: tests/test_host_logic.py checks the sources and the binary). Per-call A/B knobs are
+ *     fields of the argument structs (mtl_gemm_args.tune_*, mtl_attn_fwd_args.tune). DIAGNOSTIC builds (tools/build_variant.sh ... -DMTL_DIAG;
+ *     never shipped, reported by mtl_build_flags() and refused by hip/_native.py unless MTL_ALLOW_DIAG_LIB=1) additionally read, each once,
+ *     the dispatch switches MTL_ATTN_WIDE, MTL_ATTN_WIDE_X, MTL_ATTN_WIDE_MIN, MTL_ATTN_XMAP, MTL_ATTN_W32, MTL_ATTN_W32_NW, MTL_ATTN_MERGED,
+ *     MTL_ATTN_D128 (csrc/mtl_attention.hip), MTL_GEMM_RULES_OFF, MTL_GEMM_G, MTL_GEMM_FORCE (csrc/mtl_gemm.hip), MTL_ROPE_FUSE (csrc/mtl_backbone.hip).
  */
 #ifndef MEDTSLLM_HIP_H
 #define MEDTSLLM_HIP_H
@@ -29,13 +29,17 @@
 extern "C" {
 #endif
 
-#define MTL_ABI_VERSION 13
+#define MTL_ABI_VERSION 14
 
 enum { MTL_OK = 0, MTL_ERR_ARG = -1, MTL_ERR_ALIGN = -2, MTL_ERR_UNSUPPORTED = -3, MTL_ERR_LAUNCH = -4,
        MTL_ERR_WORKSPACE = -5 };
 enum { MTL_F32 = 0, MTL_BF16 = 1 };
 
 int mtl_abi_version(void);
+/* how this library was built: 0 = the product. Bit 0: -DMTL_DIAG (reads the diagnostic environment switches listed above); bit 1: a build that
+ * computes WRONG results on purpose for timing ablations (MTL_DIAG_NOHASH, MTL_DIAG_ATTN_NODROP, MTL_DIAG_W4VAR ...). */
+enum { MTL_BUILD_DIAG_ENV = 1, MTL_BUILD_DIAG_WRONG = 2 };
+int mtl_build_flags(void);
 const char* mtl_strerror(int code);
 
 /* ------------------------------------------------------------------ patch tokeniser (a1-a4)
@@ -156,10 +160,7 @@ typedef struct mtl_prof_row {
 } mtl_prof_row;
 int mtl_prof_enable(int on);
 int mtl_prof_read(mtl_prof_row* rows, int cap);
-/* Diagnostics read from the environment once per process (in-step A/B runs; never needed in production; constant afterwards):
- *   MTL_GEMM_RULES_OFF=<mask>  switch single automatic launch rules off (1 GELU 256x192, 2 residual 256x96, 4 two k-groups,
- *                              8 per-XCD k rotation, 16 balanced tile-group height)
- *   MTL_GEMM_FORCE="epi,N,bm,bn,stages,waves"  force one tile configuration for the launches of one epilogue and N */
+/* mtl_prof_enable(2): as 1, and the GEMM rows are kept per problem size (" [MxNxK]" appended to the kernel name). */
 /* Host-only (no device call): the tile order the persistent GEMM would use for a grid of tiles_m x tiles_n tiles of bm x bn with
  * per_cu resident workgroups per CU: bits 0-7 rows of a tile group, bit 8 per-XCD k rotation, bit 9 per-XCD column rotation
  * (negative: error code). Lets the CPU test suite check that every order visits every tile exactly once. */

@@ -1810,21 +1810,21 @@ namespace {
 
 // resident-K/V path: causal, per-sample K/V, >= 4 rows, and both tiles fit the 160 KiB LDS
 constexpr size_t kLdsBudget = 156 * 1024;
-// (per-call knobs: mtl_attn_fwd_args.tune bit 0 = chunked kernels only, bit 1 = resident backward as two launches; the environment
-//  switches below are read once and constant afterwards)
-const int g_attn_wide = getenv("MTL_ATTN_WIDE") ? atoi(getenv("MTL_ATTN_WIDE")) : 1;   // A/B knob: 0 = 64-row workgroups for long sequences too
+// (per-call knobs: mtl_attn_fwd_args.tune bit 0 = chunked kernels only, bit 1 = resident backward as two launches; the switches
+//  below are constants of the product build; -DMTL_DIAG builds read them from the environment once)
+const int g_attn_wide = mtl_env_int("MTL_ATTN_WIDE", 1);   // A/B knob: 0 = 64-row workgroups for long sequences too
 // rows from which the 128-row workgroups are used. Forward / dQ from 256 (PSM shape, Tq = 256 of T = 384: 131 -> 97 us, 184 -> 150 us); the
 // dK/dV kernel gains nothing there (190 -> 194 us) and switches at 512.
-const int g_attn_wide_x = getenv("MTL_ATTN_WIDE_X") ? atoi(getenv("MTL_ATTN_WIDE_X")) : 1;   // A/B knob: 128-row workgroups for the non-causal hd-128 (reprogramming) attention
-const int g_attn_wide_min = getenv("MTL_ATTN_WIDE_MIN") ? atoi(getenv("MTL_ATTN_WIDE_MIN")) : 256;
-const int g_attn_xmap = getenv("MTL_ATTN_XMAP") ? atoi(getenv("MTL_ATTN_XMAP")) : 1;   // A/B knob: 0 = plain (row block, head, batch) grids for the long-sequence kernels
-const int g_attn_w32_nw = getenv("MTL_ATTN_W32_NW") ? atoi(getenv("MTL_ATTN_W32_NW")) : 0;   // A/B knob: 4 / 8 waves per workgroup of the 32-row kernels (0 = automatic)
-const int g_attn_w32 = getenv("MTL_ATTN_W32") ? atoi(getenv("MTL_ATTN_W32")) : 1;   // A/B knob: 0 = the 16-rows-per-wave kernels for long causal sequences
+const int g_attn_wide_x = mtl_env_int("MTL_ATTN_WIDE_X", 1);   // A/B knob: 128-row workgroups for the non-causal hd-128 (reprogramming) attention
+const int g_attn_wide_min = mtl_env_int("MTL_ATTN_WIDE_MIN", 256);
+const int g_attn_xmap = mtl_env_int("MTL_ATTN_XMAP", 1);   // A/B knob: 0 = plain (row block, head, batch) grids for the long-sequence kernels
+const int g_attn_w32_nw = mtl_env_int("MTL_ATTN_W32_NW", 0);   // A/B knob: 4 / 8 waves per workgroup of the 32-row kernels (0 = automatic)
+const int g_attn_w32 = mtl_env_int("MTL_ATTN_W32", 1);   // A/B knob: 0 = the 16-rows-per-wave kernels for long causal sequences
 // hd-128 causal self-attention without dropout (the Llama stacks) where K / V WOULD fit the LDS: the 32-rows-per-wave forward and the 8-wave chunked dQ
 // kernel beat their resident twins from 128 query rows on, and so does the chunked dK/dV kernel under GQA or with more than 128 key rows (round 5,
 // tools/diag/attn_matrix.sh: Llama-2 cached shape forward 57.5 -> 42.0 us, dQ 66.8 -> 53.2; Llama-3 GQA dK/dV 52.9 -> 32.6). 0 = the resident kernels.
-const int g_attn_d128 = getenv("MTL_ATTN_D128") ? atoi(getenv("MTL_ATTN_D128")) : 1;
-const int g_attn_merged = getenv("MTL_ATTN_MERGED") ? atoi(getenv("MTL_ATTN_MERGED")) : 1;   // A/B knob: 0 = the resident backward as two launches (dQ, then dK / dV)
+const int g_attn_d128 = mtl_env_int("MTL_ATTN_D128", 1);
+const int g_attn_merged = mtl_env_int("MTL_ATTN_MERGED", 1);   // A/B knob: 0 = the resident backward as two launches (dQ, then dK / dV)
 
 template <typename KernelT>
 void set_lds(KernelT k, size_t bytes) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); }

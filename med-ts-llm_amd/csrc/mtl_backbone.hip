@@ -347,8 +347,8 @@ extern "C" int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, 
         ba.dk = dq + D.Hq * D.hd; ba.dk_bs = D.T * D.Nqkv; ba.dk_ts = D.Nqkv; ba.dk_hs = D.hd;
         ba.dv = dq + (D.Hq + D.Hkv) * D.hd; ba.dv_bs = D.T * D.Nqkv; ba.dv_ts = D.Nqkv; ba.dv_hs = D.hd;
         ba.delta = reinterpret_cast<float*>(wk + W.delta) + r0;
-        // Llama: the inverse rotary embedding of dq / dk rides in the attention kernels' store epilogues (MTL_ROPE_FUSE=0: a pass over dqkv)
-        static const bool rope_fuse = !(getenv("MTL_ROPE_FUSE") && atoi(getenv("MTL_ROPE_FUSE")) == 0);
+        // Llama: the inverse rotary embedding of dq / dk rides in the attention kernels' store epilogues (diagnostic builds, MTL_ROPE_FUSE=0: a pass over dqkv)
+        static const bool rope_fuse = mtl_env_int("MTL_ROPE_FUSE", 1) != 0;
         if (D.llama && rope_fuse) { ba.rope_cos = w->rope_cos; ba.rope_sin = w->rope_sin; }
         MTL_TRY(mtl_attention_bwd(&ba, stream));
         if (D.llama && !rope_fuse)

@@ -15,6 +15,15 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 #define MTL_WAVE 64
 
+// Environment switches exist in DIAGNOSTIC builds only (-DMTL_DIAG, tools/build_variant.sh): the product library reads no environment variable and
+// keeps no mutable global besides the opt-in launch profiler, so nothing in a user's shell can change its dispatch. mtl_build_flags() reports the build.
+#ifdef MTL_DIAG
+#include <cstdlib>
+inline int mtl_env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+constexpr int mtl_env_int(const char*, int dflt) { return dflt; }
+#endif
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
 // f32 -> bf16, round-to-nearest-even: written as plain conversions so that hipcc emits the gfx950 hardware packed

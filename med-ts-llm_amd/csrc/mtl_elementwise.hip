@@ -619,6 +619,17 @@ extern "C" int mtl_dropout_f32(const float* x, float* y, int64_t M, int64_t d, f
 
 extern "C" int mtl_abi_version(void) { return MTL_ABI_VERSION; }
 
+extern "C" int mtl_build_flags(void) {
+    int f = 0;
+#ifdef MTL_DIAG
+    f |= MTL_BUILD_DIAG_ENV;
+#endif
+#if defined(MTL_DIAG_NOHASH) || defined(MTL_DIAG_ATTN_NODROP) || defined(MTL_DIAG_W4VAR) || defined(MTL_DIAG_WRONG)
+    f |= MTL_BUILD_DIAG_WRONG;
+#endif
+    return f;
+}
+
 extern "C" const char* mtl_strerror(int code) {
     switch (code) {
         case MTL_OK: return "ok";

@@ -30,6 +30,7 @@ struct ProfSlot { char name[128]; int kind; int64_t launches; double work; };
 struct Profiler {
     std::mutex mu;
     std::atomic<bool> on{false};
+    std::atomic<bool> shapes{false};   // mtl_prof_enable(2): GEMM rows are kept per problem size
     std::vector<ProfRec> recs;
     std::vector<ProfSlot> slots;
 };
@@ -176,14 +177,14 @@ __device__ __forceinline__ void epilogue4(const mtl_gemm_args& p, int64_t m, int
 // a chunk waits for are OLDER than the previous chunk's stores, and hipcc's own counted s_waitcnt leaves those stores in flight.
 struct EpiRows { int64_t crow[4]; bool mok[4]; bool bwd_ok[4]; };
 
-template <int EPI, bool FULL>
+template <int EPI, bool FULL, int RS = 16>      // RS: rows between the lane's 4 row tiles (16: 16x16 MFMA tiles, 32: 32x32)
 __device__ __forceinline__ EpiRows epi_rows(const mtl_gemm_args& p, int64_t m_first) {
     // lane owns rows m_first + mi*16 (mi = 0..3). Edge tiles (!FULL) LOAD from clamped (always valid) addresses and predicate only the
     // stores: no load result is ever consumed inside a branch.
     EpiRows r;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-        const int64_t m = m_first + mi * 16;
+        const int64_t m = m_first + mi * RS;
         r.mok[mi] = FULL || m < p.M;
         r.crow[mi] = remap_row(r.mok[mi] ? m : p.M - 1, p.c_group_rows, p.c_group_stride, p.c_row_offset);
         r.bwd_ok[mi] = true;          // rows whose backward-only output is stored (GELU: aux_out, SWIGLU: C)
@@ -192,7 +193,7 @@ __device__ __forceinline__ EpiRows epi_rows(const mtl_gemm_args& p, int64_t m_fi
         if (p.bwd_group_rows > 0) {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
-                r.bwd_ok[mi] = (uint32_t)(m_first + mi * 16) % (uint32_t)p.bwd_group_rows >= (uint32_t)p.bwd_first_row;
+                r.bwd_ok[mi] = (uint32_t)(m_first + mi * RS) % (uint32_t)p.bwd_group_rows >= (uint32_t)p.bwd_first_row;
         }
     }
     return r;
@@ -211,22 +212,24 @@ struct EpiAux {
 // CONSECUTIVE columns n_base + 32t + 8g .. +7: tile ni < NPT covers n_base + (ni/2)*32 + 8g + (ni%2)*4 + 0..3; an odd last tile
 // (ni >= NPT) keeps the plain layout n_base + 16 ni + 4g + 0..3. `g` = lane >> 4.
 // columns of the chunk's NI column tiles; T0 = index of its first tile inside the wave's sub-tile, NPTW = how many of the wave's tiles are paired
-template <int NI, bool FULL, int NPTW, int T0>
+// LAY = 1 (gemm_nt_w4_kernel, 32x32x16 MFMA): a "column tile" is one 4-register quad of a 32x32 accumulator = 8 columns shared by the two lane
+// halves (g = lane >> 5); the B fragment rows are permuted so that quads 2t / 2t+1 of a lane are the 8 consecutive columns (t >> 1)*16 + 8g .. +7.
+template <int NI, bool FULL, int NPTW, int T0, int LAY = 0>
 __device__ __forceinline__ void epi_cols(const mtl_gemm_args& p, int64_t n_wave, const int g, int64_t (&ncol)[NI], bool (&nok)[NI]) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int t = T0 + ni;
-        const int64_t n = n_wave + (t < NPTW ? (t >> 1) * 32 + g * 8 + (t & 1) * 4 : t * 16 + g * 4);
+        const int64_t n = n_wave + (LAY == 1 ? (t >> 1) * 16 + g * 8 + (t & 1) * 4 : (t < NPTW ? (t >> 1) * 32 + g * 8 + (t & 1) * 4 : t * 16 + g * 4));
         nok[ni] = FULL || n < p.N;  // vector path: N % 4 == 0, so the 4 columns are valid together
         ncol[ni] = nok[ni] ? n : p.N - 4;
     }
 }
 
-template <int EPI, int CDT, int NI, bool FULL, int NPTW, int T0>
+template <int EPI, int CDT, int NI, bool FULL, int NPTW, int T0, int LAY = 0>
 __device__ __forceinline__ void epi_load(const mtl_gemm_args& p, const EpiRows& r, int64_t n_base, const int g, EpiAux<EPI, NI>& a) {
     int64_t ncol[NI];
     bool nok[NI];
-    epi_cols<NI, FULL, NPTW, T0>(p, n_base, g, ncol, nok);
+    epi_cols<NI, FULL, NPTW, T0, LAY>(p, n_base, g, ncol, nok);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) a.b4[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) {                   // uniform branch around ALL bias loads
@@ -257,12 +260,12 @@ __device__ __forceinline__ void epi_st(void* ptr, const V v) { *reinterpret_cast
 //   bf16 outputs: [0..1] = the 4 packed C values; GELU: [0..1] = saved pre-activation, [2..3] = activation; SWIGLU: [2] = the 2 packed
 //   activation columns; DSWIGLU: [0..3] = the 8 packed d(gate | up) values
 // so that the auxiliary registers are dead when the NEXT chunk's loads are issued into them, before this chunk's stores (epilogue_wave).
-template <int EPI, int CDT, int NI, bool FULL, int NPTW, int T0>
+template <int EPI, int CDT, int NI, bool FULL, int NPTW, int T0, int LAY = 0>
 __device__ __forceinline__ void epi_math(const mtl_gemm_args& p, const EpiRows& r, int64_t n_base, const int g, f32x4 (*acc)[4], const EpiAux<EPI, NI>& a,
                                          const int mi0 = 0, const int mi1 = 4) {
     int64_t ncol[NI];
     bool nok[NI];
-    epi_cols<NI, FULL, NPTW, T0>(p, n_base, g, ncol, nok);
+    epi_cols<NI, FULL, NPTW, T0, LAY>(p, n_base, g, ncol, nok);
 #pragma unroll
     for (int mi = mi0; mi < mi1; ++mi) {
 #pragma unroll
@@ -329,7 +332,7 @@ __device__ __forceinline__ void epi_math(const mtl_gemm_args& p, const EpiRows& 
 }
 
 // stores of one chunk whose results epi_math left in the accumulators
-template <int EPI, int CDT, int NI, bool FULL, int NPTW, int T0>
+template <int EPI, int CDT, int NI, bool FULL, int NPTW, int T0, int LAY = 0>
 __device__ __forceinline__ void epi_store(const mtl_gemm_args& p, const EpiRows& r, int64_t n_base, const int g, f32x4 (*acc)[4], const bool dword_stores,
                                           const int mi0 = 0, const int mi1 = 4) {
     constexpr bool PAIR = NPTW > 0;
@@ -338,7 +341,7 @@ __device__ __forceinline__ void epi_store(const mtl_gemm_args& p, const EpiRows&
     static_assert(NPT == 0 || EPI == MTL_EPI_DSWIGLU || (CDT == MTL_F32) || (T0 % 2 == 0 && NPT % 2 == 0), "a pair of column tiles stays inside one chunk");
     int64_t ncol[NI];
     bool nok[NI];
-    epi_cols<NI, FULL, NPTW, T0>(p, n_base, g, ncol, nok);
+    epi_cols<NI, FULL, NPTW, T0, LAY>(p, n_base, g, ncol, nok);
     const int64_t (&crow)[4] = r.crow;
     // bf16 outputs of a column-tile pair leave as ONE 16-byte store per lane (8 consecutive columns) when the rows are 16-B aligned
     const bool wide_c = PAIR && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (p.ldc & 7) == 0;
@@ -423,7 +426,7 @@ __device__ __forceinline__ void epi_store(const mtl_gemm_args& p, const EpiRows&
 // the next k-step's first ds_read, draining the LDS-DMA pipeline.)
 // Column tiles go NCH at a time (<= 4 in one piece; wider wave tiles 2 at a time: 64x96 .. 64x144 per wave); an odd count (NI = 9) ends with ONE
 // unpaired column tile. Per chunk: wait for its auxiliary operands, math in place, ISSUE THE NEXT CHUNK'S LOADS (into the same registers), stores.
-template <int EPI, int CDT, int NI, bool FULL, bool PAIR = false>
+template <int EPI, int CDT, int NI, bool FULL, bool PAIR = false, int LAY = 0>
 __device__ __forceinline__ void epilogue_wave(const mtl_gemm_args& p, int64_t m_first, int64_t n_base, const int g, f32x4 (&acc)[NI][4],
                                               const bool dword_stores = false) {
     // PIPE (bias-only epilogues: plain store, GELU, SwiGLU): chunk c + 1's bias loads go out between chunk c's math and its stores, so the wait
@@ -437,26 +440,26 @@ __device__ __forceinline__ void epilogue_wave(const mtl_gemm_args& p, int64_t m_
     constexpr int NTAIL = NI - NFULL * NCH;    // 0 or 1 column tile left over
     constexpr int NPTW = PAIR ? (NI & ~1) : 0; // paired column tiles of the wave's sub-tile
     static_assert(NFULL >= 1 && NFULL <= 4 && NTAIL <= 1, "chunk schedule");
-    const EpiRows r = epi_rows<EPI, FULL>(p, m_first);
+    const EpiRows r = epi_rows<EPI, FULL, LAY == 1 ? 32 : 16>(p, m_first);
     EpiAux<EPI, NCH> a;
     EpiAux<EPI, NTAIL ? NTAIL : 1> at;
-    epi_load<EPI, CDT, NCH, FULL, NPTW, 0>(p, r, n_base, g, a);
+    epi_load<EPI, CDT, NCH, FULL, NPTW, 0, LAY>(p, r, n_base, g, a);
     // edge tiles: hipcc sinks the bias/residual math into the predicated store blocks, which leaves the load results "pending" at the
     // merge and costs a vmcnt(0) before every later ds_read; a compiler-visible wait per chunk settles it (edge tiles only).
 #define MTL_EPI_NEXT(C)                                                                                                                  \
-    if constexpr ((C) + 1 < NFULL) epi_load<EPI, CDT, NCH, FULL, NPTW, ((C) + 1) * NCH>(p, r, n_base, g, a);                              \
-    else if constexpr (NTAIL > 0) epi_load<EPI, CDT, NTAIL, FULL, NPTW, NFULL * NCH>(p, r, n_base, g, at);
+    if constexpr ((C) + 1 < NFULL) epi_load<EPI, CDT, NCH, FULL, NPTW, ((C) + 1) * NCH, LAY>(p, r, n_base, g, a);                              \
+    else if constexpr (NTAIL > 0) epi_load<EPI, CDT, NTAIL, FULL, NPTW, NFULL * NCH, LAY>(p, r, n_base, g, at);
 #define MTL_EPI_STEP(C)                                                                                                                  \
     if constexpr ((C) < NFULL) {                                                                                                          \
         if constexpr (!FULL) __builtin_amdgcn_s_waitcnt(0x0f70);   /* vmcnt(0) only (gfx9 encoding) */                                    \
         if constexpr (PIPE && ((C) + 1 < NFULL || NTAIL > 0)) {                                                                           \
-            epi_math<EPI, CDT, NCH, FULL, NPTW, (C) * NCH>(p, r, n_base, g, &acc[(C) * NCH], a);                                          \
+            epi_math<EPI, CDT, NCH, FULL, NPTW, (C) * NCH, LAY>(p, r, n_base, g, &acc[(C) * NCH], a);                                          \
             MTL_EPI_NEXT(C)                                                                                                               \
-            epi_store<EPI, CDT, NCH, FULL, NPTW, (C) * NCH>(p, r, n_base, g, &acc[(C) * NCH], dword_stores);                              \
+            epi_store<EPI, CDT, NCH, FULL, NPTW, (C) * NCH, LAY>(p, r, n_base, g, &acc[(C) * NCH], dword_stores);                              \
         } else {                                                                                                                          \
             _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {          /* row by row: the first stores leave while the rest computes */  \
-                epi_math<EPI, CDT, NCH, FULL, NPTW, (C) * NCH>(p, r, n_base, g, &acc[(C) * NCH], a, mi, mi + 1);                          \
-                epi_store<EPI, CDT, NCH, FULL, NPTW, (C) * NCH>(p, r, n_base, g, &acc[(C) * NCH], dword_stores, mi, mi + 1);              \
+                epi_math<EPI, CDT, NCH, FULL, NPTW, (C) * NCH, LAY>(p, r, n_base, g, &acc[(C) * NCH], a, mi, mi + 1);                          \
+                epi_store<EPI, CDT, NCH, FULL, NPTW, (C) * NCH, LAY>(p, r, n_base, g, &acc[(C) * NCH], dword_stores, mi, mi + 1);              \
             }                                                                                                                             \
             MTL_EPI_NEXT(C)                                                                                                               \
         }                                                                                                                                 \
@@ -471,8 +474,8 @@ __device__ __forceinline__ void epilogue_wave(const mtl_gemm_args& p, int64_t m_
         if constexpr (!FULL) __builtin_amdgcn_s_waitcnt(0x0f70);
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
-            epi_math<EPI, CDT, NTAIL, FULL, NPTW, NFULL * NCH>(p, r, n_base, g, &acc[NFULL * NCH], at, mi, mi + 1);
-            epi_store<EPI, CDT, NTAIL, FULL, NPTW, NFULL * NCH>(p, r, n_base, g, &acc[NFULL * NCH], dword_stores, mi, mi + 1);
+            epi_math<EPI, CDT, NTAIL, FULL, NPTW, NFULL * NCH, LAY>(p, r, n_base, g, &acc[NFULL * NCH], at, mi, mi + 1);
+            epi_store<EPI, CDT, NTAIL, FULL, NPTW, NFULL * NCH, LAY>(p, r, n_base, g, &acc[NFULL * NCH], dword_stores, mi, mi + 1);
         }
     }
 }
@@ -937,6 +940,99 @@ __global__ __launch_bounds__(NW_ALL * 64, persist_waves_per_simd(BM_, BN_, STAGE
     if (done_tile >= 0) finish(done_tile);
 }
 
+// ---------------------------------------------------------------- 256 x 256 x 64, 4 waves, one wave per SIMD, hand-placed k-loop
+// The Llama-class instance (round 6). What the 8-wave 256 x 256 kernel above could not be made to do — keep the matrix pipe issuing while the
+// wave also reads fragments, stages the next k-tiles and meets its barriers — is a matter of per-instruction placement, so the k-loop of a tile
+// is ONE asm statement (generated: tools/gen_gemm_w4_loop.py -> mtl_gemm_w4_loop.inc, which documents the time structure):
+//   * 4 waves (2 x 2), each a 128 x 128 sub-tile as 4 x 4 v_mfma_f32_32x32x16_bf16 accumulators = 256 AGPRs (16 "+a" operands of 16 registers,
+//     allocated by the compiler, so the epilogue below is ordinary C++ on them); 128 fragment VGPRs in two k-half sets; 128 operand bytes per
+//     MFMA through the LDS instead of the 8-wave kernel's 192.
+//   * LDS image: two 32 KiB buffers per operand, row r of a tile at r * 128 B, 16-B chunk c of it at slot c ^ swz64(r) — written by the LDS-DMA
+//     (buffer_load_dwordx4 ... lds: 8 rows per wave-instruction, the swizzle applied on the per-lane SOURCE offset), read back with the same XOR.
+//     The rows an instruction fetches are given by a wave-uniform SGPR offset per instruction (row-mapped A operands: 8-row pieces never straddle
+//     a row group, the host checks), the k position by the descriptor's base address, advanced 128 B per k-tile.
+//   * B-tile fragment lane i reads tile row (i with bits 2 and 3 swapped): accumulator quads 2t / 2t+1 of a lane are then 8 CONSECUTIVE output
+//     columns (16-byte bf16 stores), cf. epi_cols<LAY = 1>.
+// Swapped MFMA operands as everywhere in this file (D = Btile . Atile^T): a lane owns output row l % 32 (+ 32 mt) and 4 consecutive columns per quad.
+// Whole tiles only (M % 256 == 0, N % 256 == 0); everything else stays with gemm_nt_persist_kernel.
+#include "mtl_gemm_w4_loop.inc"
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int EPI, int CDT, int VAR = 0>      // VAR > 0: timing ablations of diagnostic builds (-DMTL_DIAG_W4VAR; wrong results)
+__global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, const int vec_ok_i, const int tiles_m, const int tiles_n, const int gm_all) {
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int ntiles = tiles_m * tiles_n;
+    const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int xblocks = (nblk - xcd + 7) >> 3;                 // blocks living on this XCD
+    const int q = ntiles >> 3, r8 = ntiles & 7;
+    const int t0 = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
+    const int cnt = q + (xcd < r8 ? 1 : 0);
+    const int gm = gm_all & 0xff;
+    const int nkt = (int)(p.K / 64);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem_all;       // (flat LDS address: the low half is the LDS offset)
+    // fragment read addresses (k-step 0; the asm derives the other three)
+    const int prow = (l31 & 19) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);             // B rows: bits 2 <-> 3
+    const uint32_t rba = lds0 + (uint32_t)((wr * 128 + l31) * 128), xa = (uint32_t)(h ^ swz64(l31));
+    const uint32_t rbb = lds0 + 0x10000u + (uint32_t)((wc * 128 + prow) * 128), xb = (uint32_t)(h ^ swz64(prow));
+    // LDS-DMA: instruction i of wave w stages tile rows (4 i + w) * 8 .. + 7; lane -> row lane / 8, slot lane % 8
+    const uint32_t dma = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (uint32_t)wave * 1024u));
+    const int drow = lane >> 3, dsl = lane & 7;
+    const int dsw = ((wave & 1) * 4 + (lane >> 4)) & 7;                             // swz64 of the row (tile row bases are multiples of 32)
+    const uint32_t voa = (uint32_t)(drow * (int)p.lda * 2 + ((dsl ^ dsw) << 4));
+    const uint32_t vob = (uint32_t)(drow * (int)p.ldb * 2 + ((dsl ^ dsw) << 4));
+
+    for (int i = slot; i < cnt; i += xblocks) {
+        int tm, tn;
+        tile_coords(t0 + i, tiles_m, tiles_n, gm, tm, tn);
+        const int64_t m0 = (int64_t)tm * 256, n0 = (int64_t)tn * 256;
+        // row offsets of the 8 + 8 LDS-DMA instructions of this wave: lanes 0..7 carry A's, lanes 8..15 B's (the asm reads them out with v_readlane)
+        uint32_t tab;
+        {
+            const int j = lane & 7;
+            const int64_t row = (int64_t)((4 * j + wave) * 8);
+            const int64_t arow = remap_row(m0 + row, p.a_group_rows, p.a_group_stride, p.a_row_offset);
+            tab = (lane & 8) ? (uint32_t)((n0 + row) * p.ldb * 2) : (uint32_t)(arow * p.lda * 2);
+        }
+        f32x16 c0, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14, c15;
+        c0 = c1 = c2 = c3 = c4 = c5 = c6 = c7 = c8 = c9 = c10 = c11 = c12 = c13 = c14 = c15 = (f32x16)(0.f);
+#define MTL_W4_RUN(ASM)                                                                                                                                  \
+    asm volatile(ASM                                                                                                                                     \
+                 : [c0] "+a"(c0), [c1] "+a"(c1), [c2] "+a"(c2), [c3] "+a"(c3), [c4] "+a"(c4), [c5] "+a"(c5), [c6] "+a"(c6), [c7] "+a"(c7),              \
+                   [c8] "+a"(c8), [c9] "+a"(c9), [c10] "+a"(c10), [c11] "+a"(c11), [c12] "+a"(c12), [c13] "+a"(c13), [c14] "+a"(c14), [c15] "+a"(c15)    \
+                 : [pa] "s"(p.A), [pb] "s"(p.B), [voa] "v"(voa), [vob] "v"(vob), [tab] "v"(tab), [rba] "v"(rba), [xa] "v"(xa), [rbb] "v"(rbb),           \
+                   [xb] "v"(xb), [nkt] "s"(nkt), [dma] "s"(dma)                                                                                          \
+                 : MTL_W4_LOOP_CLOBBERS)
+        if constexpr (VAR == 0) MTL_W4_RUN(MTL_W4_LOOP_ASM);
+#ifdef MTL_DIAG_W4VAR
+        else if constexpr (VAR == 1) MTL_W4_RUN(MTL_W4_LOOP_ASM_V1);
+        else if constexpr (VAR == 2) MTL_W4_RUN(MTL_W4_LOOP_ASM_V2);
+        else if constexpr (VAR == 3) MTL_W4_RUN(MTL_W4_LOOP_ASM_V3);
+        else if constexpr (VAR == 4) MTL_W4_RUN(MTL_W4_LOOP_ASM_V4);
+        else if constexpr (VAR == 5) MTL_W4_RUN(MTL_W4_LOOP_ASM_V5);
+#endif
+#undef MTL_W4_RUN
+        // ---- epilogue: the wave's 128 x 128 as two 64-column halves of 8 quads ("column tiles" of 8) x 4 row tiles of 32
+        const f32x16* cc[16] = {&c0, &c1, &c2, &c3, &c4, &c5, &c6, &c7, &c8, &c9, &c10, &c11, &c12, &c13, &c14, &c15};   // [mt * 4 + nt]
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 pc[8][4];
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const f32x16& v = *cc[mt * 4 + half * 2 + (t >> 2)];
+                    const int qd = (t & 3) * 4;
+                    pc[t][mt] = (f32x4){v[qd], v[qd + 1], v[qd + 2], v[qd + 3]};
+                }
+            epilogue_wave<EPI, CDT, 8, true, true, 1>(p, m0 + wr * 128 + l31, n0 + wc * 128 + half * 64, h, pc);
+        }
+    }
+}
+
 template <int EPI, int CDT>
 __global__ void splitk_reduce_kernel(const mtl_gemm_args p, const int S, const int vec_ok_i) {
     const int64_t nq = (p.N + 3) / 4;
@@ -1170,7 +1266,7 @@ __global__ void xt_reduce_kernel(const xt_args p) {
 // MTL_GEMM_RULES_OFF=<bitmask> switches single launch rules off for in-step A/B runs of bench.py (1: 256x192 for the GELU GEMM,
 // 2: 256x96 for residual GEMMs, 4: two k-groups, 8: per-XCD k rotation, 16: balanced group height, 32: XCD-affine rows + column rotation). Diagnostic only.
 int rules_off() {
-    static const int v = getenv("MTL_GEMM_RULES_OFF") ? atoi(getenv("MTL_GEMM_RULES_OFF")) : 0;
+    static const int v = mtl_env_int("MTL_GEMM_RULES_OFF", 0);
     return v;
 }
 
@@ -1179,12 +1275,14 @@ int tile_order(int tiles_m, int tiles_n, int bm, int bn, int per_cu, int64_t K, 
     if (nt > 8 * 2 * 32 * per_cu) return 8;
     const int rotate = (one_tile_per_wg && K / BK <= 48 && !(rules_off() & 8)) ? 1 << 8 : 0;
     if (rules_off() & 16) return 8 | rotate;
-    {   // diagnostic: MTL_GEMM_G="bm,g" forces the group height of the short-chunk grids of bm-row tiles (in-step A/B)
+#ifdef MTL_DIAG
+    {   // diagnostic builds: MTL_GEMM_G="bm,g" forces the group height of the short-chunk grids of bm-row tiles (in-step A/B)
         static const char* spec = getenv("MTL_GEMM_G");
         static int fg[2] = {0, 0};
         static const bool parsed = spec && sscanf(spec, "%d,%d", &fg[0], &fg[1]) == 2;
         if (parsed && fg[0] == bm && fg[1] > 0) return (fg[1] > tiles_m ? tiles_m : fg[1]) | rotate;
     }
+#endif
     // whole tile rows per XCD (tiles_m % 8 == 0): g = tiles_m/8 makes every XCD's chunk one group (its own eighth of the rows, all
     // columns: fewest A bytes) and a per-XCD column rotation (bit 9) keeps the XCDs off the same B panels. Per-kernel A/B against
     // the sqrt rule: qkv 35.6 -> 34.2, two-k-group 21.1 -> 20.5, dGELU 33.1 -> 32.2, residual 36.0 -> 34.8, GELU 61.0 -> 59.9 us.
@@ -1200,6 +1298,19 @@ int tile_order(int tiles_m, int tiles_n, int bm, int bn, int per_cu, int64_t K, 
 }
 
 bool aligned(const void* ptr, size_t a) { return (reinterpret_cast<uintptr_t>(ptr) % a) == 0; }
+
+// may this problem run on gemm_nt_w4_kernel? (whole 256 x 256 tiles, vector epilogue, operand offsets that fit the 32-bit buffer addressing of its
+// LDS-DMA, row-mapped A operands whose 8-row staging pieces stay inside one row group)
+bool w4_ok(const mtl_gemm_args& p, int vec_ok) {
+    if (!vec_ok || p.M % 256 != 0 || p.N % 256 != 0 || p.K < 64) return false;
+    const int64_t lim = (int64_t)1 << 31;
+    int64_t a_last = p.M;
+    if (p.a_group_rows > 0) {
+        if (p.a_group_rows % 8 != 0 || p.a_row_offset < 0 || p.a_group_stride < 0) return false;
+        a_last = ((p.M - 1) / p.a_group_rows) * p.a_group_stride + p.a_row_offset + p.a_group_rows;
+    }
+    return a_last * p.lda * 2 < lim && p.N * p.ldb * 2 < lim && p.lda > 0 && p.ldb > 0;
+}
 
 // per-call experiment knobs (mtl_gemm_args.tune_*): mode 0 = one tile per workgroup, 1 = persistent flat-K (the default); 0 = automatic elsewhere
 struct Tuning { int mode = 1; int bn = 0; int stages = 0; int waves = 0; int bm = 0; };
@@ -1218,9 +1329,9 @@ int num_cus() {       // (constant of the device, cached once)
     return n;
 }
 
-// kernel name of a launch for the profiler; MTL_PROF_SHAPES=1 appends the problem size (per-shape rows: tools/gemm_shapes.py)
+// kernel name of a launch for the profiler; mtl_prof_enable(2) appends the problem size (per-shape rows: tools/gemm_shapes.py)
 __attribute__((format(printf, 4, 5))) void kname_shape(char* buf, size_t cap, const mtl_gemm_args& p, const char* fmt, ...) {
-    static const bool shapes = getenv("MTL_PROF_SHAPES") && atoi(getenv("MTL_PROF_SHAPES")) != 0;
+    const bool shapes = prof().shapes.load(std::memory_order_relaxed);
     va_list ap;
     va_start(ap, fmt);
     const int n = vsnprintf(buf, cap, fmt, ap);
@@ -1276,12 +1387,14 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st, int fbm = 0, int 
             if (bm == 128 && bn == 128 && p.N % 192 == 0 && t192 >= 2 * ncu && (EPI == MTL_EPI_STORE || EPI == MTL_EPI_GELU)) bn = 192;
             else if (bm == 128 && bn == 64 && p.N % 96 == 0) bn = 96;
         }
-        {   // diagnostic: MTL_GEMM_FORCE="epi,N,bm,bn,stages,waves" forces one tile configuration for the launches of that epilogue and N
+#ifdef MTL_DIAG
+        {   // diagnostic builds: MTL_GEMM_FORCE="epi,N,bm,bn,stages,waves" forces one tile configuration for the launches of that epilogue and N
             static const char* spec = getenv("MTL_GEMM_FORCE");
             static int f[6] = {-1, 0, 0, 0, 0, 0};
             static const bool parsed = spec && sscanf(spec, "%d,%d,%d,%d,%d,%d", &f[0], &f[1], &f[2], &f[3], &f[4], &f[5]) == 6;
             if (parsed && f[0] == EPI && f[1] == p.N && tn.bm == 0) { bm = f[2]; bn = f[3]; stages = f[4]; nw = f[5]; }
         }
+#endif
         // 256 x 256 grids whose last round of tiles would leave most CUs idle: the columns that fill WHOLE rounds go in this launch, the
         // remaining columns in a second one with half-width tiles (256 x 128 / 16 waves / 3 stages: twice the tiles for the same columns).
         // Llama-2 gate|up with the prompt-row cache: [4096 x 22016 x 4096] = 16 x 86 tiles = 5.375 rounds of 256 -> 5 rounds + 96 half-width
@@ -1308,6 +1421,35 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st, int fbm = 0, int 
                     return launch<EPI, CDT>(b, vec_ok, st, 256, 128, 3, 16);
                 }
             }
+        }
+        // 256 x 256 / 4 waves: the hand-placed instance (gemm_nt_w4_kernel). Whole tiles, 32-bit operand offsets, 8-row pieces inside one row group.
+        if (bm == 256 && bn == 256 && nw == 4) {
+            if (!w4_ok(p, vec_ok)) return MTL_ERR_UNSUPPORTED;
+            const int tm = (int)(p.M / 256), tn = (int)(p.N / 256), nt = tm * tn;
+            const int grid = nt < ncu ? nt : ncu;
+            const size_t lds = 128 * 1024;
+            const int order = tile_order(tm, tn, 256, 256, 1, p.K);
+#ifdef MTL_DIAG_W4VAR
+            if constexpr (EPI == MTL_EPI_STORE && CDT == MTL_BF16) {
+#define MTL_W4_VARIANT(V)                                                                                                                  \
+    if (stages == 2 + V) {                                                                                                                 \
+        auto kv = gemm_nt_w4_kernel<EPI, CDT, V>;                                                                                          \
+        (void)hipFuncSetAttribute((const void*)kv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
+        hipLaunchKernelGGL(kv, dim3(grid), dim3(256), lds, st, p, vec_ok, tm, tn, order);                                                  \
+        MTL_CHECK_LAUNCH();                                                                                                                \
+        return MTL_OK;                                                                                                                     \
+    }
+                MTL_W4_VARIANT(1) MTL_W4_VARIANT(2) MTL_W4_VARIANT(3) MTL_W4_VARIANT(4) MTL_W4_VARIANT(5)
+#undef MTL_W4_VARIANT
+            }
+#endif
+            auto kfn = gemm_nt_w4_kernel<EPI, CDT>;
+            static std::once_flag once;
+            std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+            kname_shape(kname, sizeof kname, p, "gemm_nt_w4_kernel<%d, %d>", EPI, CDT);
+            MTL_LAUNCH(kname, flops, 0, kfn, dim3(grid), dim3(256), lds, st, p, vec_ok, tm, tn, order);
+            MTL_CHECK_LAUNCH();
+            return MTL_OK;
         }
         const bool auto_cfg = nw == 0 && stages == 0;
         if (nw == 0) nw = bm == 256 ? 16 : (bn >= 128 ? 8 : 4);
@@ -1431,7 +1573,7 @@ extern "C" int mtl_gemm_xt(const mtl_gemm_xt_args* a, void* stream) {
     const double flops = 2.0 * (double)a->M * (double)a->N * (double)a->K;
     char kname[96];
     {
-        static const bool shapes = getenv("MTL_PROF_SHAPES") && atoi(getenv("MTL_PROF_SHAPES")) != 0;
+        const bool shapes = prof().shapes.load(std::memory_order_relaxed);
         const int n = snprintf(kname, sizeof kname, "gemm_xt_kernel<%d, %d, %d>", a->a_trans ? 1 : 0, a->b_trans ? 1 : 0, S > 1 ? MTL_F32 : a->c_dtype);
         if (shapes && n > 0) snprintf(kname + n, sizeof kname - n, " [%lldx%lldx%lld /%d]", (long long)a->M, (long long)a->N, (long long)a->K, S);
     }
@@ -1489,6 +1631,7 @@ extern "C" int mtl_prof_enable(int on) {
     Profiler& pf = prof();
     std::lock_guard<std::mutex> lk(pf.mu);
     pf.on.store(on != 0);
+    pf.shapes.store(on == 2);
     if (on) {
         for (auto& r : pf.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
         pf.recs.clear();
@@ -1552,7 +1695,7 @@ extern "C" int mtl_gemm_nt(const mtl_gemm_args* a, void* stream) {
     if (p.c_dtype != MTL_F32 && p.c_dtype != MTL_BF16) return MTL_ERR_ARG;
     if (p.tune_mode < 0 || p.tune_mode > 2 || (p.tune_bm != 0 && p.tune_bm != 128 && p.tune_bm != 256) ||
         (p.tune_bn != 0 && p.tune_bn != 64 && p.tune_bn != 128 && p.tune_bn != 96 && p.tune_bn != 192 && p.tune_bn != 256) ||
-        (p.tune_stages != 0 && (p.tune_stages < 2 || p.tune_stages > 5)) || (p.tune_waves != 0 && p.tune_waves != 4 && p.tune_waves != 8 && p.tune_waves != 16))
+        (p.tune_stages != 0 && (p.tune_stages < 2 || p.tune_stages > 7)) || (p.tune_waves != 0 && p.tune_waves != 4 && p.tune_waves != 8 && p.tune_waves != 16))
         return MTL_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int S = p.split_k > 1 ? p.split_k : 1;

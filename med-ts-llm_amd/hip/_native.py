@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("MTL_LIB_PATH") or os.path.join(_HERE, "libmedtsllm_hi
 MTL_F32, MTL_BF16 = 0, 1
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM, EPI_SWIGLU, EPI_DSWIGLU = 0, 1, 2, 3, 4, 5, 6
 ARCH_GPT2, ARCH_LLAMA = 0, 1
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 i64, vp, f32, i32 = C.c_int64, C.c_void_p, C.c_float, C.c_int
 
@@ -91,6 +91,7 @@ class BackboneWeights(C.Structure):
 # name -> (restype, argtypes); every symbol include/medtsllm_hip.h declares
 SIGNATURES = {
     "mtl_abi_version": (i32, []),
+    "mtl_build_flags": (i32, []),
     "mtl_strerror": (C.c_char_p, [i32]),
     "mtl_patch_tokenize_fwd": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, f32, f32, C.c_uint32, vp]),
     "mtl_patch_tokenize_bwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, f32, C.c_uint32, vp]),
@@ -158,6 +159,11 @@ def lib():
             fn.restype, fn.argtypes = res, args
         if l.mtl_abi_version() != ABI_VERSION:
             raise MtlError(f"ABI mismatch: library {l.mtl_abi_version()} vs binding {ABI_VERSION}")
+        flags = l.mtl_build_flags()
+        if flags and os.environ.get("MTL_ALLOW_DIAG_LIB") != "1":
+            # a diagnostic build (environment switches compiled in, or timing ablations that compute wrong results on purpose) must never
+            # stand in for the product library by accident: tools/ set MTL_ALLOW_DIAG_LIB=1 next to MTL_LIB_PATH
+            raise MtlError(f"{LIB_PATH} is a diagnostic build (mtl_build_flags() = {flags}); set MTL_ALLOW_DIAG_LIB=1 to load it from a tool")
         _lib = l
     return _lib
 

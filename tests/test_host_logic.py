@@ -462,13 +462,36 @@ def test_synth_generators_agree():
     assert np.array_equal(H.synth_tensor(20000, 5, 9, 0.3, block=8192).numpy(), H.synth_table(20000, 5, 9, 0.3))
 
 
-def test_header_lists_every_environment_switch_of_the_library():
-    """include/medtsllm_hip.h claims to name every environment variable the shipped library reads: compare with the sources"""
+def test_product_library_reads_no_environment_variable():
+    """the shipped library has no hidden state. (1) every environment read of the sources goes through mtl_env_int() (a constant in
+    the product build) or sits inside an #ifdef MTL_DIAG block; (2) the header names exactly the switches DIAGNOSTIC builds read; (3) the built
+    product .so does not even import getenv, and reports mtl_build_flags() == 0"""
     import re
-    src = "".join((ROOT / "med-ts-llm_amd" / "csrc" / f).read_text() for f in
-                  ("mtl_gemm.hip", "mtl_attention.hip", "mtl_backbone.hip", "mtl_norm.hip", "mtl_elementwise.hip", "mtl_tokenizer.hip", "mtl_optim.hip",
-                   "mtl_stats.hip", "mtl_common.h"))
-    read = set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', src))
+    import subprocess
+    files = ("mtl_gemm.hip", "mtl_attention.hip", "mtl_backbone.hip", "mtl_norm.hip", "mtl_elementwise.hip", "mtl_tokenizer.hip", "mtl_optim.hip",
+             "mtl_stats.hip", "mtl_common.h")
+    names = set()
+    for f in files:
+        text = (ROOT / "med-ts-llm_amd" / "csrc" / f).read_text()
+        names |= set(re.findall(r'mtl_env_int\("([A-Z0-9_]+)"', text))
+        depth = []                                   # stack of preprocessor conditions
+        for line in text.splitlines():
+            st = line.strip()
+            if st.startswith("#if"):
+                depth.append(st)
+            elif st.startswith("#endif") and depth:
+                depth.pop()
+            elif st.startswith("#else") and depth:
+                depth[-1] = "#else of " + depth[-1]
+            if "getenv(" in line:
+                assert any(d.startswith("#ifdef MTL_DIAG") for d in depth), (f, line)
+                names |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', line))
     head = (ROOT / "include" / "medtsllm_hip.h").read_text()
-    listed = set(re.findall(r"\bMTL_[A-Z0-9_]+\b", head[head.index("ENVIRONMENT variables"):head.index("Unset (the product's state)")]))
-    assert read == listed, (sorted(read - listed), sorted(listed - read))
+    listed = set(re.findall(r"\bMTL_[A-Z0-9_]+\b", head[head.index("the dispatch switches"):head.index("#ifndef MEDTSLLM_HIP_H")]))
+    assert names == listed, (sorted(names - listed), sorted(listed - names))
+    from med_ts_llm_amd.hip import _native
+    if _native.available() and not os.environ.get("MTL_LIB_PATH"):
+        assert _native.lib().mtl_build_flags() == 0
+        nm = subprocess.run(["nm", "-D", "--undefined-only", _native.LIB_PATH], capture_output=True, text=True)
+        if nm.returncode == 0:
+            assert "getenv" not in nm.stdout, "the product library imports getenv"

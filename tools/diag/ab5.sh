@@ -6,7 +6,7 @@ steps=20; warm=5; [ "$wl" = "gpt2s_B32_L1024_C12" ] || { steps=5; warm=2; }
 for i in $(seq $n); do
   for spec in "$@"; do
     label=${spec%%=*}; what=${spec#*=}
-    case "$what" in -) envs="";; *.so) envs="MTL_LIB_PATH=$what";; *) envs="$what";; esac
+    case "$what" in -) envs="";; *.so) envs="MTL_ALLOW_DIAG_LIB=1 MTL_LIB_PATH=$what";; *) envs="$what";; esac
     env $envs python bench.py --workload $wl --steps $steps --warmup $warm --no-cpu-baseline --no-extra-configs --no-live-traffic --detail-file /tmp/_ab5.json >/dev/null 2>/tmp/_ab5.err \
       || { echo "$label FAILED"; tail -3 /tmp/_ab5.err; continue; }
     python - "$label" "$rx" <<'PY'

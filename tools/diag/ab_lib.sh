@@ -2,7 +2,7 @@
 # in-step A/B of two libraries: alternating bench runs inside one gpurun call, per-dispatch kernel times of the profiled replay.
 # usage: tools/diag/ab_lib.sh <base_lib.so | VAR=VALUE> <kernel regex> [workload] [reps]  -> prints ms/step and the matching kernels' avg us for both
 # (first argument with a '=': the baseline is the SAME library with that environment knob set)
-base=$1; case "$base" in *=*) basevar="$base";; *) basevar="MTL_LIB_PATH=$base";; esac; rx=$2; wl=${3:-gpt2s_B32_L1024_C12}; n=${4:-3}
+base=$1; case "$base" in *=*) basevar="$base";; *) basevar="MTL_ALLOW_DIAG_LIB=1 MTL_LIB_PATH=$base";; esac; rx=$2; wl=${3:-gpt2s_B32_L1024_C12}; n=${4:-3}
 steps=20; warm=5; [ "$wl" = "gpt2s_B32_L1024_C12" ] || { steps=5; warm=2; }
 show() { python -c "
 import sys, json, re

@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Generator of med-ts-llm_amd/csrc/mtl_gemm_w4_loop.inc — the hand-placed k-loop of gemm_nt_w4_kernel (mtl_gemm.hip).
+
+One 256 x 256 x 64 k-tile per loop body, 4 waves (2 x 2), one wave per SIMD, each wave a 128 x 128 sub-tile as 4 x 4
+v_mfma_f32_32x32x16_bf16 accumulators (16 x f32x16 = 256 AGPRs, compiler-allocated "+a" operands). A k-tile is 64 MFMAs of 32 cycles each;
+every other instruction of the k-tile (32 ds_read_b128, 16 LDS-DMA loads + their M0 updates, 3 barriers, the counted waits, the scalar
+bookkeeping) sits in a FIXED slot between two MFMAs, at most two per gap, so the matrix pipe never waits for the issue of anything else.
+
+Time structure of iteration t (LDS: two buffers per operand; buffer b = t & 1 holds k-tile t, k-tile t + 1 is landing in buffer b ^ 1):
+  fragments live in two register sets: S0 = k 0..31 of the tile, S1 = k 32..63. At the top S0 holds tile t.
+  MFMA  0..31 (S0) | B reads of S1, barrier 1 (B of buffer b is free) -> LDS-DMA of B(t + 2) into it, A reads of S1, barrier 2 -> LDS-DMA of A(t + 2)
+  MFMA 32..63 (S1) | rest of the A DMA, vmcnt(those just issued) + barrier 3 (tile t + 1 has landed for everyone) -> S0 reads of tile t + 1
+The loop is unrolled twice (buffer parity is an immediate in every ds_read offset and M0 base).
+
+Physical registers named by the asm (all listed as clobbers): v[112:239] fragments, v[240:247] per-k-step read bases,
+s[72:75] / s[76:79] buffer descriptors of A / B, s[80:87] / s[88:95] the per-instruction row offsets, s96 loop counter, s97 k step, s98 advances left.
+
+usage: python tools/gen_gemm_w4_loop.py   (rewrites the .inc; the output is committed)"""
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "med-ts-llm_amd", "csrc", "mtl_gemm_w4_loop.inc")
+
+FRAG0 = 112          # first fragment VGPR
+KSB = 240            # v[240:243] A read bases per k-step, v[244:247] B read bases
+A_BUF = 0x8000       # bytes between the two buffers of an operand
+B_REGION = 0x10000   # B buffers start here
+PIECE = 0x1000       # LDS bytes of one LDS-DMA instruction of the four waves (4 x 1 KiB)
+
+
+def fa(s, ksl, mt):  # A-tile fragment (rows m): MFMA srcB
+    r = FRAG0 + (((s * 2 + ksl) * 4 + mt) * 4)
+    return f"v[{r}:{r + 3}]"
+
+
+def fb(s, ksl, nt):  # B-tile fragment (rows n): MFMA srcA
+    r = FRAG0 + 64 + (((s * 2 + ksl) * 4 + nt) * 4)
+    return f"v[{r}:{r + 3}]"
+
+
+def rd_a(s, ksl, mt, buf):
+    return f"ds_read_b128 {fa(s, ksl, mt)}, v{KSB + s * 2 + ksl} offset:{buf * A_BUF + mt * 4096}"
+
+
+def rd_b(s, ksl, nt, buf):
+    return f"ds_read_b128 {fb(s, ksl, nt)}, v{KSB + 4 + s * 2 + ksl} offset:{buf * A_BUF + nt * 4096}"
+
+
+def mfma(m):
+    s, ksl, nt, mt = m // 32, (m % 32) // 16, (m % 16) // 4, m % 4
+    c = f"%[c{mt * 4 + nt}]"
+    return f"v_mfma_f32_32x32x16_bf16 {c}, {fb(s, ksl, nt)}, {fa(s, ksl, mt)}, {c}"
+
+
+def dma(op, i):
+    if op == "a":
+        return f"buffer_load_dwordx4 %[voa], s[72:75], s{80 + i} offen lds"
+    return f"buffer_load_dwordx4 %[vob], s[76:79], s{88 + i} offen lds"
+
+
+def body(b, var=""):
+    """one k-tile, buffer parity b. Returns the instruction list. `var`: ablation letters for the DIAGNOSTIC variants (timing only, wrong results):
+    D = no in-loop LDS-DMA, B = no barriers, R = no fragment reads, W = no counted waits"""
+    fill = {m: [] for m in range(64)}          # instructions placed AFTER MFMA m
+    n_dma = 0
+    # ---- S1 reads of B (tile t), then barrier 1
+    order_b1 = [(1, ksl, nt) for ksl in range(2) for nt in range(4)]
+    for j, (s, ksl, nt) in enumerate(order_b1):
+        fill[j].append(rd_b(s, ksl, nt, b))
+    # scalar bookkeeping of the iteration: k step of this iteration's DMA (k-tile t + 2, clamped to the last one)
+    fill[8] += ["s_cmp_gt_i32 s98, 0", "s_cselect_b32 s97, 128, 0"]
+    fill[9] += ["s_sub_i32 s98, s98, 1"]
+    fill[12] += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
+    fill[13] += ["s_add_u32 s76, s76, s97", "s_addc_u32 s77, s77, 0", f"s_add_u32 m0, %[dma], {B_REGION + b * A_BUF}"]
+    # ---- DMA of B(t + 2) into buffer b, one per two MFMAs, M0 advanced in the gap between
+    for i in range(8):
+        m = 14 + 2 * i
+        fill[m].append(dma("b", i)); n_dma += 1
+        if i < 7:
+            fill[m + 1].append(f"s_add_u32 m0, m0, {PIECE}")
+    # ---- S1 reads of A (tile t), then barrier 2
+    order_a1 = [(1, ksl, mt) for ksl in range(2) for mt in range(4)]
+    for j, (s, ksl, mt) in enumerate(order_a1):
+        fill[14 + j].append(rd_a(s, ksl, mt, b))
+    fill[27] += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
+    fill[29] += ["s_add_u32 s72, s72, s97", "s_addc_u32 s73, s73, 0", f"s_add_u32 m0, %[dma], {b * A_BUF}"]
+    # ---- DMA of A(t + 2)
+    wait_at = 43
+    for i in range(8):
+        m = 30 + 2 * i
+        fill[m].append(dma("a", i))
+        if m < wait_at:
+            n_dma += 1
+        if i < 7:
+            fill[m + 1].append(f"s_add_u32 m0, m0, {PIECE}")
+    # ---- tile t + 1 has landed: everything older than this iteration's loads issued so far
+    fill[wait_at] = [f"s_waitcnt vmcnt({n_dma})", "s_barrier"] + fill[wait_at]
+    # ---- S0 reads of tile t + 1 from buffer b ^ 1, in the order the next iteration consumes them
+    order0 = []
+    for ksl in range(2):
+        order0.append(("b", 0, ksl, 0))
+        order0 += [("a", 0, ksl, mt) for mt in range(4)]
+        order0 += [("b", 0, ksl, nt) for nt in range(1, 4)]
+    for j, (op, s, ksl, x) in enumerate(order0):
+        fill[wait_at + 1 + j].append(rd_a(s, ksl, x, b ^ 1) if op == "a" else rd_b(s, ksl, x, b ^ 1))
+    assert wait_at + 1 + len(order0) - 1 <= 59
+    out = []
+    for m in range(64):
+        out.append(mfma(m))
+        for ins in fill[m]:
+            if "D" in var and ins.startswith("buffer_load"):
+                continue
+            if "B" in var and ins == "s_barrier":
+                continue
+            if "R" in var and ins.startswith("ds_read"):
+                continue
+            if "W" in var and ins.startswith("s_waitcnt"):
+                continue
+            out.append(ins)
+    return out
+
+
+def prologue():
+    o = ["s_barrier",
+         "s_mov_b64 s[72:73], %[pa]", "s_mov_b32 s74, -1", "s_mov_b32 s75, 0x20000",
+         "s_mov_b64 s[76:77], %[pb]", "s_mov_b32 s78, -1", "s_mov_b32 s79, 0x20000"]
+    for j in range(16):
+        o.append(f"v_readlane_b32 s{80 + j}, %[tab], {j}")
+    for ks in range(4):
+        o += [f"v_xor_b32 v{KSB + ks}, {2 * ks}, %[xa]", f"v_xor_b32 v{KSB + 4 + ks}, {2 * ks}, %[xb]"]
+    for ks in range(4):
+        o += [f"v_lshl_add_u32 v{KSB + ks}, v{KSB + ks}, 4, %[rba]", f"v_lshl_add_u32 v{KSB + 4 + ks}, v{KSB + 4 + ks}, 4, %[rbb]"]
+    o += ["s_mov_b32 s96, %[nkt]", "s_sub_i32 s98, %[nkt], 2", "s_nop 4"]
+
+    def tile(buf):
+        t = [f"s_add_u32 m0, %[dma], {buf * A_BUF}", "s_nop 0"]
+        for i in range(8):
+            t.append(dma("a", i))
+            if i < 7:
+                t += [f"s_add_u32 m0, m0, {PIECE}", "s_nop 0"]
+        t += [f"s_add_u32 m0, %[dma], {B_REGION + buf * A_BUF}", "s_nop 0"]
+        for i in range(8):
+            t.append(dma("b", i))
+            if i < 7:
+                t += [f"s_add_u32 m0, m0, {PIECE}", "s_nop 0"]
+        return t
+    o += tile(0)
+    # k-tile 1 (clamped to the last k-tile when the tile has only one)
+    o += ["s_cmp_gt_i32 %[nkt], 1", "s_cselect_b32 s97, 128, 0",
+          "s_add_u32 s72, s72, s97", "s_addc_u32 s73, s73, 0", "s_add_u32 s76, s76, s97", "s_addc_u32 s77, s77, 0"]
+    o += tile(1)
+    o += ["s_waitcnt vmcnt(16)", "s_barrier"]
+    for ksl in range(2):
+        for x in range(4):
+            o += [rd_b(0, ksl, x, 0), rd_a(0, ksl, x, 0)]
+    o += ["s_waitcnt lgkmcnt(0)"]
+    return o
+
+
+def program(var=""):
+    lines = prologue()
+    lines.append("L_w4_top_%=:")
+    lines += body(0, var)
+    lines += ["s_waitcnt lgkmcnt(0)", "s_sub_u32 s96, s96, 1", "s_cmp_eq_u32 s96, 0", "s_cbranch_scc1 L_w4_end_%="]
+    lines += body(1, var)
+    lines += ["s_waitcnt lgkmcnt(0)", "s_sub_u32 s96, s96, 1", "s_cmp_lg_u32 s96, 0", "s_cbranch_scc1 L_w4_top_%="]
+    lines.append("L_w4_end_%=:")
+    # the stray loads of the last two iterations land before the LDS is reused; MFMA results settle before the compiler reads them
+    lines += ["s_waitcnt vmcnt(0)", "s_nop 15", "s_nop 15"]
+    return lines
+
+
+VARIANTS = ["D", "B", "R", "DB", "DBRW"]      # MTL_W4_LOOP_ASM_V1 .. (diagnostic builds, -DMTL_DIAG_W4VAR)
+
+
+def emit(f, name, lines):
+    f.write(f"#define {name} \\\n")
+    for l in lines:
+        f.write(f'    "{l}\\n\\t" \\\n')
+    f.write('    ""\n')
+
+
+def main():
+    lines = program()
+    with open(OUT, "w") as f:
+        f.write("// GENERATED by tools/gen_gemm_w4_loop.py — do not edit by hand. The k-loop of gemm_nt_w4_kernel as ONE asm statement.\n")
+        f.write(f"// {sum(1 for l in lines if l.startswith('v_mfma'))} MFMAs, {len(lines)} instructions.\n")
+        emit(f, "MTL_W4_LOOP_ASM", lines)
+        f.write("#ifdef MTL_DIAG_W4VAR      // ablations for timing (WRONG results): what the in-loop DMA / barriers / reads / waits cost\n")
+        for i, v in enumerate(VARIANTS):
+            emit(f, f"MTL_W4_LOOP_ASM_V{i + 1}", program(v))
+        f.write("#endif\n")
+        clob = [f'"v{r}"' for r in range(FRAG0, KSB + 8)] + [f'"s{r}"' for r in range(72, 99)]
+        f.write("#define MTL_W4_LOOP_CLOBBERS " + ", ".join(clob) + ', "scc", "memory"\n')
+    print("wrote", OUT, len(lines), "instructions")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,52 @@
+"""GPU probe (tools/, not product; needs tools/diag/_lib_w4diag.so = tools/build_variant.sh w4diag only=mtl_gemm -DMTL_DIAG -DMTL_DIAG_W4VAR):
+what the parts of gemm_nt_w4_kernel's k-loop cost — the full loop against the generator's ablations (no in-loop LDS-DMA / no barriers / no fragment
+reads / neither DMA nor barriers / MFMAs only; the ablations compute garbage, only their time means something), cold operands, one-round shapes.
+usage: MTL_ALLOW_DIAG_LIB=1 MTL_LIB_PATH=tools/diag/_lib_w4diag.so [MTL_GEMM_G=256,4] python tools/probes/gemm_w4_ablate.py"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch                                          # noqa: E402
+from med_ts_llm_amd.hip import ops                    # noqa: E402
+
+BF16 = torch.bfloat16
+g = torch.Generator().manual_seed(0)
+SHAPES = [("4096 x 4096 x 22016", 4096, 4096, 22016), ("4096 x 4096 x 4096", 4096, 4096, 4096), ("4096 x 12288 x 4096", 4096, 12288, 4096)]
+VARS = [("full", 2), ("no DMA", 3), ("no barriers", 4), ("no reads", 5), ("no DMA, no barriers", 6), ("MFMA only", 7)]
+flush = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+
+
+def timed(fn, n=10):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for it in range(n):
+        fn(it)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+print("MTL_GEMM_G =", os.environ.get("MTL_GEMM_G"))
+for name, M, Nn, K in SHAPES:
+    A = torch.randn(M, K, generator=g).to(BF16).cuda()
+    B = (torch.randn(Nn, K, generator=g) * 0.05).to(BF16).cuda()
+    nA = max(2, min(8, (600 << 20) // (A.numel() * 2)))
+    nB = max(2, min(24, (600 << 20) // (B.numel() * 2)))
+    poolA, poolB = [A.clone() for _ in range(nA)], [B.clone() for _ in range(nB)]
+    poolC = [torch.empty(M, Nn, dtype=BF16, device="cuda") for _ in range(4)]
+    res = {}
+    for rnd in range(3):
+        for label, st in VARS:
+            flush.fill_(rnd)
+
+            def go(it, st=st):
+                with ops.gemm_tune(bm=256, bn=256, stages=st, waves=4):
+                    ops.gemm_nt(poolA[it % nA], poolB[it % nB], out=poolC[it % 4])
+            res.setdefault(label, []).append(timed(go))
+    nkt, rounds = K // 64, (M // 256) * (Nn // 256) / 256
+    line = f"{name:22s}"
+    for label, _ in VARS:
+        t = sorted(res[label])[1]
+        line += f" | {label} {t:7.1f} us ({t / nkt / rounds * 1e3:5.0f} ns/k-tile)"
+    print(line, flush=True)
