@@ -701,7 +701,7 @@ def compact_line(out):
     c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                              "dtype", "data")}
     c["config"] = {"workload": _short_workload(out), "global_batch": out["config"]["global_batch"], "parallelism": out["config"]["parallelism"]}
-    for k in ("per_gpu_samples_per_s", "dist_backend", "rccl_ranks", "dp_mode", "dp_modes"):
+    for k in ("per_gpu_samples_per_s", "dist_backend", "rccl_ranks", "dp_mode", "dp_modes", "dp_sharded_failed"):
         if out.get(k) is not None:
             c[k] = out[k]
     c["roofline"] = _roof_compact(out.get("roofline"))
@@ -810,56 +810,54 @@ def main():
         elif args.replicate_mapping and args.replicate_optimizer:
             dp_mode = "plain all-reduce (requested)"
         else:
-            dp_mode = "sharded: row-sharded mapping layer + reduce-scatter / owned-row Adam / bf16 all-gather for tensors >= 2^24 + bucketed all-reduce"
+            dp_mode = ("plain all-reduce" if not args.single_dp_mode else
+                       "sharded: row-sharded mapping layer + reduce-scatter / owned-row Adam / bf16 all-gather for tensors >= 2^24 + bucketed all-reduce")
         stage(f"DP pre-flight: {'ok' if ok else why}; {rccl_ranks} ranks answered; mode = {dp_mode}")
 
     full = args.full_detail
-    # N > 1: BOTH DP modes in one run, the plain one first — north_star's split: replicated trainables, ONE bucketed all-reduce of
-    # their gradients — then the default sharded mode, which gives the headline `value` when it completes. The sharded leg runs under a watchdog: if it
-    # raises or exceeds its time budget (a hung collective cannot be caught), the line is printed with the plain figure as `value` and says so, so a
-    # scaling record can tell WHICH exchange failed instead of losing the run.
-    plain_leg = None
-    if world > 1 and not args.single_dp_mode and not (args.replicate_mapping and args.replicate_optimizer):
+    # N > 1: BOTH DP modes in one run. The headline `value` is the PLAIN mode — north_star's split and the trainer's default since round 6: replicated
+    # trainables, ONE bucketed all-reduce of their gradients, replicated Adam. The row-sharded mode (setup.shard_mapping / shard_optimizer) is timed
+    # second, under a watchdog: if it raises or exceeds its time budget (a hung collective cannot be caught) the line is printed anyway, with
+    # `dp_sharded_failed: true` — machine-readable, so a scaling record can never carry the wrong mode's figure silently.
+    sharded_wanted = world > 1 and not args.single_dp_mode and not (args.replicate_mapping and args.replicate_optimizer)
+    if sharded_wanted:
         import copy
-        a2 = copy.copy(args)
-        a2.replicate_mapping = a2.replicate_optimizer = True
-        stage(f"start {args.workload} [dp mode: plain all-reduce]")
-        t_leg = time.perf_counter()
-        plain_leg = run_workload(args.workload, a2, ctx, args.steps, args.warmup, False, False, legs=False, stage=stage)
-        t_leg = time.perf_counter() - t_leg
-        if rank == 0:
-            plain_leg["rccl_ranks"], plain_leg["dp_mode"] = rccl_ranks, "plain all-reduce"
+        a_plain = copy.copy(args)
+        a_plain.replicate_mapping = a_plain.replicate_optimizer = True
+    else:
+        a_plain = args
+    stage(f"start {args.workload}" + (" [dp mode: plain all-reduce]" if world > 1 else ""))
+    t_leg = time.perf_counter()
+    out = run_workload(args.workload, a_plain, ctx, args.steps, args.warmup, not args.no_cpu_baseline, not args.no_roofline, legs=True, stage=stage)
+    t_leg = time.perf_counter() - t_leg
+    if sharded_wanted:
         budget = max(180.0, 15.0 * t_leg)
 
-        def give_up():
+        def finish_without_sharded(why):
             if rank == 0:
-                plain_leg["dp_mode"] = f"plain all-reduce (the sharded leg did not finish within {budget:.0f} s: its figure is missing)"
-                plain_leg["dp_modes"] = {"plain_allreduce": plain_leg["value"], "sharded": None}
-                print(json.dumps(compact_line(plain_leg), separators=(",", ":")), flush=True)
+                out["rccl_ranks"], out["dp_mode"] = rccl_ranks, f"plain all-reduce ({why})"
+                out["dp_modes"] = {"plain_allreduce": out["value"], "sharded": None}
+                out["dp_sharded_failed"] = True
+                print(json.dumps(compact_line(out), separators=(",", ":")), flush=True)
             os._exit(0)        # (every rank: the line above carries the failure; a non-zero worker would make the launcher kill rank 0 before it prints)
         import threading
-        watchdog = threading.Timer(budget, give_up)
+        watchdog = threading.Timer(budget, finish_without_sharded, args=(f"the sharded leg did not finish within {budget:.0f} s: its figure is missing",))
         watchdog.daemon = True
         watchdog.start()
-    stage(f"start {args.workload}")
-    try:
-        out = run_workload(args.workload, args, ctx, args.steps, args.warmup, not args.no_cpu_baseline, not args.no_roofline, legs=True, stage=stage)
-    except Exception as e:      # noqa: BLE001
-        if plain_leg is None:
-            raise
-        if rank != 0:            # rank 0 may be blocked in a collective this rank just left: its watchdog prints the plain line; wait for our own
-            time.sleep(budget + 30.0)
-            os._exit(0)
-        stage(f"sharded leg FAILED: {type(e).__name__}: {e}")
-        plain_leg["dp_mode"] = f"plain all-reduce (the sharded leg raised {type(e).__name__}: {str(e)[:80]})"
-        plain_leg["dp_modes"] = {"plain_allreduce": plain_leg["value"], "sharded": None}
-        print(json.dumps(compact_line(plain_leg), separators=(",", ":")), flush=True)
-        os._exit(0)
-    if plain_leg is not None:
+        stage(f"start {args.workload} [dp mode: sharded]")
+        try:
+            sh = run_workload(args.workload, args, ctx, args.steps, args.warmup, False, False, legs=False, stage=stage)
+        except Exception as e:      # noqa: BLE001
+            if rank != 0:            # rank 0 may be blocked in a collective this rank just left: its watchdog prints the line; wait for our own
+                time.sleep(budget + 30.0)
+                os._exit(0)
+            stage(f"sharded leg FAILED: {type(e).__name__}: {e}")
+            finish_without_sharded(f"the sharded leg raised {type(e).__name__}: {str(e)[:80]}")
         watchdog.cancel()
         if rank == 0:
-            out["dp_modes"] = {"plain_allreduce": plain_leg["value"], "sharded": out["value"],
-                               "what": "whole-job samples/s of the same step in both DP modes, measured back to back in this run; `value` is the sharded (default) one"}
+            out["dp_modes"] = {"plain_allreduce": out["value"], "sharded": sh["value"],
+                               "what": "whole-job samples/s of the same step in both DP modes, measured back to back in this run; `value` is the plain (default) one"}
+            out["dp_sharded_failed"] = False
     # Extra configs ride on the N = 1 run only: at N > 1 the line is the scaling record of the headline workload — every additional model under DP
     # is more first-contact RCCL surface that could take the headline down with it (--extra-configs-dp asks for them anyway). Each extra is
     # fenced: a failure there is reported in the line's place, never instead of the headline.

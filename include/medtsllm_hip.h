@@ -17,7 +17,7 @@
  *     fields of the argument structs (mtl_gemm_args.tune_*, mtl_attn_fwd_args.tune). DIAGNOSTIC builds (tools/build_variant.sh ... -DMTL_DIAG;
  *     never shipped, reported by mtl_build_flags() and refused by hip/_native.py unless MTL_ALLOW_DIAG_LIB=1) additionally read, each once,
  *     the dispatch switches MTL_ATTN_WIDE, MTL_ATTN_WIDE_X, MTL_ATTN_WIDE_MIN, MTL_ATTN_XMAP, MTL_ATTN_W32, MTL_ATTN_W32_NW, MTL_ATTN_MERGED,
- *     MTL_ATTN_D128 (csrc/mtl_attention.hip), MTL_GEMM_RULES_OFF, MTL_GEMM_G, MTL_GEMM_FORCE (csrc/mtl_gemm.hip), MTL_ROPE_FUSE (csrc/mtl_backbone.hip).
+ *     MTL_ATTN_D128 (csrc/mtl_attention.hip), MTL_GEMM_RULES_OFF, MTL_GEMM_G, MTL_GEMM_FORCE, MTL_W4_ROT, MTL_W4_LINSRC (csrc/mtl_gemm.hip), MTL_ROPE_FUSE (csrc/mtl_backbone.hip).
  */
 #ifndef MEDTSLLM_HIP_H
 #define MEDTSLLM_HIP_H

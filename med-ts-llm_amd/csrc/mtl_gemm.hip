@@ -973,6 +973,12 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
     const int cnt = q + (xcd < r8 ? 1 : 0);
     const int gm = gm_all & 0xff;
     const int nkt = (int)(p.K / 64);
+    // per-XCD k rotation (gm_all bit 8; one-round grids): XCD x stages its tiles' k-tiles from x * nkt / 8 on and wraps, so that the eight XCDs are
+    // never on the same lines of the shared panels at the same moment (a tile's k-steps commute; the fp32 summation order then depends on the XCD)
+    int rot = (gm_all & (1 << 8)) ? (xcd * nkt) >> 3 : 0;
+#ifdef MTL_DIAG_W4VAR      // timing experiments: bit 11 = per-WORKGROUP k stagger (workgroups of an XCD at different k), bit 10 = linear (unswizzled) DMA source
+    if (gm_all & (1 << 11)) rot = (int)(((unsigned)slot * (unsigned)nkt) >> 5) % nkt;
+#endif
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem_all;       // (flat LDS address: the low half is the LDS offset)
     // fragment read addresses (k-step 0; the asm derives the other three)
     const int prow = (l31 & 19) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);             // B rows: bits 2 <-> 3
@@ -981,10 +987,16 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
     // LDS-DMA: instruction i of wave w stages tile rows (4 i + w) * 8 .. + 7; lane -> row lane / 8, slot lane % 8
     const uint32_t dma = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (uint32_t)wave * 1024u));
     const int drow = lane >> 3, dsl = lane & 7;
-    const int dsw = ((wave & 1) * 4 + (lane >> 4)) & 7;                             // swz64 of the row (tile row bases are multiples of 32)
+    int dsw = ((wave & 1) * 4 + (lane >> 4)) & 7;                                   // swz64 of the row (tile row bases are multiples of 32)
+#ifdef MTL_DIAG_W4VAR
+    if (gm_all & (1 << 10)) dsw = 0;
+#endif
     const uint32_t voa = (uint32_t)(drow * (int)p.lda * 2 + ((dsl ^ dsw) << 4));
     const uint32_t vob = (uint32_t)(drow * (int)p.ldb * 2 + ((dsl ^ dsw) << 4));
 
+#ifdef MTL_DIAG_W4VAR      // phase stamps of the workgroup's FIRST tile (100 MHz realtime counter): entry, k-loop begin / end, epilogue end -> workspace[4 * block]
+    uint64_t stamp[4] = {__builtin_amdgcn_s_memrealtime(), 0, 0, 0};
+#endif
     for (int i = slot; i < cnt; i += xblocks) {
         int tm, tn;
         tile_coords(t0 + i, tiles_m, tiles_n, gm, tm, tn);
@@ -1004,8 +1016,11 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
                  : [c0] "+a"(c0), [c1] "+a"(c1), [c2] "+a"(c2), [c3] "+a"(c3), [c4] "+a"(c4), [c5] "+a"(c5), [c6] "+a"(c6), [c7] "+a"(c7),              \
                    [c8] "+a"(c8), [c9] "+a"(c9), [c10] "+a"(c10), [c11] "+a"(c11), [c12] "+a"(c12), [c13] "+a"(c13), [c14] "+a"(c14), [c15] "+a"(c15)    \
                  : [pa] "s"(p.A), [pb] "s"(p.B), [voa] "v"(voa), [vob] "v"(vob), [tab] "v"(tab), [rba] "v"(rba), [xa] "v"(xa), [rbb] "v"(rbb),           \
-                   [xb] "v"(xb), [nkt] "s"(nkt), [dma] "s"(dma)                                                                                          \
+                   [xb] "v"(xb), [nkt] "s"(nkt), [dma] "s"(dma), [rot] "s"(rot)                                                                          \
                  : MTL_W4_LOOP_CLOBBERS)
+#ifdef MTL_DIAG_W4VAR
+        if (i == slot) stamp[1] = __builtin_amdgcn_s_memrealtime();
+#endif
         if constexpr (VAR == 0) MTL_W4_RUN(MTL_W4_LOOP_ASM);
 #ifdef MTL_DIAG_W4VAR
         else if constexpr (VAR == 1) MTL_W4_RUN(MTL_W4_LOOP_ASM_V1);
@@ -1015,6 +1030,9 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
         else if constexpr (VAR == 5) MTL_W4_RUN(MTL_W4_LOOP_ASM_V5);
 #endif
 #undef MTL_W4_RUN
+#ifdef MTL_DIAG_W4VAR
+        if (i == slot) stamp[2] = __builtin_amdgcn_s_memrealtime();
+#endif
         // ---- epilogue: the wave's 128 x 128 as two 64-column halves of 8 quads ("column tiles" of 8) x 4 row tiles of 32
         const f32x16* cc[16] = {&c0, &c1, &c2, &c3, &c4, &c5, &c6, &c7, &c8, &c9, &c10, &c11, &c12, &c13, &c14, &c15};   // [mt * 4 + nt]
 #pragma unroll
@@ -1030,6 +1048,14 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
                 }
             epilogue_wave<EPI, CDT, 8, true, true, 1>(p, m0 + wr * 128 + l31, n0 + wc * 128 + half * 64, h, pc);
         }
+#ifdef MTL_DIAG_W4VAR
+        if (i == slot && p.workspace && threadIdx.x == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp[3] = __builtin_amdgcn_s_memrealtime();
+            uint64_t* o = reinterpret_cast<uint64_t*>(p.workspace) + 4 * blockIdx.x;
+            o[0] = stamp[0]; o[1] = stamp[1]; o[2] = stamp[2]; o[3] = stamp[3];
+        }
+#endif
     }
 }
 
@@ -1416,19 +1442,30 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st, int fbm = 0, int 
                     b.C = reinterpret_cast<char*>(p.C) + n_main * cmul * (CDT == MTL_BF16 ? 2 : 4);
                     if (p.aux_in) b.aux_in = reinterpret_cast<const char*>(p.aux_in) + n_main * cmul * 2;       // (bf16 for every epilogue listed)
                     if (p.aux_out) b.aux_out = reinterpret_cast<char*>(p.aux_out) + (EPI == MTL_EPI_SWIGLU ? n_main / 2 : n_main) * 2;
-                    const int rc = launch<EPI, CDT>(a, vec_ok, st, 256, 256, 2, 8);
+                    const int rc = launch<EPI, CDT>(a, vec_ok, st, 256, 256, 2, w4_ok(a, vec_ok) ? 4 : 8);
                     if (rc != MTL_OK) return rc;
                     return launch<EPI, CDT>(b, vec_ok, st, 256, 128, 3, 16);
                 }
             }
         }
         // 256 x 256 / 4 waves: the hand-placed instance (gemm_nt_w4_kernel). Whole tiles, 32-bit operand offsets, 8-row pieces inside one row group.
+        // Chosen wherever the 8-wave 256 x 256 tile was (cold operands, same box, profiles/r06_gemm_w4_vs_vendor.txt: [4096 x 4096 x 22016] 580 -> 510 us,
+        // [4096 x 4096 x 4096] 122 -> 112, [4096 x 4096 x 11008] 297 -> 270, [4096 x 12288 x 4096] 345 -> 332); rule 256 of MTL_GEMM_RULES_OFF (diagnostic
+        // builds) keeps the 8-wave kernel for in-step A/B runs.
+        if (bm == 256 && bn == 256 && nw == 8 && stages == 2 && fnw == 0 && tn.waves == 0 && w4_ok(p, vec_ok) && !(rules_off() & 256)) nw = 4;
         if (bm == 256 && bn == 256 && nw == 4) {
             if (!w4_ok(p, vec_ok)) return MTL_ERR_UNSUPPORTED;
             const int tm = (int)(p.M / 256), tn = (int)(p.N / 256), nt = tm * tn;
             const int grid = nt < ncu ? nt : ncu;
             const size_t lds = 128 * 1024;
-            const int order = tile_order(tm, tn, 256, 256, 1, p.K);
+            // group height of the XCD chunks: a one-round grid gives every XCD 32 tiles; 4 rows x 8 columns of them touch the fewest panel rows
+            int order = tile_order(tm, tn, 256, 256, 1, p.K) & 0xff;
+            if (nt <= ncu && tm % 4 == 0) order = 4;
+            // (per-XCD k rotation: measured no gain on this kernel, 542.8 vs 533.7 us at K = 22016 — profiles/r06_gemm_w4_experiments.txt — so it is off)
+            const int rot_on = mtl_env_int("MTL_W4_ROT", 0);
+            if (rot_on == 1) order |= 1 << 8;
+            if (rot_on == 2) order |= 1 << 11;
+            if (mtl_env_int("MTL_W4_LINSRC", 0)) order |= 1 << 10;
 #ifdef MTL_DIAG_W4VAR
             if constexpr (EPI == MTL_EPI_STORE && CDT == MTL_BF16) {
 #define MTL_W4_VARIANT(V)                                                                                                                  \

@@ -101,7 +101,10 @@ def init_from_env(device_type="cuda"):
         default = "nccl" if device_type == "cuda" else "gloo"
         # more ranks on this node than it has GPUs (the driver's `torch.distributed.run --nproc-per-node N` on a smaller box): RCCL would fail with
         # "Duplicate GPU detected"; the ranks share devices over gloo instead — a functional run, said on stderr and visible as dist_backend
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        # Only when the launcher SAYS how many ranks share this node (torch.distributed.run sets LOCAL_WORLD_SIZE): a SLURM / mpirun style
+        # launch that exports only RANK / WORLD_SIZE on a 2 x 8-GPU job must keep nccl (the global world size says nothing about this node, and
+        # nodes deciding differently would hang in init_process_group) — ADVICE r05.
+        local_world = int(os.environ["LOCAL_WORLD_SIZE"]) if "LOCAL_WORLD_SIZE" in os.environ else 0
         if device_type == "cuda" and torch.cuda.is_available() and local_world > torch.cuda.device_count() and "MTL_DIST_BACKEND" not in os.environ:
             default = "gloo"
             if rank == 0:

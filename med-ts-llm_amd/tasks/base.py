@@ -109,12 +109,15 @@ class BaseTask(ABC):
         self.load_pretrained()
         if self.world_size > 1:     # identical initial weights on every rank (seeded above), rank-specific dropout streams from here on
             torch.manual_seed(self.config.setup.seed + 7919 * (self.rank + 1))
-        if self.world_size > 1 and self.config.setup.get("shard_mapping", True) and hasattr(self.model, "shard_mapping_layer"):
+        # DP default since round 6: PLAIN data parallelism (north_star's split: replicated trainables, one bucketed all-reduce of their gradients).
+        # The row-sharded forms below are opt-in (setup.shard_mapping / setup.shard_optimizer = true) until a hardware run on >= 2 ranks has passed
+        # the pre-flight: every multi-GPU box so far was out of reach (SCALE_r01..r05 skipped), so the default is the exchange every backend has.
+        if self.world_size > 1 and self.config.setup.get("shard_mapping", False) and hasattr(self.model, "shard_mapping_layer"):
             self.model.shard_mapping_layer(self.rank, self.world_size)      # DP: rows of the mapping layer live on one rank each
         # DP: the big replicated tensors (flatten head of the wide configs, Llama-3's trainable vocabulary) get a row-sharded optimiser
         # step — reduce-scatter of their gradient, Adam on the owned rows, all-gather of the bf16 copy the forward reads (parallel.ShardedUpdate)
         self.opt_shards = None
-        if self.world_size > 1 and self.config.setup.get("shard_optimizer", True):
+        if self.world_size > 1 and self.config.setup.get("shard_optimizer", False):
             su = parallel.ShardedUpdate(list(self.model.named_parameters()), self.rank, self.world_size,
                                         min_numel=int(self.config.setup.get("shard_optimizer_min_numel", 1 << 24)))
             if su.items:

@@ -916,6 +916,55 @@ def test_gemm_two_k_groups(ops, M, Nn, K):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,Nn,K", [(256, 256, 64), (256, 512, 128), (512, 768, 320), (1024, 256, 4096), (4096, 4096, 704)])
+def test_gemm_w4_hand_placed_kernel(ops, M, Nn, K):
+    """gemm_nt_w4_kernel (256 x 256 tile, 4 waves, the generated hand-placed k-loop: tools/gen_gemm_w4_loop.py) against fp64 math on the same bf16 inputs,
+    every epilogue it is dispatched for: fp32 / bf16 store with bias, residual (+ dropout, against the 8-wave kernel's identical mask), SwiGLU, dSwiGLU;
+    odd and even k-tile counts (the loop is unrolled twice), one k-tile, several tiles per workgroup; repeated launches are bit-identical (race screen)"""
+    A = torch.randn(M, K, generator=g(M + K)).to(BF16).cuda()
+    B = (torch.randn(Nn, K, generator=g(Nn)) * 0.1).to(BF16).cuda()
+    bias = torch.randn(Nn, generator=g(3)).cuda()
+    res = torch.randn(M, Nn, generator=g(4)).cuda()
+    gu = torch.randn(M, 2 * Nn, generator=g(5)).to(BF16).cuda()
+    lin = A.double().cpu() @ B.double().cpu().t()
+
+    def run(waves):
+        with ops.gemm_tune(bm=256, bn=256, stages=2, waves=waves):
+            act = torch.empty(M, Nn // 2, dtype=BF16, device="cuda")
+            return dict(f32=ops.gemm_nt(A, B, out_dtype=F32), bf16=ops.gemm_nt(A, B, bias=bias),
+                        resid=ops.gemm_nt(A, B, bias=bias, epilogue=ops.N.EPI_RESID, aux_in=res, out_dtype=F32, drop=(0.1, 77)),
+                        swiglu=ops.gemm_nt(A, B, epilogue=ops.N.EPI_SWIGLU, aux_out=act), act=act,
+                        dswiglu=ops.gemm_nt(A, B, out=torch.empty(M, 2 * Nn, dtype=BF16, device="cuda"), epilogue=ops.N.EPI_DSWIGLU, aux_in=gu))
+    w4, w8 = run(4), run(8)
+    assert rel_err(w4["f32"], lin) < TOL_F32                          # pre-rounding output: accumulation order only
+    assert rel_err(w4["bf16"].float(), lin + bias.double().cpu()) < TOL_BF16
+    for k in ("resid", "swiglu", "act", "dswiglu"):                   # same arithmetic as the 8-wave kernel up to the fp32 summation order of a tile
+        assert rel_err(w4[k].float(), w8[k].float().double().cpu()) < (1e-4 if k == "resid" else 2e-3), k
+    again = run(4)
+    for k in w4:
+        assert torch.equal(w4[k], again[k]), k
+
+
+@pytest.mark.gpu
+def test_gemm_w4_row_mapped_operand_and_dispatch(ops):
+    """the pruned backward's row-mapped A operand through the 4-wave kernel's per-instruction row offsets; shapes the kernel does not take
+    (ragged M / N, row groups that are not multiples of 8) are refused when forced and fall to the 8-wave kernels when automatic"""
+    K, Nn = 512, 1024
+    Abig = torch.randn(8 * 384, K, generator=g(1)).to(BF16).cuda()
+    B = (torch.randn(Nn, K, generator=g(2)) * 0.1).to(BF16).cuda()
+    idx = torch.cat([torch.arange(256, 384) + 384 * i for i in range(8)])
+    with ops.gemm_tune(bm=256, bn=256, stages=2, waves=4):
+        out = ops.gemm_nt(Abig, B, M=1024, a_rows=(128, 384, 256), out_dtype=F32)
+        with pytest.raises(Exception):
+            ops.gemm_nt(Abig[:300], B, out_dtype=F32)                  # M % 256 != 0
+        with pytest.raises(Exception):
+            ops.gemm_nt(Abig, B, M=1024, a_rows=(4, 12, 8), out_dtype=F32)      # 8-row staging pieces would straddle row groups
+    assert rel_err(out, Abig[idx].double().cpu() @ B.double().cpu().t()) < TOL_F32
+    auto = ops.gemm_nt(Abig[:300], B, out_dtype=F32)                   # automatic dispatch still serves it
+    assert rel_err(auto, Abig[:300].double().cpu() @ B.double().cpu().t()) < TOL_F32
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,F,K", [(300, 96, 128), (8192, 1024, 256)])
 def test_gemm_swiglu_epilogue_and_interleaved_backward(ops, M, F, K):
     """gate|up GEMM with the SwiGLU fused into the epilogue (row-interleaved weights: column 2j = gate_j, 2j+1 = up_j) ==

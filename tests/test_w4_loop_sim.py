@@ -1,0 +1,36 @@
+"""CPU test of the generated k-loop of gemm_nt_w4_kernel (csrc/mtl_gemm_w4_loop.inc): the asm text is run through tools/sim_gemm_w4_loop.py, which
+executes its scalar bookkeeping and checks the staging / reading protocol the kernel relies on (every k-tile staged once into the right buffer, reads
+only behind a landing wait + barrier, no re-staging of a region with unfinished reads, counted waits, every MFMA operand = the fragment it must be).
+The GPU tests (test_gpu_kernels.py::test_gemm_w4_*) check the arithmetic; this one catches a schedule edit that only races."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import sim_gemm_w4_loop as sim      # noqa: E402
+
+
+def test_committed_inc_is_what_the_generator_writes(tmp_path):
+    before = open(sim.INC).read()
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_gemm_w4_loop.py")], check=True, capture_output=True)
+    assert open(sim.INC).read() == before, "med-ts-llm_amd/csrc/mtl_gemm_w4_loop.inc is stale: run tools/gen_gemm_w4_loop.py"
+
+
+@pytest.mark.parametrize("nkt", [1, 2, 3, 4, 5, 8, 64, 344])
+def test_k_loop_protocol(nkt):
+    lines = sim.load()
+    for rot in sorted({0, 1, (3 * nkt) // 8, nkt - 1} & set(range(nkt))):
+        assert sim.check(sim.run(lines, nkt, rot), nkt, rot)
+
+
+def test_checker_catches_a_short_landing_wait():
+    lines = sim.load()
+    waits = [l for l in lines if l.startswith("s_waitcnt vmcnt(") and l != "s_waitcnt vmcnt(16)" and "lgkmcnt" not in l]
+    assert waits, "no in-loop landing wait found"
+    n = int(waits[0].split("(")[1].split(")")[0])
+    bad = [l.replace(f"vmcnt({n})", f"vmcnt({n + 2})") if l == waits[0] else l for l in lines]
+    with pytest.raises(AssertionError):
+        sim.check(sim.run(bad, 6, 0), 6, 0)

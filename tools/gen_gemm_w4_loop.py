@@ -13,7 +13,7 @@ Time structure of iteration t (LDS: two buffers per operand; buffer b = t & 1 ho
 The loop is unrolled twice (buffer parity is an immediate in every ds_read offset and M0 base).
 
 Physical registers named by the asm (all listed as clobbers): v[112:239] fragments, v[240:247] per-k-step read bases,
-s[72:75] / s[76:79] buffer descriptors of A / B, s[80:87] / s[88:95] the per-instruction row offsets, s96 loop counter, s97 k step, s98 advances left.
+s[72:75] / s[76:79] buffer descriptors of A / B, s[80:87] / s[88:95] the per-instruction row offsets, s96 loop counter, s97 / s70 k step (lo / sign word), s98 advances left, s99 advances until the k wrap, s71 the wrap's step.
 
 usage: python tools/gen_gemm_w4_loop.py   (rewrites the .inc; the output is committed)"""
 import os
@@ -52,47 +52,65 @@ def mfma(m):
     return f"v_mfma_f32_32x32x16_bf16 {c}, {fb(s, ksl, nt)}, {fa(s, ksl, mt)}, {c}"
 
 
-def dma(op, i):
+def dma(op, i, pol=""):
     if op == "a":
-        return f"buffer_load_dwordx4 %[voa], s[72:75], s{80 + i} offen lds"
-    return f"buffer_load_dwordx4 %[vob], s[76:79], s{88 + i} offen lds"
+        return f"buffer_load_dwordx4 %[voa], s[72:75], s{80 + i} offen{pol} lds"
+    return f"buffer_load_dwordx4 %[vob], s[76:79], s{88 + i} offen{pol} lds"
 
 
-def body(b, var=""):
+def policy(var):
+    return " nt" if "n" in var else (" sc1" if "c" in var else (" sc0 sc1" if "C" in var else ""))
+
+
+# A schedule = the MFMA slots (0..63; an instruction is placed AFTER that MFMA) of the k-tile's other work.
+SCHED = {
+    # round-6 first version (kept for the A/B record)
+    "s0": dict(b1=0, bar1=12, dma_b=14, a1=14, bar2=29, dma_a=31, wait=43, s0=44, s0_per=1, final_lgkm=0),
+    # every wait at least 8 MFMAs behind the last instruction it waits for; the S0 reads of k 16..31 may stay out across the loop end
+    # (the next iteration's first wait, lgkmcnt(0) in front of barrier 1, precedes their first use at MFMA 16)
+    "s1": dict(b1=0, bar1=15, dma_b=17, a1=16, bar2=31, dma_a=33, wait=46, s0=47, s0_per=1, final_lgkm=8),
+    # the landing wait as late as the S0 reads allow (two reads per gap)
+    "s2": dict(b1=0, bar1=15, dma_b=17, a1=16, bar2=31, dma_a=33, wait=53, s0=54, s0_per=2, final_lgkm=8),
+    # the 16 LDS-DMA instructions spread over the iteration (one per four / three MFMAs) instead of two bursts of one per two
+    "s3": dict(b1=0, bar1=14, dma_b=16, a1=16, bar2=31, dma_a=34, dma_step=4, wait=47, s0=48, s0_per=1, final_lgkm=8),
+    "s4": dict(b1=0, bar1=14, dma_b=16, a1=16, bar2=31, dma_a=33, dma_step=3, wait=47, s0=48, s0_per=1, final_lgkm=8),
+}
+PRODUCT_SCHED = "s3"
+
+
+def body(b, sched, var=""):
     """one k-tile, buffer parity b. Returns the instruction list. `var`: ablation letters for the DIAGNOSTIC variants (timing only, wrong results):
-    D = no in-loop LDS-DMA, B = no barriers, R = no fragment reads, W = no counted waits"""
+    D = no in-loop LDS-DMA, B = no barriers, R = no fragment reads, W = no waits, V = no landing (vmcnt) wait, L = every DMA re-reads the same 8 rows"""
+    sc = SCHED[sched]
     fill = {m: [] for m in range(64)}          # instructions placed AFTER MFMA m
     n_dma = 0
+    loc = "L" in var
     # ---- S1 reads of B (tile t), then barrier 1
     order_b1 = [(1, ksl, nt) for ksl in range(2) for nt in range(4)]
     for j, (s, ksl, nt) in enumerate(order_b1):
-        fill[j].append(rd_b(s, ksl, nt, b))
+        fill[sc["b1"] + j].append(rd_b(s, ksl, nt, b))
     # scalar bookkeeping of the iteration: k step of this iteration's DMA (k-tile t + 2, clamped to the last one)
-    fill[8] += ["s_cmp_gt_i32 s98, 0", "s_cselect_b32 s97, 128, 0"]
-    fill[9] += ["s_sub_i32 s98, s98, 1"]
-    fill[12] += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
-    fill[13] += ["s_add_u32 s76, s76, s97", "s_addc_u32 s77, s77, 0", f"s_add_u32 m0, %[dma], {B_REGION + b * A_BUF}"]
-    # ---- DMA of B(t + 2) into buffer b, one per two MFMAs, M0 advanced in the gap between
-    for i in range(8):
-        m = 14 + 2 * i
-        fill[m].append(dma("b", i)); n_dma += 1
-        if i < 7:
-            fill[m + 1].append(f"s_add_u32 m0, m0, {PIECE}")
+    fill[8] += ["s_sub_i32 s99, s99, 1", "s_cmp_eq_u32 s99, 0", "s_cselect_b32 s97, s71, 128"]
+    fill[9] += ["s_cmp_gt_i32 s98, 0", "s_cselect_b32 s97, 0, 0" if loc else "s_cselect_b32 s97, s97, 0"]
+    fill[10] += ["s_sub_i32 s98, s98, 1", "s_ashr_i32 s70, s97, 31"]
+    fill[sc["bar1"]] += ["s_waitcnt lgkmcnt(0)", "s_barrier", "s_add_u32 s76, s76, s97", "s_addc_u32 s77, s77, s70"]
+    # ---- DMA of B(t + 2) / A(t + 2) into buffer b: instruction i in slot start + step * i, its M0 (absolute) set one gap earlier
     # ---- S1 reads of A (tile t), then barrier 2
     order_a1 = [(1, ksl, mt) for ksl in range(2) for mt in range(4)]
     for j, (s, ksl, mt) in enumerate(order_a1):
-        fill[14 + j].append(rd_a(s, ksl, mt, b))
-    fill[27] += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
-    fill[29] += ["s_add_u32 s72, s72, s97", "s_addc_u32 s73, s73, 0", f"s_add_u32 m0, %[dma], {b * A_BUF}"]
-    # ---- DMA of A(t + 2)
-    wait_at = 43
-    for i in range(8):
-        m = 30 + 2 * i
-        fill[m].append(dma("a", i))
+        fill[sc["a1"] + j].append(rd_a(s, ksl, mt, b))
+    assert sc["a1"] + 7 < sc["bar2"] and sc["bar1"] < sc["dma_b"] - 1 and sc["bar2"] < sc["dma_a"] - 1
+    fill[sc["bar2"]] += ["s_waitcnt lgkmcnt(0)", "s_barrier", "s_add_u32 s72, s72, s97", "s_addc_u32 s73, s73, s70"]
+    wait_at = sc["wait"]
+    step = sc.get("dma_step", 2)
+    slots = sorted([(sc["dma_b"] + step * i, "b", i) for i in range(8)] + [(sc["dma_a"] + step * i, "a", i) for i in range(8)])
+    assert len({m for m, _, _ in slots}) == 16 and slots[-1][0] <= 63, slots
+    for m, op, i in slots:
+        base = (B_REGION if op == "b" else 0) + b * A_BUF + i * PIECE
+        fill[m - 1].append(f"s_add_u32 m0, %[dma], {base}")
+        fill[m].insert(0, dma(op, 0 if loc else i, policy(var)))          # (ahead of a later DMA's M0 update that shares the gap)
         if m < wait_at:
             n_dma += 1
-        if i < 7:
-            fill[m + 1].append(f"s_add_u32 m0, m0, {PIECE}")
     # ---- tile t + 1 has landed: everything older than this iteration's loads issued so far
     fill[wait_at] = [f"s_waitcnt vmcnt({n_dma})", "s_barrier"] + fill[wait_at]
     # ---- S0 reads of tile t + 1 from buffer b ^ 1, in the order the next iteration consumes them
@@ -102,8 +120,9 @@ def body(b, var=""):
         order0 += [("a", 0, ksl, mt) for mt in range(4)]
         order0 += [("b", 0, ksl, nt) for nt in range(1, 4)]
     for j, (op, s, ksl, x) in enumerate(order0):
-        fill[wait_at + 1 + j].append(rd_a(s, ksl, x, b ^ 1) if op == "a" else rd_b(s, ksl, x, b ^ 1))
-    assert wait_at + 1 + len(order0) - 1 <= 59
+        m = sc["s0"] + j // sc["s0_per"]
+        assert wait_at < m <= 63 and m >= 32      # (S0 registers are free once MFMA 31 has issued)
+        fill[m].append(rd_a(s, ksl, x, b ^ 1) if op == "a" else rd_b(s, ksl, x, b ^ 1))
     out = []
     for m in range(64):
         out.append(mfma(m))
@@ -116,7 +135,10 @@ def body(b, var=""):
                 continue
             if "W" in var and ins.startswith("s_waitcnt"):
                 continue
+            if "V" in var and ins.startswith("s_waitcnt vmcnt"):
+                continue
             out.append(ins)
+    out.append(f"s_waitcnt lgkmcnt({sc['final_lgkm']})")
     return out
 
 
@@ -130,7 +152,11 @@ def prologue():
         o += [f"v_xor_b32 v{KSB + ks}, {2 * ks}, %[xa]", f"v_xor_b32 v{KSB + 4 + ks}, {2 * ks}, %[xb]"]
     for ks in range(4):
         o += [f"v_lshl_add_u32 v{KSB + ks}, v{KSB + ks}, 4, %[rba]", f"v_lshl_add_u32 v{KSB + 4 + ks}, v{KSB + 4 + ks}, 4, %[rbb]"]
-    o += ["s_mov_b32 s96, %[nkt]", "s_sub_i32 s98, %[nkt], 2", "s_nop 4"]
+    # k position of the LDS-DMA stream: k-tile (j + rot) mod nkt for the j-th tile staged (per-XCD rotation; rot = 0: plain order).
+    # s98 = advances left, s99 = advances until the wrap back to k-tile 0, s71 = the wrap's byte step -(nkt - 1) * 128
+    o += ["s_mov_b32 s96, %[nkt]", "s_sub_i32 s98, %[nkt], 2", "s_sub_i32 s99, %[nkt], %[rot]",
+          "s_sub_i32 s71, 1, %[nkt]", "s_lshl_b32 s71, s71, 7",
+          "s_lshl_b32 s97, %[rot], 7", "s_add_u32 s72, s72, s97", "s_addc_u32 s73, s73, 0", "s_add_u32 s76, s76, s97", "s_addc_u32 s77, s77, 0", "s_nop 4"]
 
     def tile(buf):
         t = [f"s_add_u32 m0, %[dma], {buf * A_BUF}", "s_nop 0"]
@@ -146,8 +172,9 @@ def prologue():
         return t
     o += tile(0)
     # k-tile 1 (clamped to the last k-tile when the tile has only one)
-    o += ["s_cmp_gt_i32 %[nkt], 1", "s_cselect_b32 s97, 128, 0",
-          "s_add_u32 s72, s72, s97", "s_addc_u32 s73, s73, 0", "s_add_u32 s76, s76, s97", "s_addc_u32 s77, s77, 0"]
+    o += ["s_sub_i32 s99, s99, 1", "s_cmp_eq_u32 s99, 0", "s_cselect_b32 s97, s71, 128",
+          "s_cmp_gt_i32 %[nkt], 1", "s_cselect_b32 s97, s97, 0", "s_ashr_i32 s70, s97, 31",
+          "s_add_u32 s72, s72, s97", "s_addc_u32 s73, s73, s70", "s_add_u32 s76, s76, s97", "s_addc_u32 s77, s77, s70"]
     o += tile(1)
     o += ["s_waitcnt vmcnt(16)", "s_barrier"]
     for ksl in range(2):
@@ -157,20 +184,21 @@ def prologue():
     return o
 
 
-def program(var=""):
+def program(sched=PRODUCT_SCHED, var=""):
     lines = prologue()
     lines.append("L_w4_top_%=:")
-    lines += body(0, var)
-    lines += ["s_waitcnt lgkmcnt(0)", "s_sub_u32 s96, s96, 1", "s_cmp_eq_u32 s96, 0", "s_cbranch_scc1 L_w4_end_%="]
-    lines += body(1, var)
-    lines += ["s_waitcnt lgkmcnt(0)", "s_sub_u32 s96, s96, 1", "s_cmp_lg_u32 s96, 0", "s_cbranch_scc1 L_w4_top_%="]
+    lines += body(0, sched, var)
+    lines += ["s_sub_u32 s96, s96, 1", "s_cmp_eq_u32 s96, 0", "s_cbranch_scc1 L_w4_end_%="]
+    lines += body(1, sched, var)
+    lines += ["s_sub_u32 s96, s96, 1", "s_cmp_lg_u32 s96, 0", "s_cbranch_scc1 L_w4_top_%="]
     lines.append("L_w4_end_%=:")
     # the stray loads of the last two iterations land before the LDS is reused; MFMA results settle before the compiler reads them
-    lines += ["s_waitcnt vmcnt(0)", "s_nop 15", "s_nop 15"]
+    lines += ["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_nop 15", "s_nop 15"]
     return lines
 
 
-VARIANTS = ["D", "B", "R", "DB", "DBRW"]      # MTL_W4_LOOP_ASM_V1 .. (diagnostic builds, -DMTL_DIAG_W4VAR)
+# MTL_W4_LOOP_ASM_V1 .. (diagnostic builds, -DMTL_DIAG_W4VAR): (schedule, ablation letters)
+VARIANTS = [("s1", ""), ("s3", "n"), ("s3", "c"), ("s3", "C"), ("s3", "V")]
 
 
 def emit(f, name, lines):
@@ -187,10 +215,11 @@ def main():
         f.write(f"// {sum(1 for l in lines if l.startswith('v_mfma'))} MFMAs, {len(lines)} instructions.\n")
         emit(f, "MTL_W4_LOOP_ASM", lines)
         f.write("#ifdef MTL_DIAG_W4VAR      // ablations for timing (WRONG results): what the in-loop DMA / barriers / reads / waits cost\n")
-        for i, v in enumerate(VARIANTS):
-            emit(f, f"MTL_W4_LOOP_ASM_V{i + 1}", program(v))
+        for i, (sc, v) in enumerate(VARIANTS):
+            f.write(f"// V{i + 1}: schedule {sc}, ablation '{v}'\n")
+            emit(f, f"MTL_W4_LOOP_ASM_V{i + 1}", program(sc, v))
         f.write("#endif\n")
-        clob = [f'"v{r}"' for r in range(FRAG0, KSB + 8)] + [f'"s{r}"' for r in range(72, 99)]
+        clob = [f'"v{r}"' for r in range(FRAG0, KSB + 8)] + [f'"s{r}"' for r in range(70, 100)]
         f.write("#define MTL_W4_LOOP_CLOBBERS " + ", ".join(clob) + ', "scc", "memory"\n')
     print("wrote", OUT, len(lines), "instructions")
 

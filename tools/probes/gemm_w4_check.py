@@ -37,7 +37,7 @@ if what in ("check", "all"):
         orr = run(A, B, True, out_dtype=torch.float32, bias=bias, epilogue=N.EPI_RESID, aux_in=res)
         o8r = run(A, B, False, out_dtype=torch.float32, bias=bias, epilogue=N.EPI_RESID, aux_in=res)
         er = rel(orr, o8r)
-        ok = e < 2e-5 and eb < 3e-3 and er < 1e-5
+        ok = e < 2e-5 and eb < 3e-3 and er < 1e-4
         bad += not ok
         print(f"[{M}x{Nn}x{K}] f32 store vs fp32 math {e:.2e} | bf16+bias {eb:.2e} | resid vs 8-wave kernel {er:.2e}  {'ok' if ok else 'FAIL'}", flush=True)
     # row-mapped A (the pruned backward's operand), SwiGLU / dSwiGLU epilogues against the 8-wave kernel

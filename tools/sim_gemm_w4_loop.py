@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Scalar-side simulator of the generated k-loop of gemm_nt_w4_kernel (med-ts-llm_amd/csrc/mtl_gemm_w4_loop.inc): runs the asm text's SALU
+instructions, branches and M0 updates for one wave and records, in program order, every LDS-DMA (which operand, which row piece, which k-tile,
+which LDS address), every fragment read (operand, k-step, buffer) and every barrier / wait. `check()` then asserts the protocol the kernel relies on:
+  * every k-tile of the tile is staged exactly once per operand piece, k-tile j of the stream into buffer j & 1, at the piece's LDS address;
+  * iteration t reads buffer t & 1, after a landing wait + barrier that covers tile t's loads; a buffer region is re-staged only after the barrier
+    that follows the last read of it; the counted vmcnt / lgkmcnt waits leave exactly the intended instructions outstanding;
+  * the physical k order is the per-XCD rotation (j + rot) mod nkt.
+Used by tests/test_w4_loop_sim.py (CPU) — the asm is otherwise only exercised on the GPU box."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INC = os.path.join(ROOT, "med-ts-llm_amd", "csrc", "mtl_gemm_w4_loop.inc")
+
+
+def load(name="MTL_W4_LOOP_ASM", path=INC):
+    text = open(path).read()
+    m = re.search(r"#define " + name + r" \\\n(.*?)\n    \"\"\n", text, re.S)
+    assert m, name
+    return [re.match(r'\s*"(.*?)\\n\\t" \\', l).group(1) for l in m.group(1).splitlines()]
+
+
+M32 = 0xFFFFFFFF
+
+
+def run(lines, nkt, rot=0, dma_base=0x400, max_steps=2_000_000):
+    """returns the event list. Operand values: %[pa] = 0x1000_0000_0000, %[pb] = 0x2000_0000_0000 (so that base - start = k byte offset)."""
+    PA, PB = 0x100000000000, 0x200000000000
+    s = {}                     # SGPRs (+ 'm0', 'scc')
+    sym = {"%[nkt]": nkt, "%[rot]": rot, "%[dma]": dma_base}
+    labels = {l[:-1]: i for i, l in enumerate(lines) if l.endswith(":")}
+    ev = []
+
+    def val(tok):
+        tok = tok.strip()
+        if tok in sym:
+            return sym[tok] & M32
+        if tok == "m0":
+            return s["m0"]
+        if re.fullmatch(r"s\d+", tok):
+            return s[tok]
+        return int(tok, 0) & M32
+
+    pc, steps = 0, 0
+    while pc < len(lines):
+        steps += 1
+        assert steps < max_steps, "runaway loop"
+        ins = lines[pc]
+        pc += 1
+        if ins.endswith(":"):
+            continue
+        op, _, rest = ins.partition(" ")
+        a = [x.strip() for x in rest.split(",")] if rest else []
+        if op == "s_mov_b32":
+            s[a[0]] = val(a[1])
+        elif op == "s_mov_b64":
+            lo = int(re.match(r"s\[(\d+):", a[0]).group(1))
+            v = {"%[pa]": PA, "%[pb]": PB}[a[1]]
+            s[f"s{lo}"], s[f"s{lo + 1}"] = v & M32, v >> 32
+        elif op in ("s_add_u32", "s_sub_u32", "s_sub_i32", "s_add_i32"):
+            x, y = val(a[1]), val(a[2])
+            r = x + y if op.startswith("s_add") else x - y
+            if op.endswith("u32"):
+                s["scc"] = int(r > M32 or r < 0)
+            s[a[0]] = r & M32
+        elif op == "s_addc_u32":
+            r = val(a[1]) + val(a[2]) + s["scc"]
+            s["scc"] = int(r > M32)
+            s[a[0]] = r & M32
+        elif op == "s_lshl_b32":
+            s[a[0]] = (val(a[1]) << val(a[2])) & M32
+        elif op == "s_ashr_i32":
+            x = val(a[1])
+            x = x - (1 << 32) if x >> 31 else x
+            s[a[0]] = (x >> val(a[2])) & M32
+        elif op in ("s_cmp_eq_u32", "s_cmp_lg_u32", "s_cmp_gt_i32"):
+            x, y = val(a[0]), val(a[1])
+            if op == "s_cmp_gt_i32":
+                x, y = (x - (1 << 32) if x >> 31 else x), (y - (1 << 32) if y >> 31 else y)
+                s["scc"] = int(x > y)
+            else:
+                s["scc"] = int((x == y) == (op == "s_cmp_eq_u32"))
+        elif op == "s_cselect_b32":
+            s[a[0]] = val(a[1]) if s["scc"] else val(a[2])
+        elif op in ("s_cbranch_scc1", "s_cbranch_scc0"):
+            if s["scc"] == (op == "s_cbranch_scc1"):
+                pc = labels[a[0]]
+        elif op == "buffer_load_dwordx4":
+            which = "a" if a[0] == "%[voa]" else "b"
+            lo = 72 if which == "a" else 76
+            base = s[f"s{lo}"] | (s[f"s{lo + 1}"] << 32)
+            off = base - (PA if which == "a" else PB)
+            piece = int(re.match(r"s(\d+)", a[2].split()[0]).group(1)) - (80 if which == "a" else 88)
+            assert off % 128 == 0 and 0 <= off // 128 < nkt, (which, off, nkt)
+            ev.append(("dma", which, piece, off // 128, s["m0"] - dma_base))
+        elif op == "ds_read_b128":
+            reg = int(re.match(r"v\[(\d+):", a[0]).group(1))
+            addr_reg = int(re.match(r"v(\d+)", a[1].split()[0]).group(1))
+            offset = int(re.search(r"offset:(\d+)", ins).group(1))
+            which = "a" if addr_reg < 244 else "b"
+            ev.append(("read", which, (addr_reg - 240) % 4, offset // 0x8000, (offset % 0x8000) // 4096, reg))
+        elif op == "s_waitcnt":
+            m = re.search(r"vmcnt\((\d+)\)", ins)
+            if m:
+                ev.append(("vmcnt", int(m.group(1))))
+            m = re.search(r"lgkmcnt\((\d+)\)", ins)
+            if m:
+                ev.append(("lgkmcnt", int(m.group(1))))
+        elif op == "s_barrier":
+            ev.append(("barrier",))
+        elif op == "v_mfma_f32_32x32x16_bf16":
+            srcs = [int(re.match(r"v\[(\d+):", x).group(1)) for x in a[1:3]]
+            ev.append(("mfma", a[0], srcs[0], srcs[1]))
+        elif op in ("s_nop", "v_readlane_b32", "v_xor_b32", "v_lshl_add_u32"):
+            pass
+        else:
+            raise AssertionError(f"unknown instruction: {ins}")
+    return ev
+
+
+def check(ev, nkt, rot=0):
+    """assert the staging / reading protocol (see the module docstring)"""
+    FA0, FB0 = 112, 176
+    landed = {}                 # (operand, buffer, piece) -> k-tile whose data is visible to every wave (after vmcnt + barrier)
+    pending = []                # DMAs issued and not yet known complete: (operand, buffer, piece, ktile)
+    waited = []                 # DMAs complete for this wave, not yet behind a barrier
+    reads_out = []              # fragment reads issued, not yet known complete: (operand, buffer, reg)
+    frag = {}                   # fragment register -> (operand, k-tile, k-step) once its read has been waited for
+    last_read_unbarriered = set()   # (operand, buffer) regions read since the last (lgkmcnt(0), barrier) pair
+    reads_done_since_barrier = set()
+    staged = {}                 # (operand, piece) -> list of k-tiles in stream order
+    mf = 0
+    cur = {}                    # buffer -> k-tile currently landed in it, per operand
+    for e in ev:
+        if e[0] == "dma":
+            _, which, piece, kt, m0 = e
+            region = 0 if which == "a" else 0x10000
+            rel = m0 - region
+            buf, idx = rel // 0x8000, (rel % 0x8000) // 0x1000
+            assert 0 <= rel < 0x10000 and rel % 0x1000 == 0 and idx == piece, e
+            j = len(staged.setdefault((which, piece), []))
+            assert kt == (j + rot) % nkt if j < nkt else True, (e, j)
+            assert buf == j & 1, ("stream tile j must land in buffer j & 1", e, j)
+            staged[(which, piece)].append(kt)
+            assert (which, buf) not in last_read_unbarriered, ("re-staging a region with reads not yet behind a barrier", e)
+            pending.append((which, buf, piece, j))
+        elif e[0] == "vmcnt":
+            n = e[1]
+            done, pending = pending[:max(0, len(pending) - n)], pending[max(0, len(pending) - n):]
+            waited += done
+        elif e[0] == "barrier":
+            for (which, buf, piece, j) in waited:
+                landed[(which, buf, piece)] = j
+            waited = []
+            # reads that were complete (lgkmcnt(0)) before this barrier no longer pin their regions
+            last_read_unbarriered -= reads_done_since_barrier
+            reads_done_since_barrier = set()
+        elif e[0] == "read":
+            _, which, ks, buf, tile, reg = e
+            js = {landed.get((which, buf, p)) for p in range(8)}
+            assert len(js) == 1 and None not in js, ("reading a buffer whose pieces have not all landed behind a barrier", e, js)
+            reads_out.append((which, buf, reg, js.pop(), ks))
+            last_read_unbarriered.add((which, buf))
+        elif e[0] == "lgkmcnt":
+            n = e[1]
+            done, reads_out = reads_out[:max(0, len(reads_out) - n)], reads_out[max(0, len(reads_out) - n):]
+            for (which, buf, reg, j, ks) in done:
+                frag[reg] = (which, j, ks)
+            if n == 0:
+                reads_done_since_barrier |= set(last_read_unbarriered)
+        elif e[0] == "mfma":
+            _, acc, rb, ra = e
+            t = mf // 64                        # iteration = stream tile
+            if t < nkt:
+                m = mf % 64
+                ks = (m // 32) * 2 + (m % 32) // 16
+                for reg, which in ((rb, "b"), (ra, "a")):
+                    assert reg not in {r for (_, _, r, _, _) in reads_out}, ("MFMA reads a fragment whose ds_read may still be in flight", mf, reg)
+                    assert frag.get(reg) == (which, t, ks), ("MFMA operand is not (operand, tile, k-step)", mf, reg, frag.get(reg), (which, t, ks))
+            mf += 1
+    assert mf == 64 * nkt, (mf, nkt)
+    for (which, piece), lst in staged.items():
+        assert lst[:nkt] == [(j + rot) % nkt for j in range(nkt)], (which, piece, lst[:nkt + 2])
+    assert len(staged) == 16
+    return True
+
+
+if __name__ == "__main__":
+    lines = load()
+    for nkt in (1, 2, 3, 4, 5, 8, 64):
+        for rot in sorted({0, 1, (3 * nkt) // 8, nkt - 1} & set(range(nkt))):
+            check(run(lines, nkt, rot), nkt, rot)
+    print("w4 k-loop protocol ok")
