@@ -695,6 +695,10 @@ def _check_line(line):
     return bool(line["step_mfma_frac"] <= best / MFMA_BF16_PEAK_TFLOPS + 1e-9)
 
 
+def _short_kernel(k):
+    return k.replace("gemm_nt_persist_kernel", "gemm_nt_persist").replace("_kernel", "").replace(", ", ",") if k else k
+
+
 def compact_line(out):
     """the ONE stdout line (< 4 KB): the contract's fields, the three roofline objects as numbers, the CPU baseline, and one short summary per
     extra config. Everything else (kernel instances, prose, trainer-loop / predict legs) goes to the detail file."""
@@ -707,6 +711,10 @@ def compact_line(out):
     c["roofline"] = _roof_compact(out.get("roofline"))
     c["roofline_hbm"] = _roof_compact(out.get("roofline_hbm"))
     c["roofline_attention"] = _roof_compact(out.get("roofline_attention"))
+    for k in ("roofline_hbm", "roofline_attention"):          # (the read / write split and the launch count of these two: detail file)
+        if c[k]:
+            for d in ("traffic_read", "traffic_write", "launches"):
+                c[k].pop(d, None)
     # every HBM-bound kernel family beside the dominant one (roofline_hbm picks the norm kernel with the largest total time; the other direction and Adam here)
     c["hbm_kernels"] = [{"kernel": r["kernel"], "us": r["avg_us"], "frac": round(r["gbs"] / HBM_PEAK_GBS, 3)}
                         for r in (out.get("kernel_instances") or []) if "gbs" in r and r["kernel"].startswith(("norm", "adam"))][:3]
@@ -715,7 +723,7 @@ def compact_line(out):
     cb = out.get("cpu_baseline")
     if cb:
         c["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "host_cores": cb.get("host_cores"), "kind": cb["kind"],
-                             "sample": cb["sample"][:110]}
+                             "sample": cb["sample"][:72]}
         if cb.get("configs"):
             c["cpu_baseline"]["configs0_etth1_value"] = cb["configs"][0]["value"]
     else:
@@ -730,20 +738,42 @@ def compact_line(out):
         r = e.get("roofline") or {}
         ra = e.get("roofline_attention") or {}
         cb = e.get("cpu_baseline")
-        c["configs"].append({
-            "workload": _short_workload(e), "value": e["value"], "unit": e["unit"], "steps": e["steps"], "warmup": e["warmup"], "ms_per_step": e["ms_per_step"],
-            "forward": "prompt-row cache" if str(e.get("forward", "")).startswith("prompt-row cache") else "full sequence",
-            "tflop_per_step": {"algorithmic": e["algorithmic_tflop_per_step_per_gpu"], "executed": e["executed_tflop_per_step_per_gpu"]},
+        wl = _short_workload(e)
+        entry = {
+            "workload": wl.split(":")[0] + (" " + wl.split("] ", 1)[1].split(" ")[0] if "] " in wl else ""),       # 'name T=..' (the name carries backbone, B, L, C)
+            "value": e["value"], "steps": e["steps"], "warmup": e["warmup"], "ms_per_step": e["ms_per_step"],
+            "prompt_row_cache": str(e.get("forward", "")).startswith("prompt-row cache"),
             # (executed FLOPs only: with the prompt-row cache the algorithmic count is twice the executed one and is not a utilisation; the detail file keeps it)
             "step_mfma_frac": e["step_mfma_frac"],
-            "roofline": {"kernel": r.get("kernel"), "achieved": r.get("achieved"), "frac": r.get("frac"), "avg_launch_us": r.get("avg_launch_us"),
-                         "traffic": (round(r["traffic"]["hbm_bytes"]) if isinstance(r.get("traffic"), dict) else None)},
-            "roofline_attention": {"kernel": ra.get("kernel"), "achieved": ra.get("achieved"), "frac": ra.get("frac"),
-                                   "executed_achieved": ra.get("executed_achieved"), "executed_frac": ra.get("executed_frac")},
-            "cpu_baseline": ({"value": cb["value"], "cores": cb["cores"], "kind": cb["kind"], "extrapolated": cb.get("extrapolated", False)} if cb else None),
-            "checks": {"step_frac_le_best_kernel_frac": _check_line(e)}})
+            "roofline": {"kernel": _short_kernel(r.get("kernel")), "achieved": r.get("achieved"), "frac": r.get("frac"), "avg_launch_us": r.get("avg_launch_us")},
+            "cpu_baseline": ({"value": cb["value"], "cores": cb["cores"], "extrapolated": cb.get("extrapolated", False)} if cb else None)}
+        if not _check_line(e):                     # (self-check: a whole-step MFMA fraction above the fastest GEMM's would be a wrong FLOP count)
+            entry["checks"] = {"step_frac_le_best_kernel_frac": False}
+        if "interleave" in entry["workload"]:      # the one config whose step is attention-heavy
+            entry["roofline_attention"] = {"kernel": _short_kernel(ra.get("kernel")), "frac": ra.get("frac"), "executed_frac": ra.get("executed_frac")}
+        c["configs"].append(entry)
     c["detail"] = out.get("detail_file")
     return c
+
+
+def fit_line(out, limit=4000):
+    """the compact line as a string, never longer than `limit`: what does not fit is shed in a fixed order (it all stays in the detail file) —
+    per-config extras first, then the secondary HBM kernel list, the CPU sample text, the read / write traffic split"""
+    c = compact_line(out)
+    sheds = [lambda: [e.pop("roofline_attention", None) for e in c["configs"]],
+             lambda: [e.pop("prompt_row_cache", None) for e in c["configs"]],
+             lambda: c.get("cpu_baseline") and c["cpu_baseline"].pop("sample", None),
+             lambda: c.pop("hbm_kernels", None),
+             lambda: [o.pop(k, None) for o in (c.get("roofline"), c.get("roofline_hbm"), c.get("roofline_attention")) if o for k in ("traffic_read", "traffic_write", "traffic_src", "launches")],
+             lambda: [e.pop(k, None) for e in c["configs"] for k in ("steps", "warmup")],
+             lambda: [e["roofline"].pop("kernel", None) for e in c["configs"]]]
+    line = json.dumps(c, separators=(",", ":"))
+    for shed in sheds:
+        if len(line) < limit:
+            break
+        shed()
+        line = json.dumps(c, separators=(",", ":"))
+    return line
 
 
 def main():
@@ -863,9 +893,14 @@ def main():
     # fenced: a failure there is reported in the line's place, never instead of the headline.
     if args.workload == "gpt2s_B32_L1024_C12" and not args.no_extra_configs and (world == 1 or args.extra_configs_dp):
         extras = [
+            # BASELINE.json configs[1] (ETTh1-shaped forecasting on GPT-2-small; configs[0] is the same case on the CPU: cpu_baseline.configs0_etth1_value)
+            ("gpt2s_etth1_B32_L512_C7", 5, 2, "samples/sec ([B, 512, 7] ETTh1-shaped windows, GPT-2-small) through MedTsLLM fwd+bwd"),
             # BASELINE.json configs[2] (LUDB-shaped semantic segmentation on a frozen Llama-2-7B): the configuration where the backbone GEMMs are
             # large enough for the >= 40 % MFMA target
-            ("llama2_7b_semseg_B32_L1024_C12", 5, 2, "samples/sec ([B, 1024, 12] windows, Llama-2-7B frozen backbone) through MedTsLLM fwd+bwd"),
+            ("llama2_7b_semseg_B32_L1024_C12", 3, 2, "samples/sec ([B, 1024, 12] windows, Llama-2-7B frozen backbone) through MedTsLLM fwd+bwd"),
+            # BASELINE.json configs[3] (PSM anomaly detection: 25 channels, L = 2048, Llama-2-7B) and configs[4] (Llama-3-8B, reconstruction), 1 GPU each
+            ("llama2_7b_psm_B32_L2048_C25", 3, 2, "samples/sec ([B, 2048, 25] PSM-shaped windows, Llama-2-7B frozen backbone) through MedTsLLM fwd+bwd"),
+            ("llama3_8b_recon_B32_L1024_C12", 3, 2, "samples/sec ([B, 1024, 12] windows, Llama-3-8B frozen backbone, 100 000 trainable vocabulary rows) through MedTsLLM fwd+bwd"),
             # the same backbone with interleave covariates -> T = 1664 per sample (flash attention regime)
             ("llama2_7b_semseg_interleave_B16_L1024_C12", 3, 2,
              "samples/sec ([B, 1024, 12] windows, interleave covariates: T = 1664, Llama-2-7B frozen backbone) through MedTsLLM fwd+bwd"),
@@ -884,6 +919,16 @@ def main():
             if rank == 0:
                 extra["metric"] = metric
                 out.setdefault("configs", []).append(extra)
+    if rank == 0 and out and out.get("cpu_baseline"):
+        # extra configs without a measured CPU leg (--full-detail measures them): the headline's MEASURED CPU figure scaled by algorithmic FLOPs per
+        # sample — flagged extrapolated; a ratio for orientation, never a target (a large GPU/CPU ratio says nothing about kernel quality)
+        head = out["cpu_baseline"]
+        f_head = out["algorithmic_tflop_per_step_per_gpu"] / out["config"]["global_batch"] * out["n_gpus"]
+        for e in out.get("configs", []):
+            if not e.get("cpu_baseline"):
+                f_e = e["algorithmic_tflop_per_step_per_gpu"] / e["config"]["global_batch"] * e["n_gpus"]
+                e["cpu_baseline"] = {"value": round(head["value"] * f_head / f_e, 4), "unit": head["unit"], "cores": head["cores"], "kind": head["kind"],
+                                     "extrapolated": True, "sample": "not run: the headline workload's measured CPU samples/s x (its algorithmic FLOPs per sample / this config's)"}
     if rank == 0 and out:
         out["rccl_ranks"], out["dp_mode"] = rccl_ranks, dp_mode
         committed = f"committed table profiles/pmc_traffic_<workload>.json (separate rocprofv3 --pmc passes of the same kernel sources, csrc_sha16 {csrc_sha16()})"
@@ -925,14 +970,7 @@ def main():
         except OSError as e:
             out["detail_file"] = None
             print(f"[bench] detail file not written: {e}", file=sys.stderr)
-        line = json.dumps(compact_line(out), separators=(",", ":"))
-        if len(line) >= 4000:            # never lose the line to its own size: shed the per-config extras first
-            c = compact_line(out)
-            for e in c["configs"]:
-                e.pop("roofline_attention", None), e.pop("checks", None), e.pop("tflop_per_step", None)
-            if c.get("cpu_baseline"):
-                c["cpu_baseline"].pop("sample", None)
-            line = json.dumps(c, separators=(",", ":"))
+        line = fit_line(out)
         stage(f"done; line = {len(line)} bytes")
         print(line, flush=True)
 

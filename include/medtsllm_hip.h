@@ -365,6 +365,9 @@ typedef struct {
 typedef struct { float attn_p, resid_p; uint32_t seed; } mtl_backbone_dropout;   /* per-layer seeds are derived from `seed` */
 /* bytes of the `saved` buffer (activations kept for the backward) and of the scratch `work` buffer */
 size_t mtl_backbone_saved_bytes(const mtl_backbone_weights* w, int64_t B, int64_t T);
+/* byte offset inside `saved` of the fp32 residual stream [B*T, d] AFTER decoder layer `layer` (1 .. n_layers; the HF hidden_states[layer] before the final
+ * norm, R:models/medtsllm.py:350) — parity tests read intermediate depths there; (size_t)-1 on bad arguments. */
+size_t mtl_backbone_saved_hidden_offset(const mtl_backbone_weights* w, int64_t B, int64_t T, int layer);
 size_t mtl_backbone_work_bytes(const mtl_backbone_weights* w, int64_t B, int64_t T);
 /* h0 f32 [B, T, d] (input embeddings, wpe already added for GPT-2). out bf16 [B, n_last, d]: final norm applied
  * to the last n_last tokens of every sample (only those are consumed downstream, R:models/medtsllm.py:353). */

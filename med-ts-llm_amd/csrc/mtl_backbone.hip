@@ -129,6 +129,12 @@ extern "C" size_t mtl_backbone_saved_bytes(const mtl_backbone_weights* w, int64_
     return saved_layout(dims_of(w, B, T), T).total;
 }
 
+extern "C" size_t mtl_backbone_saved_hidden_offset(const mtl_backbone_weights* w, int64_t B, int64_t T, int layer) {
+    if (check_weights(w) != MTL_OK || B <= 0 || T <= 0 || layer < 1 || layer > w->n_layers) return (size_t)-1;
+    const SavedLayout S = saved_layout(dims_of(w, B, T), T);
+    return S.h + S.h_stride * (size_t)(2 * layer - 1);          // H[2 * layer] lives in slot 2 * layer - 1 (H[0] is the caller's h0)
+}
+
 extern "C" size_t mtl_backbone_work_bytes(const mtl_backbone_weights* w, int64_t B, int64_t T) {
     if (check_weights(w) != MTL_OK || B <= 0 || T <= 0) return 0;
     return work_layout(dims_of(w, B, T)).total;

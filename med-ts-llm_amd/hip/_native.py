@@ -132,6 +132,7 @@ SIGNATURES = {
     "mtl_input_stats_workspace_bytes": (C.c_size_t, [i64, i64, i64]),
     "mtl_input_stats": (i32, [vp, vp, vp, vp, C.c_size_t, i64, i64, i64, i64, i64, vp]),
     "mtl_backbone_saved_bytes": (C.c_size_t, [C.POINTER(BackboneWeights), i64, i64]),
+    "mtl_backbone_saved_hidden_offset": (C.c_size_t, [C.POINTER(BackboneWeights), i64, i64, i32]),
     "mtl_backbone_work_bytes": (C.c_size_t, [C.POINTER(BackboneWeights), i64, i64]),
     "mtl_backbone_fwd": (i32, [C.POINTER(BackboneWeights), vp, vp, vp, vp, i64, i64, i64, i64, C.POINTER(BackboneDropout), vp, i64, vp]),
     "mtl_backbone_prefix_bytes": (C.c_size_t, [C.POINTER(BackboneWeights), i64]),

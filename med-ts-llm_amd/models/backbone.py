@@ -237,6 +237,11 @@ class FrozenBackbone:
         n_save = min(n_save, T - n_prefix)
         saved._n_save = n_save
         self.last_n_prefix = n_prefix
+        tap = getattr(self, "tap_hidden", None)
+        if tap is not None:      # parity tests: the fp32 residual stream after the requested layers, rows of the last n_last tokens of every sample
+            for layer in list(tap):
+                off = lib.mtl_backbone_saved_hidden_offset(C.byref(w), B, T, int(layer))
+                tap[layer] = saved[off:off + B * T * d * 4].view(torch.float32).view(B, T, d)[:, T - n_last:, :].clone()
         return out, (saved if keep else None)
 
     def run_backward(self, h0, dout, saved, n_last, n_grad=None, drop=None):

@@ -559,6 +559,7 @@ class MedTsLLM(nn.Module):
                 and ids.shape[1] <= h0.shape[1] - self.n_patches):
             key = self._prompt_key(ids)
             prefix = bb.prefix_cache(h0[:1, :ids.shape[1]], key, h0.shape[1])
+        bb.tap_hidden = self.debug_tap.get("hidden_after") if self.debug_tap is not None else None      # {layer: None} -> filled by run_forward
         dec = self._tap("dec", BackboneFn.apply(h0, bb, self.n_patches, n_grad, drop, prefix))   # [B', n_patches, d_llm] (final norm on the consumed rows only)
         if self.optimizer_wait is not None:
             self.optimizer_wait()        # deferred updates of the tail's parameters (side stream) must have landed before the tail reads them

@@ -48,8 +48,10 @@ GEOMETRIES = {
     # BASELINE.json configs[2] / [4] at their FULL depth and batch (32 layers, B = 32: what bench.py times) — round 5
     "llama2_7b_32layers": (LLAMA2_7B, "semantic_segmentation", 1024, -1, 32, 1024, 12),
     "llama3_8b_32layers": (LLAMA3_8B, "reconstruction", 1024, -1, 32, 1024, 12),
+    # BASELINE.json configs[3] at its FULL depth and batch (PSM: C = 25, L = 2048, T = 384 with the prompt, the 1.68 G-parameter head) — round 6
+    "llama2_7b_psm_32layers": (LLAMA2_7B, "anomaly_detection", 2048, -1, 32, 2048, 25),
 }
-DEEP = {"llama2_7b_32layers", "llama3_8b_32layers"}
+DEEP = {"llama2_7b_32layers", "llama3_8b_32layers", "llama2_7b_psm_32layers"}
 
 
 @pytest.fixture(scope="module", params=list(GEOMETRIES))

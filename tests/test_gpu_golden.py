@@ -112,6 +112,9 @@ def check_hip_vs_golden(model, meta, data, bcfg, name, grad_bar=MIXED_FACTOR):
 
     model.train()
     tap = model.debug_tap = {}
+    depth_keys = sorted((int(k.split(".")[1]), k) for k in (data.files if hasattr(data, "files") else list(data.keys())) if k.startswith("llm_hidden_after."))
+    if depth_keys:
+        tap["hidden_after"] = {layer: None for layer, _ in depth_keys}
     pred = model(inputs)
     report, failures, ratios = {}, [], []
 
@@ -126,6 +129,13 @@ def check_hip_vs_golden(model, meta, data, bcfg, name, grad_bar=MIXED_FACTOR):
             ratios.append(max(e, 1e-30) / yard)
         if not e <= bar:
             failures.append((key, e / n, bar / n))
+        if ("mixed." + key) in data:
+            # fixtures of round 6 also hold the reference-MIXED run's values: the HIP path's distance to the arithmetic it implements. Two
+            # independent bf16 noises of the fp32 truth lie ~sqrt(2) x one noise apart; the bar is 2 x the reference's own mixed-vs-fp32 distance
+            e_m = _abs(got, data["mixed." + key])
+            report[key + " |to reference-mixed"] = (e_m / n, 2.0 * yard / n)
+            if not e_m <= 2.0 * yard:
+                failures.append((key + " |to reference-mixed", e_m / n, 2.0 * yard / n))
 
     # ---- stages (R:models/layers/RevIN.py, embed.py:186-197, medtsllm.py:281-282,349-350)
     d_patch = meta["d_model"]
@@ -151,6 +161,13 @@ def check_hip_vs_golden(model, meta, data, bcfg, name, grad_bar=MIXED_FACTOR):
         check("llm_last_hidden", tap["dec"].float(), data["llm_last_hidden"], max(self_rel, FWD_FLOOR))
     else:
         check("llm_last_hidden[consumed rows]", tap["dec"].float(), data["llm_last_hidden"][:, -n_last:, :], max(self_rel, FWD_FLOOR))
+    # intermediate depths of the stack (full-depth fixtures, round 6): the pre-norm residual stream after layers 1 / 8 / 16 / 24 on the consumed rows,
+    # each against the reference's own mixed-arithmetic deviation AT THAT DEPTH — a failure of the last hidden state localises
+    for layer, key in depth_keys:
+        got = tap["hidden_after"][layer]
+        assert got is not None and got.shape[1] == meta["n_patches"]
+        rel_self = float(data["selferr." + key]) / float(np.linalg.norm(data[key]))
+        check(key, got.float(), data[key], max(rel_self, FWD_FLOOR))
     assert "pred_train" in S or pred.shape == data["pred_train"].shape
     check("pred_train", pred, data["pred_train"])
 

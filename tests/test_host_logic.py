@@ -398,6 +398,13 @@ def test_bench_round5_fields_on_the_compact_line():
     assert c["dp_modes"]["plain_allreduce"] == 40000.0
     assert all(h["kernel"].startswith(("norm", "adam")) and 0 < h["frac"] < 1 for h in c["hbm_kernels"]) and len(c["hbm_kernels"]) >= 2
     assert all("step_mfma_frac_algorithmic" not in e for e in c["configs"])       # (with the prompt-row cache that figure is not a utilisation: detail file only)
+    # round 6: every BASELINE.json config rides on the default line (five extra entries): still one line under 4 KB, each entry with its
+    # value, ms per step, dominant GEMM and an (extrapolated-flagged) CPU figure
+    full["configs"] = [dict(full["configs"][i % 2], cpu_baseline={"value": 0.0123, "cores": 16, "kind": "port", "extrapolated": True}) for i in range(5)]
+    line = bench.fit_line(full)                    # (sheds per-config extras in a fixed order when the line would not fit)
+    assert len(line) < 4000, len(line)
+    c5 = json.loads(line)["configs"]
+    assert len(c5) == 5 and all(e["cpu_baseline"]["extrapolated"] and e["roofline"]["frac"] and e["ms_per_step"] for e in c5)
 
 
 def test_causal_fraction_of_the_rectangle():
