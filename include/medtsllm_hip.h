@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MTL_ABI_VERSION 14
+#define MTL_ABI_VERSION 15
 
 enum { MTL_OK = 0, MTL_ERR_ARG = -1, MTL_ERR_ALIGN = -2, MTL_ERR_UNSUPPORTED = -3, MTL_ERR_LAUNCH = -4,
        MTL_ERR_WORKSPACE = -5 };
@@ -290,6 +290,12 @@ int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream);
 int mtl_norm_fwd(const float* x, const float* gamma, const float* beta, void* y, int64_t ld_y, float* stats,
                  int64_t M, int64_t d, float eps, int rms, int64_t group_rows, int64_t group_stride,
                  int64_t row_offset, int stats_physical, void* stream);
+/* the same with the residual stream's dtype as an argument: x_dtype MTL_F32 (above) or MTL_BF16 — the reference's setup.dtype = "bf16"
+ * (R:tasks/base.py:261-262: the whole model in bf16, i.e. a bf16 residual stream through the HF stack). bf16 stream: statistics still fp32, and
+ * RMSNorm rounds the normalised row to bf16 before the weight multiplies it, as HF:models/llama/modeling_llama.py:64-69 does for bf16 inputs. */
+int mtl_norm_fwd_t(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int64_t ld_y, float* stats,
+                   int64_t M, int64_t d, float eps, int rms, int64_t group_rows, int64_t group_stride,
+                   int64_t row_offset, int stats_physical, void* stream);
 /* dX only (gamma/beta are frozen). dres_out[m] = (dres_in ? dres_in[m] : 0) + LN'(dy[m]); optionally also
  * a bf16 copy of dres_out (A operand of the next dX GEMM). dres_in may alias dres_out. dy rows are compact (logical);
  * x / dres rows are physical (gathered); stats rows are physical when stats_physical != 0 (statistics saved by a
@@ -298,6 +304,12 @@ int mtl_norm_bwd(const void* dy, int64_t ld_dy, const float* x, const float* gam
                  const float* dres_in, float* dres_out, void* dres_out_bf16, int64_t M, int64_t d, int rms,
                  int64_t group_rows, int64_t group_stride, int64_t row_offset, int stats_physical,
                  float bf16_drop_p, uint32_t bf16_drop_seed, void* stream);
+/* stream_dtype = dtype of x, dres_in and dres_out (MTL_F32: above; MTL_BF16: the bf16 residual stream, whose gradient stream is bf16 too —
+ * dres_out_bf16 may then be NULL when no dropout mask applies: dres_out itself is the next GEMM's operand) */
+int mtl_norm_bwd_t(const void* dy, int64_t ld_dy, const void* x, int stream_dtype, const float* gamma, const float* stats,
+                   const void* dres_in, void* dres_out, void* dres_out_bf16, int64_t M, int64_t d, int rms,
+                   int64_t group_rows, int64_t group_stride, int64_t row_offset, int stats_physical,
+                   float bf16_drop_p, uint32_t bf16_drop_seed, void* stream);
 /* (bf16_drop_p > 0: the bf16 copy is dropout'(dres_out) with the keep mask of (seed, physical row, column) — the gradient
  *  that flows into the residual branch whose forward output was dropped with that mask; dres_out itself stays unmasked.)
  * Plain dropout of an f32 [M, d] matrix with the same counter hash (GPT-2 embd_pdrop on inputs_embeds + wpe,
@@ -337,6 +349,12 @@ int mtl_assemble_llm_input(const int32_t* ids, int64_t ids_B, const float* embed
                            float* h0, int64_t B, int64_t n_tok, int64_t P, int64_t d, float drop_p, uint32_t drop_seed, void* stream);
 int mtl_assemble_bwd(const float* dh0, void* dx_tok, int64_t B, int64_t n_tok, int64_t P, int64_t d, float drop_p, uint32_t drop_seed,
                      void* stream);
+/* the same for a residual stream of dtype h0_dtype / dh0_dtype (MTL_F32: above; MTL_BF16: the reference's setup.dtype = "bf16", where the embedding
+ * tables, their sum and the dropped result are bf16 tensors: each is rounded) */
+int mtl_assemble_llm_input_t(const int32_t* ids, int64_t ids_B, const float* embed, const void* x_tok, const float* wpe,
+                             void* h0, int h0_dtype, int64_t B, int64_t n_tok, int64_t P, int64_t d, float drop_p, uint32_t drop_seed, void* stream);
+int mtl_assemble_bwd_t(const void* dh0, int dh0_dtype, void* dx_tok, int64_t B, int64_t n_tok, int64_t P, int64_t d, float drop_p,
+                       uint32_t drop_seed, void* stream);
 
 /* ------------------------------------------------------------------ frozen backbone stack (a7)
  * Whole GPT-2 / Llama decoder stack forward and activation-gradient-only backward as ONE host call each
@@ -361,6 +379,11 @@ typedef struct {
     const float* const* ln2_w;  const float* const* ln2_b;
     const float* lnf_w; const float* lnf_b;
     const float* rope_cos; const float* rope_sin;                                         /* llama: f32 [T, hd]       */
+    /* dtype of the residual stream: MTL_F32 — the reference's setup.dtype = "mixed" (autocast keeps the stream fp32) and "fp32" — or MTL_BF16 — its
+     * setup.dtype = "bf16" (R:tasks/base.py:261-262,205-208: model and inputs cast to bf16, no autocast): h0, the saved residual states, the
+     * gradient stream dh0 are bf16, every residual add is rounded to bf16, half the stream's HBM bytes. The norm / bias parameters stay f32 arrays
+     * (the caller rounds them to bf16 values for this mode, as the reference's .to(bfloat16) does). */
+    int stream_dtype;
 } mtl_backbone_weights;
 typedef struct { float attn_p, resid_p; uint32_t seed; } mtl_backbone_dropout;   /* per-layer seeds are derived from `seed` */
 /* bytes of the `saved` buffer (activations kept for the backward) and of the scratch `work` buffer */
@@ -380,21 +403,21 @@ size_t mtl_backbone_work_bytes(const mtl_backbone_weights* w, int64_t B, int64_t
  * per-layer keys and values of the prompt rows from `prefix_kv` (mtl_backbone_prefix_build). h0's first n_prefix rows are not read.
  * Results for the computed rows equal the full forward's up to the summation order of differently tiled GEMMs; the matching
  * mtl_backbone_bwd needs n_grad <= T - n_prefix. Reported as executed work only: no roofline denominator takes the discount. */
-int mtl_backbone_fwd(const mtl_backbone_weights* w, const float* h0, void* out, void* saved, void* work,
+int mtl_backbone_fwd(const mtl_backbone_weights* w, const void* h0 /* [B, T, d] of w->stream_dtype */, void* out, void* saved, void* work,
                      int64_t B, int64_t T, int64_t n_last, int64_t n_save, const mtl_backbone_dropout* drop /* NULL: off */,
                      const void* prefix_kv, int64_t n_prefix, void* stream);
 /* bytes of the prompt-row cache: bf16 [n_layers, n_prefix, 2 * n_kv_heads * head_dim] (keys after RoPE | values) */
 size_t mtl_backbone_prefix_bytes(const mtl_backbone_weights* w, int64_t n_prefix);
 /* fills `prefix_kv` from the prompt rows h0_prefix f32 [1, n_prefix, d] (wpe already added for GPT-2): one forward of that single
  * sequence; `saved` / `work` sized by mtl_backbone_saved_bytes / _work_bytes(w, 1, n_prefix). w->rope_cos / rope_sin need >= n_prefix rows. */
-int mtl_backbone_prefix_build(const mtl_backbone_weights* w, const float* h0_prefix, void* prefix_kv, void* saved, void* work,
+int mtl_backbone_prefix_build(const mtl_backbone_weights* w, const void* h0_prefix /* w->stream_dtype */, void* prefix_kv, void* saved, void* work,
                               int64_t n_prefix, void* stream);
-/* dout bf16 [B, n_last, d] -> dh0 f32 [B, T, d]. `saved` from the matching forward.
+/* dout bf16 [B, n_last, d] -> dh0 [B, T, d] (f32, or bf16 on the bf16 stream). `saved` from the matching forward.
  * n_grad (n_last <= n_grad <= the forward's n_save): only the LAST n_grad tokens of every sample receive a gradient; rows before that are
  * left zero. The leading tokens are the text prompt: causal attention never lets them see a patch token, so they are
  * independent of every trainable parameter and their gradient is never consumed (SURVEY.md §7 "legal shortcut ii").
  * All backward GEMMs / norms / attention then run on B*n_grad rows. n_grad = T computes the full dh0. */
-int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, const void* dout, float* dh0, void* saved,
+int mtl_backbone_bwd(const mtl_backbone_weights* w, const void* h0, const void* dout, void* dh0 /* both of w->stream_dtype */, void* saved,
                      void* work, int64_t B, int64_t T, int64_t n_last, int64_t n_grad,
                      const mtl_backbone_dropout* drop /* the forward's */, void* stream);
 

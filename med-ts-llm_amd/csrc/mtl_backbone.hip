@@ -18,6 +18,8 @@ struct Dims {
     int64_t B, T, M, d, Hq, Hkv, hd, ffn, Nqkv, No, Nfc;
     int L;
     bool llama;
+    int sdt;           // dtype of the residual stream: MTL_F32 (the reference's dtype "mixed" / "fp32") or MTL_BF16 (its dtype "bf16")
+    size_t es;         // bytes per stream element
 };
 
 Dims dims_of(const mtl_backbone_weights* w, int64_t B, int64_t T) {
@@ -25,6 +27,8 @@ Dims dims_of(const mtl_backbone_weights* w, int64_t B, int64_t T) {
     D.B = B; D.T = T; D.M = B * T; D.d = w->d; D.Hq = w->n_heads; D.Hkv = w->n_kv_heads; D.hd = w->head_dim; D.ffn = w->ffn;
     D.Nqkv = (D.Hq + 2 * D.Hkv) * D.hd; D.No = D.Hq * D.hd; D.L = w->n_layers; D.llama = (w->arch == MTL_ARCH_LLAMA);
     D.Nfc = D.llama ? 2 * D.ffn : D.ffn;
+    D.sdt = w->stream_dtype == MTL_BF16 ? MTL_BF16 : MTL_F32;
+    D.es = D.sdt == MTL_BF16 ? 2 : 4;
     return D;
 }
 
@@ -35,7 +39,7 @@ struct SavedLayout {
 };
 SavedLayout saved_layout(const Dims& D, int64_t n_last) {
     SavedLayout s;
-    s.h_stride = align_up((size_t)D.M * D.d * 4);
+    s.h_stride = align_up((size_t)D.M * D.d * D.es);
     s.stats_stride = align_up((size_t)D.M * 2 * 4);
     s.qkv_stride = align_up((size_t)D.M * D.Nqkv * 2);
     s.attn_stride = align_up((size_t)D.M * D.No * 2);
@@ -119,6 +123,7 @@ int check_weights(const mtl_backbone_weights* w) {
     if (!w->ln1_w || !w->ln2_w || !w->lnf_w) return MTL_ERR_ARG;
     if (w->arch == MTL_ARCH_GPT2 && (!w->ln1_b || !w->ln2_b || !w->lnf_b)) return MTL_ERR_ARG;
     if (w->arch == MTL_ARCH_LLAMA && (!w->rope_cos || !w->rope_sin)) return MTL_ERR_ARG;
+    if (w->stream_dtype != MTL_F32 && w->stream_dtype != MTL_BF16) return MTL_ERR_ARG;
     return MTL_OK;
 }
 
@@ -132,7 +137,7 @@ extern "C" size_t mtl_backbone_saved_bytes(const mtl_backbone_weights* w, int64_
 extern "C" size_t mtl_backbone_saved_hidden_offset(const mtl_backbone_weights* w, int64_t B, int64_t T, int layer) {
     if (check_weights(w) != MTL_OK || B <= 0 || T <= 0 || layer < 1 || layer > w->n_layers) return (size_t)-1;
     const SavedLayout S = saved_layout(dims_of(w, B, T), T);
-    return S.h + S.h_stride * (size_t)(2 * layer - 1);          // H[2 * layer] lives in slot 2 * layer - 1 (H[0] is the caller's h0)
+    return S.h + S.h_stride * (size_t)(2 * layer - 1);          // H[2 * layer] lives in slot 2 * layer - 1 (H[0] is the caller's h0); dtype = w->stream_dtype
 }
 
 extern "C" size_t mtl_backbone_work_bytes(const mtl_backbone_weights* w, int64_t B, int64_t T) {
@@ -155,7 +160,7 @@ __global__ void prefix_kv_fill_kernel(const bf16_t* __restrict__ cache, bf16_t* 
 namespace {
 
 // the forward over the last n_fwd = T - n_prefix tokens of every sample (n_prefix == 0: all of them, identity row maps)
-int backbone_fwd_impl(const mtl_backbone_weights* w, const float* h0, void* out, void* saved, void* work, int64_t B, int64_t T, int64_t n_last,
+int backbone_fwd_impl(const mtl_backbone_weights* w, const void* h0, void* out, void* saved, void* work, int64_t B, int64_t T, int64_t n_last,
                       int64_t n_save, const mtl_backbone_dropout* drop, const void* prefix_kv, int64_t n_prefix, void* stream) {
     MTL_TRY(check_weights(w));
     if (n_save < 0 || n_save > T) return MTL_ERR_ARG;
@@ -172,8 +177,8 @@ int backbone_fwd_impl(const mtl_backbone_weights* w, const float* h0, void* out,
     char* wk = reinterpret_cast<char*>(work);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int rms = D.llama ? 1 : 0;
-    auto H = [&](int idx) -> float* {  // residual stream H[0] = h0, H[1..2L] in saved
-        return idx == 0 ? const_cast<float*>(h0) : reinterpret_cast<float*>(sv + S.h + S.h_stride * (size_t)(idx - 1));
+    auto H = [&](int idx) -> char* {  // residual stream H[0] = h0, H[1..2L] in saved (fp32 or bf16: D.sdt)
+        return idx == 0 ? reinterpret_cast<char*>(const_cast<void*>(h0)) : sv + S.h + S.h_stride * (size_t)(idx - 1);
     };
     // computed rows: the last n_fwd tokens of every sample. Buffers addressed by (b, t) keep their full-size physical layout (the
     // backward reads them there) and are touched through the row map; the norm output xln is compact.
@@ -198,8 +203,8 @@ int backbone_fwd_impl(const mtl_backbone_weights* w, const float* h0, void* out,
         const float* bf = w->b_fc ? w->b_fc[i] : nullptr;
         const float* bp = w->b_proj ? w->b_proj[i] : nullptr;
         // --- attention block
-        MTL_TRY(mtl_norm_fwd(H(2 * i), w->ln1_w[i], w->ln1_b ? w->ln1_b[i] : nullptr, wk + W.xln, D.d, st1, Mf, D.d, w->eps, rms, rm.rows, rm.stride,
-                             rm.offset, 1, stream));
+        MTL_TRY(mtl_norm_fwd_t(H(2 * i), D.sdt, w->ln1_w[i], w->ln1_b ? w->ln1_b[i] : nullptr, wk + W.xln, D.d, st1, Mf, D.d, w->eps, rms, rm.rows, rm.stride,
+                               rm.offset, 1, stream));
         MTL_TRY(gemm(wk + W.xln, D.d, w->w_qkv[i], D.d, qkv, D.Nqkv, MTL_BF16, Mf, D.Nqkv, D.d, bq, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream,
                      kIdentity, rm));
         if (D.llama) MTL_TRY(mtl_rope_inplace_rows(qkv, D.Nqkv, w->rope_cos, w->rope_sin, Mf, D.T, D.Hq + D.Hkv, D.hd, 0, rm.rows, rm.stride, rm.offset, stream));
@@ -227,11 +232,11 @@ int backbone_fwd_impl(const mtl_backbone_weights* w, const float* h0, void* out,
             fa.Tq = n_rows; fa.causal_off = q0; fa.stat_stride = D.T;
         }
         MTL_TRY(mtl_attention_fwd(&fa, stream));
-        MTL_TRY(gemm(attn, D.No, w->w_o[i], D.No, H(2 * i + 1), D.d, MTL_F32, Mr, D.d, D.No, bo, MTL_EPI_RESID, H(2 * i), D.d, nullptr, 0, stream,
+        MTL_TRY(gemm(attn, D.No, w->w_o[i], D.No, H(2 * i + 1), D.d, D.sdt, Mr, D.d, D.No, bo, MTL_EPI_RESID, H(2 * i), D.d, nullptr, 0, stream,
                      rr, rr, resid_p, drop_site_seed(dseed, i, 1)));
         // --- MLP block
-        MTL_TRY(mtl_norm_fwd(H(2 * i + 1), w->ln2_w[i], w->ln2_b ? w->ln2_b[i] : nullptr, wk + W.xln, D.d, st2, Mr, D.d, w->eps, rms, rr.rows, rr.stride,
-                             rr.offset, 1, stream));
+        MTL_TRY(mtl_norm_fwd_t(H(2 * i + 1), D.sdt, w->ln2_w[i], w->ln2_b ? w->ln2_b[i] : nullptr, wk + W.xln, D.d, st2, Mr, D.d, w->eps, rms, rr.rows, rr.stride,
+                               rr.offset, 1, stream));
         if (D.llama) {
             // gate|up GEMM with the SwiGLU fused into its epilogue (weights row-interleaved: columns 2j / 2j+1 = gate_j / up_j)
             // (the saved pre-activations are only read by the backward: stored for the last n_save tokens of every sample)
@@ -241,16 +246,16 @@ int backbone_fwd_impl(const mtl_backbone_weights* w, const float* h0, void* out,
             MTL_TRY(gemm(wk + W.xln, D.d, w->w_fc[i], D.d, wk + W.act, D.ffn, MTL_BF16, Mr, D.ffn, D.d, bf, MTL_EPI_GELU, nullptr, 0, fc, D.ffn, stream,
                          kIdentity, rr, 0.f, 0u, sv_group, sv_first));
         }
-        MTL_TRY(gemm(wk + W.act, D.ffn, w->w_proj[i], D.ffn, H(2 * i + 2), D.d, MTL_F32, Mr, D.d, D.ffn, bp, MTL_EPI_RESID, H(2 * i + 1), D.d, nullptr, 0, stream,
+        MTL_TRY(gemm(wk + W.act, D.ffn, w->w_proj[i], D.ffn, H(2 * i + 2), D.d, D.sdt, Mr, D.d, D.ffn, bp, MTL_EPI_RESID, H(2 * i + 1), D.d, nullptr, 0, stream,
                      rr, rr, resid_p, drop_site_seed(dseed, i, 2)));
     }
     float* stf = reinterpret_cast<float*>(sv + S.stats_f);
-    return mtl_norm_fwd(H(2 * D.L), w->lnf_w, w->lnf_b, out, D.d, stf, D.B * n_last, D.d, w->eps, rms, n_last, D.T, D.T - n_last, 0, stream);
+    return mtl_norm_fwd_t(H(2 * D.L), D.sdt, w->lnf_w, w->lnf_b, out, D.d, stf, D.B * n_last, D.d, w->eps, rms, n_last, D.T, D.T - n_last, 0, stream);
 }
 
 }  // namespace
 
-extern "C" int mtl_backbone_fwd(const mtl_backbone_weights* w, const float* h0, void* out, void* saved, void* work, int64_t B,
+extern "C" int mtl_backbone_fwd(const mtl_backbone_weights* w, const void* h0, void* out, void* saved, void* work, int64_t B,
                                 int64_t T, int64_t n_last, int64_t n_save, const mtl_backbone_dropout* drop, const void* prefix_kv,
                                 int64_t n_prefix, void* stream) {
     return backbone_fwd_impl(w, h0, out, saved, work, B, T, n_last, n_save, drop, prefix_kv, prefix_kv ? n_prefix : 0, stream);
@@ -261,7 +266,7 @@ extern "C" size_t mtl_backbone_prefix_bytes(const mtl_backbone_weights* w, int64
     return (size_t)w->n_layers * (size_t)n_prefix * (size_t)(2 * w->n_kv_heads * w->head_dim) * 2;
 }
 
-extern "C" int mtl_backbone_prefix_build(const mtl_backbone_weights* w, const float* h0_prefix, void* prefix_kv, void* saved, void* work,
+extern "C" int mtl_backbone_prefix_build(const mtl_backbone_weights* w, const void* h0_prefix, void* prefix_kv, void* saved, void* work,
                                          int64_t n_prefix, void* stream) {
     MTL_TRY(check_weights(w));
     if (!h0_prefix || !prefix_kv || !saved || !work || n_prefix <= 0) return MTL_ERR_ARG;
@@ -280,7 +285,7 @@ extern "C" int mtl_backbone_prefix_build(const mtl_backbone_weights* w, const fl
     return MTL_OK;
 }
 
-extern "C" int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, const void* dout, float* dh0, void* saved, void* work,
+extern "C" int mtl_backbone_bwd(const mtl_backbone_weights* w, const void* h0, const void* dout, void* dh0, void* saved, void* work,
                                 int64_t B, int64_t T, int64_t n_last, int64_t n_grad, const mtl_backbone_dropout* drop, void* stream) {
     MTL_TRY(check_weights(w));
     const float attn_p = drop ? drop->attn_p : 0.f, resid_p = drop ? drop->resid_p : 0.f;
@@ -295,9 +300,14 @@ extern "C" int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, 
     char* wk = reinterpret_cast<char*>(work);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int rms = D.llama ? 1 : 0;
-    auto H = [&](int idx) -> float* {
-        return idx == 0 ? const_cast<float*>(h0) : reinterpret_cast<float*>(sv + S.h + S.h_stride * (size_t)(idx - 1));
+    auto H = [&](int idx) -> char* {
+        return idx == 0 ? reinterpret_cast<char*>(const_cast<void*>(h0)) : sv + S.h + S.h_stride * (size_t)(idx - 1);
     };
+    // bf16 stream without resid_pdrop: the gradient stream dh0 IS the bf16 operand of the next branch's first GEMM (same [B * T, d] layout): no
+    // second copy is written. With the dropout the branch sees the masked copy (dres_b), as on the fp32 stream.
+    const bool share = D.sdt == MTL_BF16 && resid_p == 0.f;
+    char* const dA = share ? reinterpret_cast<char*>(dh0) : wk + W.dres_b;          // A operand of the branch-input GEMMs
+    void* const dB = share ? nullptr : (void*)(wk + W.dres_b);                      // masked bf16 copy written by the norm backward
     // rows that receive a gradient: the last n_grad tokens of every sample (see header). Buffers addressed by (b, t)
     // keep their full-size physical layout and are touched through the row map; dx / dact(llama) scratch is compact.
     const int64_t r0 = D.T - n_grad;
@@ -305,16 +315,16 @@ extern "C" int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, 
     const RowMap rm = (n_grad == D.T) ? kIdentity : RowMap{n_grad, D.T, r0};
     if (n_last < T) {   // rows without incoming gradient start at zero (dh0: all of them, it is the returned gradient; the bf16 scratch copy:
                         // only rows [r0, T - n_last) — the kernels never read it below r0)
-        if (hipMemsetAsync(dh0, 0, (size_t)D.M * D.d * 4, st) != hipSuccess) return MTL_ERR_LAUNCH;
-        if (n_last < n_grad &&
+        if (hipMemsetAsync(dh0, 0, (size_t)D.M * D.d * D.es, st) != hipSuccess) return MTL_ERR_LAUNCH;
+        if (!share && n_last < n_grad &&
             hipMemset2DAsync(wk + W.dres_b + (size_t)r0 * D.d * 2, (size_t)D.T * D.d * 2, 0, (size_t)(n_grad - n_last) * D.d * 2, (size_t)D.B, st) != hipSuccess)
             return MTL_ERR_LAUNCH;
     }
     const float* stf = reinterpret_cast<const float*>(sv + S.stats_f);
     // the bf16 copy of the residual gradient is the A operand of the next branch's first GEMM: it carries that branch's
     // resid_pdrop mask (the fp32 stream dh0 is the identity path and stays unmasked)
-    MTL_TRY(mtl_norm_bwd(dout, D.d, H(2 * D.L), w->lnf_w, stf, nullptr, dh0, wk + W.dres_b, D.B * n_last, D.d, rms, n_last, D.T, D.T - n_last, 0,
-                         resid_p, drop_site_seed(dseed, D.L - 1, 2), stream));
+    MTL_TRY(mtl_norm_bwd_t(dout, D.d, H(2 * D.L), D.sdt, w->lnf_w, stf, nullptr, dh0, dB, D.B * n_last, D.d, rms, n_last, D.T, D.T - n_last, 0,
+                           resid_p, drop_site_seed(dseed, D.L - 1, 2), stream));
     for (int i = D.L - 1; i >= 0; --i) {
         const float* st1 = reinterpret_cast<const float*>(sv + S.stats + S.stats_stride * (size_t)(2 * i));
         const float* st2 = reinterpret_cast<const float*>(sv + S.stats + S.stats_stride * (size_t)(2 * i + 1));
@@ -326,18 +336,18 @@ extern "C" int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, 
         if (D.llama) {
             // d(act) GEMM with the SwiGLU backward fused into its epilogue: reads the saved (gate, up) pairs, writes d(gate|up)
             // interleaved, at physical rows like the GPT-2 path (the next GEMM gathers them)
-            MTL_TRY(gemm(wk + W.dres_b, D.d, w->w_proj_t[i], D.d, wk + W.dact, D.Nfc, MTL_BF16, Mg, D.ffn, D.d, nullptr, MTL_EPI_DSWIGLU, fc, D.Nfc, nullptr, 0,
+            MTL_TRY(gemm(dA, D.d, w->w_proj_t[i], D.d, wk + W.dact, D.Nfc, MTL_BF16, Mg, D.ffn, D.d, nullptr, MTL_EPI_DSWIGLU, fc, D.Nfc, nullptr, 0,
                          stream, rm, rm));
         } else {
             // C (and the saved pre-activation read by the dgelu epilogue) keep physical rows; the next GEMM gathers them
-            MTL_TRY(gemm(wk + W.dres_b, D.d, w->w_proj_t[i], D.d, wk + W.dact, D.ffn, MTL_BF16, Mg, D.ffn, D.d, nullptr, MTL_EPI_DGELU, fc, D.ffn, nullptr, 0, stream, rm, rm));
+            MTL_TRY(gemm(dA, D.d, w->w_proj_t[i], D.d, wk + W.dact, D.ffn, MTL_BF16, Mg, D.ffn, D.d, nullptr, MTL_EPI_DGELU, fc, D.ffn, nullptr, 0, stream, rm, rm));
         }
         MTL_TRY(gemm(wk + W.dact, D.Nfc, w->w_fc_t[i], D.Nfc, wk + W.dx, D.d, MTL_BF16, Mg, D.d, D.Nfc, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream,
                      rm));
-        MTL_TRY(mtl_norm_bwd(wk + W.dx, D.d, H(2 * i + 1), w->ln2_w[i], st2, dh0, dh0, wk + W.dres_b, Mg, D.d, rms, rm.rows, rm.stride, rm.offset, 1,
-                             resid_p, drop_site_seed(dseed, i, 1), stream));
+        MTL_TRY(mtl_norm_bwd_t(wk + W.dx, D.d, H(2 * i + 1), D.sdt, w->ln2_w[i], st2, dh0, dh0, dB, Mg, D.d, rms, rm.rows, rm.stride, rm.offset, 1,
+                               resid_p, drop_site_seed(dseed, i, 1), stream));
         // --- attention block backward: h_mid = h_in + o_proj(attn(qkv(norm1(h_in))))
-        MTL_TRY(gemm(wk + W.dres_b, D.d, w->w_o_t[i], D.d, wk + W.dO, D.No, MTL_BF16, Mg, D.No, D.d, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream, rm, rm));
+        MTL_TRY(gemm(dA, D.d, w->w_o_t[i], D.d, wk + W.dO, D.No, MTL_BF16, Mg, D.No, D.d, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream, rm, rm));
         mtl_attn_bwd_args ba = {};
         attn_args(D, qkv, attn, lse, &ba.f);
         ba.f.dropout_p = attn_p; ba.f.dropout_seed = drop_site_seed(dseed, i, 0);
@@ -360,8 +370,8 @@ extern "C" int mtl_backbone_bwd(const mtl_backbone_weights* w, const float* h0, 
         if (D.llama && !rope_fuse)
             MTL_TRY(mtl_rope_inplace_rows(wk + W.dqkv, D.Nqkv, w->rope_cos, w->rope_sin, Mg, D.T, D.Hq + D.Hkv, D.hd, 1, rm.rows, rm.stride, rm.offset, stream));
         MTL_TRY(gemm(wk + W.dqkv, D.Nqkv, w->w_qkv_t[i], D.Nqkv, wk + W.dx, D.d, MTL_BF16, Mg, D.d, D.Nqkv, nullptr, MTL_EPI_STORE, nullptr, 0, nullptr, 0, stream, rm));
-        MTL_TRY(mtl_norm_bwd(wk + W.dx, D.d, H(2 * i), w->ln1_w[i], st1, dh0, dh0, wk + W.dres_b, Mg, D.d, rms, rm.rows, rm.stride, rm.offset, 1,
-                             i > 0 ? resid_p : 0.f, drop_site_seed(dseed, i - 1, 2), stream));
+        MTL_TRY(mtl_norm_bwd_t(wk + W.dx, D.d, H(2 * i), D.sdt, w->ln1_w[i], st1, dh0, dh0, dB, Mg, D.d, rms, rm.rows, rm.stride, rm.offset, 1,
+                               i > 0 ? resid_p : 0.f, drop_site_seed(dseed, i - 1, 2), stream));
     }
     return MTL_OK;
 }

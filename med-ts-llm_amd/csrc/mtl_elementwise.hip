@@ -227,13 +227,23 @@ __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* _
 }
 
 // ---------------------------------------------------------------- LLM input assembly: one block per (b, t) row
+// OUT_BF: the residual stream is bf16 (the reference's dtype "bf16": embedding tables, their sum and the dropped result are bf16 tensors there)
+__device__ __forceinline__ float4 rbf4(float4 v) {
+    const u32x2 k = {pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+    return make_float4(__uint_as_float(k[0] << 16), __uint_as_float(k[0] & 0xffff0000u), __uint_as_float(k[1] << 16), __uint_as_float(k[1] & 0xffff0000u));
+}
+template <bool OUT_BF>
+__device__ __forceinline__ void st_stream4(void* base, int64_t idx, float4 v) {
+    if constexpr (OUT_BF) *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(base) + idx) = (u32x2){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+    else *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + idx) = v;
+}
+template <bool OUT_BF>
 __global__ __launch_bounds__(256) void assemble_kernel(const int32_t* __restrict__ ids, int64_t ids_B, const float* __restrict__ embed,
                                                        const bf16_t* __restrict__ x_tok, const float* __restrict__ wpe,
-                                                       float* __restrict__ h0, int64_t n_tok, int64_t P, int64_t d, uint32_t drop_thr,
+                                                       void* __restrict__ h0, int64_t n_tok, int64_t P, int64_t d, uint32_t drop_thr,
                                                        uint32_t drop_seed) {
     const int64_t T = n_tok + P;
     const int64_t row = blockIdx.x, b = row / T, t = row % T;
-    float* out = h0 + row * d;
     const float* pe = wpe ? wpe + t * d : nullptr;
     // GPT-2 embd_pdrop on inputs_embeds + wpe (HF:models/gpt2/modeling_gpt2.py:579), mask of (seed, flattened row, column) = mtl_dropout_f32's
     const uint32_t dbase = drop_base(drop_seed, 0u);
@@ -250,9 +260,15 @@ __global__ __launch_bounds__(256) void assemble_kernel(const int32_t* __restrict
         const float* e = embed + id * d;
         for (int64_t c = (int64_t)threadIdx.x * 4; c < d; c += 1024) {
             float4 v = *reinterpret_cast<const float4*>(e + c);
-            if (pe) { const float4 p4 = *reinterpret_cast<const float4*>(pe + c); v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w; }
+            if constexpr (OUT_BF) v = rbf4(v);
+            if (pe) {
+                float4 p4 = *reinterpret_cast<const float4*>(pe + c);
+                if constexpr (OUT_BF) p4 = rbf4(p4);
+                v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w;
+                if constexpr (OUT_BF) v = rbf4(v);
+            }
             drop4(v, c);
-            *reinterpret_cast<float4*>(out + c) = v;
+            st_stream4<OUT_BF>(h0, row * d + c, v);
         }
     } else {
         const bf16_t* xr = x_tok + (b * P + (t - n_tok)) * d;
@@ -260,22 +276,34 @@ __global__ __launch_bounds__(256) void assemble_kernel(const int32_t* __restrict
             const u32x2 k = *reinterpret_cast<const u32x2*>(xr + c);
             float4 v = make_float4(__uint_as_float(k[0] << 16), __uint_as_float(k[0] & 0xffff0000u), __uint_as_float(k[1] << 16),
                                    __uint_as_float(k[1] & 0xffff0000u));
-            if (pe) { const float4 p4 = *reinterpret_cast<const float4*>(pe + c); v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w; }
+            if (pe) {
+                float4 p4 = *reinterpret_cast<const float4*>(pe + c);
+                if constexpr (OUT_BF) p4 = rbf4(p4);
+                v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w;
+                if constexpr (OUT_BF) v = rbf4(v);
+            }
             drop4(v, c);
-            *reinterpret_cast<float4*>(out + c) = v;
+            st_stream4<OUT_BF>(h0, row * d + c, v);
         }
     }
 }
 
 // backward of the assembly (+ embd dropout): dx_tok[b, p, :] = bf16(mask * dh0[b, n_tok + p, :]) — the token rows only, one pass
-__global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restrict__ dh0, bf16_t* __restrict__ dx, int64_t n_tok, int64_t P, int64_t d,
+template <bool IN_BF>
+__global__ __launch_bounds__(256) void assemble_bwd_kernel(const void* __restrict__ dh0, bf16_t* __restrict__ dx, int64_t n_tok, int64_t P, int64_t d,
                                                            uint32_t drop_thr, uint32_t drop_seed) {
     const int64_t T = n_tok + P;
     const int64_t r = blockIdx.x, b = r / P, pp = r % P, row = b * T + n_tok + pp;
     const uint32_t dbase = drop_base(drop_seed, 0u);
     const float dscale = drop_scale_of(drop_thr);
     for (int64_t c = (int64_t)threadIdx.x * 4; c < d; c += 1024) {
-        float4 v = *reinterpret_cast<const float4*>(dh0 + row * d + c);
+        float4 v;
+        if constexpr (IN_BF) {
+            const u32x2 k = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(dh0) + row * d + c);
+            v = make_float4(__uint_as_float(k[0] << 16), __uint_as_float(k[0] & 0xffff0000u), __uint_as_float(k[1] << 16), __uint_as_float(k[1] & 0xffff0000u));
+        } else {
+            v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dh0) + row * d + c);
+        }
         if (drop_thr) {
             const uint2 w = drop_quad(dbase, (uint32_t)row, (uint32_t)c >> 2);
             v.x = (w.x & 0xffffu) >= drop_thr ? v.x * dscale : 0.f; v.y = (w.x >> 16) >= drop_thr ? v.y * dscale : 0.f;
@@ -552,12 +580,40 @@ extern "C" int mtl_swiglu_bwd(const void* gu, const void* dh, void* dgu, int64_t
     return mtl_swiglu_bwd_rows(gu, dh, dgu, M, F, 0, 0, 0, 0, stream);
 }
 
+extern "C" int mtl_assemble_bwd_t(const void* dh0, int dh0_dtype, void* dx_tok, int64_t B, int64_t n_tok, int64_t P, int64_t d, float drop_p,
+                                  uint32_t drop_seed, void* stream) {
+    if (!dh0 || !dx_tok || B <= 0 || P <= 0 || d <= 0 || n_tok < 0 || drop_p < 0.f || drop_p >= 1.f) return MTL_ERR_ARG;
+    if (dh0_dtype != MTL_F32 && dh0_dtype != MTL_BF16) return MTL_ERR_ARG;
+    if (d % 4 != 0) return MTL_ERR_ALIGN;
+    const uint32_t thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
+    if (dh0_dtype == MTL_BF16)
+        hipLaunchKernelGGL(assemble_bwd_kernel<true>, dim3((unsigned)(B * P)), dim3(256), 0, (hipStream_t)stream, dh0, (bf16_t*)dx_tok, n_tok, P, d, thr, drop_seed);
+    else
+        hipLaunchKernelGGL(assemble_bwd_kernel<false>, dim3((unsigned)(B * P)), dim3(256), 0, (hipStream_t)stream, dh0, (bf16_t*)dx_tok, n_tok, P, d, thr, drop_seed);
+    MTL_CHECK_LAUNCH();
+    return MTL_OK;
+}
+
 extern "C" int mtl_assemble_bwd(const float* dh0, void* dx_tok, int64_t B, int64_t n_tok, int64_t P, int64_t d, float drop_p,
                                 uint32_t drop_seed, void* stream) {
-    if (!dh0 || !dx_tok || B <= 0 || P <= 0 || d <= 0 || n_tok < 0 || drop_p < 0.f || drop_p >= 1.f) return MTL_ERR_ARG;
+    return mtl_assemble_bwd_t(dh0, MTL_F32, dx_tok, B, n_tok, P, d, drop_p, drop_seed, stream);
+}
+
+extern "C" int mtl_assemble_llm_input_t(const int32_t* ids, int64_t ids_B, const float* embed, const void* x_tok, const float* wpe,
+                                        void* h0, int h0_dtype, int64_t B, int64_t n_tok, int64_t P, int64_t d, float drop_p, uint32_t drop_seed,
+                                        void* stream) {
+    if (drop_p < 0.f || drop_p >= 1.f) return MTL_ERR_ARG;
+    if (!x_tok || !h0 || B <= 0 || P <= 0 || d <= 0 || n_tok < 0) return MTL_ERR_ARG;
+    if (h0_dtype != MTL_F32 && h0_dtype != MTL_BF16) return MTL_ERR_ARG;
+    if (n_tok > 0 && (!ids || !embed || (ids_B != 1 && ids_B != B))) return MTL_ERR_ARG;
     if (d % 4 != 0) return MTL_ERR_ALIGN;
-    hipLaunchKernelGGL(assemble_bwd_kernel, dim3((unsigned)(B * P)), dim3(256), 0, (hipStream_t)stream, dh0, (bf16_t*)dx_tok, n_tok, P, d,
-                       drop_p > 0.f ? drop_threshold(drop_p) : 0u, drop_seed);
+    const uint32_t thr = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
+    if (h0_dtype == MTL_BF16)
+        hipLaunchKernelGGL(assemble_kernel<true>, dim3((unsigned)(B * (n_tok + P))), dim3(256), 0, (hipStream_t)stream, ids, ids_B, embed,
+                           (const bf16_t*)x_tok, wpe, h0, n_tok, P, d, thr, drop_seed);
+    else
+        hipLaunchKernelGGL(assemble_kernel<false>, dim3((unsigned)(B * (n_tok + P))), dim3(256), 0, (hipStream_t)stream, ids, ids_B, embed,
+                           (const bf16_t*)x_tok, wpe, h0, n_tok, P, d, thr, drop_seed);
     MTL_CHECK_LAUNCH();
     return MTL_OK;
 }
@@ -565,14 +621,7 @@ extern "C" int mtl_assemble_bwd(const float* dh0, void* dx_tok, int64_t B, int64
 extern "C" int mtl_assemble_llm_input(const int32_t* ids, int64_t ids_B, const float* embed, const void* x_tok, const float* wpe,
                                       float* h0, int64_t B, int64_t n_tok, int64_t P, int64_t d, float drop_p, uint32_t drop_seed,
                                       void* stream) {
-    if (drop_p < 0.f || drop_p >= 1.f) return MTL_ERR_ARG;
-    if (!x_tok || !h0 || B <= 0 || P <= 0 || d <= 0 || n_tok < 0) return MTL_ERR_ARG;
-    if (n_tok > 0 && (!ids || !embed || (ids_B != 1 && ids_B != B))) return MTL_ERR_ARG;
-    if (d % 4 != 0) return MTL_ERR_ALIGN;
-    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)(B * (n_tok + P))), dim3(256), 0, (hipStream_t)stream, ids, ids_B, embed,
-                       (const bf16_t*)x_tok, wpe, h0, n_tok, P, d, drop_p > 0.f ? drop_threshold(drop_p) : 0u, drop_seed);
-    MTL_CHECK_LAUNCH();
-    return MTL_OK;
+    return mtl_assemble_llm_input_t(ids, ids_B, embed, x_tok, wpe, h0, MTL_F32, B, n_tok, P, d, drop_p, drop_seed, stream);
 }
 
 extern "C" int mtl_revin_denorm(const void* y, int y_dtype, const float* mean, const float* stdev, void* out, int out_dtype, int64_t B, int64_t T,

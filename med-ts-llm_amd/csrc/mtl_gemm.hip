@@ -97,22 +97,32 @@ __device__ __forceinline__ void epilogue4(const mtl_gemm_args& p, int64_t m, int
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = gelu_new_f(bf16_to_f32(f32_to_bf16(o[e])));
     } else if constexpr (EPI == MTL_EPI_RESID) {
-        // v is rounded to bf16 first (a bf16 Linear output) and then added to the fp32 residual stream
-        const float* r = reinterpret_cast<const float*>(p.aux_in) + crow * p.ld_aux_in + n;
+        // v is rounded to bf16 first (a bf16 Linear output) and then added to the residual stream: fp32 (CDT f32: the reference's "mixed" stream) or
+        // bf16 (CDT bf16 = its dtype "bf16": the dropped branch is a bf16 tensor too, and the sum is rounded by the store)
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = bf16_to_f32(f32_to_bf16(o[e]));
         if (p.drop_p > 0.f) {   // resid_pdrop: same (seed, physical row, column) hash as epilogue_wave
             const uint32_t thr = drop_threshold(p.drop_p), dbase = drop_base(p.drop_seed, 0u);
             const float sc = drop_scale_of(thr);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = drop_keep(dbase, (uint32_t)crow, (uint32_t)(n + e), thr) ? o[e] * sc : 0.f;
+            for (int e = 0; e < 4; ++e) {
+                o[e] = drop_keep(dbase, (uint32_t)crow, (uint32_t)(n + e), thr) ? o[e] * sc : 0.f;
+                if constexpr (CDT == MTL_BF16) o[e] = bf16_to_f32(f32_to_bf16(o[e]));
+            }
         }
-        if (vec_ok) {
-            const float4 r4 = *reinterpret_cast<const float4*>(r);
-            o[0] += r4.x; o[1] += r4.y; o[2] += r4.z; o[3] += r4.w;
-        } else {
+        if constexpr (CDT == MTL_BF16) {
+            const bf16_t* r = reinterpret_cast<const bf16_t*>(p.aux_in) + crow * p.ld_aux_in + n;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (e < nvalid) o[e] += r[e];
+            for (int e = 0; e < 4; ++e) if (e < nvalid) o[e] += bf16_to_f32(r[e]);
+        } else {
+            const float* r = reinterpret_cast<const float*>(p.aux_in) + crow * p.ld_aux_in + n;
+            if (vec_ok) {
+                const float4 r4 = *reinterpret_cast<const float4*>(r);
+                o[0] += r4.x; o[1] += r4.y; o[2] += r4.z; o[3] += r4.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (e < nvalid) o[e] += r[e];
+            }
         }
     } else if constexpr (EPI == MTL_EPI_DGELU) {
         const bf16_t* h = reinterpret_cast<const bf16_t*>(p.aux_in) + crow * p.ld_aux_in + n;
@@ -204,7 +214,7 @@ template <int EPI, int NI>
 struct EpiAux {
     float4 b4[NI];
     float4 res[EPI == MTL_EPI_RESID || EPI == MTL_EPI_ACCUM ? NI : 1][4];
-    u32x2 hk[EPI == MTL_EPI_DGELU ? NI : 1][4];
+    u32x2 hk[EPI == MTL_EPI_DGELU || EPI == MTL_EPI_RESID ? NI : 1][4];     // (RESID: the bf16 residual stream's 4 values, CDT bf16)
     u32x4 gq[EPI == MTL_EPI_DSWIGLU ? NI : 1][4];        // saved (gate, up) pairs of the lane's 4 activation columns
 };
 
@@ -241,7 +251,8 @@ __device__ __forceinline__ void epi_load(const mtl_gemm_args& p, const EpiRows& 
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                if constexpr (EPI == MTL_EPI_RESID) a.res[ni][mi] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.aux_in) + r.crow[mi] * p.ld_aux_in + ncol[ni]);
+                if constexpr (EPI == MTL_EPI_RESID && CDT == MTL_F32) a.res[ni][mi] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.aux_in) + r.crow[mi] * p.ld_aux_in + ncol[ni]);
+                if constexpr (EPI == MTL_EPI_RESID && CDT == MTL_BF16) a.hk[ni][mi] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.aux_in) + r.crow[mi] * p.ld_aux_in + ncol[ni]);
                 if constexpr (EPI == MTL_EPI_ACCUM) a.res[ni][mi] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.C) + r.crow[mi] * p.ldc + ncol[ni]);
                 if constexpr (EPI == MTL_EPI_DGELU) a.hk[ni][mi] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.aux_in) + r.crow[mi] * p.ld_aux_in + ncol[ni]);
                 if constexpr (EPI == MTL_EPI_DSWIGLU) a.gq[ni][mi] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(p.aux_in) + r.crow[mi] * p.ld_aux_in + 2 * ncol[ni]);
@@ -291,7 +302,17 @@ __device__ __forceinline__ void epi_math(const mtl_gemm_args& p, const EpiRows& 
                     const uint32_t w0 = wq.x, w1 = wq.y;
                     v[0] = (w0 & 0xffffu) >= thr ? v[0] * sc : 0.f; v[1] = (w0 >> 16) >= thr ? v[1] * sc : 0.f;
                     v[2] = (w1 & 0xffffu) >= thr ? v[2] * sc : 0.f; v[3] = (w1 >> 16) >= thr ? v[3] * sc : 0.f;
+                    if constexpr (CDT == MTL_BF16) {                                       // bf16 stream: the dropped branch is a bf16 tensor
+                        const u32x2 dk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        v[0] = __uint_as_float(dk[0] << 16); v[1] = __uint_as_float(dk[0] & 0xffff0000u);
+                        v[2] = __uint_as_float(dk[1] << 16); v[3] = __uint_as_float(dk[1] & 0xffff0000u);
+                    }
                 }
+                if constexpr (CDT == MTL_BF16) {       // bf16 residual stream in and out (the reference's dtype "bf16"): one rounding of the sum
+                    const u32x2 hr = a.hk[ni][mi];
+                    out = (u32x4){pack_bf16x2(__uint_as_float(hr[0] << 16) + v[0], __uint_as_float(hr[0] & 0xffff0000u) + v[1]),
+                                  pack_bf16x2(__uint_as_float(hr[1] << 16) + v[2], __uint_as_float(hr[1] & 0xffff0000u) + v[3]), 0u, 0u};
+                } else
                 out = (u32x4){__float_as_uint(a.res[ni][mi].x + v[0]), __float_as_uint(a.res[ni][mi].y + v[1]), __float_as_uint(a.res[ni][mi].z + v[2]),
                               __float_as_uint(a.res[ni][mi].w + v[3])};
             } else if constexpr (EPI == MTL_EPI_DGELU) {
@@ -1749,8 +1770,12 @@ extern "C" int mtl_gemm_nt(const mtl_gemm_args* a, void* stream) {
             if (p.c_dtype != MTL_BF16 || !p.aux_out) return MTL_ERR_ARG;
             vec_ok = vec_ok && (p.ld_aux_out % 4 == 0) && aligned(p.aux_out, 8);
             return launch<MTL_EPI_GELU, MTL_BF16>(p, vec_ok, st);
-        case MTL_EPI_RESID:
-            if (p.c_dtype != MTL_F32 || !p.aux_in) return MTL_ERR_ARG;
+        case MTL_EPI_RESID:      // the residual stream (aux_in) has the output's dtype: fp32 ("mixed") or bf16 (the reference's dtype "bf16")
+            if (!p.aux_in) return MTL_ERR_ARG;
+            if (p.c_dtype == MTL_BF16) {
+                vec_ok = vec_ok && (p.ld_aux_in % 4 == 0) && aligned(p.aux_in, 8);
+                return launch<MTL_EPI_RESID, MTL_BF16>(p, vec_ok, st);
+            }
             vec_ok = vec_ok && (p.ld_aux_in % 4 == 0) && aligned(p.aux_in, 16);
             return launch<MTL_EPI_RESID, MTL_F32>(p, vec_ok, st);
         case MTL_EPI_DGELU:

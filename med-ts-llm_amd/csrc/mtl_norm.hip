@@ -15,11 +15,33 @@ __device__ __forceinline__ int64_t remap_row(int64_t m, int64_t group_rows, int6
     return (m / group_rows) * group_stride + off + (m % group_rows);
 }
 
+// the residual stream is fp32 (the reference's dtype = "mixed" / "fp32") or bf16 (its dtype = "bf16": R:tasks/base.py:261-262, the whole model in
+// bf16): XT = float | bf16_t. 4 consecutive elements of a row <-> float4.
+template <typename XT>
+__device__ __forceinline__ float4 ld4(const XT* p) {
+    if constexpr (std::is_same<XT, float>::value) {
+        return *reinterpret_cast<const float4*>(p);
+    } else {
+        const u32x2 k = *reinterpret_cast<const u32x2*>(p);
+        return make_float4(__uint_as_float(k[0] << 16), __uint_as_float(k[0] & 0xffff0000u), __uint_as_float(k[1] << 16), __uint_as_float(k[1] & 0xffff0000u));
+    }
+}
+template <typename XT>
+__device__ __forceinline__ void st4(XT* p, const float4 v) {
+    if constexpr (std::is_same<XT, float>::value) {
+        *reinterpret_cast<float4*>(p) = v;
+    } else {
+        const u32x2 k = {pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+        *reinterpret_cast<u32x2*>(p) = k;
+    }
+}
+__device__ __forceinline__ float rbf(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
 #ifndef MTL_NORM_RPW
 #define MTL_NORM_RPW 1      // rows per wave of the forward kernel (narrow rows): all rows' loads are in flight before the first reduction
 #endif
-template <int NV, bool RMS, int RPW = 1>
-__global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+template <int NV, bool RMS, int RPW = 1, typename XT = float>
+__global__ __launch_bounds__(256) void norm_fwd_kernel(const XT* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                        int64_t ld_y, float* __restrict__ stats, int64_t M, int d, float eps,
                                                        int64_t group_rows, int64_t group_stride, int64_t row_offset, int stats_physical) {
@@ -32,11 +54,11 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__
     for (int j = 0; j < RPW; ++j) {
         const int64_t row = row0 + j < M ? row0 + j : M - 1;
         prow[j] = remap_row(row, group_rows, group_stride, row_offset);
-        const float* xr = x + prow[j] * (int64_t)d;
+        const XT* xr = x + prow[j] * (int64_t)d;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (lane + 64 * i) * 4;
-            v[j][i] = c < d ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[j][i] = c < d ? ld4<XT>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     // narrow rows: the affine parameters are requested with the rows (one round trip for everything); wide rows (NV float4 of the row per lane)
@@ -79,9 +101,11 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__
                 float o0, o1, o2, o3;
                 const float4 g4 = PRE ? gm[PRE ? i : 0] : *reinterpret_cast<const float4*>(gamma + c);
                 if (RMS) {
-                    // HF LlamaRMSNorm: weight * (x * rsqrt(var + eps)).to(input_dtype) ; input dtype is fp32 here
-                    o0 = g4.x * (v[j][i].x * rstd); o1 = g4.y * (v[j][i].y * rstd);
-                    o2 = g4.z * (v[j][i].z * rstd); o3 = g4.w * (v[j][i].w * rstd);
+                    // HF LlamaRMSNorm: weight * (x * rsqrt(var + eps)).to(input_dtype): the input dtype is fp32 on the fp32 stream; on the bf16
+                    // stream the normalised row is a bf16 tensor before the (bf16) weight multiplies it (HF:models/llama/modeling_llama.py:64-69)
+                    float n0 = v[j][i].x * rstd, n1 = v[j][i].y * rstd, n2 = v[j][i].z * rstd, n3 = v[j][i].w * rstd;
+                    if constexpr (!std::is_same<XT, float>::value) { n0 = rbf(n0); n1 = rbf(n1); n2 = rbf(n2); n3 = rbf(n3); }
+                    o0 = g4.x * n0; o1 = g4.y * n1; o2 = g4.z * n2; o3 = g4.w * n3;
                 } else {
                     const float4 b4 = PRE ? bt[PRE ? i : 0] : *reinterpret_cast<const float4*>(beta + c);
                     o0 = (v[j][i].x - mean) * rstd * g4.x + b4.x; o1 = (v[j][i].y - mean) * rstd * g4.y + b4.y;
@@ -101,10 +125,10 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const float* __restrict__
 
 // WPR waves share a row (wide rows: d >= 2048): the row's NV float4 per lane would otherwise pin ~190 registers (two waves per SIMD, 3.3 TB/s
 // at d = 4096); with four waves per row a lane keeps NV / 4 of them and the two row sums cross the waves through LDS.
-template <int NV, bool RMS, int WPR = 1>
-__global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict__ dy, int64_t ld_dy, const float* __restrict__ x,
+template <int NV, bool RMS, int WPR = 1, typename XT = float>
+__global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict__ dy, int64_t ld_dy, const XT* __restrict__ x,
                                                        const float* __restrict__ gamma, const float* __restrict__ stats,
-                                                       const float* dres_in, float* dres_out, bf16_t* dres_out_bf16,
+                                                       const XT* dres_in, XT* dres_out, bf16_t* dres_out_bf16,
                                                        int64_t M, int d, int64_t group_rows, int64_t group_stride,
                                                        int64_t row_offset, int stats_physical, float drop_p, uint32_t drop_seed) {
     static_assert(NV % WPR == 0 && 4 % WPR == 0, "waves per row");
@@ -115,7 +139,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict_
     if (WPR == 1 && !row_ok) return;
     const int64_t row = row_ok ? row_raw : M - 1;       // (WPR > 1: every wave reaches the barrier; stores are predicated)
     const int64_t prow = remap_row(row, group_rows, group_stride, row_offset);
-    const float* xr = x + prow * (int64_t)d;
+    const XT* xr = x + prow * (int64_t)d;
     const bf16_t* dyr = dy + row * ld_dy;
     const int64_t srow = stats_physical ? prow : row;
     const float mean = RMS ? 0.f : stats[srow * 2];
@@ -128,7 +152,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict_
         if (c < d) {
             const u32x2 dk = *reinterpret_cast<const u32x2*>(dyr + c);
             const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
-            const float4 xv = *reinterpret_cast<const float4*>(xr + c);
+            const float4 xv = ld4<XT>(xr + c);
             g[i].x = __uint_as_float(dk[0] << 16) * gm.x; g[i].y = __uint_as_float(dk[0] & 0xffff0000u) * gm.y;
             g[i].z = __uint_as_float(dk[1] << 16) * gm.z; g[i].w = __uint_as_float(dk[1] & 0xffff0000u) * gm.w;
             xh[i].x = (xv.x - mean) * rstd; xh[i].y = (xv.y - mean) * rstd;
@@ -162,10 +186,14 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_t* __restrict_
             o.x = rstd * (g[i].x - c1 - xh[i].x * c2); o.y = rstd * (g[i].y - c1 - xh[i].y * c2);
             o.z = rstd * (g[i].z - c1 - xh[i].z * c2); o.w = rstd * (g[i].w - c1 - xh[i].w * c2);
             if (dres_in) {
-                const float4 r = *reinterpret_cast<const float4*>(dres_in + prow * (int64_t)d + c);
+                if constexpr (!std::is_same<XT, float>::value) {       // bf16 stream: the branch gradient is a bf16 tensor before the add
+                    o.x = rbf(o.x); o.y = rbf(o.y); o.z = rbf(o.z); o.w = rbf(o.w);
+                }
+                const float4 r = ld4<XT>(dres_in + prow * (int64_t)d + c);
                 o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
             }
-            *reinterpret_cast<float4*>(dres_out + prow * (int64_t)d + c) = o;
+            st4<XT>(dres_out + prow * (int64_t)d + c, o);
+            if constexpr (!std::is_same<XT, float>::value) { o.x = rbf(o.x); o.y = rbf(o.y); o.z = rbf(o.z); o.w = rbf(o.w); }
             if (dres_out_bf16) {
                 if (drop_p > 0.f) {   // gradient entering a residual branch whose forward output was dropped with this mask
                     const uint32_t thr = drop_threshold(drop_p), dbase = drop_base(drop_seed, 0u);
@@ -197,10 +225,11 @@ int dispatch_nv(int64_t d, F&& f) {
 
 }  // namespace
 
-extern "C" int mtl_norm_fwd(const float* x, const float* gamma, const float* beta, void* y, int64_t ld_y, float* stats,
-                            int64_t M, int64_t d, float eps, int rms, int64_t group_rows, int64_t group_stride,
-                            int64_t row_offset, int stats_physical, void* stream) {
+extern "C" int mtl_norm_fwd_t(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int64_t ld_y, float* stats,
+                              int64_t M, int64_t d, float eps, int rms, int64_t group_rows, int64_t group_stride,
+                              int64_t row_offset, int stats_physical, void* stream) {
     if (!x || !gamma || !y || M <= 0 || d <= 0 || (!rms && !beta)) return MTL_ERR_ARG;
+    if (x_dtype != MTL_F32 && x_dtype != MTL_BF16) return MTL_ERR_ARG;
     if (d % 4 != 0 || ld_y % 4 != 0) return MTL_ERR_ALIGN;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 block(256);
@@ -209,14 +238,51 @@ extern "C" int mtl_norm_fwd(const float* x, const float* gamma, const float* bet
         constexpr int RPW = NV <= 4 ? MTL_NORM_RPW : 1;      // (wide rows already keep NV float4 per lane in flight)
         const dim3 grid((unsigned)((M + 4 * RPW - 1) / (4 * RPW)));
         char kname[64];
-        snprintf(kname, sizeof kname, "norm_fwd_kernel<%d, %s>", NV, rms ? "true" : "false");
-        const double bytes = (double)M * d * (4 + 2) + (stats ? (double)M * 8 : 0.0);      // fp32 row in, bf16 row out, 2 statistics
-        if (rms)
-            MTL_LAUNCH(kname, bytes, 1, (norm_fwd_kernel<NV, true, RPW>), grid, block, 0, st, x, gamma, beta, (bf16_t*)y, ld_y, stats, M, (int)d,
-                       eps, group_rows, group_stride, row_offset, stats_physical);
-        else
-            MTL_LAUNCH(kname, bytes, 1, (norm_fwd_kernel<NV, false, RPW>), grid, block, 0, st, x, gamma, beta, (bf16_t*)y, ld_y, stats, M, (int)d,
-                       eps, group_rows, group_stride, row_offset, stats_physical);
+        snprintf(kname, sizeof kname, "norm_fwd_kernel<%d, %s%s>", NV, rms ? "true" : "false", x_dtype == MTL_BF16 ? ", bf16" : "");
+        const double bytes = (double)M * d * ((x_dtype == MTL_BF16 ? 2 : 4) + 2) + (stats ? (double)M * 8 : 0.0);      // row in, bf16 row out, 2 statistics
+#define MTL_NORM_FWD(RMSV, XT)                                                                                                            \
+    MTL_LAUNCH(kname, bytes, 1, (norm_fwd_kernel<NV, RMSV, RPW, XT>), grid, block, 0, st, (const XT*)x, gamma, beta, (bf16_t*)y, ld_y, stats, M, \
+               (int)d, eps, group_rows, group_stride, row_offset, stats_physical)
+        if (x_dtype == MTL_BF16) { if (rms) MTL_NORM_FWD(true, bf16_t); else MTL_NORM_FWD(false, bf16_t); }
+        else { if (rms) MTL_NORM_FWD(true, float); else MTL_NORM_FWD(false, float); }
+#undef MTL_NORM_FWD
+        MTL_CHECK_LAUNCH();
+        return MTL_OK;
+    };
+    return dispatch_nv<false>(d, go);
+}
+
+extern "C" int mtl_norm_fwd(const float* x, const float* gamma, const float* beta, void* y, int64_t ld_y, float* stats,
+                            int64_t M, int64_t d, float eps, int rms, int64_t group_rows, int64_t group_stride,
+                            int64_t row_offset, int stats_physical, void* stream) {
+    return mtl_norm_fwd_t(x, MTL_F32, gamma, beta, y, ld_y, stats, M, d, eps, rms, group_rows, group_stride, row_offset, stats_physical, stream);
+}
+
+extern "C" int mtl_norm_bwd_t(const void* dy, int64_t ld_dy, const void* x, int stream_dtype, const float* gamma, const float* stats,
+                              const void* dres_in, void* dres_out, void* dres_out_bf16, int64_t M, int64_t d, int rms,
+                              int64_t group_rows, int64_t group_stride, int64_t row_offset, int stats_physical,
+                              float bf16_drop_p, uint32_t bf16_drop_seed, void* stream) {
+    if (!dy || !x || !gamma || !stats || !dres_out || M <= 0 || d <= 0 || bf16_drop_p < 0.f || bf16_drop_p >= 1.f) return MTL_ERR_ARG;
+    if (stream_dtype != MTL_F32 && stream_dtype != MTL_BF16) return MTL_ERR_ARG;
+    if (d % 4 != 0 || ld_dy % 4 != 0) return MTL_ERR_ALIGN;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 block(256);
+    auto go = [&](auto nv) -> int {
+        constexpr int NV = decltype(nv)::value;
+        constexpr int WPR = NV >= 8 ? 4 : 1;
+        const dim3 grid((unsigned)((M + 4 / WPR - 1) / (4 / WPR)));
+        char kname[64];
+        snprintf(kname, sizeof kname, "norm_bwd_kernel<%d, %s%s>", NV, rms ? "true" : "false", stream_dtype == MTL_BF16 ? ", bf16" : "");
+        // bf16 dy + the stream's x in (+ the incoming residual gradient), residual gradient out (+ its masked bf16 copy)
+        const double e = stream_dtype == MTL_BF16 ? 2 : 4;
+        const double bytes = (double)M * d * (2 + e + (dres_in ? e : 0) + e + (dres_out_bf16 ? 2 : 0)) + (double)M * 8;
+#define MTL_NORM_BWD(RMSV, XT)                                                                                                             \
+    MTL_LAUNCH(kname, bytes, 1, (norm_bwd_kernel<NV, RMSV, WPR, XT>), grid, block, 0, st, (const bf16_t*)dy, ld_dy, (const XT*)x, gamma, stats, \
+               (const XT*)dres_in, (XT*)dres_out, (bf16_t*)dres_out_bf16, M, (int)d, group_rows, group_stride, row_offset, stats_physical,  \
+               bf16_drop_p, bf16_drop_seed)
+        if (stream_dtype == MTL_BF16) { if (rms) MTL_NORM_BWD(true, bf16_t); else MTL_NORM_BWD(false, bf16_t); }
+        else { if (rms) MTL_NORM_BWD(true, float); else MTL_NORM_BWD(false, float); }
+#undef MTL_NORM_BWD
         MTL_CHECK_LAUNCH();
         return MTL_OK;
     };
@@ -227,26 +293,6 @@ extern "C" int mtl_norm_bwd(const void* dy, int64_t ld_dy, const float* x, const
                             const float* dres_in, float* dres_out, void* dres_out_bf16, int64_t M, int64_t d, int rms,
                             int64_t group_rows, int64_t group_stride, int64_t row_offset, int stats_physical,
                             float bf16_drop_p, uint32_t bf16_drop_seed, void* stream) {
-    if (!dy || !x || !gamma || !stats || !dres_out || M <= 0 || d <= 0 || bf16_drop_p < 0.f || bf16_drop_p >= 1.f) return MTL_ERR_ARG;
-    if (d % 4 != 0 || ld_dy % 4 != 0) return MTL_ERR_ALIGN;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const dim3 block(256);
-    auto go = [&](auto nv) -> int {
-        constexpr int NV = decltype(nv)::value;
-        constexpr int WPR = NV >= 8 ? 4 : 1;
-        const dim3 grid((unsigned)((M + 4 / WPR - 1) / (4 / WPR)));
-        char kname[64];
-        snprintf(kname, sizeof kname, "norm_bwd_kernel<%d, %s>", NV, rms ? "true" : "false");
-        // bf16 dy + fp32 x in (+ fp32 incoming residual gradient), fp32 residual gradient out (+ its bf16 copy)
-        const double bytes = (double)M * d * (2 + 4 + (dres_in ? 4 : 0) + 4 + (dres_out_bf16 ? 2 : 0)) + (double)M * 8;
-        if (rms)
-            MTL_LAUNCH(kname, bytes, 1, (norm_bwd_kernel<NV, true, WPR>), grid, block, 0, st, (const bf16_t*)dy, ld_dy, x, gamma, stats, dres_in,
-                       dres_out, (bf16_t*)dres_out_bf16, M, (int)d, group_rows, group_stride, row_offset, stats_physical, bf16_drop_p, bf16_drop_seed);
-        else
-            MTL_LAUNCH(kname, bytes, 1, (norm_bwd_kernel<NV, false, WPR>), grid, block, 0, st, (const bf16_t*)dy, ld_dy, x, gamma, stats, dres_in,
-                       dres_out, (bf16_t*)dres_out_bf16, M, (int)d, group_rows, group_stride, row_offset, stats_physical, bf16_drop_p, bf16_drop_seed);
-        MTL_CHECK_LAUNCH();
-        return MTL_OK;
-    };
-    return dispatch_nv<false>(d, go);
+    return mtl_norm_bwd_t(dy, ld_dy, x, MTL_F32, gamma, stats, dres_in, dres_out, dres_out_bf16, M, d, rms, group_rows, group_stride, row_offset,
+                          stats_physical, bf16_drop_p, bf16_drop_seed, stream);
 }

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("MTL_LIB_PATH") or os.path.join(_HERE, "libmedtsllm_hi
 MTL_F32, MTL_BF16 = 0, 1
 EPI_STORE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_ACCUM, EPI_SWIGLU, EPI_DSWIGLU = 0, 1, 2, 3, 4, 5, 6
 ARCH_GPT2, ARCH_LLAMA = 0, 1
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 i64, vp, f32, i32 = C.c_int64, C.c_void_p, C.c_float, C.c_int
 
@@ -85,7 +85,7 @@ class BackboneWeights(C.Structure):
                 ("w_fc", PP), ("w_fc_t", PP), ("b_fc", PP),
                 ("w_proj", PP), ("w_proj_t", PP), ("b_proj", PP),
                 ("ln1_w", PP), ("ln1_b", PP), ("ln2_w", PP), ("ln2_b", PP),
-                ("lnf_w", vp), ("lnf_b", vp), ("rope_cos", vp), ("rope_sin", vp)]
+                ("lnf_w", vp), ("lnf_b", vp), ("rope_cos", vp), ("rope_sin", vp), ("stream_dtype", i32)]
 
 
 # name -> (restype, argtypes); every symbol include/medtsllm_hip.h declares
@@ -121,6 +121,8 @@ SIGNATURES = {
     "mtl_attention_bwd": (i32, [C.POINTER(AttnBwdArgs), vp]),
     "mtl_norm_fwd": (i32, [vp, vp, vp, vp, i64, vp, i64, i64, f32, i32, i64, i64, i64, i32, vp]),
     "mtl_norm_bwd": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, i64, i64, i32, i64, i64, i64, i32, f32, C.c_uint32, vp]),
+    "mtl_norm_fwd_t": (i32, [vp, i32, vp, vp, vp, i64, vp, i64, i64, f32, i32, i64, i64, i64, i32, vp]),
+    "mtl_norm_bwd_t": (i32, [vp, i64, vp, i32, vp, vp, vp, vp, vp, i64, i64, i32, i64, i64, i64, i32, f32, C.c_uint32, vp]),
     "mtl_dropout_f32": (i32, [vp, vp, i64, i64, f32, C.c_uint32, vp]),
     "mtl_rope_inplace": (i32, [vp, i64, vp, vp, i64, i64, i64, i64, i32, vp]),
     "mtl_rope_inplace_rows": (i32, [vp, i64, vp, vp, i64, i64, i64, i64, i32, i64, i64, i64, vp]),
@@ -129,6 +131,8 @@ SIGNATURES = {
     "mtl_swiglu_bwd": (i32, [vp, vp, vp, i64, i64, vp]),
     "mtl_assemble_llm_input": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, f32, C.c_uint32, vp]),
     "mtl_assemble_bwd": (i32, [vp, vp, i64, i64, i64, i64, f32, C.c_uint32, vp]),
+    "mtl_assemble_llm_input_t": (i32, [vp, i64, vp, vp, vp, vp, i32, i64, i64, i64, i64, f32, C.c_uint32, vp]),
+    "mtl_assemble_bwd_t": (i32, [vp, i32, vp, i64, i64, i64, i64, f32, C.c_uint32, vp]),
     "mtl_input_stats_workspace_bytes": (C.c_size_t, [i64, i64, i64]),
     "mtl_input_stats": (i32, [vp, vp, vp, vp, C.c_size_t, i64, i64, i64, i64, i64, vp]),
     "mtl_backbone_saved_bytes": (C.c_size_t, [C.POINTER(BackboneWeights), i64, i64]),

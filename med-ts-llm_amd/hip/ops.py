@@ -385,12 +385,13 @@ def swiglu_bwd(gu, dh, interleaved=False):
     return dgu
 
 
-def assemble_llm_input(ids, embed, x_tok, wpe, drop=(0.0, 0)):
+def assemble_llm_input(ids, embed, x_tok, wpe, drop=(0.0, 0), out_dtype=F32):
+    """out_dtype: the residual stream's dtype (fp32; bf16 = the reference's setup.dtype "bf16")"""
     B, P, d = x_tok.shape
     n_tok = 0 if ids is None else ids.shape[1]
-    h0 = torch.empty((B, n_tok + P, d), dtype=F32, device=x_tok.device)
-    check(lib().mtl_assemble_llm_input(ptr(ids), 0 if ids is None else ids.shape[0], ptr(embed), ptr(x_tok), ptr(wpe), ptr(h0),
-                                       B, n_tok, P, d, float(drop[0]), int(drop[1]) & 0xFFFFFFFF, stream()), "mtl_assemble_llm_input")
+    h0 = torch.empty((B, n_tok + P, d), dtype=out_dtype, device=x_tok.device)
+    check(lib().mtl_assemble_llm_input_t(ptr(ids), 0 if ids is None else ids.shape[0], ptr(embed), ptr(x_tok), ptr(wpe), ptr(h0), _dt(h0),
+                                         B, n_tok, P, d, float(drop[0]), int(drop[1]) & 0xFFFFFFFF, stream()), "mtl_assemble_llm_input")
     return h0
 
 
@@ -399,7 +400,7 @@ def assemble_bwd(dh0, n_tok, drop=(0.0, 0)):
     dh0 = dh0.contiguous()
     B, T, d = dh0.shape
     out = torch.empty((B, T - n_tok, d), dtype=BF16, device=dh0.device)
-    check(lib().mtl_assemble_bwd(ptr(dh0), ptr(out), B, n_tok, T - n_tok, d, float(drop[0]), int(drop[1]) & 0xFFFFFFFF, stream()), "mtl_assemble_bwd")
+    check(lib().mtl_assemble_bwd_t(ptr(dh0), _dt(dh0), ptr(out), B, n_tok, T - n_tok, d, float(drop[0]), int(drop[1]) & 0xFFFFFFFF, stream()), "mtl_assemble_bwd")
     return out
 
 
@@ -749,16 +750,16 @@ class AssembleFn(torch.autograd.Function):
     """h0 = cat[embed[ids], x_tok] (+ wpe) in fp32 (R:models/medtsllm.py:331-337,349; HF gpt2 :576-577)."""
 
     @staticmethod
-    def forward(ctx, x_tok, ids, embed, wpe, drop_p=0.0, drop_seed=0):
+    def forward(ctx, x_tok, ids, embed, wpe, drop_p=0.0, drop_seed=0, out_dtype=F32):
         """drop_p > 0: GPT-2's embd_pdrop fused into the assembly (same mask as EmbdDropoutFn on the assembled tensor)"""
         ctx.drop = (float(drop_p), int(drop_seed))
-        h0 = assemble_llm_input(ids, embed, x_tok.contiguous(), wpe, ctx.drop)
+        h0 = assemble_llm_input(ids, embed, x_tok.contiguous(), wpe, ctx.drop, out_dtype)
         ctx.n_tok = 0 if ids is None else ids.shape[1]
         return h0
 
     @staticmethod
     def backward(ctx, dh0):
-        return assemble_bwd(dh0, ctx.n_tok, ctx.drop), None, None, None, None, None
+        return assemble_bwd(dh0, ctx.n_tok, ctx.drop), None, None, None, None, None, None
 
 
 def dropout_f32(x, p, seed, out=None):
@@ -775,12 +776,12 @@ class EmbdDropoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h0, p, seed):
         ctx.meta = (p, seed)
-        return dropout_f32(h0, p, seed)
+        return dropout_f32(h0, p, seed) if h0.dtype == F32 else dropout_f32(h0.float(), p, seed).to(h0.dtype)     # (bf16 stream: rare path, "examples")
 
     @staticmethod
     def backward(ctx, dh):
         p, seed = ctx.meta
-        return dropout_f32(dh, p, seed), None, None
+        return (dropout_f32(dh, p, seed) if dh.dtype == F32 else dropout_f32(dh.float(), p, seed).to(dh.dtype)), None, None
 
 
 class BackboneFn(torch.autograd.Function):

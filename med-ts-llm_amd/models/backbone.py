@@ -98,7 +98,13 @@ def normalise_config(cfg):
 class FrozenBackbone:
     """Device-resident frozen stack. Not an nn.Module on purpose: nothing here is a parameter of the trainer."""
 
-    def __init__(self, cfg, state_dict, device, n_layers=-1):
+    def __init__(self, cfg, state_dict, device, n_layers=-1, stream_dtype=F32):
+        """stream_dtype: dtype of the residual stream through the stack — fp32 (the reference's setup.dtype = "mixed" / "fp32") or bf16 (its
+        setup.dtype = "bf16", R:tasks/base.py:261-262: the whole model is cast to bf16, so norm parameters, biases and position embeddings hold
+        bf16 VALUES there too: they are rounded here, once, and kept as fp32 arrays for the kernels)"""
+        if stream_dtype not in (F32, BF16):
+            raise ValueError(f"residual stream dtype {stream_dtype}: fp32 or bf16")
+        self.stream_dtype = stream_dtype
         self.cfg = c = normalise_config(cfg)
         if 0 < n_layers < c["n_layers"]:     # R:models/medtsllm.py:145-146 (llm_layers)
             c["n_layers"] = n_layers
@@ -112,7 +118,8 @@ class FrozenBackbone:
             return t.to(dev, BF16).contiguous()
 
         def f32(t):
-            return t.to(dev, F32).contiguous()
+            t = t.to(dev, F32)
+            return (t.to(BF16).to(F32) if stream_dtype == BF16 else t).contiguous()
 
         k = {n: [] for n in ("w_qkv", "w_qkv_t", "b_qkv", "w_o", "w_o_t", "b_o", "w_fc", "w_fc_t", "b_fc", "w_proj", "w_proj_t",
                              "b_proj", "ln1_w", "ln1_b", "ln2_w", "ln2_b")}
@@ -148,7 +155,7 @@ class FrozenBackbone:
             self.wpe = None
             emb = sd["embed_tokens.weight"]
             self.rope = {}
-        self.embed_f32 = f32(emb)            # [V_full, d] prompt-token gather table
+        self.embed_f32 = emb.to(dev, F32).contiguous()            # [V_full, d] prompt-token gather table (the bf16-stream assembly kernel rounds what it gathers)
         self._arrays = {n: _ptr_array(v) for n, v in k.items() if v}
         self._structs = {}
 
@@ -176,6 +183,7 @@ class FrozenBackbone:
                 setattr(w, n, C.cast(self._arrays[n], N.PP))
         w.lnf_w = self.lnf_w.data_ptr()
         w.lnf_b = self.lnf_b.data_ptr() if self.lnf_b is not None else None
+        w.stream_dtype = N.MTL_BF16 if self.stream_dtype == BF16 else N.MTL_F32
         if self.arch == "llama":
             cos, sin = self._rope(T)
             w.rope_cos, w.rope_sin = cos.data_ptr(), sin.data_ptr()
@@ -212,12 +220,14 @@ class FrozenBackbone:
         return cache, n_prefix
 
     def run_forward(self, h0, n_last, keep=True, drop=None, n_save=None, prefix=None):
-        """h0 f32 [B,T,d] (wpe already added for GPT-2) -> (out bf16 [B,n_last,d], saved buffer).
+        """h0 [B,T,d] of the stream dtype (wpe already added for GPT-2) -> (out bf16 [B,n_last,d], saved buffer).
         prefix = (cache, n_prefix) from prefix_cache(): forward on the last T - n_prefix rows of every sample only.
         drop = (attn_p, resid_p, seed): GPT-2's train-mode dropouts inside the stack (the backward needs the same tuple).
         n_save: trailing tokens per sample whose backward-only state (MLP pre-activations) is stored — the n_grad the backward
         will use; default all T when the buffer is kept, 0 otherwise."""
         B, T, d = h0.shape
+        if h0.dtype != self.stream_dtype:
+            raise ValueError(f"backbone input is {h0.dtype}, the stack was prepared for a {self.stream_dtype} residual stream")
         n_save = (T if keep else 0) if n_save is None else min(max(int(n_save), 0), T)
         if self.arch == "gpt2" and T > self.cfg["n_positions"]:
             raise ValueError(f"sequence length {T} exceeds GPT-2's {self.cfg['n_positions']} learned positions")
@@ -241,7 +251,7 @@ class FrozenBackbone:
         if tap is not None:      # parity tests: the fp32 residual stream after the requested layers, rows of the last n_last tokens of every sample
             for layer in list(tap):
                 off = lib.mtl_backbone_saved_hidden_offset(C.byref(w), B, T, int(layer))
-                tap[layer] = saved[off:off + B * T * d * 4].view(torch.float32).view(B, T, d)[:, T - n_last:, :].clone()
+                tap[layer] = saved[off:off + B * T * d * h0.element_size()].view(h0.dtype).view(B, T, d)[:, T - n_last:, :].clone()
         return out, (saved if keep else None)
 
     def run_backward(self, h0, dout, saved, n_last, n_grad=None, drop=None):

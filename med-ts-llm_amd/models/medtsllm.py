@@ -195,8 +195,11 @@ class MedTsLLM(nn.Module):
             raise ValueError(f"HIP attention kernels support head dims 32/64/128 (d_ff={self.d_ff}, backbone head_dim={self._head_dim})")
         if (self.n_attention_heads * self.d_ff) % 64 or self.d_llm % 64:
             raise ValueError("HIP GEMMs need n_heads*d_ff and d_llm to be multiples of 64")
-        if self.backbone is None or self.backbone.device != device:
-            self.backbone = FrozenBackbone(self._hf_cfg, self._hf_state, device, n_layers=self.llm_layers)
+        # setup.dtype = "bf16" (R:tasks/base.py:261-262: the whole model in bf16): bf16 trainable parameters -> a bf16 residual stream through the
+        # frozen stack too (FrozenBackbone(stream_dtype)); fp32 parameters ("mixed" / "fp32") -> the fp32 stream
+        sdt = BF16 if self.mapping_layer.weight.dtype == BF16 else torch.float32
+        if self.backbone is None or self.backbone.device != device or self.backbone.stream_dtype != sdt:
+            self.backbone = FrozenBackbone(self._hf_cfg, self._hf_state, device, n_layers=self.llm_layers, stream_dtype=sdt)
             bb = self.backbone
             V, d = self.vocab_size, self.d_llm
             Vp = pad_vocab(V + 1) if not self.word_embeddings.requires_grad else pad64(V + 1)
@@ -531,7 +534,7 @@ class MedTsLLM(nn.Module):
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if llm_drop else 0          # host RNG: no device sync
         embd_p = bb.cfg["embd_pdrop"] if llm_drop else 0.0
         fuse_embd = embd_p > 0 and splice is None           # (spliced examples are added before the dropout: separate pass there)
-        h0 = AssembleFn.apply(x_tok, ids, bb.embed_f32, bb.wpe, embd_p if fuse_embd else 0.0, seed ^ 0x5bd1e995)
+        h0 = AssembleFn.apply(x_tok, ids, bb.embed_f32, bb.wpe, embd_p if fuse_embd else 0.0, seed ^ 0x5bd1e995, bb.stream_dtype)
         # only the x_tok rows of h0 have a trainable ancestor: prompt-row gradients are dead
         n_grad = x_tok.shape[1] if self.prune_dead_prompt_grads else None
         if splice is not None:
@@ -540,7 +543,7 @@ class MedTsLLM(nn.Module):
             rows = pos[:, None] + torch.arange(emb.shape[1], device=pos.device)[None, :]
             bidx = torch.arange(emb.shape[0], device=pos.device)[:, None].expand_as(rows)
             delta = emb.float() - bb.embed_f32[self._get_tokenizer().pad_token_id]
-            h0 = h0.index_put((bidx, rows), delta, accumulate=True)
+            h0 = h0.index_put((bidx, rows), delta.to(h0.dtype), accumulate=True)
             if n_grad is not None:                       # gradients are alive from the first example row on
                 n_grad = h0.shape[1] - splice["first"]
         drop = None

@@ -196,7 +196,7 @@ class AllGatherRows(torch.autograd.Function):
 
 
 class FlatGradAllReduce:
-    """Averages the trainable gradients over the ranks through a few large flat fp32 buffers.
+    """Averages the trainable gradients over the ranks through a few large flat buffers (fp32; bf16 for an all-bf16 model).
 
     Buckets are filled in REVERSE parameter order (the order backward produces gradients: the output head first, the
     patch/reprogramming front end last) and each bucket's all-reduce is launched asynchronously from a
@@ -224,7 +224,12 @@ class FlatGradAllReduce:
         dev = self.params[0].device if self.params else "cpu"
         # + one control slot behind the gradients (it travels in the LAST bucket launched): the ranks' pre-emption flag, so that a
         # decision every rank must take together (checkpoint and exit: collectives) costs no collective of its own
-        self.flat = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        # the buckets take the parameters' dtype: fp32 masters ("mixed" / "fp32"), or bf16 when the whole model is bf16 (setup.dtype = "bf16":
+        # p.grad must have p's dtype, and a bf16 model's gradients are bf16 tensors in the reference too). One dtype per model.
+        dts = {p.dtype for p in self.params}
+        if len(dts) > 1:
+            raise ValueError(f"FlatGradAllReduce: trainable parameters of several dtypes {sorted(map(str, dts))} (one flat buffer, one dtype)")
+        self.flat = torch.zeros(n + 1, dtype=dts.pop() if dts else torch.float32, device=dev)
         self._flag = False
         self.buckets, self._where = [], {}
         off, cur = 0, None

@@ -90,12 +90,11 @@ class BaseTask(ABC):
             raise ValueError(f"setup.dtype = {config.setup.dtype!r} (fp16 parameters) is not supported by the MI355X path: use "
                              "\"mixed\" (fp32 masters, bf16 operands — the reference's default), \"bf16\" or \"fp32\"")
         # setup.dtype = "bf16" (R:tasks/base.py:261-262,205-208: the whole model and every floating-point input are cast to bf16, no autocast):
-        # the trainable parameters ARE bf16 here too (checkpoints, optimiser updates, gradients in bf16; Adam's moments stay fp32), the inputs
-        # arrive in bf16 and the prediction leaves in bf16. Between those roundings the kernels run exactly as in "mixed" (bf16 MFMA operands,
-        # fp32 accumulation / residual stream / statistics), i.e. closer to fp32 than the reference's bf16 ATen ops.
+        # NATIVE since round 6 — the trainable parameters are bf16 (checkpoints, optimiser updates, gradients in bf16; Adam's moments stay fp32), the
+        # inputs arrive in bf16, the prediction leaves in bf16, and the frozen stack runs on a bf16 RESIDUAL STREAM (FrozenBackbone(stream_dtype):
+        # bf16 hidden states saved for the backward, every residual add rounded to bf16, a bf16 gradient stream) — half the stream's HBM bytes of
+        # "mixed". Data parallel: the gradient buckets take the parameters' dtype (parallel.FlatGradAllReduce).
         self.rank, self.world_size, self.local_rank = parallel.init_from_env(self.device.type)
-        if self.dtype == torch.bfloat16 and self.world_size > 1:
-            raise NotImplementedError("setup.dtype = \"bf16\" with data parallelism: the gradient buckets are fp32 views (use \"mixed\")")
         if self.device.type == "cuda" and self.world_size > 1:
             self.device = torch.device("cuda", self.local_rank % torch.cuda.device_count())
         if self.world_size > 1:

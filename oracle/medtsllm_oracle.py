@@ -232,6 +232,7 @@ def llama_forward(h, w, cfg):
     hd = cfg.get("head_dim") or d // H
     eps = cfg["rms_norm_eps"]
     cos, sin = rope_tables(T, hd, cfg["rope_theta"])
+    cos, sin = cos.to(h.dtype), sin.to(h.dtype)          # HF:models/llama/modeling_llama.py:126-127 (tables in the hidden states' dtype)
     for i in range(cfg["num_hidden_layers"]):
         pre = f"layers.{i}."
         x = rms_norm(h, w[pre + "input_layernorm.weight"], eps)

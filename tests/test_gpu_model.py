@@ -86,8 +86,9 @@ def _check_full_model(kind, task, B, L, C, pred, cov, down, prompt_on, d_model=8
                       hf=None, sd=None, prompting=None, descriptions=None, llm_layers=-1, dataset=None, pure_bf16=False):
     """hf / sd: a full backbone config + CPU fp32 state dict instead of the small helpers.hf_cfg(kind) one (tests/test_gpu_realwidth.py);
     prompting: the config's prompting table as shipped (overrides prompt_on); descriptions: per-sample clip descriptions (`clip` prompts).
-    pure_bf16: setup.dtype = "bf16" (R:tasks/base.py:261-262,205-208) — model.to(bf16), bf16 inputs; the oracle gets the SAME bf16-rounded
-    parameters and inputs in fp32 (the reference itself refuses bf16 on a CPU, R:tasks/base.py:269-270: no golden can be captured)."""
+    pure_bf16: setup.dtype = "bf16" (R:tasks/base.py:261-262,205-208) — model.to(bf16), bf16 inputs, bf16 residual stream; the oracle gets the SAME
+    bf16-rounded parameters and inputs in fp32, and the yardstick is the oracle run with everything cast to bf16 (tests/golden/rw_*_bf16 pin the
+    same mode against the reference model itself)."""
     from med_ts_llm_amd.models import model_lookup
     from med_ts_llm_amd.models.backbone import random_state_dict
     from med_ts_llm_amd.utils import dict_to_object
@@ -154,10 +155,17 @@ def _check_full_model(kind, task, B, L, C, pred, cov, down, prompt_on, d_model=8
     assert pred_hip.dtype == (BF16 if pure_bf16 else ref.dtype) or not pure_bf16
     # L3 bar = 1.5 x the reference's OWN bf16-vs-fp32 deviation on THIS model: the oracle run under CPU bf16 autocast is
     # the reference's dtype="mixed" arithmetic (same ATen autocast policy: bf16 linear/matmul, fp32 norm/softmax).
-    p16 = {n: t.detach().clone().requires_grad_(t.requires_grad) for n, t in p.items()}
+    # pure_bf16 (round 6: the HIP path runs its NATIVE bf16 mode there — bf16 residual stream): the yardstick is the reference's dtype = "bf16"
+    # arithmetic instead — the same oracle with every parameter, frozen weight and input cast to bf16, no autocast (R:tasks/base.py:261-262)
+    p16 = {n: (t.detach().to(BF16) if pure_bf16 else t.detach().clone()).requires_grad_(t.requires_grad) for n, t in p.items()}
     we_kw16 = {"word_emb": p16["word_embeddings"]} if trainable_emb else {}
-    with torch.autocast("cpu", dtype=torch.bfloat16):
-        ref16 = O.medtsllm_forward(x, p16, sd, cfg, m, token_ids=tok_ids, pad_token_id=model.tokenizer.pad_token_id, training=True, **we_kw16)
+    if pure_bf16:
+        sd16 = {k: v.to(BF16) if v.is_floating_point() else v for k, v in sd.items()}
+        ref16 = O.medtsllm_forward(x.to(BF16), p16, sd16, cfg, m, token_ids=tok_ids, pad_token_id=model.tokenizer.pad_token_id, training=True, **we_kw16)
+        del sd16
+    else:
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            ref16 = O.medtsllm_forward(x, p16, sd, cfg, m, token_ids=tok_ids, pad_token_id=model.tokenizer.pad_token_id, training=True, **we_kw16)
     self_err = rel_err(ref16.float(), ref)
     bar = fwd_bar(self_err)
     e = rel_err(pred_hip, ref)
@@ -171,8 +179,11 @@ def _check_full_model(kind, task, B, L, C, pred, cov, down, prompt_on, d_model=8
     else:
         tgt = torch.randn(ref.shape, generator=g)
     golden_loss(ref, tgt, task).backward()
-    with torch.autocast("cpu", dtype=torch.bfloat16):
-        l16 = golden_loss(ref16, tgt, task)
+    if pure_bf16:
+        l16 = golden_loss(ref16.float(), tgt, task)
+    else:
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            l16 = golden_loss(ref16, tgt, task)
     l16.backward()
     loss = golden_loss(pred_hip, tgt.cuda().to(pred_hip.dtype) if (pure_bf16 and tgt.is_floating_point()) else tgt.cuda(), task)
     loss.backward()

@@ -124,7 +124,10 @@ def test_hip_vs_reference_real_width(name):
     assert not unexpected and set(missing) <= {"word_embeddings"}, (missing, unexpected)
     del backbone, params
     # long sequences (interleave: ~1 600 query rows per sample against 64 shared prototypes): helpers.LONGT_GRAD_FACTOR, as tests/test_gpu_longT.py
-    check_hip_vs_golden(model.to("cuda"), meta, data, bcfg, name, **({"grad_bar": LONGT_GRAD_FACTOR} if meta["covariate_mode"] == "interleave" else {}))
+    # fixtures whose second reference run is the all-bf16 one (R:tasks/base.py:261-262): the HIP model in its native bf16 mode (bf16 parameters, bf16
+    # inputs, bf16 residual stream) against the fp32 reference, yardstick = the reference-bf16 run's own deviation
+    model = model.to("cuda", torch.bfloat16) if meta.get("second_run") == "bf16" else model.to("cuda")
+    check_hip_vs_golden(model, meta, data, bcfg, name, **({"grad_bar": LONGT_GRAD_FACTOR} if meta["covariate_mode"] == "interleave" else {}))
 
 
 # ----------------------------------------------------------------------------- a10 at the real width: the reference TRAINER's 8-step run
