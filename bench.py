@@ -270,7 +270,7 @@ def table_lookup(table, kernel):
     return None
 
 
-def live_pmc_traffic(workload, kernels, timeout_s=150.0):
+def live_pmc_traffic(workload, kernels, timeout_s=150.0, extra_args=()):
     """HBM bytes per launch of `kernels`, measured NOW by this run: two child runs of this very workload (3 steps, nothing else) under
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` — separate passes, counters only beside the kernel trace, units and
     the gfx950 read-side correction as GUIDE MI355X_MICROARCH §HBM prescribes (tools/pmc_traffic.py holds the arithmetic). Returns
@@ -293,7 +293,8 @@ def live_pmc_traffic(workload, kernels, timeout_s=150.0):
     per = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", os.path.join(tmp, counter), "-o", "r", "--", sys.executable, os.path.abspath(__file__),
-               "--workload", workload, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-extra-configs", "--no-live-traffic"]
+               "--workload", workload, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-extra-configs", "--no-live-traffic",
+               *extra_args]
         p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
         try:
             rc = p.wait(timeout=timeout_s)
@@ -478,6 +479,11 @@ def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline, legs=T
     torch.manual_seed(0)
     model = model_lookup["medtsllm"](dict_to_object(model_cfg(L, pred, task, cov)), DS(C_, 4 if task == "semantic_segmentation" else 0),
                                      backbone_state=(hf_cfg, sd)).to(device)
+    # --dtype bf16: the reference's setup.dtype = "bf16" (R:tasks/base.py:261-262,205-208): parameters, inputs and — natively since round 6 — the
+    # residual stream of the frozen stack in bf16, no autocast. A separately reported configuration: the headline stays the reference default "mixed".
+    pure_bf16 = getattr(args, "dtype", "mixed") == "bf16"
+    if pure_bf16:
+        model = model.to(torch.bfloat16)
     prompt_ids = torch.randint(0, hf_cfg["vocab_size"], (1, n_tok), generator=torch.Generator().manual_seed(1), dtype=torch.int32)
     model.fixed_prompt_ids = prompt_ids
     model.prune_dead_prompt_grads = not args.full_backward
@@ -512,10 +518,12 @@ def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline, legs=T
     sync = parallel.FlatGradAllReduce(params, force_collectives=force) if dp else None
     loss_fn = torch.nn.MSELoss() if task != "semantic_segmentation" else torch.nn.CrossEntropyLoss()
     batches = [make_batch(B, L, C_, pred, 1000 + rank * 97 + i, device, task) for i in range(4)]
+    if pure_bf16:
+        batches = [{k: (v.to(torch.bfloat16) if v.is_floating_point() else v) for k, v in b.items()} for b in batches]
 
     def step(i):
         inputs = batches[i % len(batches)]
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=True):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not pure_bf16):
             pred_ = model(inputs)
             loss = loss_fn(pred_ if task != "semantic_segmentation" else pred_.permute(0, 2, 1), inputs["y"])
         loss.backward()
@@ -630,7 +638,8 @@ def run_workload(name, args, ctx, steps, warmup, want_cpu, want_roofline, legs=T
             "metric": "samples/sec (1024-step, 12-ch windows) through MedTsLLM fwd+bwd", "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{name}: [B={B}/GPU, L={L}, C={C_}] windows, P={P}, prompt {n_tok} tok -> T={T}, "
+            "setup_dtype": "bf16" if pure_bf16 else "mixed",
+            "config": {"workload": f"{name}{'@bf16' if pure_bf16 else ''}: [B={B}/GPU, L={L}, C={C_}] windows, P={P}, prompt {n_tok} tok -> T={T}, "
                                    f"frozen {name.split('_')[0] + '-' + name.split('_')[1] if big else 'GPT-2-small'} (random init) backbone, {cov} covariates, "
                                    f"{task} pred_len={pred}, training.dropout=0.1 (patch-embedding + reprogramming-attention dropout live"
                                    f"{', GPT-2 embd/attn/resid dropouts live' if (not big and not args.no_llm_dropout) else ''}), "
@@ -749,6 +758,8 @@ def compact_line(out):
             "cpu_baseline": ({"value": cb["value"], "cores": cb["cores"], "extrapolated": cb.get("extrapolated", False)} if cb else None)}
         if not _check_line(e):                     # (self-check: a whole-step MFMA fraction above the fastest GEMM's would be a wrong FLOP count)
             entry["checks"] = {"step_frac_le_best_kernel_frac": False}
+        if e.get("roofline_step"):
+            entry["hbm_bytes_per_step"] = e["roofline_step"]["bytes_per_step"]
         if "interleave" in entry["workload"]:      # the one config whose step is attention-heavy
             entry["roofline_attention"] = {"kernel": _short_kernel(ra.get("kernel")), "frac": ra.get("frac"), "executed_frac": ra.get("executed_frac")}
         c["configs"].append(entry)
@@ -782,6 +793,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="gpt2s_B32_L1024_C12", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="mixed", choices=["mixed", "bf16"], help="the reference's setup.dtype: mixed (default: fp32 masters and residual stream, bf16 "
+                    "operands) or bf16 (parameters, inputs and the residual stream in bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dp-plumbing", action="store_true", help="N = 1 only: run the step with the DP machinery live in a one-rank RCCL group")
@@ -893,6 +906,8 @@ def main():
     # fenced: a failure there is reported in the line's place, never instead of the headline.
     if args.workload == "gpt2s_B32_L1024_C12" and not args.no_extra_configs and (world == 1 or args.extra_configs_dp):
         extras = [
+            # the metric workload under setup.dtype = "bf16" (native bf16 residual stream, round 6): never the headline, reported next to it
+            ("gpt2s_B32_L1024_C12@bf16", 10, 3, "samples/sec (1024-step, 12-ch windows) through MedTsLLM fwd+bwd, setup.dtype = bf16"),
             # BASELINE.json configs[1] (ETTh1-shaped forecasting on GPT-2-small; configs[0] is the same case on the CPU: cpu_baseline.configs0_etth1_value)
             ("gpt2s_etth1_B32_L512_C7", 5, 2, "samples/sec ([B, 512, 7] ETTh1-shaped windows, GPT-2-small) through MedTsLLM fwd+bwd"),
             # BASELINE.json configs[2] (LUDB-shaped semantic segmentation on a frozen Llama-2-7B): the configuration where the backbone GEMMs are
@@ -907,8 +922,13 @@ def main():
         ]
         for wl, n_steps, n_warm, metric in extras:
             stage(f"start {wl}")
+            a_x = args
+            if wl.endswith("@bf16"):
+                import copy
+                a_x, wl = copy.copy(args), wl[:-len("@bf16")]
+                a_x.dtype = "bf16"
             try:
-                extra = run_workload(wl, args, ctx, steps=n_steps, warmup=n_warm, want_cpu=full and not args.no_cpu_baseline,
+                extra = run_workload(wl, a_x, ctx, steps=n_steps, warmup=n_warm, want_cpu=full and not args.no_cpu_baseline,
                                      want_roofline=not args.no_roofline, legs=full, stage=stage)
             except Exception as e:      # noqa: BLE001 — the headline is already measured: keep it
                 if world > 1:
@@ -918,6 +938,13 @@ def main():
                 continue
             if rank == 0:
                 extra["metric"] = metric
+                if a_x is not args and world == 1 and not args.no_live_traffic and not args.no_roofline:
+                    # the bf16 configuration's whole-step HBM traffic next to the headline's roofline_step (what the bf16 residual stream saves)
+                    torch.cuda.synchronize()
+                    torch.cuda.empty_cache()
+                    stage(f"live PMC passes ({wl} --dtype bf16)")
+                    _, note_x, step_x = live_pmc_traffic(wl, [], extra_args=("--dtype", "bf16"))
+                    extra["roofline_step"] = roofline_step(step_x, extra, note_x)
                 out.setdefault("configs", []).append(extra)
     if rank == 0 and out and out.get("cpu_baseline"):
         # extra configs without a measured CPU leg (--full-detail measures them): the headline's MEASURED CPU figure scaled by algorithmic FLOPs per

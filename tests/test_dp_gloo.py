@@ -298,3 +298,48 @@ def test_preflight_and_native_switch_on_a_plain_backend(monkeypatch):
     monkeypatch.setitem(parallel._NATIVE, "enabled", True)
     parallel.disable_native_collectives("test")
     assert parallel._NATIVE["enabled"] is False and parallel._NATIVE["why"] == "test"
+
+
+def _bf16_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from med_ts_llm_amd import parallel
+    parallel.init_from_env("cpu")
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3)).to(torch.bfloat16)
+    g = torch.Generator().manual_seed(1)
+    x, y = torch.randn(8, 6, generator=g).to(torch.bfloat16), torch.randn(8, 3, generator=g).to(torch.bfloat16)
+    sl = slice(rank * 4, (rank + 1) * 4)
+    torch.nn.functional.mse_loss(model(x[sl]).float(), y[sl].float()).backward()
+    sync = parallel.FlatGradAllReduce(list(model.parameters()))
+    assert sync.flat.dtype == torch.bfloat16          # setup.dtype = "bf16": the buckets take the parameters' dtype (p.grad must have it)
+    sync()
+    assert all(p_.grad.dtype == torch.bfloat16 for p_ in model.parameters())
+    grads = torch.cat([p_.grad.float().flatten() for p_ in model.parameters()])
+    if rank == 0:
+        ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+        ref.load_state_dict({k: v.float() for k, v in model.state_dict().items()})
+        torch.nn.functional.mse_loss(ref(x.float()), y.float()).backward()
+        want = torch.cat([p_.grad.flatten() for p_ in ref.parameters()])
+        q.put(bool((grads - want).norm() / want.norm() < 2e-2))        # bf16 activations, bf16 gradients, a bf16 average of two ranks
+    # a mixed-dtype parameter set is refused (one flat buffer, one dtype)
+    try:
+        parallel.FlatGradAllReduce(list(model.parameters()) + [torch.nn.Parameter(torch.zeros(3))])
+        q.put(False)
+    except ValueError:
+        pass
+    dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_with_bf16_parameters():
+    """setup.dtype = "bf16" under data parallelism (round 6: the restriction is lifted): bf16 buckets, bf16 p.grad, the global-batch gradient"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bf16_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    for p_ in procs:
+        p_.join(120)
+        assert p_.exitcode == 0
+    assert q.get(timeout=5) is True
+    assert q.empty()

@@ -314,7 +314,8 @@ def test_attention_cross_shared_kv(ops, B, L, S, H, E):
     assert torch.equal(o2, o) and torch.equal(o32.to(BF16), o)
     # the PRE-rounding output: what is left in it is the bf16 rounding of the probabilities in front of P.V — an error of
     # 2^-9 per probability that averages out over the keys — and the statistic has no rounding at all
-    assert rel_err(o32, ref.detach()) < TOL_PRE_ATTN
+    # (measured: 1.25e-3 with 32 keys — few keys to average the probabilities' 2^-9 roundings over — below 1e-3 from ~100 keys on)
+    assert rel_err(o32, ref.detach()) < (TOL_PRE_ATTN if S >= 128 else 1.5 * TOL_PRE_ATTN)
     assert rel_err(lse2, torch.logsumexp((scale * scores.detach()).double(), dim=-1)) < TOL_PRE
     dq2, dk2, dv2 = ops.attention_bwd(dev(q), dev(k), dev(v), o2, lse2, dev(do), H, H, E, scale, False, shared_kv=True, o32=o32)
     assert rel_err(dq2.float(), qf.grad) < TOL_ATTN_BWD
