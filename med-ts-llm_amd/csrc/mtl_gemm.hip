@@ -1015,6 +1015,8 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
     const uint32_t voa = (uint32_t)(drow * (int)p.lda * 2 + ((dsl ^ dsw) << 4));
     const uint32_t vob = (uint32_t)(drow * (int)p.ldb * 2 + ((dsl ^ dsw) << 4));
 
+    // (Measured and dropped, profiles/r06_gemm_w4_experiments.txt: starting XCD x late by x * 0.4 / 0.8 / 1.6 us so that the rounds' store bursts of the
+    //  eight XCDs interleave with the other XCDs' main loops — in-step Llama-2-7B 102.29 / 102.11 / 101.95 / 102.09 ms per step, i.e. nothing.)
 #ifdef MTL_DIAG_W4VAR      // phase stamps of the workgroup's FIRST tile (100 MHz realtime counter): entry, k-loop begin / end, epilogue end -> workspace[4 * block]
     uint64_t stamp[4] = {__builtin_amdgcn_s_memrealtime(), 0, 0, 0};
 #endif

@@ -41,6 +41,9 @@ __global__ __launch_bounds__(THREADS) void adam_multi_kernel(const AdamTable tab
     const bf16_t* gp16 = reinterpret_cast<const bf16_t*>(t.g);
     bf16_t* pp16 = reinterpret_cast<bf16_t*>(t.p);
     const bool vec = !p16 && (((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0;
+    // bf16 parameter + gradient: 8-byte vectors of both, 16-byte vectors of the fp32 moments (element-wise 2-byte accesses ran the [1024, 50257] mapping
+    // weight's update at 575 us against 366 us for the fp32 parameter that moves MORE bytes: profiles/r06_bf16_kernel_stats.txt)
+    const bool vec16 = p16 && (((uintptr_t)t.p | (uintptr_t)t.g) & 7) == 0 && (((uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0;
     bf16_t* sh = reinterpret_cast<bf16_t*>(t.shadow);
 #pragma unroll
     for (int i = 0; i < VEC_PER_THREAD; ++i) {
@@ -56,6 +59,13 @@ __global__ __launch_bounds__(THREADS) void adam_multi_kernel(const AdamTable tab
             gg[0] = g4.x; gg[1] = g4.y; gg[2] = g4.z; gg[3] = g4.w;
             mm[0] = m4.x; mm[1] = m4.y; mm[2] = m4.z; mm[3] = m4.w;
             vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
+        } else if (vec16 && nv == 4) {
+            const u32x2 pk = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(pp16 + e0)), gk = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(gp16 + e0));
+            const f32x4 m4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(t.m + e0)), v4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(t.v + e0));
+            pp[0] = __uint_as_float(pk[0] << 16); pp[1] = __uint_as_float(pk[0] & 0xffff0000u); pp[2] = __uint_as_float(pk[1] << 16); pp[3] = __uint_as_float(pk[1] & 0xffff0000u);
+            gg[0] = __uint_as_float(gk[0] << 16); gg[1] = __uint_as_float(gk[0] & 0xffff0000u); gg[2] = __uint_as_float(gk[1] << 16); gg[3] = __uint_as_float(gk[1] & 0xffff0000u);
+            mm[0] = m4.x; mm[1] = m4.y; mm[2] = m4.z; mm[3] = m4.w;
+            vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -69,6 +79,12 @@ __global__ __launch_bounds__(THREADS) void adam_multi_kernel(const AdamTable tab
         for (int e = 0; e < 4; ++e) pp[e] = adam_one(pp[e], gg[e], mm[e], vv[e], h);
         if (vec && nv == 4) {
             __builtin_nontemporal_store((f32x4){pp[0], pp[1], pp[2], pp[3]}, reinterpret_cast<f32x4*>(t.p + e0));
+            __builtin_nontemporal_store((f32x4){mm[0], mm[1], mm[2], mm[3]}, reinterpret_cast<f32x4*>(t.m + e0));
+            __builtin_nontemporal_store((f32x4){vv[0], vv[1], vv[2], vv[3]}, reinterpret_cast<f32x4*>(t.v + e0));
+        } else if (vec16 && nv == 4) {
+            // one rounding of the updated parameter per step; the shadow below takes the ROUNDED values, so that it stays bit-identical to the parameter
+            const u32x2 pk = {pack_bf16x2(pp[0], pp[1]), pack_bf16x2(pp[2], pp[3])};
+            __builtin_nontemporal_store(pk, reinterpret_cast<u32x2*>(pp16 + e0));
             __builtin_nontemporal_store((f32x4){mm[0], mm[1], mm[2], mm[3]}, reinterpret_cast<f32x4*>(t.m + e0));
             __builtin_nontemporal_store((f32x4){vv[0], vv[1], vv[2], vv[3]}, reinterpret_cast<f32x4*>(t.v + e0));
         } else {

@@ -459,22 +459,24 @@ class LinearFn(torch.autograd.Function):
             x2 = x2.contiguous()
         direct = Nn % 8 == 0 and _LINEAR_XT            # (row strides of dY must be whole 16-byte chunks for the K-major reads)
         use_sh = direct and shadow is not None and shadow.param is W and tuple(shadow.tensor.shape) == (Nn, Kx) and shadow.tensor.device == x.device
-        Wd = W.detach().contiguous().float()
+        def Wd():           # (only when a cast is due: with bf16 parameters — setup.dtype = "bf16" — .float() is a real pass over W)
+            return W.detach().contiguous().float()
         wb = shadow.tensor if use_sh else torch.empty((Nn, Kx), dtype=BF16, device=x.device)
         wt = None
         if use_sh:
             if not shadow.fresh():
-                cast_pad(Wd, dst=wb)
+                cast_pad(Wd(), dst=wb)
                 shadow.version = W._version
         elif direct:
-            cast_pad(Wd, dst=wb)
+            cast_pad(Wd(), dst=wb)
         else:
             Np = pad64(Nn)
             wt = torch.zeros((Kx, Np), dtype=BF16, device=x.device) if (Kx > Kin) else torch.empty((Kx, Np), dtype=BF16, device=x.device)
-            cast_pad(Wd, dst=wb, dst_t=wt)
+            cast_pad(Wd(), dst=wb, dst_t=wt)
         y = gemm_nt(x2, wb, bias=None if b is None else b.detach().float().contiguous())
         ctx.save_for_backward(x2, wb if direct else wt)
         ctx.meta = (tuple(x.shape), Nn, Kin, b is not None, direct)
+        ctx.w_dtype = W.dtype if W.dtype in (F32, BF16) else F32      # the weight gradient leaves in the parameter's dtype (no autograd cast pass)
         # the shadow is a PERSISTENT tensor that HipAdam rewrites through raw pointers (autograd's version counter never sees it):
         # remember which weight version this forward multiplied by, so that a backward after an optimiser step fails loudly
         ctx.shadow_at = (shadow, shadow.version) if use_sh else None
@@ -497,7 +499,7 @@ class LinearFn(torch.autograd.Function):
                 dx = gemm_xt(dy2, w, b_trans=True).reshape(xshape)                     # [M, Kx] = dY [M, N] . W [N, Kx]
             if ctx.needs_input_grad[1]:
                 xk = x2[:, :Kin] if Kin != Kx else x2
-                res = gemm_xt(dy2, xk, a_trans=True, b_trans=True, out_dtype=F32, want_colsum=want_b)   # [N, Kin] = dY^T . X
+                res = gemm_xt(dy2, xk, a_trans=True, b_trans=True, out_dtype=ctx.w_dtype, want_colsum=want_b)   # [N, Kin] = dY^T . X
                 dW, db = res if want_b else (res, None)
             elif want_b:
                 db = colsum(dy2)
@@ -605,6 +607,7 @@ class MappingFn(torch.autograd.Function):
         src = gemm_nt(wm, wT, split_k=split_k)
         ctx.save_for_backward(w)
         ctx.meta = (S, V)
+        ctx.w_dtype = Wmap.dtype if Wmap.dtype in (F32, BF16) else F32
         return src
 
     @staticmethod
@@ -614,7 +617,10 @@ class MappingFn(torch.autograd.Function):
         dsrc = dsrc.contiguous()
         dW = None
         if ctx.needs_input_grad[0]:                                                   # [S, V] = dsrc[S,d] @ Wemb[V,d]^T
-            dW = torch.empty((S, V), dtype=F32, device=dsrc.device)
+            # (bf16 parameters: the gradient is a bf16 tensor — written once by the GEMM; 16-byte row alignment of a [S, 50257] bf16 matrix does
+            #  not hold, so that case keeps the fp32 output + autograd's cast)
+            odt = ctx.w_dtype if (ctx.w_dtype == F32 or V % 8 == 0) else F32
+            dW = torch.empty((S, V), dtype=odt, device=dsrc.device)
             n_main = _whole_rounds_columns(S, V, dsrc.device)
             if n_main:
                 # 788 tiles of 256 x 256 on 256 CUs are 3.08 rounds = the time of 4: the columns that fill whole rounds go in one launch,
