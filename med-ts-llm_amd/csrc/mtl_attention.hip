@@ -1835,9 +1835,12 @@ void set_lds(KernelT k, size_t bytes) { (void)hipFuncSetAttribute((const void*)k
 namespace {
 
 size_t pad32(int64_t v) { return (size_t)((v + 31) & ~(int64_t)31); }
-bool resident_ok(const mtl_attn_fwd_args& f, int64_t rows) {
+// `pad`: the LDS row padding of the kernel that would run — attn_pad_res for the resident forward / the one-launch backward, attn_pad for the two-launch
+// resident dQ and dK/dV kernels (each kernel gets its own fit test: with one test on the wider padding, hd-64 causal shapes with T in (480, 512] fell
+// to the chunked backward although the two-launch resident kernels fit — ADVICE r05)
+bool resident_ok(const mtl_attn_fwd_args& f, int64_t rows, int pad) {
     return !(f.tune & 1) && f.causal && f.k_bs != 0 && f.dropout_p < 1.f && (f.D == 64 || f.D == 128) &&
-           2 * pad32(rows) * (f.D + attn_pad_res((int)f.D)) * 2 + 2 * pad32(rows) * 4 <= kLdsBudget;       // (the wider of the two paddings)
+           2 * pad32(rows) * (f.D + pad) * 2 + 2 * pad32(rows) * 4 <= kLdsBudget;
 }
 
 }  // namespace
@@ -1856,7 +1859,7 @@ extern "C" int mtl_attention_fwd(const mtl_attn_fwd_args* a, void* stream) {
     const double fl_fwd = 4.0 * (double)a->B * a->Hq * a->Tq * a->Tk * a->D;
     (void)fl_fwd;
     const bool d128_fwd = g_attn_d128 == 1 && a->causal && a->D == 128 && a->dropout_p == 0.f && !a->o_f32 && a->Tq >= 128 && a->k_bs != 0 && g_attn_wide == 1 && g_attn_w32 == 1;
-    if (resident_ok(*a, a->Tk) && !d128_fwd) {
+    if (resident_ok(*a, a->Tk, attn_pad_res((int)a->D)) && !d128_fwd) {
         const size_t lds = 2 * pad32(a->Tk) * (a->D + attn_pad_res((int)a->D)) * 2;
         const int npairs = (int)(((a->Tq + 15) / 16 + 1) / 2);
         if (a->D == 64 && a->dropout_p > 0.f) {
@@ -1953,7 +1956,7 @@ extern "C" int mtl_attention_bwd(const mtl_attn_bwd_args* a, void* stream) {
     // not counted), split evenly over the dQ kernel (dP, dQ) and the dK/dV kernel (dV, dK)
     const double fl_half = 4.0 * (double)f.B * f.Hq * f.Tq * f.Tk * f.D;
     (void)fl_half;
-    if (resident_ok(f, f.Tk) && resident_ok(f, f.Tq)) {
+    if (resident_ok(f, f.Tk, attn_pad((int)f.D)) && resident_ok(f, f.Tq, attn_pad((int)f.D))) {
         if (a->kv_row0 < 0 || a->kv_row0 >= f.Tk) return MTL_ERR_ARG;
         // few tiles on both sides (the backbone's pruned backward: n_grad query rows, dK / dV for the patch keys): ONE launch stages the head once
         const size_t lds_m = (2 * pad32(f.Tk) + 3 * pad32(f.Tq)) * (f.D + attn_pad_res((int)f.D)) * 2 + 2 * pad32(f.Tq) * 4;
