@@ -88,7 +88,7 @@ if what in ("time", "all"):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n * 1e3
 
-    print(f"{'shape':22s} {'M':>6s} {'N':>6s} {'K':>6s} | {'8-wave (shipped r5)':>22s} | {'4-wave hand-placed':>22s} | {'torch.matmul (vendor)':>22s} | vendor/w4")
+    print(f"{'shape':22s} {'M':>6s} {'N':>6s} {'K':>6s} | {'8-wave 256x256 (r5)':>22s} | {'4-wave hand-placed':>22s} | {'torch.matmul (vendor)':>22s} | vendor/w4")
     for name, M, Nn, K in SHAPES:
         A = torch.randn(M, K, generator=g).to(BF16).cuda()
         B = (torch.randn(Nn, K, generator=g) * 0.05).to(BF16).cuda()
@@ -96,14 +96,16 @@ if what in ("time", "all"):
         nB = max(2, min(24, (600 << 20) // (B.numel() * 2)))
         poolA, poolB = [A.clone() for _ in range(nA)], [B.clone() for _ in range(nB)]
         poolC = [torch.empty(M, Nn, dtype=BF16, device="cuda") for _ in range(4)]
-        t8, t4, tv = [], [], []
+        t8, t4, tv, ta = [], [], [], []
         for rnd in range(5):
             flush.fill_(rnd)
-            t8.append(timed(lambda it: ops.gemm_nt(poolA[it % nA], poolB[it % nB], out=poolC[it % 4])))
+            t8.append(timed(lambda it: run(poolA[it % nA], poolB[it % nB], False, out=poolC[it % 4])))
+            flush.fill_(rnd + 1)
+            ta.append(timed(lambda it: ops.gemm_nt(poolA[it % nA], poolB[it % nB], out=poolC[it % 4])))
             flush.fill_(rnd + 3)
             t4.append(timed(lambda it: run(poolA[it % nA], poolB[it % nB], True, out=poolC[it % 4])))
             flush.fill_(rnd + 7)
             tv.append(timed(lambda it: torch.matmul(poolA[it % nA], poolB[it % nB].t(), out=poolC[it % 4])))
-        a, b, c = sorted(t8)[2], sorted(t4)[2], sorted(tv)[2]
+        a, b, c, auto = sorted(t8)[2], sorted(t4)[2], sorted(tv)[2], sorted(ta)[2]
         fl = 2.0 * M * Nn * K
-        print(f"{name:22s} {M:6d} {Nn:6d} {K:6d} | {a:8.1f} us {fl / a / 1e6:7.0f} TF/s | {b:8.1f} us {fl / b / 1e6:7.0f} TF/s | {c:8.1f} us {fl / c / 1e6:7.0f} TF/s | {b / c:5.2f}", flush=True)
+        print(f"{name:22s} {M:6d} {Nn:6d} {K:6d} | {a:8.1f} us {fl / a / 1e6:7.0f} TF/s | {b:8.1f} us {fl / b / 1e6:7.0f} TF/s | {c:8.1f} us {fl / c / 1e6:7.0f} TF/s | {b / c:5.2f} | automatic dispatch {auto:8.1f} us = {auto / c:4.2f} x vendor", flush=True)
