@@ -66,6 +66,9 @@ __device__ __forceinline__ int64_t remap_row(int64_t m, int64_t group_rows, int6
     return (int64_t)q * group_stride + off + (int64_t)(mm - q * gr);
 }
 
+#ifndef MTL_W4_NCHW
+#define MTL_W4_NCHW 4      // column quads per epilogue chunk of the residual-type epilogues (A/B builds: -DMTL_W4_NCHW=2|4)
+#endif
 template <int EPI, int CDT>
 __device__ __forceinline__ void epilogue4(const mtl_gemm_args& p, int64_t m, int64_t n, f32x4 v, bool vec_ok) {
     const int64_t crow = remap_row(m, p.c_group_rows, p.c_group_stride, p.c_row_offset);
@@ -447,7 +450,7 @@ __device__ __forceinline__ void epi_store(const mtl_gemm_args& p, const EpiRows&
 // the next k-step's first ds_read, draining the LDS-DMA pipeline.)
 // Column tiles go NCH at a time (<= 4 in one piece; wider wave tiles 2 at a time: 64x96 .. 64x144 per wave); an odd count (NI = 9) ends with ONE
 // unpaired column tile. Per chunk: wait for its auxiliary operands, math in place, ISSUE THE NEXT CHUNK'S LOADS (into the same registers), stores.
-template <int EPI, int CDT, int NI, bool FULL, bool PAIR = false, int LAY = 0>
+template <int EPI, int CDT, int NI, bool FULL, bool PAIR = false, int LAY = 0, int NCHW = 0>      // NCHW: column tiles per chunk (0 = the rule below)
 __device__ __forceinline__ void epilogue_wave(const mtl_gemm_args& p, int64_t m_first, int64_t n_base, const int g, f32x4 (&acc)[NI][4],
                                               const bool dword_stores = false) {
     // PIPE (bias-only epilogues: plain store, GELU, SwiGLU): chunk c + 1's bias loads go out between chunk c's math and its stores, so the wait
@@ -456,7 +459,7 @@ __device__ __forceinline__ void epilogue_wave(const mtl_gemm_args& p, int64_t m_
     // auxiliary loads' own round trip, and more chunks in flight do not fit the 256-register wide-tile kernels (measured, same A/B: two chunks
     // of prefetch spilled into the main loop, 222 -> 495 us; one-tile chunks exposed 8 load round trips per tile, dSwiGLU 376 -> 402 us).
     constexpr bool PIPE = (EPI == MTL_EPI_STORE || EPI == MTL_EPI_GELU || EPI == MTL_EPI_SWIGLU);
-    constexpr int NCH = NI > 4 ? 2 : NI;
+    constexpr int NCH = NCHW > 0 ? NCHW : (NI > 4 ? 2 : NI);
     constexpr int NFULL = NI / NCH;            // whole chunks
     constexpr int NTAIL = NI - NFULL * NCH;    // 0 or 1 column tile left over
     constexpr int NPTW = PAIR ? (NI & ~1) : 0; // paired column tiles of the wave's sub-tile
@@ -1069,7 +1072,11 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
                     const int qd = (t & 3) * 4;
                     pc[t][mt] = (f32x4){v[qd], v[qd + 1], v[qd + 2], v[qd + 3]};
                 }
-            epilogue_wave<EPI, CDT, 8, true, true, 1>(p, m0 + wr * 128 + l31, n0 + wc * 128 + half * 64, h, pc);
+            // Residual-type epilogues (16 B of auxiliary operand per output quad) are load -> math -> store per CHUNK: with the 8-column "tiles" of this
+            // layout the default 2-tile chunks made 16 dependent memory round trips per wave tile (dSwiGLU: +25 us per tile over the plain store, RESID
+            // +13). The fragment registers are dead here, so 4-quad chunks (64 auxiliary VGPRs) fit: measured in the Llama-2 step dSwiGLU 377 -> 359 us, RESID flat (8-quad chunks: 363, more scratch).
+            constexpr int NCHW = (EPI == MTL_EPI_RESID || EPI == MTL_EPI_ACCUM || EPI == MTL_EPI_DGELU || EPI == MTL_EPI_DSWIGLU) ? MTL_W4_NCHW : 0;
+            epilogue_wave<EPI, CDT, 8, true, true, 1, NCHW>(p, m0 + wr * 128 + l31, n0 + wc * 128 + half * 64, h, pc);
         }
 #ifdef MTL_DIAG_W4VAR
         if (i == slot && p.workspace && threadIdx.x == 0) {
