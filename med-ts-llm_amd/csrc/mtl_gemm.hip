@@ -1020,8 +1020,8 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
 
     // (Measured and dropped, profiles/r06_gemm_w4_experiments.txt: starting XCD x late by x * 0.4 / 0.8 / 1.6 us so that the rounds' store bursts of the
     //  eight XCDs interleave with the other XCDs' main loops — in-step Llama-2-7B 102.29 / 102.11 / 101.95 / 102.09 ms per step, i.e. nothing.)
-#ifdef MTL_DIAG_W4VAR      // phase stamps of the workgroup's FIRST tile (100 MHz realtime counter): entry, k-loop begin / end, epilogue end -> workspace[4 * block]
-    uint64_t stamp[4] = {__builtin_amdgcn_s_memrealtime(), 0, 0, 0};
+#ifdef MTL_DIAG_W4VAR      // phase stamps of the workgroup's FIRST tile (100 MHz realtime counter): entry, k-loop begin / end, epilogue end -> workspace[6 * block]
+    uint64_t stamp[4] = {__builtin_amdgcn_s_memrealtime(), 0, 0, 0}, cyc[2] = {0, 0};       // cyc: the SHADER clock counter around the k-loop (cycles per k-tile, actual clock)
 #endif
     for (int i = slot; i < cnt; i += xblocks) {
         int tm, tn;
@@ -1035,17 +1035,17 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
             const int64_t arow = remap_row(m0 + row, p.a_group_rows, p.a_group_stride, p.a_row_offset);
             tab = (lane & 8) ? (uint32_t)((n0 + row) * p.ldb * 2) : (uint32_t)(arow * p.lda * 2);
         }
-        f32x16 c0, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14, c15;
-        c0 = c1 = c2 = c3 = c4 = c5 = c6 = c7 = c8 = c9 = c10 = c11 = c12 = c13 = c14 = c15 = (f32x16)(0.f);
+        f32x16 c0, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14, c15;      // write-only for the asm: the first MFMA of each takes C = 0
 #define MTL_W4_RUN(ASM)                                                                                                                                  \
     asm volatile(ASM                                                                                                                                     \
-                 : [c0] "+a"(c0), [c1] "+a"(c1), [c2] "+a"(c2), [c3] "+a"(c3), [c4] "+a"(c4), [c5] "+a"(c5), [c6] "+a"(c6), [c7] "+a"(c7),              \
-                   [c8] "+a"(c8), [c9] "+a"(c9), [c10] "+a"(c10), [c11] "+a"(c11), [c12] "+a"(c12), [c13] "+a"(c13), [c14] "+a"(c14), [c15] "+a"(c15)    \
+                 : [c0] "=&a"(c0), [c1] "=&a"(c1), [c2] "=&a"(c2), [c3] "=&a"(c3), [c4] "=&a"(c4), [c5] "=&a"(c5), [c6] "=&a"(c6), [c7] "=&a"(c7),      \
+                   [c8] "=&a"(c8), [c9] "=&a"(c9), [c10] "=&a"(c10), [c11] "=&a"(c11), [c12] "=&a"(c12), [c13] "=&a"(c13), [c14] "=&a"(c14),              \
+                   [c15] "=&a"(c15)                                                                                                                      \
                  : [pa] "s"(p.A), [pb] "s"(p.B), [voa] "v"(voa), [vob] "v"(vob), [tab] "v"(tab), [rba] "v"(rba), [xa] "v"(xa), [rbb] "v"(rbb),           \
                    [xb] "v"(xb), [nkt] "s"(nkt), [dma] "s"(dma), [rot] "s"(rot)                                                                          \
                  : MTL_W4_LOOP_CLOBBERS)
 #ifdef MTL_DIAG_W4VAR
-        if (i == slot) stamp[1] = __builtin_amdgcn_s_memrealtime();
+        if (i == slot) { stamp[1] = __builtin_amdgcn_s_memrealtime(); cyc[0] = __builtin_amdgcn_s_memtime(); }
 #endif
         if constexpr (VAR == 0) MTL_W4_RUN(MTL_W4_LOOP_ASM);
 #ifdef MTL_DIAG_W4VAR
@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
 #endif
 #undef MTL_W4_RUN
 #ifdef MTL_DIAG_W4VAR
-        if (i == slot) stamp[2] = __builtin_amdgcn_s_memrealtime();
+        if (i == slot) { cyc[1] = __builtin_amdgcn_s_memtime(); stamp[2] = __builtin_amdgcn_s_memrealtime(); }
 #endif
         // ---- epilogue: the wave's 128 x 128 as two 64-column halves of 8 quads ("column tiles" of 8) x 4 row tiles of 32
         const f32x16* cc[16] = {&c0, &c1, &c2, &c3, &c4, &c5, &c6, &c7, &c8, &c9, &c10, &c11, &c12, &c13, &c14, &c15};   // [mt * 4 + nt]
@@ -1082,8 +1082,8 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
         if (i == slot && p.workspace && threadIdx.x == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stamp[3] = __builtin_amdgcn_s_memrealtime();
-            uint64_t* o = reinterpret_cast<uint64_t*>(p.workspace) + 4 * blockIdx.x;
-            o[0] = stamp[0]; o[1] = stamp[1]; o[2] = stamp[2]; o[3] = stamp[3];
+            uint64_t* o = reinterpret_cast<uint64_t*>(p.workspace) + 6 * blockIdx.x;
+            o[0] = stamp[0]; o[1] = stamp[1]; o[2] = stamp[2]; o[3] = stamp[3]; o[4] = cyc[0]; o[5] = cyc[1];
         }
 #endif
     }

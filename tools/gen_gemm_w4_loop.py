@@ -46,10 +46,10 @@ def rd_b(s, ksl, nt, buf):
     return f"ds_read_b128 {fb(s, ksl, nt)}, v{KSB + 4 + s * 2 + ksl} offset:{buf * A_BUF + nt * 4096}"
 
 
-def mfma(m):
+def mfma(m, zero=False):
     s, ksl, nt, mt = m // 32, (m % 32) // 16, (m % 16) // 4, m % 4
     c = f"%[c{mt * 4 + nt}]"
-    return f"v_mfma_f32_32x32x16_bf16 {c}, {fb(s, ksl, nt)}, {fa(s, ksl, mt)}, {c}"
+    return f"v_mfma_f32_32x32x16_bf16 {c}, {fb(s, ksl, nt)}, {fa(s, ksl, mt)}, {'0' if zero else c}"
 
 
 def dma(op, i, pol=""):
@@ -78,8 +78,9 @@ SCHED = {
 PRODUCT_SCHED = "s3"
 
 
-def body(b, sched, var=""):
-    """one k-tile, buffer parity b. Returns the instruction list. `var`: ablation letters for the DIAGNOSTIC variants (timing only, wrong results):
+def body(b, sched, var="", first=False):
+    """one k-tile, buffer parity b. Returns the instruction list. first: the tile's first k-tile — its first 16 MFMAs (one per accumulator) take the
+    constant 0 as C, so the accumulators are write-only operands of the asm statement and nobody zero-fills 256 AGPRs per tile. `var`: ablation letters for the DIAGNOSTIC variants (timing only, wrong results):
     D = no in-loop LDS-DMA, B = no barriers, R = no fragment reads, W = no waits, V = no landing (vmcnt) wait, L = every DMA re-reads the same 8 rows"""
     sc = SCHED[sched]
     fill = {m: [] for m in range(64)}          # instructions placed AFTER MFMA m
@@ -91,7 +92,10 @@ def body(b, sched, var=""):
         fill[sc["b1"] + j].append(rd_b(s, ksl, nt, b))
     # scalar bookkeeping of the iteration: k step of this iteration's DMA (k-tile t + 2, clamped to the last one)
     fill[8] += ["s_sub_i32 s99, s99, 1", "s_cmp_eq_u32 s99, 0", "s_cselect_b32 s97, s71, 128"]
-    fill[9] += ["s_cmp_gt_i32 s98, 0", "s_cselect_b32 s97, 0, 0" if loc else "s_cselect_b32 s97, s97, 0"]
+    # the last two iterations have nothing left to stage: their 16 LDS-DMA instructions keep their slots (the counted waits stay static) but run with
+    # num_records = 0 — out of range, no memory access — instead of re-fetching the last k-tile (2 x 64 KB per tile through the L2, and a landing
+    # wait for them at the loop end)
+    fill[9] += ["s_cmp_gt_i32 s98, 0", "s_cselect_b32 s97, 0, 0" if loc else "s_cselect_b32 s97, s97, 0", "s_cselect_b32 s74, -1, 0", "s_cselect_b32 s78, -1, 0"]
     fill[10] += ["s_sub_i32 s98, s98, 1", "s_ashr_i32 s70, s97, 31"]
     fill[sc["bar1"]] += ["s_waitcnt lgkmcnt(0)", "s_barrier", "s_add_u32 s76, s76, s97", "s_addc_u32 s77, s77, s70"]
     # ---- DMA of B(t + 2) / A(t + 2) into buffer b: instruction i in slot start + step * i, its M0 (absolute) set one gap earlier
@@ -125,7 +129,7 @@ def body(b, sched, var=""):
         fill[m].append(rd_a(s, ksl, x, b ^ 1) if op == "a" else rd_b(s, ksl, x, b ^ 1))
     out = []
     for m in range(64):
-        out.append(mfma(m))
+        out.append(mfma(m, first and m < 16))
         for ins in fill[m]:
             if "D" in var and ins.startswith("buffer_load"):
                 continue
@@ -171,9 +175,9 @@ def prologue():
                 t += [f"s_add_u32 m0, m0, {PIECE}", "s_nop 0"]
         return t
     o += tile(0)
-    # k-tile 1 (clamped to the last k-tile when the tile has only one)
+    # k-tile 1 (a tile with one k-tile: out of range, nothing fetched)
     o += ["s_sub_i32 s99, s99, 1", "s_cmp_eq_u32 s99, 0", "s_cselect_b32 s97, s71, 128",
-          "s_cmp_gt_i32 %[nkt], 1", "s_cselect_b32 s97, s97, 0", "s_ashr_i32 s70, s97, 31",
+          "s_cmp_gt_i32 %[nkt], 1", "s_cselect_b32 s97, s97, 0", "s_cselect_b32 s74, -1, 0", "s_cselect_b32 s78, -1, 0", "s_ashr_i32 s70, s97, 31",
           "s_add_u32 s72, s72, s97", "s_addc_u32 s73, s73, s70", "s_add_u32 s76, s76, s97", "s_addc_u32 s77, s77, s70"]
     o += tile(1)
     o += ["s_waitcnt vmcnt(16)", "s_barrier"]
@@ -186,10 +190,12 @@ def prologue():
 
 def program(sched=PRODUCT_SCHED, var=""):
     lines = prologue()
-    lines.append("L_w4_top_%=:")
-    lines += body(0, sched, var)
+    lines += body(0, sched, var, first=True)
     lines += ["s_sub_u32 s96, s96, 1", "s_cmp_eq_u32 s96, 0", "s_cbranch_scc1 L_w4_end_%="]
+    lines.append("L_w4_top_%=:")
     lines += body(1, sched, var)
+    lines += ["s_sub_u32 s96, s96, 1", "s_cmp_eq_u32 s96, 0", "s_cbranch_scc1 L_w4_end_%="]
+    lines += body(0, sched, var)
     lines += ["s_sub_u32 s96, s96, 1", "s_cmp_lg_u32 s96, 0", "s_cbranch_scc1 L_w4_top_%="]
     lines.append("L_w4_end_%=:")
     # the stray loads of the last two iterations land before the LDS is reused; MFMA results settle before the compiler reads them
@@ -198,7 +204,7 @@ def program(sched=PRODUCT_SCHED, var=""):
 
 
 # MTL_W4_LOOP_ASM_V1 .. (diagnostic builds, -DMTL_DIAG_W4VAR): (schedule, ablation letters)
-VARIANTS = [("s1", ""), ("s3", "n"), ("s3", "c"), ("s3", "C"), ("s3", "V")]
+VARIANTS = [("s1", ""), ("s3", "D"), ("s3", "DBRW"), ("s3", "V"), ("s3", "L")]
 
 
 def emit(f, name, lines):

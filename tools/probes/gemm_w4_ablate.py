@@ -13,7 +13,7 @@ from med_ts_llm_amd.hip import ops, _native as N     # noqa: E402
 BF16 = torch.bfloat16
 g = torch.Generator().manual_seed(0)
 SHAPES = [("4096 x 4096 x 22016", 4096, 4096, 22016), ("4096 x 4096 x 4096", 4096, 4096, 4096), ("4096 x 12288 x 4096", 4096, 12288, 4096)]
-VARS = [("s3", 2), ("s1", 3)]      # = the generator's VARIANTS list (tune_stages - 2)
+VARS = [("s3", 2), ("s1", 3), ("no DMA", 4), ("MFMA only", 5), ("no landing wait", 6), ("local DMA", 7)]      # = the generator's VARIANTS list (tune_stages - 2)
 flush = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
 
 
@@ -52,24 +52,30 @@ for name, M, Nn, K in SHAPES:
     print(line, flush=True)
 
 
-# phase stamps of every workgroup's first tile (diagnostic build): entry -> k-loop begin -> k-loop end -> epilogue stores complete, 10 ns ticks
+# phase stamps of every workgroup's first tile (diagnostic build): entry -> k-loop begin -> k-loop end -> epilogue stores complete, 10 ns ticks;
+# and the SHADER clock counter (s_memtime) around the k-loop: cycles per k-tile against the 2048 its 64 MFMAs occupy, and the clock the loop ran at
 import ctypes as C                                   # noqa: E402
 for name, M, Nn, K in SHAPES[:2]:
     A = torch.randn(M, K, generator=g).to(BF16).cuda()
     B = (torch.randn(Nn, K, generator=g) * 0.05).to(BF16).cuda()
     out = torch.empty(M, Nn, dtype=BF16, device="cuda")
-    ws = torch.zeros(4 * 256, dtype=torch.int64, device="cuda")
-    ga = N.GemmArgs()
-    ga.A, ga.lda, ga.B, ga.ldb, ga.C, ga.ldc, ga.c_dtype = A.data_ptr(), K, B.data_ptr(), K, out.data_ptr(), Nn, N.MTL_BF16
-    ga.M, ga.N, ga.K, ga.alpha, ga.split_k, ga.epilogue = M, Nn, K, 1.0, 1, N.EPI_STORE
-    ga.workspace, ga.workspace_bytes = ws.data_ptr(), ws.numel() * 8
-    ga.tune_mode, ga.tune_bm, ga.tune_bn, ga.tune_stages, ga.tune_waves = 2, 256, 256, 2, 4
-    for rep in range(3):
-        flush.fill_(rep)
-        ops.check(N.lib().mtl_gemm_nt(C.byref(ga), ops.stream()), "mtl_gemm_nt")
-        torch.cuda.synchronize()
-    t = ws.view(256, 4).cpu().double()
-    t0 = t[:, 0].min()
-    d = lambda a: f"{float(a.mean()) / 100:6.2f} us (min {float(a.min()) / 100:6.2f}, max {float(a.max()) / 100:6.2f})"
-    print(f"{name}: start skew {d(t[:, 0] - t0)} | setup {d(t[:, 1] - t[:, 0])} | k-loop {d(t[:, 2] - t[:, 1])} = {float((t[:, 2] - t[:, 1]).mean()) * 10 / (K // 64):6.0f} ns/k-tile"
-          f" | epilogue {d(t[:, 3] - t[:, 2])} | end of last workgroup {float(t[:, 3].max() - t0) / 100:6.2f} us")
+    for vlabel, vst in (("full loop", 2), ("no DMA", 4), ("MFMA only", 5)):
+        ws = torch.zeros(6 * 256, dtype=torch.int64, device="cuda")
+        ga = N.GemmArgs()
+        ga.A, ga.lda, ga.B, ga.ldb, ga.C, ga.ldc, ga.c_dtype = A.data_ptr(), K, B.data_ptr(), K, out.data_ptr(), Nn, N.MTL_BF16
+        ga.M, ga.N, ga.K, ga.alpha, ga.split_k, ga.epilogue = M, Nn, K, 1.0, 1, N.EPI_STORE
+        ga.workspace, ga.workspace_bytes = ws.data_ptr(), ws.numel() * 8
+        ga.tune_mode, ga.tune_bm, ga.tune_bn, ga.tune_stages, ga.tune_waves = 2, 256, 256, vst, 4
+        for rep in range(3):
+            flush.fill_(rep)
+            ops.check(N.lib().mtl_gemm_nt(C.byref(ga), ops.stream()), "mtl_gemm_nt")
+            torch.cuda.synchronize()
+        t = ws.view(256, 6).cpu().double()
+        t0 = t[:, 0].min()
+        d = lambda a: f"{float(a.mean()) / 100:6.2f} us (min {float(a.min()) / 100:6.2f}, max {float(a.max()) / 100:6.2f})"
+        print(f"{name} [{vlabel}]: start skew {d(t[:, 0] - t0)} | setup {d(t[:, 1] - t[:, 0])} | k-loop {d(t[:, 2] - t[:, 1])} = "
+              f"{float((t[:, 2] - t[:, 1]).mean()) * 10 / (K // 64):6.0f} ns/k-tile | epilogue {d(t[:, 3] - t[:, 2])} | end of last workgroup {float(t[:, 3].max() - t0) / 100:6.2f} us")
+        cyc = t[:, 5] - t[:, 4]
+        mhz = cyc / ((t[:, 2] - t[:, 1]) / 100)
+        print(f"    k-loop {float(cyc.mean()) / (K // 64):7.0f} s_memtime ticks per k-tile (64 MFMAs x 32 cycles = 2048) -> MFMA issue share {2048 * (K // 64) / float(cyc.mean()):.3f} "
+              f"if a tick is a shader cycle; ticks per us during the loop {float(mhz.mean()):6.0f} (min {float(mhz.min()):6.0f}, max {float(mhz.max()):6.0f})", flush=True)

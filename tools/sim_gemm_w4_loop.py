@@ -5,7 +5,8 @@ which LDS address), every fragment read (operand, k-step, buffer) and every barr
   * every k-tile of the tile is staged exactly once per operand piece, k-tile j of the stream into buffer j & 1, at the piece's LDS address;
   * iteration t reads buffer t & 1, after a landing wait + barrier that covers tile t's loads; a buffer region is re-staged only after the barrier
     that follows the last read of it; the counted vmcnt / lgkmcnt waits leave exactly the intended instructions outstanding;
-  * the physical k order is the per-XCD rotation (j + rot) mod nkt.
+  * the physical k order is the per-XCD rotation (j + rot) mod nkt; the loads of the two trailing iterations run out of range (num_records = 0);
+  * every accumulator's first MFMA takes the constant 0 as C (the asm statement's accumulators are write-only operands).
 Used by tests/test_w4_loop_sim.py (CPU) — the asm is otherwise only exercised on the GPU box."""
 import os
 import re
@@ -93,7 +94,7 @@ def run(lines, nkt, rot=0, dma_base=0x400, max_steps=2_000_000):
             off = base - (PA if which == "a" else PB)
             piece = int(re.match(r"s(\d+)", a[2].split()[0]).group(1)) - (80 if which == "a" else 88)
             assert off % 128 == 0 and 0 <= off // 128 < nkt, (which, off, nkt)
-            ev.append(("dma", which, piece, off // 128, s["m0"] - dma_base))
+            ev.append(("dma", which, piece, off // 128, s["m0"] - dma_base, s[f"s{lo + 2}"] != 0))      # last: num_records != 0 (0 = out of range: no memory access)
         elif op == "ds_read_b128":
             reg = int(re.match(r"v\[(\d+):", a[0]).group(1))
             addr_reg = int(re.match(r"v(\d+)", a[1].split()[0]).group(1))
@@ -111,7 +112,7 @@ def run(lines, nkt, rot=0, dma_base=0x400, max_steps=2_000_000):
             ev.append(("barrier",))
         elif op == "v_mfma_f32_32x32x16_bf16":
             srcs = [int(re.match(r"v\[(\d+):", x).group(1)) for x in a[1:3]]
-            ev.append(("mfma", a[0], srcs[0], srcs[1]))
+            ev.append(("mfma", a[0], srcs[0], srcs[1], a[3]))
         elif op in ("s_nop", "v_readlane_b32", "v_xor_b32", "v_lshl_add_u32"):
             pass
         else:
@@ -131,16 +132,18 @@ def check(ev, nkt, rot=0):
     reads_done_since_barrier = set()
     staged = {}                 # (operand, piece) -> list of k-tiles in stream order
     mf = 0
+    zeroed = set()              # accumulators whose first MFMA (C = 0) has issued
     cur = {}                    # buffer -> k-tile currently landed in it, per operand
     for e in ev:
         if e[0] == "dma":
-            _, which, piece, kt, m0 = e
+            _, which, piece, kt, m0, live = e
             region = 0 if which == "a" else 0x10000
             rel = m0 - region
             buf, idx = rel // 0x8000, (rel % 0x8000) // 0x1000
             assert 0 <= rel < 0x10000 and rel % 0x1000 == 0 and idx == piece, e
             j = len(staged.setdefault((which, piece), []))
             assert kt == (j + rot) % nkt if j < nkt else True, (e, j)
+            assert live == (j < nkt), ("the tile's k-tiles are fetched, the two trailing iterations' loads are out of range (no traffic)", e, j)
             assert buf == j & 1, ("stream tile j must land in buffer j & 1", e, j)
             staged[(which, piece)].append(kt)
             assert (which, buf) not in last_read_unbarriered, ("re-staging a region with reads not yet behind a barrier", e)
@@ -170,7 +173,10 @@ def check(ev, nkt, rot=0):
             if n == 0:
                 reads_done_since_barrier |= set(last_read_unbarriered)
         elif e[0] == "mfma":
-            _, acc, rb, ra = e
+            _, acc, rb, ra, csrc = e
+            assert csrc == ("0" if mf < 16 else acc), ("the first MFMA of every accumulator takes C = 0, all later ones accumulate", mf, acc, csrc)
+            if mf < 16:
+                zeroed.add(acc)
             t = mf // 64                        # iteration = stream tile
             if t < nkt:
                 m = mf % 64
@@ -179,7 +185,7 @@ def check(ev, nkt, rot=0):
                     assert reg not in {r for (_, _, r, _, _) in reads_out}, ("MFMA reads a fragment whose ds_read may still be in flight", mf, reg)
                     assert frag.get(reg) == (which, t, ks), ("MFMA operand is not (operand, tile, k-step)", mf, reg, frag.get(reg), (which, t, ks))
             mf += 1
-    assert mf == 64 * nkt, (mf, nkt)
+    assert mf == 64 * nkt and len(zeroed) == 16, (mf, nkt, len(zeroed))
     for (which, piece), lst in staged.items():
         assert lst[:nkt] == [(j + rot) % nkt for j in range(nkt)], (which, piece, lst[:nkt + 2])
     assert len(staged) == 16
