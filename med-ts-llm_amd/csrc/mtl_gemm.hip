@@ -1042,7 +1042,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
                    [c8] "=&a"(c8), [c9] "=&a"(c9), [c10] "=&a"(c10), [c11] "=&a"(c11), [c12] "=&a"(c12), [c13] "=&a"(c13), [c14] "=&a"(c14),              \
                    [c15] "=&a"(c15)                                                                                                                      \
                  : [pa] "s"(p.A), [pb] "s"(p.B), [voa] "v"(voa), [vob] "v"(vob), [tab] "v"(tab), [rba] "v"(rba), [xa] "v"(xa), [rbb] "v"(rbb),           \
-                   [xb] "v"(xb), [nkt] "s"(nkt), [dma] "s"(dma), [rot] "s"(rot)                                                                          \
+                   [xb] "v"(xb), [nkt] "s"(nkt), [dma] "s"(dma), [rot] "s"(rot), [wv] "s"(wave)                                                           \
                  : MTL_W4_LOOP_CLOBBERS)
 #ifdef MTL_DIAG_W4VAR
         if (i == slot) { stamp[1] = __builtin_amdgcn_s_memrealtime(); cyc[0] = __builtin_amdgcn_s_memtime(); }

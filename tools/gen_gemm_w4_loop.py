@@ -74,11 +74,14 @@ SCHED = {
     # the 16 LDS-DMA instructions spread over the iteration (one per four / three MFMAs) instead of two bursts of one per two
     "s3": dict(b1=0, bar1=14, dma_b=16, a1=16, bar2=31, dma_a=34, dma_step=4, wait=47, s0=48, s0_per=1, final_lgkm=8),
     "s4": dict(b1=0, bar1=14, dma_b=16, a1=16, bar2=31, dma_a=33, dma_step=3, wait=47, s0=48, s0_per=1, final_lgkm=8),
+    # s3 with room for a per-wave offset of 0..3 slots on every LDS-DMA (ablation letter 'w': one copy of the loop per wave, wave w issues its DMA w slots
+    # later, so that the four waves' 1 KiB instructions reach the CU's one address unit one per MFMA slot instead of four at once)
+    "s5": dict(b1=0, bar1=14, dma_b=16, a1=16, bar2=29, dma_a=31, dma_step=4, wait=47, s0=48, s0_per=1, final_lgkm=8),
 }
 PRODUCT_SCHED = "s3"
 
 
-def body(b, sched, var="", first=False):
+def body(b, sched, var="", first=False, wave=0):
     """one k-tile, buffer parity b. Returns the instruction list. first: the tile's first k-tile — its first 16 MFMAs (one per accumulator) take the
     constant 0 as C, so the accumulators are write-only operands of the asm statement and nobody zero-fills 256 AGPRs per tile. `var`: ablation letters for the DIAGNOSTIC variants (timing only, wrong results):
     D = no in-loop LDS-DMA, B = no barriers, R = no fragment reads, W = no waits, V = no landing (vmcnt) wait, L = every DMA re-reads the same 8 rows"""
@@ -107,7 +110,8 @@ def body(b, sched, var="", first=False):
     fill[sc["bar2"]] += ["s_waitcnt lgkmcnt(0)", "s_barrier", "s_add_u32 s72, s72, s97", "s_addc_u32 s73, s73, s70"]
     wait_at = sc["wait"]
     step = sc.get("dma_step", 2)
-    slots = sorted([(sc["dma_b"] + step * i, "b", i) for i in range(8)] + [(sc["dma_a"] + step * i, "a", i) for i in range(8)])
+    wo = wave if "w" in var else 0
+    slots = sorted([(sc["dma_b"] + step * i + wo, "b", i) for i in range(8)] + [(sc["dma_a"] + step * i + wo, "a", i) for i in range(8)])
     assert len({m for m, _, _ in slots}) == 16 and slots[-1][0] <= 63, slots
     for m, op, i in slots:
         base = (B_REGION if op == "b" else 0) + b * A_BUF + i * PIECE
@@ -190,13 +194,22 @@ def prologue():
 
 def program(sched=PRODUCT_SCHED, var=""):
     lines = prologue()
-    lines += body(0, sched, var, first=True)
-    lines += ["s_sub_u32 s96, s96, 1", "s_cmp_eq_u32 s96, 0", "s_cbranch_scc1 L_w4_end_%="]
-    lines.append("L_w4_top_%=:")
-    lines += body(1, sched, var)
-    lines += ["s_sub_u32 s96, s96, 1", "s_cmp_eq_u32 s96, 0", "s_cbranch_scc1 L_w4_end_%="]
-    lines += body(0, sched, var)
-    lines += ["s_sub_u32 s96, s96, 1", "s_cmp_lg_u32 s96, 0", "s_cbranch_scc1 L_w4_top_%="]
+    waves = range(4) if "w" in var else [0]
+    if "w" in var:                              # one copy of the loop per wave (4 x 3.5 KB of code: well inside the instruction cache)
+        for w in (1, 2, 3):
+            lines += [f"s_cmp_eq_u32 %[wv], {w}", f"s_cbranch_scc1 L_w4_copy{w}_%="]
+    for w in waves:
+        if w:
+            lines.append(f"L_w4_copy{w}_%=:")
+        lines += body(0, sched, var, first=True, wave=w)
+        lines += ["s_sub_u32 s96, s96, 1", "s_cmp_eq_u32 s96, 0", "s_cbranch_scc1 L_w4_end_%="]
+        lines.append(f"L_w4_top{w}_%=:")
+        lines += body(1, sched, var, wave=w)
+        lines += ["s_sub_u32 s96, s96, 1", "s_cmp_eq_u32 s96, 0", "s_cbranch_scc1 L_w4_end_%="]
+        lines += body(0, sched, var, wave=w)
+        lines += ["s_sub_u32 s96, s96, 1", "s_cmp_lg_u32 s96, 0", f"s_cbranch_scc1 L_w4_top{w}_%="]
+        if w != waves[-1]:
+            lines.append("s_branch L_w4_end_%=")
     lines.append("L_w4_end_%=:")
     # the stray loads of the last two iterations land before the LDS is reused; MFMA results settle before the compiler reads them
     lines += ["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_nop 15", "s_nop 15"]
@@ -204,7 +217,7 @@ def program(sched=PRODUCT_SCHED, var=""):
 
 
 # MTL_W4_LOOP_ASM_V1 .. (diagnostic builds, -DMTL_DIAG_W4VAR): (schedule, ablation letters)
-VARIANTS = [("s1", ""), ("s3", "D"), ("s3", "DBRW"), ("s3", "V"), ("s3", "L")]
+VARIANTS = [("s5", "w"), ("s3", "D"), ("s3", "DBRW"), ("s5", ""), ("s3", "L")]
 
 
 def emit(f, name, lines):

@@ -13,7 +13,7 @@ from med_ts_llm_amd.hip import ops, _native as N     # noqa: E402
 BF16 = torch.bfloat16
 g = torch.Generator().manual_seed(0)
 SHAPES = [("4096 x 4096 x 22016", 4096, 4096, 22016), ("4096 x 4096 x 4096", 4096, 4096, 4096), ("4096 x 12288 x 4096", 4096, 12288, 4096)]
-VARS = [("s3", 2), ("s1", 3), ("no DMA", 4), ("MFMA only", 5), ("no landing wait", 6), ("local DMA", 7)]      # = the generator's VARIANTS list (tune_stages - 2)
+VARS = [("s3", 2), ("s5 per-wave DMA slots", 3), ("no DMA", 4), ("MFMA only", 5), ("s5", 6), ("local DMA", 7)]      # = the generator's VARIANTS list (tune_stages - 2)
 flush = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
 
 

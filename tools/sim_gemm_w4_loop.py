@@ -25,11 +25,11 @@ def load(name="MTL_W4_LOOP_ASM", path=INC):
 M32 = 0xFFFFFFFF
 
 
-def run(lines, nkt, rot=0, dma_base=0x400, max_steps=2_000_000):
+def run(lines, nkt, rot=0, dma_base=0x400, max_steps=2_000_000, wave=0):
     """returns the event list. Operand values: %[pa] = 0x1000_0000_0000, %[pb] = 0x2000_0000_0000 (so that base - start = k byte offset)."""
     PA, PB = 0x100000000000, 0x200000000000
     s = {}                     # SGPRs (+ 'm0', 'scc')
-    sym = {"%[nkt]": nkt, "%[rot]": rot, "%[dma]": dma_base}
+    sym = {"%[nkt]": nkt, "%[rot]": rot, "%[dma]": dma_base, "%[wv]": wave}
     labels = {l[:-1]: i for i, l in enumerate(lines) if l.endswith(":")}
     ev = []
 
@@ -84,6 +84,8 @@ def run(lines, nkt, rot=0, dma_base=0x400, max_steps=2_000_000):
                 s["scc"] = int((x == y) == (op == "s_cmp_eq_u32"))
         elif op == "s_cselect_b32":
             s[a[0]] = val(a[1]) if s["scc"] else val(a[2])
+        elif op == "s_branch":
+            pc = labels[a[0]]
         elif op in ("s_cbranch_scc1", "s_cbranch_scc0"):
             if s["scc"] == (op == "s_cbranch_scc1"):
                 pc = labels[a[0]]
