@@ -1023,17 +1023,29 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
 #ifdef MTL_DIAG_W4VAR      // phase stamps of the workgroup's FIRST tile (100 MHz realtime counter): entry, k-loop begin / end, epilogue end -> workspace[6 * block]
     uint64_t stamp[4] = {__builtin_amdgcn_s_memrealtime(), 0, 0, 0}, cyc[2] = {0, 0};       // cyc: the SHADER clock counter around the k-loop (cycles per k-tile, actual clock)
 #endif
+    // row offsets of the 8 + 8 LDS-DMA instructions of this wave for tile (m0, n0): lanes 0..7 carry A's, lanes 8..15 B's (the asm reads them out with v_readlane)
+    auto row_table = [&](int64_t m0, int64_t n0) -> uint32_t {
+        const int j = lane & 7;
+        const int64_t row = (int64_t)((4 * j + wave) * 8);
+        const int64_t arow = remap_row(m0 + row, p.a_group_rows, p.a_group_stride, p.a_row_offset);
+        return (lane & 8) ? (uint32_t)((n0 + row) * p.ldb * 2) : (uint32_t)(arow * p.lda * 2);
+    };
+    // tile chaining (mtl_gemm_w4_loop.inc): a workgroup's tile i stages k-tiles 0 / 1 of its tile i + 1 in its two trailing iterations, so that tile
+    // i + 1's k-loop starts as soon as tile i's epilogue stores are ISSUED (they drain under its first iterations) instead of after they have drained
+    // plus a load round trip. Even k-tile counts only (the next tile's k-tile 0 must land in LDS buffer 0); no per-XCD rotation.
+    const bool chain = (nkt & 1) == 0 && rot == 0 && VAR == 0;
     for (int i = slot; i < cnt; i += xblocks) {
         int tm, tn;
         tile_coords(t0 + i, tiles_m, tiles_n, gm, tm, tn);
         const int64_t m0 = (int64_t)tm * 256, n0 = (int64_t)tn * 256;
-        // row offsets of the 8 + 8 LDS-DMA instructions of this wave: lanes 0..7 carry A's, lanes 8..15 B's (the asm reads them out with v_readlane)
-        uint32_t tab;
-        {
-            const int j = lane & 7;
-            const int64_t row = (int64_t)((4 * j + wave) * 8);
-            const int64_t arow = remap_row(m0 + row, p.a_group_rows, p.a_group_stride, p.a_row_offset);
-            tab = (lane & 8) ? (uint32_t)((n0 + row) * p.ldb * 2) : (uint32_t)(arow * p.lda * 2);
+        const uint32_t tab = row_table(m0, n0);
+        uint32_t tabn = tab;
+        int flags = (chain && i > slot) ? 1 : 0;
+        if (chain && i + xblocks < cnt) {
+            int tmn, tnn;
+            tile_coords(t0 + i + xblocks, tiles_m, tiles_n, gm, tmn, tnn);
+            tabn = row_table((int64_t)tmn * 256, (int64_t)tnn * 256);
+            flags |= 2;
         }
         f32x16 c0, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14, c15;      // write-only for the asm: the first MFMA of each takes C = 0
 #define MTL_W4_RUN(ASM)                                                                                                                                  \
@@ -1042,7 +1054,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
                    [c8] "=&a"(c8), [c9] "=&a"(c9), [c10] "=&a"(c10), [c11] "=&a"(c11), [c12] "=&a"(c12), [c13] "=&a"(c13), [c14] "=&a"(c14),              \
                    [c15] "=&a"(c15)                                                                                                                      \
                  : [pa] "s"(p.A), [pb] "s"(p.B), [voa] "v"(voa), [vob] "v"(vob), [tab] "v"(tab), [rba] "v"(rba), [xa] "v"(xa), [rbb] "v"(rbb),           \
-                   [xb] "v"(xb), [nkt] "s"(nkt), [dma] "s"(dma), [rot] "s"(rot), [wv] "s"(wave)                                                           \
+                   [xb] "v"(xb), [nkt] "s"(nkt), [dma] "s"(dma), [rot] "s"(rot), [tabn] "v"(tabn), [flags] "v"(flags)                                     \
                  : MTL_W4_LOOP_CLOBBERS)
 #ifdef MTL_DIAG_W4VAR
         if (i == slot) { stamp[1] = __builtin_amdgcn_s_memrealtime(); cyc[0] = __builtin_amdgcn_s_memtime(); }

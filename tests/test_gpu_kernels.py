@@ -933,11 +933,14 @@ def test_gemm_two_k_groups(ops, M, Nn, K):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,Nn,K", [(256, 256, 64), (256, 512, 128), (512, 768, 320), (1024, 256, 4096), (4096, 4096, 704)])
+@pytest.mark.parametrize("M,Nn,K", [(256, 256, 64), (256, 512, 128), (512, 768, 320), (1024, 256, 4096), (4096, 4096, 704),
+                                    (4096, 8192, 256), (4096, 12288, 128), (4096, 8192, 320)])
 def test_gemm_w4_hand_placed_kernel(ops, M, Nn, K):
     """gemm_nt_w4_kernel (256 x 256 tile, 4 waves, the generated hand-placed k-loop: tools/gen_gemm_w4_loop.py) against fp64 math on the same bf16 inputs,
     every epilogue it is dispatched for: fp32 / bf16 store with bias, residual (+ dropout, against the 8-wave kernel's identical mask), SwiGLU, dSwiGLU;
-    odd and even k-tile counts (the loop is unrolled twice), one k-tile, several tiles per workgroup; repeated launches are bit-identical (race screen)"""
+    odd and even k-tile counts (the loop is unrolled twice), one k-tile; 2 and 3 tiles per workgroup on a 256-CU device with an even k-tile count
+    (the CHAINED path: a tile's trailing iterations stage the next tile's first k-tiles — cold entry, chained entry with and without a successor) and
+    with an odd one (several tiles, no chaining); repeated launches are bit-identical (race screen)"""
     A = torch.randn(M, K, generator=g(M + K)).to(BF16).cuda()
     B = (torch.randn(Nn, K, generator=g(Nn)) * 0.1).to(BF16).cuda()
     bias = torch.randn(Nn, generator=g(3)).cuda()
@@ -979,6 +982,14 @@ def test_gemm_w4_row_mapped_operand_and_dispatch(ops):
     assert rel_err(out, Abig[idx].double().cpu() @ B.double().cpu().t()) < TOL_F32
     auto = ops.gemm_nt(Abig[:300], B, out_dtype=F32)                   # automatic dispatch still serves it
     assert rel_err(auto, Abig[:300].double().cpu() @ B.double().cpu().t()) < TOL_F32
+    # several tiles per workgroup (512 tiles: chained entries) with the row map: the NEXT tile's row offsets go through the same map
+    K2, N2 = 256, 8192
+    A2 = torch.randn(32 * 384, K2, generator=g(5)).to(BF16).cuda()
+    B2 = (torch.randn(N2, K2, generator=g(6)) * 0.1).to(BF16).cuda()
+    idx2 = torch.cat([torch.arange(256, 384) + 384 * i for i in range(32)])
+    with ops.gemm_tune(bm=256, bn=256, stages=2, waves=4):
+        out2 = ops.gemm_nt(A2, B2, M=4096, a_rows=(128, 384, 256), out_dtype=F32)
+    assert rel_err(out2, A2[idx2].double().cpu() @ B2.double().cpu().t()) < TOL_F32
 
 
 @pytest.mark.gpu

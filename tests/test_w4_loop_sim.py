@@ -34,3 +34,21 @@ def test_checker_catches_a_short_landing_wait():
     bad = [l.replace(f"vmcnt({n})", f"vmcnt({n + 2})") if l == waits[0] else l for l in lines]
     with pytest.raises(AssertionError):
         sim.check(sim.run(bad, 6, 0), 6, 0)
+
+
+@pytest.mark.parametrize("nkt", [2, 4, 8, 64, 172])
+def test_tile_chaining_protocol(nkt):
+    """a persistent workgroup's chain of tiles: cold entry with a next tile -> chained entry with a next tile -> chained entry, last tile. The trailing
+    iterations stage the next tile's k-tiles 0 / 1 from ITS row table into buffers 0 / 1, the final vmcnt(0) covers them, and a chained entry
+    issues neither a load nor a landing wait before its second iteration"""
+    lines = sim.load()
+    assert sim.check(sim.run(lines, nkt, flags=2), nkt, has_next=True)
+    assert sim.check(sim.run(lines, nkt, flags=3), nkt, has_prev=True, has_next=True)
+    assert sim.check(sim.run(lines, nkt, flags=1), nkt, has_prev=True)
+
+
+def test_checker_catches_a_chain_into_the_wrong_row_table():
+    lines = sim.load()
+    bad = [l.replace("%[tabn]", "%[tab]") for l in lines]
+    with pytest.raises(AssertionError):
+        sim.check(sim.run(bad, 8, flags=2), 8, has_next=True)

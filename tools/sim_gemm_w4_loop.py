@@ -6,7 +6,9 @@ which LDS address), every fragment read (operand, k-step, buffer) and every barr
   * iteration t reads buffer t & 1, after a landing wait + barrier that covers tile t's loads; a buffer region is re-staged only after the barrier
     that follows the last read of it; the counted vmcnt / lgkmcnt waits leave exactly the intended instructions outstanding;
   * the physical k order is the per-XCD rotation (j + rot) mod nkt; the loads of the two trailing iterations run out of range (num_records = 0);
-  * every accumulator's first MFMA takes the constant 0 as C (the asm statement's accumulators are write-only operands).
+  * every accumulator's first MFMA takes the constant 0 as C (the asm statement's accumulators are write-only operands);
+  * tile chaining (%[flags]): with a next tile the trailing iterations stage ITS k-tiles 0 / 1 (row table %[tabn]) into buffers 0 / 1 and the final
+    vmcnt(0) covers them; a chained entry issues no load and no landing wait before its iteration 1.
 Used by tests/test_w4_loop_sim.py (CPU) — the asm is otherwise only exercised on the GPU box."""
 import os
 import re
@@ -25,11 +27,12 @@ def load(name="MTL_W4_LOOP_ASM", path=INC):
 M32 = 0xFFFFFFFF
 
 
-def run(lines, nkt, rot=0, dma_base=0x400, max_steps=2_000_000, wave=0):
+def run(lines, nkt, rot=0, dma_base=0x400, max_steps=2_000_000, flags=0):
     """returns the event list. Operand values: %[pa] = 0x1000_0000_0000, %[pb] = 0x2000_0000_0000 (so that base - start = k byte offset)."""
     PA, PB = 0x100000000000, 0x200000000000
     s = {}                     # SGPRs (+ 'm0', 'scc')
-    sym = {"%[nkt]": nkt, "%[rot]": rot, "%[dma]": dma_base, "%[wv]": wave}
+    sym = {"%[nkt]": nkt, "%[rot]": rot, "%[dma]": dma_base, "%[flags]": flags}
+    table = {}                 # row-offset SGPR -> "tab" (this tile's rows) / "tabn" (the next tile's)
     labels = {l[:-1]: i for i, l in enumerate(lines) if l.endswith(":")}
     ev = []
 
@@ -69,6 +72,13 @@ def run(lines, nkt, rot=0, dma_base=0x400, max_steps=2_000_000, wave=0):
             r = val(a[1]) + val(a[2]) + s["scc"]
             s["scc"] = int(r > M32)
             s[a[0]] = r & M32
+        elif op == "s_and_b32":
+            s[a[0]] = val(a[1]) & val(a[2])
+        elif op == "v_readfirstlane_b32":
+            s[a[0]] = val(a[1])
+        elif op == "v_readlane_b32":
+            table[a[0]] = a[1].strip("%[]")
+            assert int(a[0][1:]) - 80 == int(a[2]), ins
         elif op == "s_lshl_b32":
             s[a[0]] = (val(a[1]) << val(a[2])) & M32
         elif op == "s_ashr_i32":
@@ -96,7 +106,7 @@ def run(lines, nkt, rot=0, dma_base=0x400, max_steps=2_000_000, wave=0):
             off = base - (PA if which == "a" else PB)
             piece = int(re.match(r"s(\d+)", a[2].split()[0]).group(1)) - (80 if which == "a" else 88)
             assert off % 128 == 0 and 0 <= off // 128 < nkt, (which, off, nkt)
-            ev.append(("dma", which, piece, off // 128, s["m0"] - dma_base, s[f"s{lo + 2}"] != 0))      # last: num_records != 0 (0 = out of range: no memory access)
+            ev.append(("dma", which, piece, off // 128, s["m0"] - dma_base, s[f"s{lo + 2}"] != 0, table[a[2].split()[0]]))   # num_records != 0 (0 = out of range: no memory access), row table
         elif op == "ds_read_b128":
             reg = int(re.match(r"v\[(\d+):", a[0]).group(1))
             addr_reg = int(re.match(r"v(\d+)", a[1].split()[0]).group(1))
@@ -115,15 +125,17 @@ def run(lines, nkt, rot=0, dma_base=0x400, max_steps=2_000_000, wave=0):
         elif op == "v_mfma_f32_32x32x16_bf16":
             srcs = [int(re.match(r"v\[(\d+):", x).group(1)) for x in a[1:3]]
             ev.append(("mfma", a[0], srcs[0], srcs[1], a[3]))
-        elif op in ("s_nop", "v_readlane_b32", "v_xor_b32", "v_lshl_add_u32"):
+        elif op in ("s_nop", "v_xor_b32", "v_lshl_add_u32"):
             pass
         else:
             raise AssertionError(f"unknown instruction: {ins}")
     return ev
 
 
-def check(ev, nkt, rot=0):
-    """assert the staging / reading protocol (see the module docstring)"""
+def check(ev, nkt, rot=0, has_prev=False, has_next=False):
+    """assert the staging / reading protocol (see the module docstring). has_prev: the previous tile of the workgroup staged this tile's k-tiles 0 / 1
+    (they are landed and published at entry); has_next: this tile's two trailing iterations stage k-tiles 0 / 1 of the next tile from ITS row table"""
+    assert not (has_prev or has_next) or (rot == 0 and nkt % 2 == 0 and nkt >= 2)
     FA0, FB0 = 112, 176
     landed = {}                 # (operand, buffer, piece) -> k-tile whose data is visible to every wave (after vmcnt + barrier)
     pending = []                # DMAs issued and not yet known complete: (operand, buffer, piece, ktile)
@@ -133,25 +145,35 @@ def check(ev, nkt, rot=0):
     last_read_unbarriered = set()   # (operand, buffer) regions read since the last (lgkmcnt(0), barrier) pair
     reads_done_since_barrier = set()
     staged = {}                 # (operand, piece) -> list of k-tiles in stream order
+    if has_prev:
+        for which in "ab":
+            for piece in range(8):
+                staged[(which, piece)] = [0, 1]
+                landed[(which, 0, piece)], landed[(which, 1, piece)] = 0, 1
     mf = 0
     zeroed = set()              # accumulators whose first MFMA (C = 0) has issued
     cur = {}                    # buffer -> k-tile currently landed in it, per operand
     for e in ev:
         if e[0] == "dma":
-            _, which, piece, kt, m0, live = e
+            _, which, piece, kt, m0, live, tab = e
             region = 0 if which == "a" else 0x10000
             rel = m0 - region
             buf, idx = rel // 0x8000, (rel % 0x8000) // 0x1000
             assert 0 <= rel < 0x10000 and rel % 0x1000 == 0 and idx == piece, e
             j = len(staged.setdefault((which, piece), []))
-            assert kt == (j + rot) % nkt if j < nkt else True, (e, j)
-            assert live == (j < nkt), ("the tile's k-tiles are fetched, the two trailing iterations' loads are out of range (no traffic)", e, j)
+            if j < nkt:
+                assert kt == (j + rot) % nkt and live and tab == "tab", ("the tile's own k-tile j from its own rows", e, j)
+            elif has_next:
+                assert kt == j - nkt and live and tab == "tabn", ("trailing iterations stage the NEXT tile's k-tiles 0 / 1 from its rows", e, j)
+            else:
+                assert not live, ("without a next tile the trailing iterations' loads are out of range (no traffic)", e, j)
             assert buf == j & 1, ("stream tile j must land in buffer j & 1", e, j)
             staged[(which, piece)].append(kt)
             assert (which, buf) not in last_read_unbarriered, ("re-staging a region with reads not yet behind a barrier", e)
             pending.append((which, buf, piece, j))
         elif e[0] == "vmcnt":
             n = e[1]
+            assert not has_prev or mf >= 64, "a chained entry waits for no load before its second iteration (it would wait for the previous epilogue's stores)"
             done, pending = pending[:max(0, len(pending) - n)], pending[max(0, len(pending) - n):]
             waited += done
         elif e[0] == "barrier":
@@ -188,6 +210,10 @@ def check(ev, nkt, rot=0):
                     assert frag.get(reg) == (which, t, ks), ("MFMA operand is not (operand, tile, k-step)", mf, reg, frag.get(reg), (which, t, ks))
             mf += 1
     assert mf == 64 * nkt and len(zeroed) == 16, (mf, nkt, len(zeroed))
+    assert not pending, "the statement's final vmcnt(0) covers every load (the next tile enters without a landing wait)"
+    if has_next:
+        for (which, piece), lst in staged.items():
+            assert lst[nkt:] == [0, 1], (which, piece, lst[nkt:])
     for (which, piece), lst in staged.items():
         assert lst[:nkt] == [(j + rot) % nkt for j in range(nkt)], (which, piece, lst[:nkt + 2])
     assert len(staged) == 16
@@ -199,4 +225,8 @@ if __name__ == "__main__":
     for nkt in (1, 2, 3, 4, 5, 8, 64):
         for rot in sorted({0, 1, (3 * nkt) // 8, nkt - 1} & set(range(nkt))):
             check(run(lines, nkt, rot), nkt, rot)
+    for nkt in (2, 4, 8, 64):          # a chain of three tiles: cold entry -> chained -> chained, last
+        check(run(lines, nkt, flags=2), nkt, has_next=True)
+        check(run(lines, nkt, flags=3), nkt, has_prev=True, has_next=True)
+        check(run(lines, nkt, flags=1), nkt, has_prev=True)
     print("w4 k-loop protocol ok")
