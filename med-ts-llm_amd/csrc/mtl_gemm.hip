@@ -1059,7 +1059,11 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
 #ifdef MTL_DIAG_W4VAR
         if (i == slot) { stamp[1] = __builtin_amdgcn_s_memrealtime(); cyc[0] = __builtin_amdgcn_s_memtime(); }
 #endif
+#ifdef MTL_W4_ASM_SELECT      // A/B builds (tools/build_variant.sh ... -DMTL_W4_ASM_SELECT=MTL_W4_LOOP_ASM_V1): one of the generator's timing ablations in the product's place
+        if constexpr (VAR == 0) MTL_W4_RUN(MTL_W4_ASM_SELECT);
+#else
         if constexpr (VAR == 0) MTL_W4_RUN(MTL_W4_LOOP_ASM);
+#endif
 #ifdef MTL_DIAG_W4VAR
         else if constexpr (VAR == 1) MTL_W4_RUN(MTL_W4_LOOP_ASM_V1);
         else if constexpr (VAR == 2) MTL_W4_RUN(MTL_W4_LOOP_ASM_V2);

@@ -148,7 +148,13 @@ def body(b, sched, var="", first=False, chained_entry=False):
         fill[m].append(rd_a(s, ksl, x, b ^ 1) if op == "a" else rd_b(s, ksl, x, b ^ 1))
     out = []
     for m in range(64):
-        out.append(mfma(m, first and m < 16))
+        if "S" in var:      # ablation: the same FLOPs as two v_mfma_f32_16x16x32_bf16 on physical AGPR quads (garbage results: what the MFMA shape does to time / clock)
+            s_, ksl, nt, mt = m // 32, (m % 32) // 16, (m % 16) // 4, m % 4
+            for half in range(2):
+                q = ((m % 32) * 2 + half) * 4
+                out.append(f"v_mfma_f32_16x16x32_bf16 a[{q}:{q + 3}], {fb(s_, ksl, nt)}, {fa(s_, ksl, mt)}, a[{q}:{q + 3}]")
+        else:
+            out.append(mfma(m, first and m < 16))
         for ins in fill[m]:
             if "D" in var and ins.startswith("buffer_load"):
                 continue
@@ -247,7 +253,7 @@ def program(sched=PRODUCT_SCHED, var=""):
 
 
 # MTL_W4_LOOP_ASM_V1 .. (diagnostic builds, -DMTL_DIAG_W4VAR): (schedule, ablation letters)
-VARIANTS = [("s1", ""), ("s3", "D"), ("s3", "DBRW"), ("s3", "V"), ("s3", "L")]
+VARIANTS = [("s3", "S"), ("s3", "D"), ("s3", "DBRW"), ("s3", "SDBRW"), ("s3", "L")]
 
 
 def emit(f, name, lines):
@@ -263,7 +269,7 @@ def main():
         f.write("// GENERATED by tools/gen_gemm_w4_loop.py — do not edit by hand. The k-loop of gemm_nt_w4_kernel as ONE asm statement.\n")
         f.write(f"// {sum(1 for l in lines if l.startswith('v_mfma'))} MFMAs, {len(lines)} instructions.\n")
         emit(f, "MTL_W4_LOOP_ASM", lines)
-        f.write("#ifdef MTL_DIAG_W4VAR      // ablations for timing (WRONG results): what the in-loop DMA / barriers / reads / waits cost\n")
+        f.write("#if defined(MTL_DIAG_W4VAR) || defined(MTL_W4_ASM_SELECT)      // ablations for timing (WRONG results): what the in-loop DMA / barriers / reads / waits cost\n")
         for i, (sc, v) in enumerate(VARIANTS):
             f.write(f"// V{i + 1}: schedule {sc}, ablation '{v}'\n")
             emit(f, f"MTL_W4_LOOP_ASM_V{i + 1}", program(sc, v))
