@@ -988,7 +988,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    const int l31 = lane & 31, h = lane >> 5;
+    const int l15 = lane & 15, g = lane >> 4;
     const int ntiles = tiles_m * tiles_n;
     const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
     const int xblocks = (nblk - xcd + 7) >> 3;                 // blocks living on this XCD
@@ -1004,10 +1004,10 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
     if (gm_all & (1 << 11)) rot = (int)(((unsigned)slot * (unsigned)nkt) >> 5) % nkt;
 #endif
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem_all;       // (flat LDS address: the low half is the LDS offset)
-    // fragment read addresses (k-step 0; the asm derives the other three)
-    const int prow = (l31 & 19) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);             // B rows: bits 2 <-> 3
-    const uint32_t rba = lds0 + (uint32_t)((wr * 128 + l31) * 128), xa = (uint32_t)(h ^ swz64(l31));
-    const uint32_t rbb = lds0 + 0x10000u + (uint32_t)((wc * 128 + prow) * 128), xb = (uint32_t)(h ^ swz64(prow));
+    // fragment read addresses: lane (l15, g) reads row l15 of a 16-row block, 16-byte chunk 4 ks + g of its k-tile row (k-step ks; the asm derives both
+    // k-steps and adds 2 KiB per block); block bases are multiples of 16 rows, so the row's swizzle is swz64(l15)
+    const uint32_t rba = lds0 + (uint32_t)((wr * 128 + l15) * 128), xa = (uint32_t)(g ^ swz64(l15));
+    const uint32_t rbb = lds0 + 0x10000u + (uint32_t)((wc * 128 + l15) * 128), xb = xa;
     // LDS-DMA: instruction i of wave w stages tile rows (4 i + w) * 8 .. + 7; lane -> row lane / 8, slot lane % 8
     const uint32_t dma = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (uint32_t)wave * 1024u));
     const int drow = lane >> 3, dsl = lane & 7;
@@ -1047,12 +1047,15 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
             tabn = row_table((int64_t)tmn * 256, (int64_t)tnn * 256);
             flags |= 2;
         }
-        f32x16 c0, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14, c15;      // write-only for the asm: the first MFMA of each takes C = 0
+        // the wave's 8 x 8 output tiles of 16 x 16 (v_mfma_f32_16x16x32_bf16): tile (row block mi, column block ni) lives in the PHYSICAL accumulator quad
+        // a[4 (8 mi + ni) .. + 3] — the asm names them directly; c_k = a[16 k .. 16 k + 15] = tiles 4 k .. 4 k + 3 tells the compiler. Write-only for the asm
+        // (the first MFMA of each tile takes C = 0).
+        f32x16 c0, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14, c15;
 #define MTL_W4_RUN(ASM)                                                                                                                                  \
     asm volatile(ASM                                                                                                                                     \
-                 : [c0] "=&a"(c0), [c1] "=&a"(c1), [c2] "=&a"(c2), [c3] "=&a"(c3), [c4] "=&a"(c4), [c5] "=&a"(c5), [c6] "=&a"(c6), [c7] "=&a"(c7),      \
-                   [c8] "=&a"(c8), [c9] "=&a"(c9), [c10] "=&a"(c10), [c11] "=&a"(c11), [c12] "=&a"(c12), [c13] "=&a"(c13), [c14] "=&a"(c14),              \
-                   [c15] "=&a"(c15)                                                                                                                      \
+                 : "={a[0:15]}"(c0), "={a[16:31]}"(c1), "={a[32:47]}"(c2), "={a[48:63]}"(c3), "={a[64:79]}"(c4), "={a[80:95]}"(c5), "={a[96:111]}"(c6),        \
+                   "={a[112:127]}"(c7), "={a[128:143]}"(c8), "={a[144:159]}"(c9), "={a[160:175]}"(c10), "={a[176:191]}"(c11), "={a[192:207]}"(c12),             \
+                   "={a[208:223]}"(c13), "={a[224:239]}"(c14), "={a[240:255]}"(c15)                                                                            \
                  : [pa] "s"(p.A), [pb] "s"(p.B), [voa] "v"(voa), [vob] "v"(vob), [tab] "v"(tab), [rba] "v"(rba), [xa] "v"(xa), [rbb] "v"(rbb),           \
                    [xb] "v"(xb), [nkt] "s"(nkt), [dma] "s"(dma), [rot] "s"(rot), [tabn] "v"(tabn), [flags] "v"(flags)                                     \
                  : MTL_W4_LOOP_CLOBBERS)
@@ -1075,24 +1078,22 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
 #ifdef MTL_DIAG_W4VAR
         if (i == slot) { cyc[1] = __builtin_amdgcn_s_memtime(); stamp[2] = __builtin_amdgcn_s_memrealtime(); }
 #endif
-        // ---- epilogue: the wave's 128 x 128 as two 64-column halves of 8 quads ("column tiles" of 8) x 4 row tiles of 32
-        const f32x16* cc[16] = {&c0, &c1, &c2, &c3, &c4, &c5, &c6, &c7, &c8, &c9, &c10, &c11, &c12, &c13, &c14, &c15};   // [mt * 4 + nt]
+        // ---- epilogue: the wave's 128 x 128 as two 64-row halves of 4 row blocks x 8 column blocks: the 16 x 16-tile layout of the 8-wave kernels'
+        //      wave-level epilogue (lane: row l15 of a row block, 4 consecutive columns 4 g .. 4 g + 3 of a column block)
+        const f32x16* cc[16] = {&c0, &c1, &c2, &c3, &c4, &c5, &c6, &c7, &c8, &c9, &c10, &c11, &c12, &c13, &c14, &c15};
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             f32x4 pc[8][4];
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
+            for (int ni = 0; ni < 8; ++ni)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    const f32x16& v = *cc[mt * 4 + half * 2 + (t >> 2)];
+                for (int mi = 0; mi < 4; ++mi) {
+                    const int t = (half * 4 + mi) * 8 + ni;          // output tile index -> c_(t / 4), quad t % 4
+                    const f32x16& v = *cc[t >> 2];
                     const int qd = (t & 3) * 4;
-                    pc[t][mt] = (f32x4){v[qd], v[qd + 1], v[qd + 2], v[qd + 3]};
+                    pc[ni][mi] = (f32x4){v[qd], v[qd + 1], v[qd + 2], v[qd + 3]};
                 }
-            // Residual-type epilogues (16 B of auxiliary operand per output quad) are load -> math -> store per CHUNK: with the 8-column "tiles" of this
-            // layout the default 2-tile chunks made 16 dependent memory round trips per wave tile (dSwiGLU: +25 us per tile over the plain store, RESID
-            // +13). The fragment registers are dead here, so 4-quad chunks (64 auxiliary VGPRs) fit: measured in the Llama-2 step dSwiGLU 377 -> 359 us, RESID flat (8-quad chunks: 363, more scratch).
-            constexpr int NCHW = (EPI == MTL_EPI_RESID || EPI == MTL_EPI_ACCUM || EPI == MTL_EPI_DGELU || EPI == MTL_EPI_DSWIGLU) ? MTL_W4_NCHW : 0;
-            epilogue_wave<EPI, CDT, 8, true, true, 1, NCHW>(p, m0 + wr * 128 + l31, n0 + wc * 128 + half * 64, h, pc);
+            epilogue_wave<EPI, CDT, 8, true, false, 0>(p, m0 + wr * 128 + half * 64 + l15, n0 + wc * 128, g, pc);
         }
 #ifdef MTL_DIAG_W4VAR
         if (i == slot && p.workspace && threadIdx.x == 0) {

@@ -36,28 +36,36 @@ B_REGION = 0x10000   # B buffers start here
 PIECE = 0x1000       # LDS bytes of one LDS-DMA instruction of the four waves (4 x 1 KiB)
 
 
-def fa(s, ksl, mt):  # A-tile fragment (rows m): MFMA srcB
-    r = FRAG0 + (((s * 2 + ksl) * 4 + mt) * 4)
+def fa(s, blk):      # A-tile fragment of k-step s (k 32 s .. 32 s + 31), 16-row block blk of the wave's 128 rows: MFMA srcB
+    r = FRAG0 + (s * 16 + blk) * 4
     return f"v[{r}:{r + 3}]"
 
 
-def fb(s, ksl, nt):  # B-tile fragment (rows n): MFMA srcA
-    r = FRAG0 + 64 + (((s * 2 + ksl) * 4 + nt) * 4)
+def fb(s, blk):      # B-tile fragment (rows n): MFMA srcA
+    r = FRAG0 + (s * 16 + 8 + blk) * 4
     return f"v[{r}:{r + 3}]"
 
 
-def rd_a(s, ksl, mt, buf):
-    return f"ds_read_b128 {fa(s, ksl, mt)}, v{KSB + s * 2 + ksl} offset:{buf * A_BUF + mt * 4096}"
+def rd_a(s, blk, buf):
+    return f"ds_read_b128 {fa(s, blk)}, v{KSB + s} offset:{buf * A_BUF + blk * 2048}"
 
 
-def rd_b(s, ksl, nt, buf):
-    return f"ds_read_b128 {fb(s, ksl, nt)}, v{KSB + 4 + s * 2 + ksl} offset:{buf * A_BUF + nt * 4096}"
+def rd_b(s, blk, buf):
+    return f"ds_read_b128 {fb(s, blk)}, v{KSB + 4 + s} offset:{buf * A_BUF + blk * 2048}"
 
 
-def mfma(m, zero=False):
-    s, ksl, nt, mt = m // 32, (m % 32) // 16, (m % 16) // 4, m % 4
-    c = f"%[c{mt * 4 + nt}]"
-    return f"v_mfma_f32_32x32x16_bf16 {c}, {fb(s, ksl, nt)}, {fa(s, ksl, mt)}, {'0' if zero else c}"
+def acc(mi, ni):     # accumulator of output tile (row block mi, column block ni) of the wave's 8 x 8: physical AGPR quad
+    q = 4 * (mi * 8 + ni)
+    return f"a[{q}:{q + 3}]"
+
+
+def mfma_tile(j):    # j-th MFMA of a k-step -> (mi, ni): row blocks 0..3 against all eight column blocks first, then row blocks 4..7
+    return (j % 4, j // 4) if j < 32 else (4 + (j - 32) % 4, (j - 32) // 4)
+
+
+def mfma(n, zero=False):     # n-th of the k-tile's 128 MFMAs
+    s, (mi, ni) = n // 64, mfma_tile(n % 64)
+    return f"v_mfma_f32_16x16x32_bf16 {acc(mi, ni)}, {fb(s, ni)}, {fa(s, mi)}, {'0' if zero else acc(mi, ni)}"
 
 
 def dma(op, i, pol=""):
@@ -76,12 +84,12 @@ SCHED = {
     "s0": dict(b1=0, bar1=12, dma_b=14, a1=14, bar2=29, dma_a=31, wait=43, s0=44, s0_per=1, final_lgkm=0),
     # every wait at least 8 MFMAs behind the last instruction it waits for; the S0 reads of k 16..31 may stay out across the loop end
     # (the next iteration's first wait, lgkmcnt(0) in front of barrier 1, precedes their first use at MFMA 16)
-    "s1": dict(b1=0, bar1=15, dma_b=17, a1=16, bar2=31, dma_a=33, wait=46, s0=47, s0_per=1, final_lgkm=8),
+    "s1": dict(b1=0, bar1=15, dma_b=17, a1=16, bar2=31, dma_a=33, wait=46, s0=47, s0_per=1, final_lgkm=4),
     # the landing wait as late as the S0 reads allow (two reads per gap)
-    "s2": dict(b1=0, bar1=15, dma_b=17, a1=16, bar2=31, dma_a=33, wait=53, s0=54, s0_per=2, final_lgkm=8),
+    "s2": dict(b1=0, bar1=15, dma_b=17, a1=16, bar2=31, dma_a=33, wait=53, s0=54, s0_per=2, final_lgkm=4),
     # the 16 LDS-DMA instructions spread over the iteration (one per four / three MFMAs) instead of two bursts of one per two
-    "s3": dict(b1=0, bar1=14, dma_b=16, a1=16, bar2=31, dma_a=34, dma_step=4, wait=47, s0=48, s0_per=1, final_lgkm=8),
-    "s4": dict(b1=0, bar1=14, dma_b=16, a1=16, bar2=31, dma_a=33, dma_step=3, wait=47, s0=48, s0_per=1, final_lgkm=8),
+    "s3": dict(b1=0, bar1=14, dma_b=16, a1=16, bar2=31, dma_a=34, dma_step=4, wait=47, s0=48, s0_per=1, final_lgkm=4),
+    "s4": dict(b1=0, bar1=14, dma_b=16, a1=16, bar2=31, dma_a=33, dma_step=3, wait=47, s0=48, s0_per=1, final_lgkm=4),
 }
 PRODUCT_SCHED = "s3"
 
@@ -98,9 +106,8 @@ def body(b, sched, var="", first=False, chained_entry=False):
     n_dma = 0
     loc = "L" in var
     # ---- S1 reads of B (tile t), then barrier 1
-    order_b1 = [(1, ksl, nt) for ksl in range(2) for nt in range(4)]
-    for j, (s, ksl, nt) in enumerate(order_b1):
-        fill[sc["b1"] + j].append(rd_b(s, ksl, nt, b))
+    for j in range(8):
+        fill[sc["b1"] + j].append(rd_b(1, j, b))
     # scalar bookkeeping of the iteration: k step of this iteration's DMA (k-tile t + 2). s99 reaches 0 where the k position wraps back to k-tile 0
     # (per-XCD rotation; with rot = 0 that is iteration nkt - 2, the first of the two trailing ones)
     fill[8] += ["s_sub_i32 s99, s99, 1", "s_cmp_eq_u32 s99, 0", "s_cselect_b32 s97, s71, 128"]
@@ -118,9 +125,8 @@ def body(b, sched, var="", first=False, chained_entry=False):
     fill[sc["bar1"]] += ["s_waitcnt lgkmcnt(0)", "s_barrier", "s_add_u32 s76, s76, s97", "s_addc_u32 s77, s77, s70"]
     # ---- DMA of B(t + 2) / A(t + 2) into buffer b: instruction i in slot start + step * i, its M0 (absolute) set one gap earlier
     # ---- S1 reads of A (tile t), then barrier 2
-    order_a1 = [(1, ksl, mt) for ksl in range(2) for mt in range(4)]
-    for j, (s, ksl, mt) in enumerate(order_a1):
-        fill[sc["a1"] + j].append(rd_a(s, ksl, mt, b))
+    for j in range(8):
+        fill[sc["a1"] + j].append(rd_a(1, j, b))
     assert sc["a1"] + 7 < sc["bar2"] and sc["bar1"] < sc["dma_b"] - 1 and sc["bar2"] < sc["dma_a"] - 1 and sc["bar1"] > 12
     fill[sc["bar2"]] += ["s_waitcnt lgkmcnt(0)", "s_barrier", "s_add_u32 s72, s72, s97", "s_addc_u32 s73, s73, s70"]
     wait_at = sc["wait"]
@@ -137,24 +143,13 @@ def body(b, sched, var="", first=False, chained_entry=False):
     # (a chained entry's tile t + 1 = k-tile 1 landed before the previous tile's epilogue: no wait — it would wait for that epilogue's stores)
     fill[wait_at] = ([] if chained_entry else [f"s_waitcnt vmcnt({n_dma})"]) + ["s_barrier"] + fill[wait_at]
     # ---- S0 reads of tile t + 1 from buffer b ^ 1, in the order the next iteration consumes them
-    order0 = []
-    for ksl in range(2):
-        order0.append(("b", 0, ksl, 0))
-        order0 += [("a", 0, ksl, mt) for mt in range(4)]
-        order0 += [("b", 0, ksl, nt) for nt in range(1, 4)]
-    for j, (op, s, ksl, x) in enumerate(order0):
+    for j, (op, x) in enumerate(S0_ORDER):
         m = sc["s0"] + j // sc["s0_per"]
-        assert wait_at < m <= 63 and m >= 32      # (S0 registers are free once MFMA 31 has issued)
-        fill[m].append(rd_a(s, ksl, x, b ^ 1) if op == "a" else rd_b(s, ksl, x, b ^ 1))
+        assert wait_at < m <= 63 and m >= 32      # (S0 registers are free once slot 31 has issued)
+        fill[m].append(rd_a(0, x, b ^ 1) if op == "a" else rd_b(0, x, b ^ 1))
     out = []
     for m in range(64):
-        if "S" in var:      # ablation: the same FLOPs as two v_mfma_f32_16x16x32_bf16 on physical AGPR quads (garbage results: what the MFMA shape does to time / clock)
-            s_, ksl, nt, mt = m // 32, (m % 32) // 16, (m % 16) // 4, m % 4
-            for half in range(2):
-                q = ((m % 32) * 2 + half) * 4
-                out.append(f"v_mfma_f32_16x16x32_bf16 a[{q}:{q + 3}], {fb(s_, ksl, nt)}, {fa(s_, ksl, mt)}, a[{q}:{q + 3}]")
-        else:
-            out.append(mfma(m, first and m < 16))
+        out += [mfma(2 * m, first and m < 32), mfma(2 * m + 1, first and m < 32)]
         for ins in fill[m]:
             if "D" in var and ins.startswith("buffer_load"):
                 continue
@@ -178,9 +173,9 @@ def setup():
          "s_mov_b64 s[76:77], %[pb]", "s_mov_b32 s78, -1", "s_mov_b32 s79, 0x20000"]
     for j in range(16):
         o.append(f"v_readlane_b32 s{80 + j}, %[tab], {j}")
-    for ks in range(4):
-        o += [f"v_xor_b32 v{KSB + ks}, {2 * ks}, %[xa]", f"v_xor_b32 v{KSB + 4 + ks}, {2 * ks}, %[xb]"]
-    for ks in range(4):
+    for ks in range(2):        # k-step ks: the lane's 16-byte chunk 4 ks + (lane >> 4), XOR the row's swizzle
+        o += [f"v_xor_b32 v{KSB + ks}, {4 * ks}, %[xa]", f"v_xor_b32 v{KSB + 4 + ks}, {4 * ks}, %[xb]"]
+    for ks in range(2):
         o += [f"v_lshl_add_u32 v{KSB + ks}, v{KSB + ks}, 4, %[rba]", f"v_lshl_add_u32 v{KSB + 4 + ks}, v{KSB + 4 + ks}, 4, %[rbb]"]
     # k position of the LDS-DMA stream: k-tile (j + rot) mod nkt for the j-th tile staged (per-XCD rotation; rot = 0: plain order).
     # s98 = advances left, s99 = advances until the wrap back to k-tile 0, s71 = the wrap's byte step -(nkt - 1) * 128
@@ -190,12 +185,14 @@ def setup():
     return o
 
 
+# S0 (k-step 0) fragments in the order the next iteration consumes them: row blocks 0..3 and column block 0 at once, column block ni from MFMA 4 ni on,
+# row blocks 4..7 from MFMA 32 (= slot 16) on — those four may stay out across the loop end (final_lgkm = 4: the next wait, lgkmcnt(0) in front of
+# barrier 1 at slot 14, precedes their first use)
+S0_ORDER = [("a", 0), ("a", 1), ("a", 2), ("a", 3)] + [("b", x) for x in range(8)] + [("a", 4), ("a", 5), ("a", 6), ("a", 7)]
+
+
 def s0_reads():
-    o = []
-    for ksl in range(2):
-        for x in range(4):
-            o += [rd_b(0, ksl, x, 0), rd_a(0, ksl, x, 0)]
-    return o + ["s_waitcnt lgkmcnt(0)"]
+    return [rd_a(0, x, 0) if op == "a" else rd_b(0, x, 0) for op, x in S0_ORDER] + ["s_waitcnt lgkmcnt(0)"]
 
 
 def cold_stage():
@@ -253,7 +250,7 @@ def program(sched=PRODUCT_SCHED, var=""):
 
 
 # MTL_W4_LOOP_ASM_V1 .. (diagnostic builds, -DMTL_DIAG_W4VAR): (schedule, ablation letters)
-VARIANTS = [("s3", "S"), ("s3", "D"), ("s3", "DBRW"), ("s3", "SDBRW"), ("s3", "L")]
+VARIANTS = [("s1", ""), ("s3", "D"), ("s3", "DBRW"), ("s3", "V"), ("s3", "L")]
 
 
 def emit(f, name, lines):

@@ -112,7 +112,7 @@ def run(lines, nkt, rot=0, dma_base=0x400, max_steps=2_000_000, flags=0):
             addr_reg = int(re.match(r"v(\d+)", a[1].split()[0]).group(1))
             offset = int(re.search(r"offset:(\d+)", ins).group(1))
             which = "a" if addr_reg < 244 else "b"
-            ev.append(("read", which, (addr_reg - 240) % 4, offset // 0x8000, (offset % 0x8000) // 4096, reg))
+            ev.append(("read", which, (addr_reg - 240) % 4, offset // 0x8000, (offset % 0x8000) // 2048, reg))      # k-step, buffer, 16-row block, destination
         elif op == "s_waitcnt":
             m = re.search(r"vmcnt\((\d+)\)", ins)
             if m:
@@ -122,7 +122,7 @@ def run(lines, nkt, rot=0, dma_base=0x400, max_steps=2_000_000, flags=0):
                 ev.append(("lgkmcnt", int(m.group(1))))
         elif op == "s_barrier":
             ev.append(("barrier",))
-        elif op == "v_mfma_f32_32x32x16_bf16":
+        elif op == "v_mfma_f32_16x16x32_bf16":
             srcs = [int(re.match(r"v\[(\d+):", x).group(1)) for x in a[1:3]]
             ev.append(("mfma", a[0], srcs[0], srcs[1], a[3]))
         elif op in ("s_nop", "v_xor_b32", "v_lshl_add_u32"):
@@ -151,6 +151,7 @@ def check(ev, nkt, rot=0, has_prev=False, has_next=False):
                 staged[(which, piece)] = [0, 1]
                 landed[(which, 0, piece)], landed[(which, 1, piece)] = 0, 1
     mf = 0
+    seen = {}                   # (tile, k-step) -> output tiles accumulated
     zeroed = set()              # accumulators whose first MFMA (C = 0) has issued
     cur = {}                    # buffer -> k-tile currently landed in it, per operand
     for e in ev:
@@ -173,7 +174,7 @@ def check(ev, nkt, rot=0, has_prev=False, has_next=False):
             pending.append((which, buf, piece, j))
         elif e[0] == "vmcnt":
             n = e[1]
-            assert not has_prev or mf >= 64, "a chained entry waits for no load before its second iteration (it would wait for the previous epilogue's stores)"
+            assert not has_prev or mf >= 128, "a chained entry waits for no load before its second iteration (it would wait for the previous epilogue's stores)"
             done, pending = pending[:max(0, len(pending) - n)], pending[max(0, len(pending) - n):]
             waited += done
         elif e[0] == "barrier":
@@ -187,29 +188,32 @@ def check(ev, nkt, rot=0, has_prev=False, has_next=False):
             _, which, ks, buf, tile, reg = e
             js = {landed.get((which, buf, p)) for p in range(8)}
             assert len(js) == 1 and None not in js, ("reading a buffer whose pieces have not all landed behind a barrier", e, js)
-            reads_out.append((which, buf, reg, js.pop(), ks))
+            reads_out.append((which, buf, reg, js.pop(), ks, tile))
             last_read_unbarriered.add((which, buf))
         elif e[0] == "lgkmcnt":
             n = e[1]
             done, reads_out = reads_out[:max(0, len(reads_out) - n)], reads_out[max(0, len(reads_out) - n):]
-            for (which, buf, reg, j, ks) in done:
-                frag[reg] = (which, j, ks)
+            for (which, buf, reg, j, ks, blk) in done:
+                frag[reg] = (which, j, ks, blk)
             if n == 0:
                 reads_done_since_barrier |= set(last_read_unbarriered)
         elif e[0] == "mfma":
             _, acc, rb, ra, csrc = e
-            assert csrc == ("0" if mf < 16 else acc), ("the first MFMA of every accumulator takes C = 0, all later ones accumulate", mf, acc, csrc)
-            if mf < 16:
+            assert csrc == ("0" if mf < 64 else acc), ("the first MFMA of every accumulator takes C = 0, all later ones accumulate", mf, acc, csrc)
+            if mf < 64:
                 zeroed.add(acc)
-            t = mf // 64                        # iteration = stream tile
+            q = int(re.match(r"a\[(\d+):", acc).group(1))
+            mi, ni = (q // 4) // 8, (q // 4) % 8          # accumulator quad -> output tile (row block, column block) of the wave's 8 x 8
+            t = mf // 128                       # iteration = stream tile
             if t < nkt:
-                m = mf % 64
-                ks = (m // 32) * 2 + (m % 32) // 16
-                for reg, which in ((rb, "b"), (ra, "a")):
-                    assert reg not in {r for (_, _, r, _, _) in reads_out}, ("MFMA reads a fragment whose ds_read may still be in flight", mf, reg)
-                    assert frag.get(reg) == (which, t, ks), ("MFMA operand is not (operand, tile, k-step)", mf, reg, frag.get(reg), (which, t, ks))
+                ks = (mf % 128) // 64
+                for reg, which, blk in ((rb, "b", ni), (ra, "a", mi)):
+                    assert reg not in {r for (_, _, r, _, _, _) in reads_out}, ("MFMA reads a fragment whose ds_read may still be in flight", mf, reg)
+                    assert frag.get(reg) == (which, t, ks, blk), ("MFMA operand is not (operand, tile, k-step, block)", mf, reg, frag.get(reg), (which, t, ks, blk))
+                seen.setdefault((t, ks), set()).add((mi, ni))
             mf += 1
-    assert mf == 64 * nkt and len(zeroed) == 16, (mf, nkt, len(zeroed))
+    assert mf == 128 * nkt and len(zeroed) == 64, (mf, nkt, len(zeroed))
+    assert all(len(v) == 64 for v in seen.values()) and len(seen) == 2 * nkt, "every k-step accumulates into each of the 64 output tiles exactly once"
     assert not pending, "the statement's final vmcnt(0) covers every load (the next tile enters without a landing wait)"
     if has_next:
         for (which, piece), lst in staged.items():
