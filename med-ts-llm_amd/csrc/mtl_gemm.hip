@@ -1007,7 +1007,11 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
     // fragment read addresses: lane (l15, g) reads row l15 of a 16-row block, 16-byte chunk 4 ks + g of its k-tile row (k-step ks; the asm derives both
     // k-steps and adds 2 KiB per block); block bases are multiples of 16 rows, so the row's swizzle is swz64(l15)
     const uint32_t rba = lds0 + (uint32_t)((wr * 128 + l15) * 128), xa = (uint32_t)(g ^ swz64(l15));
-    const uint32_t rbb = lds0 + 0x10000u + (uint32_t)((wc * 128 + l15) * 128), xb = xa;
+    // B column blocks are read in PAIRS (epilogue_wave's PAIR layout: a lane's 4 + 4 columns of blocks 2t / 2t + 1 are 8 consecutive columns): lane row
+    // 8 (l15 >> 2) + (l15 & 3) of the pair's 32 rows (+ 4 for the odd block, an immediate in the asm). The B image's swizzle uses row bits 1, 3, 4
+    // (swzb below, the LDS-DMA writes it the same way): the 16 rows of such a read then fall on 16 distinct bank groups.
+    const int browl = (l15 >> 2) * 8 + (l15 & 3);
+    const uint32_t rbb = lds0 + 0x10000u + (uint32_t)((wc * 128 + browl) * 128), xb = (uint32_t)(g ^ (((browl >> 1) & 1) | (((browl >> 3) & 3) << 1)));
     // LDS-DMA: instruction i of wave w stages tile rows (4 i + w) * 8 .. + 7; lane -> row lane / 8, slot lane % 8
     const uint32_t dma = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (uint32_t)wave * 1024u));
     const int drow = lane >> 3, dsl = lane & 7;
@@ -1016,7 +1020,11 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
     if (gm_all & (1 << 10)) dsw = 0;
 #endif
     const uint32_t voa = (uint32_t)(drow * (int)p.lda * 2 + ((dsl ^ dsw) << 4));
-    const uint32_t vob = (uint32_t)(drow * (int)p.ldb * 2 + ((dsl ^ dsw) << 4));
+    int dswb = ((lane >> 4) & 1) | (wave << 1);           // B image: swzb(row) = bit 1 | bits 3..4 << 1 of the tile row (4 i + wave) * 8 + drow
+#ifdef MTL_DIAG_W4VAR
+    if (gm_all & (1 << 10)) dswb = 0;
+#endif
+    const uint32_t vob = (uint32_t)(drow * (int)p.ldb * 2 + ((dsl ^ dswb) << 4));
 
     // (Measured and dropped, profiles/r06_gemm_w4_experiments.txt: starting XCD x late by x * 0.4 / 0.8 / 1.6 us so that the rounds' store bursts of the
     //  eight XCDs interleave with the other XCDs' main loops — in-step Llama-2-7B 102.29 / 102.11 / 101.95 / 102.09 ms per step, i.e. nothing.)
@@ -1093,7 +1101,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
                     const int qd = (t & 3) * 4;
                     pc[ni][mi] = (f32x4){v[qd], v[qd + 1], v[qd + 2], v[qd + 3]};
                 }
-            epilogue_wave<EPI, CDT, 8, true, false, 0>(p, m0 + wr * 128 + half * 64 + l15, n0 + wc * 128, g, pc);
+            epilogue_wave<EPI, CDT, 8, true, true, 0>(p, m0 + wr * 128 + half * 64 + l15, n0 + wc * 128, g, pc);
         }
 #ifdef MTL_DIAG_W4VAR
         if (i == slot && p.workspace && threadIdx.x == 0) {

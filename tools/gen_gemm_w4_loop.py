@@ -51,7 +51,9 @@ def rd_a(s, blk, buf):
 
 
 def rd_b(s, blk, buf):
-    return f"ds_read_b128 {fb(s, blk)}, v{KSB + 4 + s} offset:{buf * A_BUF + blk * 2048}"
+    # column blocks come in PAIRS: lane (l15, g) of blocks 2t / 2t + 1 reads B-tile row 32 t + 8 (l15 >> 2) + (l15 & 3) [+ 4], so that the lane's 4 + 4 output
+    # columns of the pair are the 8 consecutive columns 32 t + 8 g .. + 7 (16-byte bf16 stores in the epilogue). The lane part sits in the base register.
+    return f"ds_read_b128 {fb(s, blk)}, v{KSB + 4 + s} offset:{buf * A_BUF + (blk >> 1) * 4096 + (blk & 1) * 512}"
 
 
 def acc(mi, ni):     # accumulator of output tile (row block mi, column block ni) of the wave's 8 x 8: physical AGPR quad

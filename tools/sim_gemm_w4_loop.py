@@ -112,7 +112,10 @@ def run(lines, nkt, rot=0, dma_base=0x400, max_steps=2_000_000, flags=0):
             addr_reg = int(re.match(r"v(\d+)", a[1].split()[0]).group(1))
             offset = int(re.search(r"offset:(\d+)", ins).group(1))
             which = "a" if addr_reg < 244 else "b"
-            ev.append(("read", which, (addr_reg - 240) % 4, offset // 0x8000, (offset % 0x8000) // 2048, reg))      # k-step, buffer, 16-row block, destination
+            off = offset % 0x8000
+            blk = off // 2048 if which == "a" else (off // 4096) * 2 + (off % 4096) // 512        # (B column blocks are read in pairs: 32 t rows + 4 rows for the odd one)
+            assert (off % 2048 == 0) if which == "a" else (off % 4096 in (0, 512)), ins
+            ev.append(("read", which, (addr_reg - 240) % 4, offset // 0x8000, blk, reg))      # k-step, buffer, block, destination
         elif op == "s_waitcnt":
             m = re.search(r"vmcnt\((\d+)\)", ins)
             if m:
