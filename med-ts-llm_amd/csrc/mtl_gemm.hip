@@ -968,16 +968,18 @@ __global__ __launch_bounds__(NW_ALL * 64, persist_waves_per_simd(BM_, BN_, STAGE
 // The Llama-class instance (round 6). What the 8-wave 256 x 256 kernel above could not be made to do — keep the matrix pipe issuing while the
 // wave also reads fragments, stages the next k-tiles and meets its barriers — is a matter of per-instruction placement, so the k-loop of a tile
 // is ONE asm statement (generated: tools/gen_gemm_w4_loop.py -> mtl_gemm_w4_loop.inc, which documents the time structure):
-//   * 4 waves (2 x 2), each a 128 x 128 sub-tile as 4 x 4 v_mfma_f32_32x32x16_bf16 accumulators = 256 AGPRs (16 "+a" operands of 16 registers,
-//     allocated by the compiler, so the epilogue below is ordinary C++ on them); 128 fragment VGPRs in two k-half sets; 128 operand bytes per
-//     MFMA through the LDS instead of the 8-wave kernel's 192.
-//   * LDS image: two 32 KiB buffers per operand, row r of a tile at r * 128 B, 16-B chunk c of it at slot c ^ swz64(r) — written by the LDS-DMA
+//   * 4 waves (2 x 2), each a 128 x 128 sub-tile as 8 x 8 output tiles of v_mfma_f32_16x16x32_bf16 = 256 AGPRs: tile (mi, ni) in the PHYSICAL quad
+//     a[4 (8 mi + ni) .. + 3], named by the asm and handed to the C++ epilogue through 16 "={a[16 k : 16 k + 15]}" operands; 128 fragment VGPRs in
+//     two k-step sets; 128 operand bytes per 32 KFLOP through the LDS instead of the 8-wave kernel's 192. (The first version used 4 x 4
+//     v_mfma_f32_32x32x16_bf16: the same cycles, but the chip clocks 5 - 9 % lower under that shape — profiles/r06_gemm_w4_experiments.txt section 15.)
+//   * LDS image: two 32 KiB buffers per operand, row r of a tile at r * 128 B, 16-B chunk c of it at slot c ^ swz(r) — written by the LDS-DMA
 //     (buffer_load_dwordx4 ... lds: 8 rows per wave-instruction, the swizzle applied on the per-lane SOURCE offset), read back with the same XOR.
+//     A image: swz = row bits 1..3 (swz64); B image: row bits 1, 3, 4 — its column blocks are read in pairs (lane row 8 (l15 >> 2) + (l15 & 3)).
 //     The rows an instruction fetches are given by a wave-uniform SGPR offset per instruction (row-mapped A operands: 8-row pieces never straddle
 //     a row group, the host checks), the k position by the descriptor's base address, advanced 128 B per k-tile.
-//   * B-tile fragment lane i reads tile row (i with bits 2 and 3 swapped): accumulator quads 2t / 2t+1 of a lane are then 8 CONSECUTIVE output
-//     columns (16-byte bf16 stores), cf. epi_cols<LAY = 1>.
-// Swapped MFMA operands as everywhere in this file (D = Btile . Atile^T): a lane owns output row l % 32 (+ 32 mt) and 4 consecutive columns per quad.
+//   * Swapped MFMA operands as everywhere in this file (D = Btile . Atile^T): a lane owns output row l15 of a row block and 4 consecutive columns of
+//     a column block; the paired B reads make the 4 + 4 columns of blocks 2t / 2t + 1 the 8 consecutive columns 32 t + 8 g .. + 7 (epilogue_wave's
+//     PAIR layout: 16-byte bf16 stores) — the epilogue is the 8-wave kernels' own, called once per 64-row half of the wave's sub-tile.
 // Whole tiles only (M % 256 == 0, N % 256 == 0); everything else stays with gemm_nt_persist_kernel.
 #include "mtl_gemm_w4_loop.inc"
 typedef __attribute__((ext_vector_type(16))) float f32x16;

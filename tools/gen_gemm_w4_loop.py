@@ -1,15 +1,19 @@
 #!/usr/bin/env python3
 """Generator of med-ts-llm_amd/csrc/mtl_gemm_w4_loop.inc — the hand-placed k-loop of gemm_nt_w4_kernel (mtl_gemm.hip).
 
-One 256 x 256 x 64 k-tile per loop body, 4 waves (2 x 2), one wave per SIMD, each wave a 128 x 128 sub-tile as 4 x 4
-v_mfma_f32_32x32x16_bf16 accumulators (16 x f32x16 = 256 AGPRs, compiler-allocated "+a" operands). A k-tile is 64 MFMAs of 32 cycles each;
-every other instruction of the k-tile (32 ds_read_b128, 16 LDS-DMA loads + their M0 updates, 3 barriers, the counted waits, the scalar
-bookkeeping) sits in a FIXED slot between two MFMAs, at most two per gap, so the matrix pipe never waits for the issue of anything else.
+One 256 x 256 x 64 k-tile per loop body, 4 waves (2 x 2), one wave per SIMD, each wave a 128 x 128 sub-tile as 8 x 8 output tiles of
+v_mfma_f32_16x16x32_bf16 (64 accumulator quads = the 256 AGPRs, PHYSICAL: tile (mi, ni) = a[4 (8 mi + ni) .. + 3]; the kernel's asm operands
+"={a[16 k : 16 k + 15]}" tell the compiler). A k-tile is 128 MFMAs of 16 cycles each, two per SLOT (the slot structure of the first, 32 x 32 x 16
+version — same cycles per FLOP, but the chip clocks 5 - 9 % lower under that shape: profiles/r06_gemm_w4_experiments.txt section 15); every other
+instruction of the k-tile (32 ds_read_b128, 16 LDS-DMA loads + their M0 updates, 3 barriers, the counted waits, the scalar bookkeeping) sits in
+a FIXED slot, so the matrix pipe never waits for the issue of anything else.
 
 Time structure of iteration t (LDS: two buffers per operand; buffer b = t & 1 holds k-tile t, k-tile t + 1 is landing in buffer b ^ 1):
-  fragments live in two register sets: S0 = k 0..31 of the tile, S1 = k 32..63. At the top S0 holds tile t.
-  MFMA  0..31 (S0) | B reads of S1, barrier 1 (B of buffer b is free) -> LDS-DMA of B(t + 2) into it, A reads of S1, barrier 2 -> LDS-DMA of A(t + 2)
-  MFMA 32..63 (S1) | rest of the A DMA, vmcnt(those just issued) + barrier 3 (tile t + 1 has landed for everyone) -> S0 reads of tile t + 1
+  fragments live in two register sets: S0 = k-step 0 (k 0..31 of the tile), S1 = k-step 1 (k 32..63); per set 8 A row blocks + 8 B column blocks of 4 VGPRs.
+  At the top S0 holds tile t.
+  slots  0..31 (S0: 64 MFMAs) | B reads of S1, barrier 1 (B of buffer b is free) -> LDS-DMA of B(t + 2) into it, A reads of S1, barrier 2 -> LDS-DMA of A(t + 2)
+  slots 32..63 (S1: 64 MFMAs) | rest of the A DMA, vmcnt(those just issued) + barrier 3 (tile t + 1 has landed for everyone) -> S0 reads of tile t + 1
+  MFMA order of a k-step: row blocks 0..3 against the eight column blocks, then row blocks 4..7 (every accumulator once per k-step, 64 MFMAs apart).
 The loop is unrolled twice (buffer parity is an immediate in every ds_read offset and M0 base).
 
 Tile chaining (a persistent workgroup's tiles i, i + 1, ...; %[flags] bit 1 = a next tile follows, bit 0 = the previous tile staged for this one): with a
@@ -19,7 +23,7 @@ i + 1 enters without any load or landing wait: its k-loop starts right after the
 iterations (gfx950 retires loads and stores through one in-order counter, so a tile that stages after the stores waits for all of them). Needs an even
 number of k-tiles (tile i + 1's k-tile 0 must land in buffer 0) and rot = 0.
 
-Physical registers named by the asm (all listed as clobbers): v[112:239] fragments, v[240:247] per-k-step read bases,
+Physical registers named by the asm (all listed as clobbers): v[112:239] fragments, v[240:241] / v[244:245] per-k-step read bases of A / B, a[0:255] the accumulators (operands),
 s[72:75] / s[76:79] buffer descriptors of A / B, s[80:87] / s[88:95] the per-instruction row offsets, s96 loop counter, s97 / s70 k step (lo / sign word), s98 advances left, s99 advances until the k wrap, s71 the wrap's step,
 s68 next-tile flag, s69 scratch.
 
