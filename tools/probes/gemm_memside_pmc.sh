@@ -9,6 +9,7 @@ run ea TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RD
 run stall TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_RDREQ_GMI_CREDIT_STALL_sum TCC_HIT_sum TCC_MISS_sum
 run tcp TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_REQUEST_sum
 run grbm GRBM_GUI_ACTIVE TCC_REQ_sum
+run sq SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES
 cd $R
 python - <<'PY' > $OUT/gemm_memside.txt
 import glob, sqlite3
@@ -40,6 +41,7 @@ for si, shape in enumerate(SHAPES):
               f"EA reads {g('TCC_EA0_RDREQ_sum') / 1e6:6.2f} M (to DRAM/MALL {g('TCC_EA0_RDREQ_DRAM_sum') / 1e6:6.2f} M)  EA latency {g('TCC_EA0_RDREQ_LEVEL_sum') / g('TCC_EA0_RDREQ_sum'):6.0f} cyc  "
               f"L1->L2 latency {g('TCP_TCC_READ_REQ_LATENCY_sum') / g('TCP_TCC_READ_REQ_sum'):5.0f} cyc  DRAM credit stalls {g('TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum'):6.0f}  "
               f"TLB misses {g('TCP_UTCL1_TRANSLATION_MISS_sum'):5.0f}  GUI {g('GRBM_GUI_ACTIVE') / 8 / 1e3:7.1f} k cycles", end="")
+        print(f"  LDS conflict / active {g('SQ_LDS_BANK_CONFLICT') / max(1.0, g('SQ_LDS_IDX_ACTIVE')):.3f}  MFMA busy {g('SQ_VALU_MFMA_BUSY_CYCLES') / max(1.0, 32.0 * g('SQ_BUSY_CYCLES')):.3f}", end="")
         ds = dur.get(k, [])[6 * si:6 * si + 6]
         if ds:
             us = sum(ds) / len(ds) / 1e3
