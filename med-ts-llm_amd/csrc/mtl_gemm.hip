@@ -67,7 +67,7 @@ __device__ __forceinline__ int64_t remap_row(int64_t m, int64_t group_rows, int6
 }
 
 #ifndef MTL_W4_NCHW
-#define MTL_W4_NCHW 4      // column quads per epilogue chunk of the residual-type epilogues (A/B builds: -DMTL_W4_NCHW=2|4)
+#define MTL_W4_NCHW 4      // column blocks per epilogue chunk of the residual-type epilogues (A/B builds: -DMTL_W4_NCHW=2|4)
 #endif
 template <int EPI, int CDT>
 __device__ __forceinline__ void epilogue4(const mtl_gemm_args& p, int64_t m, int64_t n, f32x4 v, bool vec_ok) {
@@ -1103,7 +1103,10 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
                     const int qd = (t & 3) * 4;
                     pc[ni][mi] = (f32x4){v[qd], v[qd + 1], v[qd + 2], v[qd + 3]};
                 }
-            epilogue_wave<EPI, CDT, 8, true, true, 0>(p, m0 + wr * 128 + half * 64 + l15, n0 + wc * 128, g, pc);
+            // residual-type epilogues (16 B of auxiliary operand per output quad) go load -> math -> store per chunk of column blocks: 4 blocks per chunk
+            // (64 auxiliary VGPRs — the fragment registers are dead here) = 4 dependent round trips per wave tile instead of the default rule's 8
+            constexpr int NCHW = (EPI == MTL_EPI_RESID || EPI == MTL_EPI_ACCUM || EPI == MTL_EPI_DGELU || EPI == MTL_EPI_DSWIGLU) ? MTL_W4_NCHW : 0;
+            epilogue_wave<EPI, CDT, 8, true, true, 0, NCHW>(p, m0 + wr * 128 + half * 64 + l15, n0 + wc * 128, g, pc);
         }
 #ifdef MTL_DIAG_W4VAR
         if (i == slot && p.workspace && threadIdx.x == 0) {

@@ -155,7 +155,15 @@ def body(b, sched, var="", first=False, chained_entry=False):
         fill[m].append(rd_a(0, x, b ^ 1) if op == "a" else rd_b(0, x, b ^ 1))
     out = []
     for m in range(64):
-        out += [mfma(2 * m, first and m < 32), mfma(2 * m + 1, first and m < 32)]
+        out.append(mfma(2 * m, first and m < 32))
+        if "P" not in var and len(fill[m]) >= 2:      # a slot's instructions go into BOTH of its MFMA gaps (a 16-cycle MFMA leaves 12 issue cycles per gap); ablation 'P': all behind the pair
+            k = 1 if len(fill[m]) == 2 else (len(fill[m]) + 1) // 2
+            early, fill[m] = fill[m][:k], fill[m][k:]
+            if not any(i.endswith(":") or i.startswith("s_cbranch") for i in early + fill[m]):
+                out += early
+            else:
+                fill[m] = early + fill[m]
+        out.append(mfma(2 * m + 1, first and m < 32))
         for ins in fill[m]:
             if "D" in var and ins.startswith("buffer_load"):
                 continue
@@ -256,7 +264,7 @@ def program(sched=PRODUCT_SCHED, var=""):
 
 
 # MTL_W4_LOOP_ASM_V1 .. (diagnostic builds, -DMTL_DIAG_W4VAR): (schedule, ablation letters)
-VARIANTS = [("s1", ""), ("s3", "D"), ("s3", "DBRW"), ("s3", "V"), ("s3", "L")]
+VARIANTS = [("s3", "P"), ("s3", "D"), ("s3", "DBRW"), ("s3", "V"), ("s3", "L")]
 
 
 def emit(f, name, lines):
