@@ -13,7 +13,8 @@ Time structure of iteration t (LDS: two buffers per operand; buffer b = t & 1 ho
   At the top S0 holds tile t.
   slots  0..31 (S0: 64 MFMAs) | B reads of S1, barrier 1 (B of buffer b is free) -> LDS-DMA of B(t + 2) into it, A reads of S1, barrier 2 -> LDS-DMA of A(t + 2)
   slots 32..63 (S1: 64 MFMAs) | rest of the A DMA, vmcnt(those just issued) + barrier 3 (tile t + 1 has landed for everyone) -> S0 reads of tile t + 1
-  MFMA order of a k-step: row blocks 0..3 against the eight column blocks, then row blocks 4..7 (every accumulator once per k-step, 64 MFMAs apart).
+  MFMA order of a k-step: row blocks 0..3 against the eight column blocks (snaking: consecutive MFMAs share a fragment), then row blocks 4..7
+  (every accumulator once per k-step, 64 MFMAs apart).
 The loop is unrolled twice (buffer parity is an immediate in every ds_read offset and M0 base).
 
 Tile chaining (a persistent workgroup's tiles i, i + 1, ...; %[flags] bit 1 = a next tile follows, bit 0 = the previous tile staged for this one): with a
@@ -65,8 +66,17 @@ def acc(mi, ni):     # accumulator of output tile (row block mi, column block ni
     return f"a[{q}:{q + 3}]"
 
 
-def mfma_tile(j):    # j-th MFMA of a k-step -> (mi, ni): row blocks 0..3 against all eight column blocks first, then row blocks 4..7
-    return (j % 4, j // 4) if j < 32 else (4 + (j - 32) % 4, (j - 32) // 4)
+ORDER = ["snake"]     # MFMA order inside a k-step: "snake" (product) / "colmajor" / "amajor" (ablations; set by program())
+
+
+def mfma_tile(j):    # j-th MFMA of a k-step -> (mi, ni): row blocks 0..3 against all eight column blocks first (snaking), then row blocks 4..7
+    h, jj = (0, j) if j < 32 else (4, j - 32)
+    if ORDER[0] == "amajor":          # row block by row block: consecutive MFMAs share the A fragment
+        return h + jj // 8, jj % 8
+    mi, ni = jj % 4, jj // 4            # "colmajor": column block by column block, row blocks always upwards
+    if ORDER[0] == "snake" and ni % 2:  # ... the row blocks alternately up and down: consecutive MFMAs always share one fragment
+        mi = 3 - mi
+    return h + mi, ni
 
 
 def mfma(n, zero=False):     # n-th of the k-tile's 128 MFMAs
@@ -241,6 +251,7 @@ def chained_stage():
 
 def program(sched=PRODUCT_SCHED, var=""):
     _LBL[0] = 0
+    ORDER[0] = "colmajor" if "k" in var else ("amajor" if "j" in var else "snake")       # product: snake (cold probe: 4096^3 101.9 -> 99.1 us, qkv 294.7 -> 290.6)
     dec_end = ["s_sub_u32 s96, s96, 1", "s_cmp_eq_u32 s96, 0", "s_cbranch_scc1 L_w4_end_%="]
     lines = setup()
     lines += ["s_and_b32 s69, s69, 1", "s_cmp_eq_u32 s69, 0", "s_cbranch_scc0 L_w4_chained_%="]       # (%[flags] is wave-uniform but arrives in a VGPR)
@@ -264,7 +275,7 @@ def program(sched=PRODUCT_SCHED, var=""):
 
 
 # MTL_W4_LOOP_ASM_V1 .. (diagnostic builds, -DMTL_DIAG_W4VAR): (schedule, ablation letters)
-VARIANTS = [("s3", "P"), ("s3", "D"), ("s3", "DBRW"), ("s3", "V"), ("s3", "L")]
+VARIANTS = [("s3", "k"), ("s3", "j"), ("s3", "DBRW"), ("s3", "P"), ("s3", "L")]
 
 
 def emit(f, name, lines):
