@@ -66,6 +66,9 @@ __device__ __forceinline__ int64_t remap_row(int64_t m, int64_t group_rows, int6
     return (int64_t)q * group_stride + off + (int64_t)(mm - q * gr);
 }
 
+#ifndef MTL_PERSIST_SNAKE
+#define MTL_PERSIST_SNAKE 0   // MFMA order of the 8-wave kernels' k-step: 1 = snake over the row tiles (A/B: tools/build_variant.sh psnake only=mtl_gemm -DMTL_PERSIST_SNAKE=1)
+#endif
 #ifndef MTL_W4_NCHW
 #define MTL_W4_NCHW 4      // column blocks per epilogue chunk of the residual-type epilogues (A/B builds: -DMTL_W4_NCHW=2|4)
 #endif
@@ -716,7 +719,10 @@ __device__ __forceinline__ void frag_units(f32x4 (&acc)[NI][4], bf16x8 (&afa)[2]
         else
             asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bq[slot]) : "n"(younger));
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[slot], afa[ks][mi], acc[ni][mi], 0, 0, 0);
+        for (int mj = 0; mj < 4; ++mj) {
+            const int mi = (MTL_PERSIST_SNAKE && (ni & 1)) ? 3 - mj : mj;      // (snake order: consecutive MFMAs share a fragment — A/B builds, see gemm_nt_w4_kernel)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[slot], afa[ks][mi], acc[ni][mi], 0, 0, 0);
+        }
         frag_units<NI, NPT, ROWB, D, U + 1>(acc, afa, bq, abase, bpair, bplain);
     }
 }
@@ -930,8 +936,10 @@ __global__ __launch_bounds__(NW_ALL * 64, persist_waves_per_simd(BM_, BN_, STAGE
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+                for (int mj = 0; mj < 4; ++mj) {
+                    const int mi = (MTL_PERSIST_SNAKE && (ni & 1)) ? 3 - mj : mj;
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
+                }
         }
         }
         c_buf = (c_buf + 1 == STAGES) ? 0 : c_buf + 1;
