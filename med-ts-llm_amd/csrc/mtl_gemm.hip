@@ -1052,17 +1052,20 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
     // i + 1's k-loop starts as soon as tile i's epilogue stores are ISSUED (they drain under its first iterations) instead of after they have drained
     // plus a load round trip. Even k-tile counts only (the next tile's k-tile 0 must land in LDS buffer 0); no per-XCD rotation.
     const bool chain = (nkt & 1) == 0 && rot == 0 && VAR == 0;
+    int tm_next = 0, tn_next = 0;
+    uint32_t tab_next = 0;
+    bool have_next = false;                        // the previous iteration already worked out this tile (it staged its first k-tiles)
     for (int i = slot; i < cnt; i += xblocks) {
-        int tm, tn;
-        tile_coords(t0 + i, tiles_m, tiles_n, gm, tm, tn);
+        int tm = tm_next, tn = tn_next;
+        if (!have_next) tile_coords(t0 + i, tiles_m, tiles_n, gm, tm, tn);
         const int64_t m0 = (int64_t)tm * 256, n0 = (int64_t)tn * 256;
-        const uint32_t tab = row_table(m0, n0);
+        const uint32_t tab = have_next ? tab_next : row_table(m0, n0);
         uint32_t tabn = tab;
         int flags = (chain && i > slot) ? 1 : 0;
-        if (chain && i + xblocks < cnt) {
-            int tmn, tnn;
-            tile_coords(t0 + i + xblocks, tiles_m, tiles_n, gm, tmn, tnn);
-            tabn = row_table((int64_t)tmn * 256, (int64_t)tnn * 256);
+        have_next = chain && i + xblocks < cnt;
+        if (have_next) {
+            tile_coords(t0 + i + xblocks, tiles_m, tiles_n, gm, tm_next, tn_next);
+            tabn = tab_next = row_table((int64_t)tm_next * 256, (int64_t)tn_next * 256);
             flags |= 2;
         }
         // the wave's 8 x 8 output tiles of 16 x 16 (v_mfma_f32_16x16x32_bf16): tile (row block mi, column block ni) lives in the PHYSICAL accumulator quad
