@@ -13,7 +13,7 @@ from med_ts_llm_amd.hip import ops, _native as N     # noqa: E402
 BF16 = torch.bfloat16
 g = torch.Generator().manual_seed(0)
 SHAPES = [("4096 x 4096 x 22016", 4096, 4096, 22016), ("4096 x 4096 x 4096", 4096, 4096, 4096), ("4096 x 12288 x 4096", 4096, 12288, 4096)]
-VARS = [("s3", 2), ("s3 with 16x16x32 MFMAs", 3), ("no DMA", 4), ("MFMA only", 5), ("16x16x32 MFMAs only", 6), ("local DMA", 7)]      # = the generator's VARIANTS list (tune_stages - 2)
+VARS = [("shipped", 2), ("column-major MFMA order", 3), ("row-block-major MFMA order", 4), ("MFMA only", 5), ("slot instructions behind the MFMA pair", 6), ("local DMA", 7)]      # = the generator's VARIANTS list (tune_stages - 2)
 flush = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
 
 
@@ -59,7 +59,7 @@ for name, M, Nn, K in SHAPES[:2]:
     A = torch.randn(M, K, generator=g).to(BF16).cuda()
     B = (torch.randn(Nn, K, generator=g) * 0.05).to(BF16).cuda()
     out = torch.empty(M, Nn, dtype=BF16, device="cuda")
-    for vlabel, vst in (("full loop", 2), ("full loop, 16x16x32 MFMAs", 3), ("MFMA only", 5), ("16x16x32 MFMAs only", 6)):
+    for vlabel, vst in (("full loop", 2), ("MFMA only", 5)):
         ws = torch.zeros(6 * 256, dtype=torch.int64, device="cuda")
         ga = N.GemmArgs()
         ga.A, ga.lda, ga.B, ga.ldb, ga.C, ga.ldc, ga.c_dtype = A.data_ptr(), K, B.data_ptr(), K, out.data_ptr(), Nn, N.MTL_BF16
@@ -77,5 +77,5 @@ for name, M, Nn, K in SHAPES[:2]:
               f"{float((t[:, 2] - t[:, 1]).mean()) * 10 / (K // 64):6.0f} ns/k-tile | epilogue {d(t[:, 3] - t[:, 2])} | end of last workgroup {float(t[:, 3].max() - t0) / 100:6.2f} us")
         cyc = t[:, 5] - t[:, 4]
         mhz = cyc / ((t[:, 2] - t[:, 1]) / 100)
-        print(f"    k-loop {float(cyc.mean()) / (K // 64):7.0f} s_memtime ticks per k-tile (64 MFMAs x 32 cycles = 2048) -> MFMA issue share {2048 * (K // 64) / float(cyc.mean()):.3f} "
+        print(f"    k-loop {float(cyc.mean()) / (K // 64):7.0f} s_memtime ticks per k-tile (128 MFMAs x 16 cycles = 2048) -> MFMA issue share {2048 * (K // 64) / float(cyc.mean()):.3f} "
               f"if a tick is a shader cycle; ticks per us during the loop {float(mhz.mean()):6.0f} (min {float(mhz.min()):6.0f}, max {float(mhz.max()):6.0f})", flush=True)
