@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
             // residual-type epilogues (16 B of auxiliary operand per output quad) go load -> math -> store per chunk of column blocks: 4 blocks per chunk
             // (64 auxiliary VGPRs — the fragment registers are dead here) = 4 dependent round trips per wave tile instead of the default rule's 8
             constexpr int NCHW = (EPI == MTL_EPI_RESID || EPI == MTL_EPI_ACCUM || EPI == MTL_EPI_DGELU || EPI == MTL_EPI_DSWIGLU) ? MTL_W4_NCHW : 0;
-            epilogue_wave<EPI, CDT, 8, true, true, 0, NCHW>(p, m0 + wr * 128 + half * 64 + l15, n0 + wc * 128, g, pc);
+            epilogue_wave<EPI, CDT, 8, true, true, 0, NCHW>(p, m0 + wr * 128 + half * 64 + l15, n0 + wc * 128, g, pc, vec_ok_i == 0);      // (fp32 plain store into 4-B aligned rows: dword stores)
         }
 #ifdef MTL_DIAG_W4VAR
         if (i == slot && p.workspace && threadIdx.x == 0) {
@@ -1396,7 +1396,7 @@ int tile_order(int tiles_m, int tiles_n, int bm, int bn, int per_cu, int64_t K, 
 
 bool aligned(const void* ptr, size_t a) { return (reinterpret_cast<uintptr_t>(ptr) % a) == 0; }
 
-// may this problem run on gemm_nt_w4_kernel? (whole 256 x 256 tiles, vector epilogue, operand offsets that fit the 32-bit buffer addressing of its
+// may this problem run on gemm_nt_w4_kernel? (whole 256 x 256 tiles, vector epilogue — or the plain fp32 store's dword form: the caller passes vec_ok || dword_ok —, operand offsets that fit the 32-bit buffer addressing of its
 // LDS-DMA, row-mapped A operands whose 8-row staging pieces stay inside one row group)
 bool w4_ok(const mtl_gemm_args& p, int vec_ok) {
     if (!vec_ok || p.M % 256 != 0 || p.N % 256 != 0 || p.K < 64) return false;
@@ -1513,7 +1513,7 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st, int fbm = 0, int 
                     b.C = reinterpret_cast<char*>(p.C) + n_main * cmul * (CDT == MTL_BF16 ? 2 : 4);
                     if (p.aux_in) b.aux_in = reinterpret_cast<const char*>(p.aux_in) + n_main * cmul * 2;       // (bf16 for every epilogue listed)
                     if (p.aux_out) b.aux_out = reinterpret_cast<char*>(p.aux_out) + (EPI == MTL_EPI_SWIGLU ? n_main / 2 : n_main) * 2;
-                    const int rc = launch<EPI, CDT>(a, vec_ok, st, 256, 256, 2, w4_ok(a, vec_ok) ? 4 : 8);
+                    const int rc = launch<EPI, CDT>(a, vec_ok, st, 256, 256, 2, w4_ok(a, vec_ok || dword_ok) ? 4 : 8);
                     if (rc != MTL_OK) return rc;
                     return launch<EPI, CDT>(b, vec_ok, st, 256, 128, 3, 16);
                 }
@@ -1523,9 +1523,9 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st, int fbm = 0, int 
         // Chosen wherever the 8-wave 256 x 256 tile was (cold operands, same box, profiles/r06_gemm_w4_vs_vendor.txt: [4096 x 4096 x 22016] 580 -> 510 us,
         // [4096 x 4096 x 4096] 122 -> 112, [4096 x 4096 x 11008] 297 -> 270, [4096 x 12288 x 4096] 345 -> 332); rule 256 of MTL_GEMM_RULES_OFF (diagnostic
         // builds) keeps the 8-wave kernel for in-step A/B runs.
-        if (bm == 256 && bn == 256 && nw == 8 && stages == 2 && fnw == 0 && tn.waves == 0 && w4_ok(p, vec_ok) && !(rules_off() & 256)) nw = 4;
+        if (bm == 256 && bn == 256 && nw == 8 && stages == 2 && fnw == 0 && tn.waves == 0 && w4_ok(p, vec_ok || dword_ok) && !(rules_off() & 256)) nw = 4;
         if (bm == 256 && bn == 256 && nw == 4) {
-            if (!w4_ok(p, vec_ok)) return MTL_ERR_UNSUPPORTED;
+            if (!w4_ok(p, vec_ok || dword_ok)) return MTL_ERR_UNSUPPORTED;
             const int tm = (int)(p.M / 256), tn = (int)(p.N / 256), nt = tm * tn;
             const int grid = nt < ncu ? nt : ncu;
             const size_t lds = 128 * 1024;
