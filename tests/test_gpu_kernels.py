@@ -982,6 +982,11 @@ def test_gemm_w4_row_mapped_operand_and_dispatch(ops):
     assert rel_err(out, Abig[idx].double().cpu() @ B.double().cpu().t()) < TOL_F32
     auto = ops.gemm_nt(Abig[:300], B, out_dtype=F32)                   # automatic dispatch still serves it
     assert rel_err(auto, Abig[:300].double().cpu() @ B.double().cpu().t()) < TOL_F32
+    # plain fp32 store into rows that are only 4-byte aligned (odd row length, as the mapping layer's [1024, 50257] weight gradient): dword stores
+    wide = torch.zeros(1024, Nn + 1, dtype=F32, device="cuda")
+    with ops.gemm_tune(bm=256, bn=256, stages=2, waves=4):
+        ops.gemm_nt(Abig[:1024], B, out=wide[:, :Nn])
+    assert rel_err(wide[:, :Nn], Abig[:1024].double().cpu() @ B.double().cpu().t()) < TOL_F32 and float(wide[:, Nn].abs().max()) == 0.0
     # several tiles per workgroup (512 tiles: chained entries) with the row map: the NEXT tile's row offsets go through the same map
     K2, N2 = 256, 8192
     A2 = torch.randn(32 * 384, K2, generator=g(5)).to(BF16).cuda()
