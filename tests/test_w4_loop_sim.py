@@ -52,3 +52,20 @@ def test_checker_catches_a_chain_into_the_wrong_row_table():
     bad = [l.replace("%[tabn]", "%[tab]") for l in lines]
     with pytest.raises(AssertionError):
         sim.check(sim.run(bad, 8, flags=2), 8, has_next=True)
+
+
+def test_checker_catches_a_wrong_accumulator_or_fragment():
+    """the 16 x 16 x 32 kernel names its 64 accumulator quads and 32 fragments physically: an MFMA that accumulates tile (mi, ni) from another block's fragment,
+    or two MFMAs of a k-step that hit the same accumulator, must not pass"""
+    lines = sim.load()
+    idx = [i for i, l in enumerate(lines) if l.startswith("v_mfma_f32_16x16x32_bf16")]
+    a, b = lines[idx[3]].split(", "), lines[idx[4]].split(", ")      # MFMAs 3 / 4 of the k-step: column blocks 0 / 1 (snake order), same row block
+    assert a[1] != b[1] and a[0] != b[0]
+    swapped = list(lines)
+    swapped[idx[3]] = ", ".join([a[0], b[1], a[2], a[3]])             # the neighbour's B fragment under this tile's accumulator
+    with pytest.raises(AssertionError):
+        sim.check(sim.run(swapped, 4), 4)
+    doubled = list(lines)
+    doubled[idx[4]] = ", ".join([a[0]] + b[1:3] + [a[3]])      # MFMA 4 writes MFMA 3's accumulator quad a second time
+    with pytest.raises(AssertionError):
+        sim.check(sim.run(doubled, 4), 4)
