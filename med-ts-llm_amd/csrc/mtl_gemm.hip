@@ -1000,9 +1000,15 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
     const int wr = wave >> 1, wc = wave & 1;
     const int l15 = lane & 15, g = lane >> 4;
     const int ntiles = tiles_m * tiles_n;
+    // split-K (gm_all bits 16..23 = S > 1): the work items are (tile, k-slab) pairs, slab-major (neighbouring items share panels at the same k); every item
+    // stores its raw fp32 partial sums into workspace slab [S][M][N] and splitk_reduce_kernel applies the epilogue. Slabs may be uneven (nkt / S rounded
+    // up for the first nkt % S slabs): the item's k-tile count and first k-tile travel to the asm in its packed word.
+    const int S = (gm_all >> 16) & 0xff;
+    const bool split = S > 1;
+    const int nitems = split ? ntiles * S : ntiles;
     const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
     const int xblocks = (nblk - xcd + 7) >> 3;                 // blocks living on this XCD
-    const int q = ntiles >> 3, r8 = ntiles & 7;
+    const int q = nitems >> 3, r8 = nitems & 7;
     const int t0 = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
     const int cnt = q + (xcd < r8 ? 1 : 0);
     const int gm = gm_all & 0xff;
@@ -1051,13 +1057,20 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
     // tile chaining (mtl_gemm_w4_loop.inc): a workgroup's tile i stages k-tiles 0 / 1 of its tile i + 1 in its two trailing iterations, so that tile
     // i + 1's k-loop starts as soon as tile i's epilogue stores are ISSUED (they drain under its first iterations) instead of after they have drained
     // plus a load round trip. Even k-tile counts only (the next tile's k-tile 0 must land in LDS buffer 0); no per-XCD rotation.
-    const bool chain = (nkt & 1) == 0 && rot == 0 && VAR == 0;
+    const bool chain = !split && (nkt & 1) == 0 && rot == 0 && VAR == 0;
     int tm_next = 0, tn_next = 0;
     uint32_t tab_next = 0;
     bool have_next = false;                        // the previous iteration already worked out this tile (it staged its first k-tiles)
     for (int i = slot; i < cnt; i += xblocks) {
         int tm = tm_next, tn = tn_next;
-        if (!have_next) tile_coords(t0 + i, tiles_m, tiles_n, gm, tm, tn);
+        const int item = t0 + i, slab = split ? item / ntiles : 0;
+        if (!have_next) tile_coords(split ? item - slab * ntiles : item, tiles_m, tiles_n, gm, tm, tn);
+        int nkt_i = nkt, k0 = 0;
+        if (split) {
+            const int qk = nkt / S, rk = nkt - qk * S;
+            k0 = slab * qk + (slab < rk ? slab : rk);
+            nkt_i = qk + (slab < rk ? 1 : 0);
+        }
         const int64_t m0 = (int64_t)tm * 256, n0 = (int64_t)tn * 256;
         const uint32_t tab = have_next ? tab_next : row_table(m0, n0);
         uint32_t tabn = tab;
@@ -1068,6 +1081,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
             tabn = tab_next = row_table((int64_t)tm_next * 256, (int64_t)tn_next * 256);
             flags |= 2;
         }
+        flags |= (nkt_i << 2) | (k0 << 16);           // the asm's packed word: chaining flags | k-tile count | first k-tile
         // the wave's 8 x 8 output tiles of 16 x 16 (v_mfma_f32_16x16x32_bf16): tile (row block mi, column block ni) lives in the PHYSICAL accumulator quad
         // a[4 (8 mi + ni) .. + 3] — the asm names them directly; c_k = a[16 k .. 16 k + 15] = tiles 4 k .. 4 k + 3 tells the compiler. Write-only for the asm
         // (the first MFMA of each tile takes C = 0).
@@ -1078,7 +1092,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
                    "={a[112:127]}"(c7), "={a[128:143]}"(c8), "={a[144:159]}"(c9), "={a[160:175]}"(c10), "={a[176:191]}"(c11), "={a[192:207]}"(c12),             \
                    "={a[208:223]}"(c13), "={a[224:239]}"(c14), "={a[240:255]}"(c15)                                                                            \
                  : [pa] "s"(p.A), [pb] "s"(p.B), [voa] "v"(voa), [vob] "v"(vob), [tab] "v"(tab), [rba] "v"(rba), [xa] "v"(xa), [rbb] "v"(rbb),           \
-                   [xb] "v"(xb), [nkt] "s"(nkt), [dma] "s"(dma), [rot] "s"(rot), [tabn] "v"(tabn), [flags] "v"(flags)                                     \
+                   [xb] "v"(xb), [dma] "s"(dma), [rot] "s"(rot), [tabn] "v"(tabn), [flags] "v"(flags)                                                     \
                  : MTL_W4_LOOP_CLOBBERS)
 #ifdef MTL_DIAG_W4VAR
         if (i == slot) { stamp[1] = __builtin_amdgcn_s_memrealtime(); cyc[0] = __builtin_amdgcn_s_memtime(); }
@@ -1117,6 +1131,13 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const mtl_gemm_args p, 
             // residual-type epilogues (16 B of auxiliary operand per output quad) go load -> math -> store per chunk of column blocks: 4 blocks per chunk
             // (64 auxiliary VGPRs — the fragment registers are dead here) = 4 dependent round trips per wave tile instead of the default rule's 8
             constexpr int NCHW = (EPI == MTL_EPI_RESID || EPI == MTL_EPI_ACCUM || EPI == MTL_EPI_DGELU || EPI == MTL_EPI_DSWIGLU) ? MTL_W4_NCHW : 0;
+            if constexpr (EPI == MTL_EPI_STORE && CDT == MTL_F32) if (split) {       // raw partial sums -> this slab of the workspace (the host launches THIS instance for split-K; 16-byte aligned slabs)
+                mtl_gemm_args ps = p;
+                ps.C = reinterpret_cast<char*>(p.workspace) + (size_t)slab * (size_t)p.M * (size_t)p.N * sizeof(float);
+                ps.ldc = p.N; ps.c_dtype = MTL_F32; ps.alpha = 1.0f; ps.bias = nullptr; ps.c_group_rows = 0;
+                epilogue_wave<MTL_EPI_STORE, MTL_F32, 8, true, true, 0, 0>(ps, m0 + wr * 128 + half * 64 + l15, n0 + wc * 128, g, pc);
+                continue;
+            }
             epilogue_wave<EPI, CDT, 8, true, true, 0, NCHW>(p, m0 + wr * 128 + half * 64 + l15, n0 + wc * 128, g, pc, vec_ok_i == 0);      // (fp32 plain store into 4-B aligned rows: dword stores)
         }
 #ifdef MTL_DIAG_W4VAR
@@ -1611,7 +1632,23 @@ int launch(const mtl_gemm_args& p, int vec_ok, hipStream_t st, int fbm = 0, int 
     } else {
         const int ws_vec = (p.N % 4 == 0) && aligned(p.workspace, 16);
         const int nkt_total = (int)(p.K / BK);
-        if (tn.mode == 1 && ws_vec && nkt_total % S == 0) {
+        const bool w4_split = tn.mode == 1 && ws_vec && aligned(p.workspace, 16) && S <= 255 && nkt_total / S >= 8 && w4_ok(p, 1) && !(rules_off() & 256);
+        if (w4_split && (nkt_total % S != 0 || (tn.bm == 256 && tn.bn == 256 && tn.waves == 4))) {
+            // split-K on the 4-wave kernel: (tile, k-slab) items with UNEVEN slabs, raw partial sums to the workspace, the reduce kernel below applies the
+            // epilogue. Taken where S does not divide the k-steps (the 8-wave split path below needs that and such calls used to fall to the one-tile
+            // kernel) or when forced (tune 256 x 256 / 4 waves). Not the default for divisible S: on the mapping GEMM [1024 x 768 x 51200] it measured
+            // 131 us (S = 21) / 142 (16) against the 8-wave path's 125 (S = 16) — that GEMM streams 0.3 GB of operands and partial sums, it is not MFMA-bound
+            // (tools/probes/mapping_fwd_split.py, profiles/r06_gemm_w4_experiments.txt section 23)
+            const int tm = (int)(p.M / 256), tnn = (int)(p.N / 256), items = tm * tnn * S;
+            const int ncu = num_cus(), grid = items < ncu ? items : ncu;
+            const size_t lds = 128 * 1024;
+            const int order = (tile_order(tm, tnn, 256, 256, 1, p.K) & 0xff) | (S << 16);
+            auto kfn = gemm_nt_w4_kernel<MTL_EPI_STORE, MTL_F32>;
+            static std::once_flag once;
+            std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+            kname_shape(kname, sizeof kname, p, "gemm_nt_w4_kernel<0, 0> split-K x%d", S);
+            MTL_LAUNCH(kname, flops, 0, kfn, dim3(grid), dim3(256), lds, st, p, 1, tm, tnn, order);
+        } else if (tn.mode == 1 && ws_vec && nkt_total % S == 0) {
             // persistent split-K: S x tiles work items of K/S each through the 128x128 / 8-wave pipeline (mapping GEMM:
             // K = padded vocabulary; the one-tile-per-workgroup kernel below reached 395 TF/s on it)
             auto go = [&](auto bmv, auto bnv) {

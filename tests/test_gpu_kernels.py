@@ -966,6 +966,27 @@ def test_gemm_w4_hand_placed_kernel(ops, M, Nn, K):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,Nn,K,S", [(512, 768, 64 * 75, 7), (256, 256, 64 * 16, 2), (1024, 768, 51200, 21)])
+def test_gemm_w4_split_k_uneven_slabs(ops, M, Nn, K, S):
+    """split-K on the 4-wave kernel: (tile, k-slab) work items whose slabs need not divide the k-steps (75 = 7 x 10 + 5; the mapping GEMM's 800 = 21 x 38 + 2),
+    raw partial sums through the workspace, epilogue (bias, bf16 rounding) in the reduce kernel; against fp64 math and the unsplit kernel"""
+    A = torch.randn(M, K, generator=g(M + S)).to(BF16).cuda()
+    B = (torch.randn(Nn, K, generator=g(Nn)) * 0.05).to(BF16).cuda()
+    bias = torch.randn(Nn, generator=g(3)).cuda()
+    lin = A.double().cpu() @ B.double().cpu().t()
+    with ops.gemm_tune(bm=256, bn=256, stages=2, waves=4):              # (automatic only where S does not divide the k-steps: the first case)
+        f32 = ops.gemm_nt(A, B, out_dtype=F32, split_k=S)
+        b16 = ops.gemm_nt(A, B, bias=bias, split_k=S)
+        again = ops.gemm_nt(A, B, out_dtype=F32, split_k=S)
+    assert rel_err(f32, lin) < TOL_F32
+    assert rel_err(b16.float(), lin + bias.double().cpu()) < TOL_BF16
+    assert rel_err(f32, ops.gemm_nt(A, B, out_dtype=F32, split_k=1).double().cpu()) < 1e-5
+    assert torch.equal(f32, again)                                     # repeated launches bit-identical
+    if (K // 64) % S:
+        assert torch.equal(f32, ops.gemm_nt(A, B, out_dtype=F32, split_k=S))      # the automatic dispatch takes the same kernel
+
+
+@pytest.mark.gpu
 def test_gemm_w4_row_mapped_operand_and_dispatch(ops):
     """the pruned backward's row-mapped A operand through the 4-wave kernel's per-instruction row offsets; shapes the kernel does not take
     (ragged M / N, row groups that are not multiples of 8) are refused when forced and fall to the 8-wave kernels when automatic"""

@@ -69,3 +69,9 @@ def test_checker_catches_a_wrong_accumulator_or_fragment():
     doubled[idx[4]] = ", ".join([a[0]] + b[1:3] + [a[3]])      # MFMA 4 writes MFMA 3's accumulator quad a second time
     with pytest.raises(AssertionError):
         sim.check(sim.run(doubled, 4), 4)
+
+
+@pytest.mark.parametrize("nkt,k0", [(37, 5), (38, 712), (1, 785), (10, 65)])
+def test_k_slab_items(nkt, k0):
+    """split-K work items: the k-loop of a slab that starts k0 k-tiles into the K range (count and offset arrive in the packed flags word)"""
+    assert sim.check(sim.run(sim.load(), nkt, k0=k0), nkt)

@@ -26,7 +26,7 @@ number of k-tiles (tile i + 1's k-tile 0 must land in buffer 0) and rot = 0.
 
 Physical registers named by the asm (all listed as clobbers): v[112:239] fragments, v[240:241] / v[244:245] per-k-step read bases of A / B, a[0:255] the accumulators (operands),
 s[72:75] / s[76:79] buffer descriptors of A / B, s[80:87] / s[88:95] the per-instruction row offsets, s96 loop counter, s97 / s70 k step (lo / sign word), s98 advances left, s99 advances until the k wrap, s71 the wrap's step,
-s68 next-tile flag, s69 scratch.
+s66 the item's k-tile count, s67 its k byte offset, s68 next-tile flag, s69 scratch.
 
 usage: python tools/gen_gemm_w4_loop.py   (rewrites the .inc; the output is committed)"""
 import os
@@ -203,8 +203,12 @@ def setup():
         o += [f"v_lshl_add_u32 v{KSB + ks}, v{KSB + ks}, 4, %[rba]", f"v_lshl_add_u32 v{KSB + 4 + ks}, v{KSB + 4 + ks}, 4, %[rbb]"]
     # k position of the LDS-DMA stream: k-tile (j + rot) mod nkt for the j-th tile staged (per-XCD rotation; rot = 0: plain order).
     # s98 = advances left, s99 = advances until the wrap back to k-tile 0, s71 = the wrap's byte step -(nkt - 1) * 128
-    o += ["s_mov_b32 s96, %[nkt]", "s_sub_i32 s98, %[nkt], 2", "s_sub_i32 s99, %[nkt], %[rot]",
-          "s_sub_i32 s71, 1, %[nkt]", "s_lshl_b32 s71, s71, 7", "v_readfirstlane_b32 s69, %[flags]", "s_and_b32 s68, s69, 2",
+    # %[flags] (wave-uniform, in a VGPR): bits 1:0 = chaining flags, bits 15:2 = the item's k-tile count, bits 31:16 = its first k-tile (split-K items
+    # start inside the K range: k-slab of a (tile, slab) work item; 0 otherwise). s66 = nkt, s67 = byte offset of the first k-tile.
+    o += ["v_readfirstlane_b32 s69, %[flags]", "s_bfe_u32 s66, s69, 0xe0002", "s_lshr_b32 s67, s69, 16", "s_lshl_b32 s67, s67, 7", "s_and_b32 s68, s69, 2",
+          "s_add_u32 s72, s72, s67", "s_addc_u32 s73, s73, 0", "s_add_u32 s76, s76, s67", "s_addc_u32 s77, s77, 0",
+          "s_mov_b32 s96, s66", "s_sub_i32 s98, s66, 2", "s_sub_i32 s99, s66, %[rot]",
+          "s_sub_i32 s71, 1, s66", "s_lshl_b32 s71, s71, 7",
           "s_lshl_b32 s97, %[rot], 7", "s_add_u32 s72, s72, s97", "s_addc_u32 s73, s73, 0", "s_add_u32 s76, s76, s97", "s_addc_u32 s77, s77, 0", "s_nop 4"]
     return o
 
@@ -236,7 +240,7 @@ def cold_stage():
     o = tile(0)
     # k-tile 1 (a tile with one k-tile: out of range, nothing fetched)
     o += ["s_sub_i32 s99, s99, 1", "s_cmp_eq_u32 s99, 0", "s_cselect_b32 s97, s71, 128",
-          "s_cmp_gt_i32 %[nkt], 1", "s_cselect_b32 s97, s97, 0", "s_cselect_b32 s74, -1, 0", "s_cselect_b32 s78, -1, 0", "s_ashr_i32 s70, s97, 31",
+          "s_cmp_gt_i32 s66, 1", "s_cselect_b32 s97, s97, 0", "s_cselect_b32 s74, -1, 0", "s_cselect_b32 s78, -1, 0", "s_ashr_i32 s70, s97, 31",
           "s_add_u32 s72, s72, s97", "s_addc_u32 s73, s73, s70", "s_add_u32 s76, s76, s97", "s_addc_u32 s77, s77, s70"]
     o += tile(1)
     o += ["s_waitcnt vmcnt(16)", "s_barrier"]
@@ -296,7 +300,7 @@ def main():
             f.write(f"// V{i + 1}: schedule {sc}, ablation '{v}'\n")
             emit(f, f"MTL_W4_LOOP_ASM_V{i + 1}", program(sc, v))
         f.write("#endif\n")
-        clob = [f'"v{r}"' for r in range(FRAG0, KSB + 8)] + [f'"s{r}"' for r in range(68, 100)]
+        clob = [f'"v{r}"' for r in range(FRAG0, KSB + 8)] + [f'"s{r}"' for r in range(66, 100)]
         f.write("#define MTL_W4_LOOP_CLOBBERS " + ", ".join(clob) + ', "scc", "memory"\n')
     print("wrote", OUT, len(lines), "instructions")
 

@@ -27,11 +27,11 @@ def load(name="MTL_W4_LOOP_ASM", path=INC):
 M32 = 0xFFFFFFFF
 
 
-def run(lines, nkt, rot=0, dma_base=0x400, max_steps=2_000_000, flags=0):
+def run(lines, nkt, rot=0, dma_base=0x400, max_steps=2_000_000, flags=0, k0=0):
     """returns the event list. Operand values: %[pa] = 0x1000_0000_0000, %[pb] = 0x2000_0000_0000 (so that base - start = k byte offset)."""
     PA, PB = 0x100000000000, 0x200000000000
     s = {}                     # SGPRs (+ 'm0', 'scc')
-    sym = {"%[nkt]": nkt, "%[rot]": rot, "%[dma]": dma_base, "%[flags]": flags}
+    sym = {"%[rot]": rot, "%[dma]": dma_base, "%[flags]": flags | (nkt << 2) | (k0 << 16)}      # the kernel's packed word: chain flags, k-tile count, first k-tile
     table = {}                 # row-offset SGPR -> "tab" (this tile's rows) / "tabn" (the next tile's)
     labels = {l[:-1]: i for i, l in enumerate(lines) if l.endswith(":")}
     ev = []
@@ -72,6 +72,11 @@ def run(lines, nkt, rot=0, dma_base=0x400, max_steps=2_000_000, flags=0):
             r = val(a[1]) + val(a[2]) + s["scc"]
             s["scc"] = int(r > M32)
             s[a[0]] = r & M32
+        elif op == "s_bfe_u32":
+            c = val(a[2])
+            s[a[0]] = (val(a[1]) >> (c & 31)) & ((1 << ((c >> 16) & 0x7f)) - 1)
+        elif op == "s_lshr_b32":
+            s[a[0]] = val(a[1]) >> val(a[2])
         elif op == "s_and_b32":
             s[a[0]] = val(a[1]) & val(a[2])
         elif op == "v_readfirstlane_b32":
@@ -103,7 +108,7 @@ def run(lines, nkt, rot=0, dma_base=0x400, max_steps=2_000_000, flags=0):
             which = "a" if a[0] == "%[voa]" else "b"
             lo = 72 if which == "a" else 76
             base = s[f"s{lo}"] | (s[f"s{lo + 1}"] << 32)
-            off = base - (PA if which == "a" else PB)
+            off = base - (PA if which == "a" else PB) - k0 * 128              # relative to the item's first k-tile
             piece = int(re.match(r"s(\d+)", a[2].split()[0]).group(1)) - (80 if which == "a" else 88)
             assert off % 128 == 0 and 0 <= off // 128 < nkt, (which, off, nkt)
             ev.append(("dma", which, piece, off // 128, s["m0"] - dma_base, s[f"s{lo + 2}"] != 0, table[a[2].split()[0]]))   # num_records != 0 (0 = out of range: no memory access), row table
@@ -232,6 +237,8 @@ if __name__ == "__main__":
     for nkt in (1, 2, 3, 4, 5, 8, 64):
         for rot in sorted({0, 1, (3 * nkt) // 8, nkt - 1} & set(range(nkt))):
             check(run(lines, nkt, rot), nkt, rot)
+    for nkt, k0 in ((37, 5), (38, 712), (1, 785)):          # split-K items: a k-slab that starts inside the K range
+        check(run(lines, nkt, k0=k0), nkt)
     for nkt in (2, 4, 8, 64):          # a chain of three tiles: cold entry -> chained -> chained, last
         check(run(lines, nkt, flags=2), nkt, has_next=True)
         check(run(lines, nkt, flags=3), nkt, has_prev=True, has_next=True)
